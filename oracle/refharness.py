@@ -1,0 +1,182 @@
+"""Harness that imports the Python reference (BUILD-CONTAINER ONLY; TEST INFRASTRUCTURE).
+
+The reference (`/root/reference`, read-only) is pure Python and needs `gymnasium`, which this image lacks.
+No arithmetic lives in gymnasium, so a ~25-line stand-in module is registered before the import (SURVEY.md
+Appendix C).  Nothing of the reference is copied: it is imported from where it lies, and only input/output
+VECTORS produced with it are committed (tests/golden/, see oracle/gen_golden.py).
+
+Harness conventions the reference leaves open (also restated in DESIGN.md):
+  * per-env "global random": the reference shares the process-wide `random` module between all envs; here
+    every env owns a stream, seeded `random.seed(G(seed))`, G(seed) = (seed + 16000) mod 2**32, that is swapped
+    in and out around every call into that env.
+  * scorer-level joker semantics (flag `scorer_jokers`): `UnifiedGameState.to_dict()` hands the scorer joker
+    NAMES (as unified_scoring.py:313-351 does) instead of dicts, which makes the joker chain live.
+  * counter-hash policy: action = k-th valid action, k = hash(policy_seed, env_index, t) mod n_valid.
+"""
+from __future__ import annotations
+
+import os
+import random
+import sys
+import types
+
+REFERENCE_ROOT = os.environ.get("BALATRO_REFERENCE", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "balatro_gym"))
+
+
+def _install_gymnasium_shim():
+    if "gymnasium" in sys.modules:
+        return
+    gym = types.ModuleType("gymnasium")
+    spaces = types.ModuleType("gymnasium.spaces")
+
+    class Env:
+        metadata = {}
+
+        def __init__(self, *a, **k):
+            pass
+
+    class _Space:
+        def __init__(self, *a, **k):
+            pass
+
+    class Discrete(_Space):
+        def __init__(self, n, *a, **k):
+            self.n = int(n)
+
+    class Dict_(_Space):
+        def __init__(self, d=None, **k):
+            self.spaces = dict(d or {}, **k)
+
+    spaces.Discrete, spaces.Box, spaces.MultiBinary, spaces.Dict = Discrete, _Space, _Space, Dict_
+    gym.Env, gym.Wrapper, gym.spaces = Env, type("Wrapper", (Env,), {}), spaces
+    sys.modules["gymnasium"], sys.modules["gymnasium.spaces"] = gym, spaces
+
+
+_loaded = {}
+
+
+def load_reference():
+    """Import the reference modules (once) and return them in a dict."""
+    if _loaded:
+        return _loaded
+    if not reference_available():
+        raise RuntimeError(f"reference not found at {REFERENCE_ROOT}")
+    sys.dont_write_bytecode = True
+    _install_gymnasium_shim()
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import balatro_gym.balatro_env_2 as env2
+    import balatro_gym.unified_scoring as us
+    import balatro_gym.scoring_engine as se
+    import balatro_gym.complete_joker_effects as cje
+    import balatro_gym.balatro_game as bg
+    import balatro_gym.cards as cards
+    import balatro_gym.jokers as jokers
+    import balatro_gym.boss_blinds as bb
+
+    # scorer-level joker semantics switch (see module docstring)
+    orig_to_dict = env2.UnifiedGameState.to_dict
+
+    def to_dict(self):
+        d = orig_to_dict(self)
+        if _loaded.get("_scorer_jokers_active"):
+            d["jokers"] = [j.name for j in self.jokers]
+        return d
+
+    env2.UnifiedGameState.to_dict = to_dict
+    _loaded.update(env2=env2, us=us, se=se, cje=cje, bg=bg, cards=cards, jokers=jokers, bb=bb)
+    return _loaded
+
+
+MASK64 = (1 << 64) - 1
+
+
+def global_seed(seed: int) -> int:
+    return (seed + 16000) % (2 ** 32)
+
+
+def policy_hash(policy_seed: int, env_index: int, t: int) -> int:
+    x = (policy_seed + 0x9E3779B97F4A7C15 * (env_index + 1) + 0xD1B54A32D192ED03 * (t + 1)) & MASK64
+    x ^= x >> 30
+    x = (x * 0xBF58476D1CE4E5B9) & MASK64
+    x ^= x >> 27
+    x = (x * 0x94D049BB133111EB) & MASK64
+    x ^= x >> 31
+    return x >> 32
+
+
+POLICY_UNIFORM, POLICY_SMALL_ONLY, POLICY_CYCLE3 = 0, 1, 2
+
+
+def policy_action(mask, phase: int, policy: int, policy_seed: int, env_index: int, t: int) -> int:
+    if policy != POLICY_UNIFORM:
+        if phase == 2:
+            return 45 + (env_index % 3 if policy == POLICY_CYCLE3 else 0)
+        if phase == 1:
+            return 31
+    valid = [a for a in range(60) if mask[a]]
+    if not valid:
+        return 0
+    return valid[policy_hash(policy_seed, env_index, t) % len(valid)]
+
+
+class RefEnv:
+    """One reference env with its own 'global random' stream."""
+
+    def __init__(self, seed: int, scorer_jokers: bool = False, max_ante: int = 0):
+        self.ref = load_reference()
+        self.scorer_jokers = scorer_jokers
+        self.max_ante = max_ante
+        random.seed(global_seed(seed))
+        self._enter()
+        try:
+            self.env = self.ref["env2"].BalatroEnv(seed=seed)
+        finally:
+            self._leave()
+
+    def _enter(self):
+        self.ref["_scorer_jokers_active"] = self.scorer_jokers
+        if hasattr(self, "_g"):
+            random.setstate(self._g)
+
+    def _leave(self):
+        self._g = random.getstate()
+        self.ref["_scorer_jokers_active"] = False
+
+    def reset(self, seed=None):
+        self._enter()
+        try:
+            return self.env.reset(seed=seed)[0]
+        finally:
+            self._leave()
+
+    def obs(self):
+        return self.env._get_observation()
+
+    def step(self, action: int):
+        self._enter()
+        try:
+            obs, reward, terminated, truncated, info = self.env.step(int(action))
+        finally:
+            self._leave()
+        if self.max_ante and self.env.state.ante > self.max_ante:
+            terminated = True
+            info["curriculum_limit_reached"] = True
+        return obs, float(reward), bool(terminated), bool(truncated), info
+
+    def set_jokers(self, ids):
+        lib = {j.id: j for j in self.ref["jokers"].JOKER_LIBRARY}
+        self.env.state.jokers = [lib[i] for i in ids]
+
+    def set_card_state(self, deck_idx, enh=0, edi=0, seal=0):
+        c = self.ref["cards"]
+        self.env.state.card_states[deck_idx] = c.CardState(deck_idx, c.Enhancement(enh), c.Edition(edi), c.Seal(seal))
+
+    def set_hand_level(self, hand_type, level):
+        ht = self.ref["se"].HandType(hand_type)
+        self.env.engine.set_hand_level(ht, level)
+        self.env.state.hand_levels[ht] = self.env.engine.get_hand_level(ht)
