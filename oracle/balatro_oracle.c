@@ -417,7 +417,7 @@ void bo_reset(bo_env* e, int has_seed, int64_t seed) { /* balatro_env_2.py:505-5
   e->boss_type = 0; e->boss_played_types = 0; e->boss_played_cards = 0; e->boss_first_hand = 1;
   e->boss_hands_played = 0; e->boss_cards_required = 5; e->face_down = 0;
   /* ScoreEngine() scoring_engine.py:64-72 */
-  for (int i = 0; i < 12; i++) { e->hand_levels[i] = 1; e->play_counts[i] = 0; }
+  for (int i = 0; i < 12; i++) { e->hand_levels[i] = 1; e->obs_levels[i] = 1; e->play_counts[i] = 0; }
   /* deck :519-525: for suit in Suit: for rank in Rank */
   int p = 0;
   for (int s = 0; s < 4; s++) for (int r = 2; r <= 14; r++) e->deck[p++] = (uint8_t)((r - 2) * 4 + s);
@@ -439,7 +439,9 @@ void bo_set_jokers(bo_env* e, const int32_t* ids, int n) {
   for (int i = 0; i < e->njokers; i++) e->jokers[i] = ids[i];
 }
 void bo_set_card_state(bo_env* e, int idx, int enh, int edi, int seal) { e->enh[idx] = (uint8_t)enh; e->edi[idx] = (uint8_t)edi; e->seal[idx] = (uint8_t)seal; }
-void bo_set_hand_level(bo_env* e, int ht, int level) { e->hand_levels[ht] = (uint8_t)(level < 1 ? 1 : level > 15 ? 15 : level); }
+void bo_set_money(bo_env* e, int64_t money) { e->money = money; }
+void bo_set_ante(bo_env* e, int ante) { e->ante = ante; }
+void bo_set_hand_level(bo_env* e, int ht, int level) { e->hand_levels[ht] = (uint8_t)(level < 1 ? 1 : level > 15 ? 15 : level); e->obs_levels[ht] = e->hand_levels[ht]; }
 
 void bo_action_mask(const bo_env* e, int8_t* mask) { /* balatro_env_2.py:1426-1471 */
   memset(mask, 0, BO_NACT);
@@ -487,7 +489,7 @@ void bo_get_obs(const bo_env* e, bo_obs* o) { /* balatro_env_2.py:1473-1541 */
   for (int i = 0; i < e->nconsumables && i < 5; i++) o->consumables[i] = (int16_t)e->consumables[i];
   o->consumable_slots = (int8_t)e->consumable_slots;
   o->shop_rerolls = (int16_t)e->shop_reroll_cost_state;
-  for (int i = 0; i < 12; i++) o->hand_levels[i] = (int8_t)e->hand_levels[i];
+  for (int i = 0; i < 12; i++) o->hand_levels[i] = (int8_t)e->obs_levels[i];
   o->phase = (int8_t)e->phase;
   bo_action_mask(e, o->action_mask);
   o->hands_played = (int32_t)e->hands_played_total;
@@ -1014,8 +1016,22 @@ void bo_step(bo_env* e, int action, double* reward, uint8_t* terminated, bo_info
         if (at >= 0) { for (int i = at; i + 1 < e->nsel; i++) e->sel[i] = e->sel[i + 1]; e->nsel--; }
         else e->sel[e->nsel++] = pos;
       }
-    } else { /* 10..14 consumables: outside the restated path */
-      *reward = -1.0; info->error = BO_ERR_CONSUMABLE;
+    } else { /* 10..14 _use_consumable :1066-1172 -- planets only (consumables.py:644-652); tarots/spectrals are
+              * outside the restated path and report BO_ERR_CONSUMABLE */
+      int ci = action - 10;
+      int id = e->consumables[ci];
+      if (id >= 30 && id <= 41) {
+        static const int PLANET_HT[12] = {1, 2, 3, 4, 5, 6, 7, 8, 0, 9, 10, 11}; /* Mercury..Eris :1103-1116 */
+        int ht = PLANET_HT[id - 30];
+        for (int i = ci; i + 1 < e->nconsumables; i++) e->consumables[i] = e->consumables[i + 1];
+        e->nconsumables--;
+        if (e->hand_levels[ht] < 15) e->hand_levels[ht]++;  /* engine.apply_planet scoring_engine.py:82-85 */
+        e->obs_levels[ht]++;                                 /* state.hand_levels[...] += 1 (uncapped) :1119 */
+        *reward = 10.0;
+      } else {
+        *reward = -1.0; info->error = BO_ERR_CONSUMABLE;
+      }
+      e->nsel = 0; /* :1171 */
     }
   } else if (e->phase == BO_PHASE_SHOP) step_shop(e, action, reward, info);
   else if (e->phase == BO_PHASE_BLIND_SELECT) step_blind_select(e, action, reward, info);

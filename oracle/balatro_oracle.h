@@ -8,7 +8,7 @@
  *
  * PARITY PIN: checked against (1) the reference's own known answers (tests/chips_test.py:5-24 and
  * balatro_trajectories.json play_hand transitions), (2) golden vectors generated in the build container by
- * importing the Python reference (tests/golden/*, generator oracle/gen_golden.py), and (3) -- only when
+ * importing the Python reference (tests/golden/, generator oracle/gen_golden.py), and (3) -- only when
  * /root/reference is present -- the imported reference itself (tests/test_oracle_vs_reference.py).
  *
  * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use this library.  The shipped
@@ -136,7 +136,8 @@ typedef struct bo_env {
   int32_t joker_slots, consumable_slots;
   int64_t shop_reroll_cost_state; /* state.shop_reroll_cost (stale after rerolls) */
   int64_t hands_played_total, hands_played_ante, best_hand_this_ante, jokers_sold;
-  uint8_t hand_levels[12];   /* engine.hand_levels; state.hand_levels mirrors it */
+  uint8_t hand_levels[12];   /* engine.hand_levels (scoring_engine.py:66), capped at 15 */
+  int32_t obs_levels[12];    /* state.hand_levels (observation only; += 1 per planet, uncapped) */
   uint32_t play_counts[12];
   uint8_t enh[52], edi[52], seal[52]; /* state.card_states (injection only) */
   /* BalatroGame */
@@ -189,6 +190,8 @@ void bo_step(bo_env* e, int action, double* reward, uint8_t* terminated, bo_info
 void bo_set_jokers(bo_env* e, const int32_t* ids, int n);          /* harness injection (config 3) */
 void bo_set_card_state(bo_env* e, int deck_idx, int enh, int edi, int seal);
 void bo_set_hand_level(bo_env* e, int hand_type, int level);
+void bo_set_money(bo_env* e, int64_t money);   /* harness injection: state.money */
+void bo_set_ante(bo_env* e, int ante);         /* harness injection: state.ante */
 int bo_policy_action(const bo_env* e, int policy, uint64_t policy_seed, uint64_t env_index, uint64_t t);
 
 /* policies */

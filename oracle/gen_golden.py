@@ -1,0 +1,303 @@
+#!/usr/bin/env python3
+"""Generate the committed golden vectors under tests/golden/ by importing the Python reference.
+
+BUILD-CONTAINER ONLY (needs /root/reference); TEST INFRASTRUCTURE.  Run:  python3 oracle/gen_golden.py
+Only DATA (inputs + the reference's outputs) is written; no reference source travels.
+
+Files:
+  F1 mt_streams.json   CPython random.Random known answers + shuffled decks from DeterministicRNG stream 0
+  F2 classify.npz      random 1..8-card subsets -> BalatroGame._classify_hand; checksum over all C(52,5) hands
+  F3 score_hand.json   UnifiedScorer.score_hand cases with joker NAME lists (operator-level joker chain)
+  F4 trace_<cfg>.npz   BalatroEnv traces under the counter-hash policy: actions, rewards, terminated, info and the
+                       full observation after every step
+  F7 kat.json          the reference's own known answers (tests/chips_test.py:5-24, balatro_trajectories.json)
+"""
+from __future__ import annotations
+
+import json
+import os
+import random
+import sys
+import zlib
+from itertools import combinations
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+from oracle import refharness as rh  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+OBS_KEYS = [
+    "hand", "hand_size", "deck_size", "selected_cards", "chips_scored", "round_chips_scored", "progress_ratio",
+    "mult", "chips_needed", "money", "ante", "round", "hands_left", "discards_left", "joker_count", "joker_ids",
+    "joker_slots", "consumable_count", "consumables", "consumable_slots", "shop_items", "shop_costs",
+    "shop_rerolls", "hand_levels", "phase", "action_mask", "hands_played", "best_hand_this_ante",
+    "boss_blind_active", "boss_blind_type", "face_down_cards",
+]
+
+# the 51 jokers complete_joker_effects.py implements (ids from jokers.py)
+IMPLEMENTED = [1, 136, 27, 38, 61, 16, 34, 108, 23, 22, 53, 97, 50, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
+               131, 132, 133, 134, 135, 48, 128, 122, 72, 140, 31, 39, 40, 41, 101, 124, 26, 33, 104, 147, 118, 119,
+               116, 117]
+
+
+def gen_mt():
+    out = {"seeds": [], "u32": [], "randbelow": [], "random": [], "deck": [], "shop_seed": []}
+    ref = rh.load_reference()
+    seeds = [1, 7, 42, 382, 2 ** 32 - 1, 2 ** 32 + 5, 10 ** 12, 123456789, 0x7FFFFFFF, 2 ** 31, 1000, 1001, 65535,
+             2 ** 40 + 3, 999999937, 31337] + [random.Random(99).randrange(1, 2 ** 48) for _ in range(48)]
+    for s in seeds:
+        r = random.Random(s)
+        out["seeds"].append(s)
+        out["u32"].append([r.getrandbits(32) for _ in range(16)])
+        r = random.Random(s)
+        out["randbelow"].append([[n, r._randbelow(n)] for n in (52, 3, 145, 2, 28, 24, 2 ** 31, 51, 8, 7, 6, 2 ** 32 - 1)])
+        r = random.Random(s)
+        out["random"].append([r.random().hex() for _ in range(8)])
+        rng = ref["env2"].DeterministicRNG(s)
+        deck = [ref["cards"].Card(rank=rk, suit=su) for su in ref["cards"].Suit for rk in ref["cards"].Rank]
+        rng.shuffle("deck_shuffle", deck)
+        out["deck"].append([int(c) for c in deck])
+        out["shop_seed"].append([rng.get_int("shop_generation", 0, 2 ** 31 - 1) for _ in range(3)])
+    with open(os.path.join(GOLD, "mt_streams.json"), "w") as f:
+        json.dump(out, f)
+    print("F1 mt_streams.json", len(seeds), "seeds")
+
+
+def gen_classify():
+    ref = rh.load_reference()
+    Card, Rank, Suit = ref["cards"].Card, ref["cards"].Rank, ref["cards"].Suit
+    game = ref["bg"].BalatroGame()
+    allc = [Card(rank=Rank(c // 4 + 2), suit=Suit(c % 4)) for c in range(52)]
+    r = random.Random(2024)
+    N = 20000
+    cards = np.full((N, 8), 255, dtype=np.uint8)
+    n = np.zeros(N, dtype=np.uint8)
+    ht = np.zeros(N, dtype=np.uint8)
+    for i in range(N):
+        k = r.randint(1, 8)
+        if i % 4 == 0:  # bias towards made hands: few ranks / one suit
+            pool = [c for c in range(52) if (c // 4) in r.sample(range(13), r.randint(1, 6))] if i % 8 == 0 else \
+                   [c for c in range(52) if (c % 4) == r.randrange(4) or r.random() < 0.1]
+            if len(pool) < k:
+                pool = list(range(52))
+        else:
+            pool = list(range(52))
+        pick = r.sample(pool, k)
+        cards[i, :k] = pick
+        n[i] = k
+        ht[i] = int(game._classify_hand([allc[c] for c in pick])[0])
+    # all C(52,5) hands in lexicographic order -> per-type counts and a CRC32 over the type bytes
+    types = bytearray()
+    for combo in combinations(range(52), 5):
+        types.append(int(game._classify_hand([allc[c] for c in combo])[0]))
+    counts = np.bincount(np.frombuffer(bytes(types), dtype=np.uint8), minlength=12)
+    np.savez_compressed(os.path.join(GOLD, "classify.npz"), cards=cards, n=n, hand_type=ht,
+                        all5_counts=counts, all5_crc32=np.uint32(zlib.crc32(bytes(types))))
+    print("F2 classify.npz", N, "subsets; all5 counts", counts.tolist())
+
+
+def gen_score_hand():
+    ref = rh.load_reference()
+    us, se, cje = ref["us"], ref["se"], ref["cje"]
+    names = {j.id: j.name for j in ref["jokers"].JOKER_LIBRARY}
+    ENV_NAMES = ["High Card", "One Pair", "Two Pair", "Three Kind", "Straight", "Flush", "Full House", "Four Kind",
+                 "Straight Flush", "Five Kind", "Flush House", "Flush Five"]
+    SIM_NAMES = ["High Card", "Pair", "Two Pair", "Three of a Kind", "Straight", "Flush", "Full House",
+                 "Four of a Kind", "Straight Flush", "Five of a Kind", "Flush House", "Flush Five"]
+    SUITS = ["Clubs", "Diamonds", "Hearts", "Spades", "Stone"]
+    r = random.Random(77)
+    cases = []
+    for i in range(3000):
+        ncards = r.randint(1, 8)
+        cards = []
+        for _ in range(ncards):
+            rank = r.randint(2, 14)
+            suit = r.randrange(4)
+            chips = 11 if rank == 14 else min(rank, 10)
+            if r.random() < 0.05:
+                rank, suit, chips = 0, 4, chips + 50  # stone (balatro_env_2.py:304-306)
+            elif r.random() < 0.1:
+                chips += r.choice([30, 50, 80])
+            cards.append([rank, suit, chips])
+        nscoring = ncards if r.random() < 0.7 else r.randint(1, ncards)
+        style = i & 1
+        ht = r.randrange(12) if r.random() < 0.2 else r.randrange(9)
+        level = r.randint(1, 15) if r.random() < 0.3 else 1
+        nj = r.randint(0, 5)
+        pool = IMPLEMENTED if r.random() < 0.8 else list(range(1, 151))
+        jokers = r.sample(pool, nj)
+        hands_left, discards_left = r.randint(1, 4), r.randint(0, 3)
+        deck_len = 52
+        gseed = r.randrange(2 ** 32)
+        engine = se.ScoreEngine()
+        engine.set_hand_level(se.HandType(ht), level)
+        scorer = us.UnifiedScorer(engine, cje.CompleteJokerEffects())
+        objs = [type("Card", (), {"rank": c[0], "suit": SUITS[c[1]], "chip_value": (lambda v=c[2]: v)}) for c in cards]
+        ctx = us.ScoringContext(cards=objs, scoring_cards=objs[:nscoring], hand_type=se.HandType(ht),
+                                hand_type_name=(SIM_NAMES if style else ENV_NAMES)[ht],
+                                game_state={"jokers": [names[j] for j in jokers], "hands_left": hands_left,
+                                            "discards_left": discards_left, "deck": [0] * deck_len, "money": 0})
+        random.seed(gseed)
+        score, bd = scorer.score_hand(ctx)
+        probe = random.getrandbits(32)  # identifies how far the global stream advanced
+        cases.append({"cards": cards, "nscoring": nscoring, "style": style, "hand_type": ht, "level": level,
+                      "jokers": jokers, "hands_left": hands_left, "discards_left": discards_left,
+                      "deck_len": deck_len, "gseed": gseed, "score": int(score), "chips": int(bd["final_chips"]),
+                      "mult": int(bd["final_mult"]), "x_mult": float(bd["final_x_mult"]).hex(),
+                      "money": int(bd["money_gained"]), "probe": probe})
+    with open(os.path.join(GOLD, "score_hand.json"), "w") as f:
+        json.dump(cases, f, separators=(",", ":"))
+    print("F3 score_hand.json", len(cases), "cases")
+
+
+def trace(cfg_name, seeds, T, policy, scorer=False, jokers_fn=None, max_ante=0, money_fn=None, ante_fn=None,
+          cards_fn=None, levels_fn=None, pseed=7):
+    S = len(seeds)
+    rec = {
+        "seeds": np.array(seeds, dtype=np.int64), "policy": np.int32(policy), "policy_seed": np.uint64(pseed),
+        "scorer_jokers": np.int32(scorer), "max_ante": np.int32(max_ante),
+        "actions": np.zeros((S, T), np.uint8), "rewards": np.zeros((S, T), np.float64),
+        "terminated": np.zeros((S, T), np.uint8), "final_score": np.zeros((S, T), np.int64),
+        "hand_type": np.full((S, T), -1, np.int8), "error": np.zeros((S, T), np.uint8),
+        "inj_jokers": np.zeros((S, 5), np.int32), "inj_njokers": np.zeros(S, np.int32),
+        "inj_money": np.full(S, -1, np.int64), "inj_ante": np.full(S, -1, np.int32),
+        "inj_cards": np.zeros((S, 52, 3), np.uint8), "inj_levels": np.zeros((S, 12), np.uint8),
+    }
+    obs_rec = None
+    for si, seed in enumerate(seeds):
+        env = rh.RefEnv(seed, scorer_jokers=scorer, max_ante=max_ante)
+        js = jokers_fn(si) if jokers_fn else []
+        money = money_fn(si) if money_fn else None
+        ante = ante_fn(si) if ante_fn else None
+        cs = cards_fn(si) if cards_fn else []
+        lv = levels_fn(si) if levels_fn else []
+        rec["inj_njokers"][si] = len(js)
+        rec["inj_jokers"][si, :len(js)] = js
+        if money is not None:
+            rec["inj_money"][si] = money
+        if ante is not None:
+            rec["inj_ante"][si] = ante
+        for (i, e, d, s) in cs:
+            rec["inj_cards"][si, i] = (e, d, s)
+        for (ht, l) in lv:
+            rec["inj_levels"][si, ht] = l
+
+        def inject():
+            if js:
+                env.set_jokers(js)
+            if money is not None:
+                env.set_money(money)
+            if ante is not None:
+                env.set_ante(ante)
+            for (i, e, d, s) in cs:
+                env.set_card_state(i, e, d, s)
+            for (ht, l) in lv:
+                env.set_hand_level(ht, l)
+
+        inject()
+        obs = env.obs()
+        if obs_rec is None:
+            obs_rec = {k: np.zeros((S, T) + np.asarray(obs[k]).shape, np.asarray(obs[k]).dtype) for k in OBS_KEYS}
+            obs0 = {k: np.zeros((S,) + np.asarray(obs[k]).shape, np.asarray(obs[k]).dtype) for k in OBS_KEYS}
+        for k in OBS_KEYS:
+            obs0[k][si] = obs[k]
+        for t in range(T):
+            a = rh.policy_action(obs["action_mask"], int(obs["phase"]), policy, pseed, si, t)
+            obs, r, term, _, info = env.step(a)
+            rec["actions"][si, t] = a
+            rec["rewards"][si, t] = r
+            rec["terminated"][si, t] = term
+            if "final_score" in info:
+                rec["final_score"][si, t] = info["final_score"]
+                rec["hand_type"][si, t] = int(info["hand_type"])
+            rec["error"][si, t] = 1 if "error" in info else 0
+            for k in OBS_KEYS:
+                obs_rec[k][si, t] = obs[k]
+            if term:
+                env.reset()
+                inject()
+                obs = env.obs()
+    for k in OBS_KEYS:
+        rec["obs_" + k] = obs_rec[k]
+        rec["obs0_" + k] = obs0[k]
+    path = os.path.join(GOLD, f"trace_{cfg_name}.npz")
+    np.savez_compressed(path, **rec)
+    plays = int((rec["hand_type"] >= 0).sum())
+    print(f"F4 trace_{cfg_name}.npz seeds={S} T={T} plays={plays} episodes={int(rec['terminated'].sum())} "
+          f"size={os.path.getsize(path) / 1024:.0f} KiB")
+
+
+def gen_traces():
+    # C1: the reference's own smoke policy (balatro_env_2.py:1841-1849)
+    trace("c1_small_only", [42, 7, 382] + [2000 + i for i in range(21)], 400, rh.POLICY_SMALL_ONLY)
+    # C2: Ante-1 three blinds (45/46/47 by env index), boss blinds draw from the per-env global stream
+    trace("c2_cycle3", [1000 + i for i in range(36)], 400, rh.POLICY_CYCLE3)
+    # C3: 5 implemented jokers per env, scorer-level joker semantics, ante cap 4
+    trace("c3_jokers", [1000 + i for i in range(36)], 400, rh.POLICY_CYCLE3, scorer=True,
+          jokers_fn=lambda i: random.Random(i).sample(IMPLEMENTED, 5), max_ante=4)
+    # C5-like: uniform over ALL valid actions incl. boss / shop buy / reroll / sell, full joker id range
+    trace("c5_uniform", [3000 + i for i in range(30)], 600, rh.POLICY_UNIFORM)
+    trace("c5_uniform_rich", [4000 + i for i in range(18)], 500, rh.POLICY_UNIFORM, scorer=True, max_ante=20,
+          money_fn=lambda i: [500, 3000, 100000][i % 3], ante_fn=lambda i: [1, 2, 5, 9, 20][i % 5],
+          jokers_fn=lambda i: random.Random(100 + i).sample(list(range(1, 151)), i % 6))
+
+    def cards_fn(i):
+        rr = random.Random(500 + i)
+        return [(d, rr.choice([0, 0, 1, 2, 3, 4, 5, 6, 7, 8]), rr.choice([0, 0, 1, 2, 3]), rr.choice([0, 0, 1, 2, 3, 3]))
+                for d in range(12)]
+
+    trace("cards_levels", [5000 + i for i in range(18)], 400, rh.POLICY_UNIFORM, scorer=True, max_ante=20,
+          cards_fn=cards_fn, levels_fn=lambda i: [(ht, random.Random(900 + i * 13 + ht).randint(1, 15)) for ht in range(9)],
+          jokers_fn=lambda i: random.Random(700 + i).sample(list(range(1, 151)), i % 6),
+          ante_fn=lambda i: [1, 3, 4, 6][i % 4])
+
+
+def gen_kat():
+    """The reference's own known answers, as data."""
+    kat = {"chips_test": [
+        # tests/chips_test.py:5-24 -- (cards as [rank, suit], expected chips, hand type the old evaluator used)
+        {"cards": [[14, 3]] * 5, "score": 3440, "hand_type": 11},
+        {"cards": [[6, 1]] * 5, "score": 3040, "hand_type": 11},
+        {"cards": [[r, 3] for r in (2, 3, 4, 5, 6)], "score": 960, "hand_type": 8},
+        {"cards": [[r, 1] for r in (14, 13, 12, 11, 10)], "score": 1208, "hand_type": 8},
+        {"cards": [[r, 0] for r in (2, 3, 4, 5, 14)], "score": 1000, "hand_type": 8},
+        {"cards": [[2, 0], [3, 0], [4, 0], [5, 0], [14, 1]], "score": 220, "hand_type": 4},
+        {"cards": [[14, 3]], "score": 16, "hand_type": 0},
+    ], "trajectories": []}
+    suit_id = {"Clubs": 0, "Diamonds": 1, "Hearts": 2, "Spades": 3}
+    with open(os.path.join(rh.REFERENCE_ROOT, "balatro_gym", "balatro_trajectories.json")) as f:
+        trajs = json.load(f)
+    for traj in trajs:
+        for tr in traj:
+            if tr["action"]["type"] != "play_hand":
+                continue
+            hand = tr["state"]["hand_cards"]
+            played = [hand[i] for i in tr["action"]["card_indices"]]
+            gained = tr["next_state"]["score"] - tr["state"]["score"]
+            kat["trajectories"].append({"cards": [[c[0], suit_id[c[1]]] for c in played], "score": gained})
+    with open(os.path.join(GOLD, "kat.json"), "w") as f:
+        json.dump(kat, f)
+    print("F7 kat.json", len(kat["chips_test"]), "+", len(kat["trajectories"]), "known answers")
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    which = sys.argv[1:] or ["mt", "classify", "score", "traces", "kat"]
+    if "mt" in which:
+        gen_mt()
+    if "classify" in which:
+        gen_classify()
+    if "score" in which:
+        gen_score_hand()
+    if "traces" in which:
+        gen_traces()
+    if "kat" in which:
+        gen_kat()
+
+
+if __name__ == "__main__":
+    main()

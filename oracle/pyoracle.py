@@ -106,6 +106,8 @@ def lib():
         L.bo_set_jokers.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.bo_set_card_state.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]
         L.bo_set_hand_level.argtypes = [C.c_void_p, C.c_int, C.c_int]
+        L.bo_set_money.argtypes = [C.c_void_p, C.c_int64]
+        L.bo_set_ante.argtypes = [C.c_void_p, C.c_int]
         L.bo_policy_action.restype = C.c_int
         L.bo_policy_action.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]
         L.bo_classify.restype = C.c_int
@@ -191,6 +193,12 @@ class OracleEnv:
 
     def set_hand_level(self, hand_type, level):
         self._L.bo_set_hand_level(self._h, hand_type, level)
+
+    def set_money(self, money):
+        self._L.bo_set_money(self._h, money)
+
+    def set_ante(self, ante):
+        self._L.bo_set_ante(self._h, ante)
 
     def policy_action(self, policy, policy_seed, env_index, t):
         return self._L.bo_policy_action(self._h, policy, policy_seed, env_index, t)

@@ -180,3 +180,9 @@ class RefEnv:
         ht = self.ref["se"].HandType(hand_type)
         self.env.engine.set_hand_level(ht, level)
         self.env.state.hand_levels[ht] = self.env.engine.get_hand_level(ht)
+
+    def set_money(self, money):
+        self.env.state.money = money
+
+    def set_ante(self, ante):
+        self.env.state.ante = ante

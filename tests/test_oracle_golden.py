@@ -1,0 +1,151 @@
+"""CPU tests: the C oracle against the committed golden vectors generated from the Python reference
+(oracle/gen_golden.py) and against the reference's own known answers (tests/golden/kat.json)."""
+import ctypes as C
+import json
+import os
+import zlib
+from itertools import combinations
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from tests.helpers import GOLD, OBS_KEYS, TRACES, assert_obs_equal, load_trace, trace_injection
+
+
+def test_mt_known_answers():
+    L = po.lib()
+    g = json.load(open(os.path.join(GOLD, "mt_streams.json")))
+    for i, seed in enumerate(g["seeds"]):
+        mt = po.MT()
+        L.bo_mt_seed(C.byref(mt), seed)
+        assert [L.bo_mt_u32(C.byref(mt)) for _ in range(16)] == g["u32"][i]
+        L.bo_mt_seed(C.byref(mt), seed)
+        for n, want in g["randbelow"][i]:
+            assert L.bo_mt_randbelow(C.byref(mt), n) == want
+        L.bo_mt_seed(C.byref(mt), seed)
+        assert [float(L.bo_mt_random(C.byref(mt))).hex() for _ in range(8)] == g["random"][i]
+
+
+def test_deck_shuffle_and_shop_seed_known_answers():
+    """DeterministicRNG stream 0 shuffle (balatro_env_2.py:525) and stream 2 get_int (:1389)."""
+    L = po.lib()
+    g = json.load(open(os.path.join(GOLD, "mt_streams.json")))
+    for i, seed in enumerate(g["seeds"]):
+        mt = po.MT()
+        L.bo_mt_seed(C.byref(mt), seed % 2 ** 32)
+        deck = (C.c_uint8 * 52)(*[(r - 2) * 4 + s for s in range(4) for r in range(2, 15)])
+        L.bo_mt_shuffle_u8(C.byref(mt), deck, 52)
+        assert list(deck) == g["deck"][i]
+        L.bo_mt_seed(C.byref(mt), (seed + 2000) % 2 ** 32)
+        assert [L.bo_mt_randbelow(C.byref(mt), 2 ** 31) for _ in range(3)] == g["shop_seed"][i]
+    # SURVEY 8(a2) deck KATs
+    for seed, first8 in ((42, [36, 41, 49, 12, 33, 50, 13, 3]), (7, [17, 3, 22, 40, 7, 44, 0, 25]),
+                         (382, [9, 49, 51, 48, 11, 50, 21, 3])):
+        env = po.OracleEnv(seed)
+        env.step(45)
+        assert env.obs()["hand"].tolist() == first8
+
+
+def test_classify_golden():
+    g = np.load(os.path.join(GOLD, "classify.npz"))
+    for cards, n, want in zip(g["cards"], g["n"], g["hand_type"]):
+        assert po.classify([int(c) for c in cards[:n]]) == want
+
+
+def test_classify_all_five_card_hands():
+    g = np.load(os.path.join(GOLD, "classify.npz"))
+    L = po.lib()
+    types = bytearray()
+    buf = (C.c_uint8 * 5)()
+    for combo in combinations(range(52), 5):
+        buf[:] = combo
+        types.append(L.bo_classify(buf, 5))
+    counts = np.bincount(np.frombuffer(bytes(types), dtype=np.uint8), minlength=12)
+    assert counts.tolist() == g["all5_counts"].tolist()
+    assert zlib.crc32(bytes(types)) == int(g["all5_crc32"])
+
+
+def test_score_hand_golden():
+    cases = json.load(open(os.path.join(GOLD, "score_hand.json")))
+    L = po.lib()
+    for i, c in enumerate(cases):
+        cards = [tuple(x) for x in c["cards"]]
+        out = po.score_hand(cards, cards[:c["nscoring"]], c["hand_type"], c["style"], c["level"], c["jokers"],
+                            c["hands_left"], c["discards_left"], c["deck_len"], c["gseed"])
+        ctx = f"case {i}: {c}"
+        assert out.score == c["score"], ctx
+        assert out.chips == c["chips"] and out.mult == c["mult"], ctx
+        assert float(out.x_mult).hex() == c["x_mult"], ctx
+        assert out.money == c["money"], ctx
+        # the global stream must have advanced by exactly the reference's number of draws
+        mt = po.MT()
+        L.bo_mt_seed(C.byref(mt), c["gseed"])
+        for _ in range(out.draws):
+            L.bo_mt_u32(C.byref(mt))
+        assert L.bo_mt_u32(C.byref(mt)) == c["probe"], ctx
+
+
+def test_reference_known_answers():
+    """tests/chips_test.py:5-24 and balatro_trajectories.json (the reference's own pinned results)."""
+    kat = json.load(open(os.path.join(GOLD, "kat.json")))
+    L = po.lib()
+
+    def score(cards, ht):
+        chips, mult = C.c_int64(), C.c_int64()
+        L.bo_hand_chips_mult.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.bo_hand_chips_mult(ht, 1, C.byref(chips), C.byref(mult))
+        L.bo_rank_base_chips.restype = C.c_int
+        return (chips.value + sum(L.bo_rank_base_chips(r) for r, _ in cards)) * mult.value
+
+    for k in kat["chips_test"]:
+        distinct = len({tuple(c) for c in k["cards"]}) == len(k["cards"])
+        if distinct:  # five identical cards cannot be classified by balatro_game.py (never emits FLUSH_FIVE)
+            assert po.classify([(r - 2) * 4 + s for r, s in k["cards"]]) == k["hand_type"]
+        assert score(k["cards"], k["hand_type"]) == k["score"]
+    for k in kat["trajectories"]:
+        ht = po.classify([(r - 2) * 4 + s for r, s in k["cards"]])
+        assert score(k["cards"], ht) == k["score"], k
+
+
+def replay_trace(name, make_env):
+    tr = load_trace(name)
+    S, T = tr["actions"].shape
+    for si in range(S):
+        seed = int(tr["seeds"][si])
+        env = make_env(seed, bool(tr["scorer_jokers"]), int(tr["max_ante"]))
+        inj = trace_injection(tr, si)
+
+        def inject():
+            if inj["jokers"]:
+                env.set_jokers(inj["jokers"])
+            if inj["money"] is not None:
+                env.set_money(inj["money"])
+            if inj["ante"] is not None:
+                env.set_ante(inj["ante"])
+            for (d, e, ed, s) in inj["cards"]:
+                env.set_card_state(d, e, ed, s)
+            for (ht, l) in inj["levels"]:
+                env.set_hand_level(ht, l)
+
+        inject()
+        assert_obs_equal(env.obs(), {k: tr["obs0_" + k][si] for k in OBS_KEYS}, f"{name} seed {seed} initial")
+        for t in range(T):
+            a = int(tr["actions"][si, t])
+            assert env.policy_action(int(tr["policy"]), int(tr["policy_seed"]), si, t) == a
+            obs, r, term, _, info = env.step(a)
+            ctx = f"{name} seed {seed} t {t} action {a}"
+            assert r == tr["rewards"][si, t], f"{ctx}: reward {r!r} vs {tr['rewards'][si, t]!r}"
+            assert term == bool(tr["terminated"][si, t]), ctx
+            assert info.final_score == tr["final_score"][si, t], ctx
+            assert info.hand_type == tr["hand_type"][si, t], ctx
+            assert (info.error != 0) == bool(tr["error"][si, t]) or info.error >= 9, ctx
+            assert_obs_equal(obs, {k: tr["obs_" + k][si, t] for k in OBS_KEYS}, ctx)
+            if term:
+                env.reset()
+                inject()
+
+
+@pytest.mark.parametrize("name", TRACES)
+def test_env_trace_golden(name):
+    replay_trace(name, lambda seed, scorer, max_ante: po.OracleEnv(seed, scorer_jokers=scorer, max_ante=max_ante))

@@ -1,0 +1,108 @@
+"""CPU tests that run the imported Python reference side by side with the C oracle.
+
+Only runs where /root/reference exists (the build container); skipped on the GPU box.  This is the direct pin of
+the oracle: same seeds, same counter-hash policy, every observation key / reward / info compared bit-exactly.
+"""
+import random
+
+import numpy as np
+import pytest
+
+from oracle import pyoracle as po
+from oracle import refharness as rh
+from tests.helpers import OBS_KEYS, assert_obs_equal
+
+pytestmark = pytest.mark.skipif(not rh.reference_available(), reason="reference tree not present")
+
+TERMS = ["progress", "milestone", "score", "hand_quality", "efficiency", "synergy", "strategy", "ante_bonus"]
+
+
+def lockstep(seed, steps, policy, scorer=False, jokers=None, max_ante=0, env_index=0, money=None, ante=None,
+             cards=None, levels=None, pseed=11):
+    r = rh.RefEnv(seed, scorer_jokers=scorer, max_ante=max_ante)
+    o = po.OracleEnv(seed, scorer_jokers=scorer, max_ante=max_ante)
+
+    def inject():
+        for e in (r, o):
+            if jokers:
+                e.set_jokers(jokers)
+            if money is not None:
+                e.set_money(money)
+            if ante is not None:
+                e.set_ante(ante)
+            for (d, en, ed, s) in (cards or []):
+                e.set_card_state(d, en, ed, s)
+            for (ht, l) in (levels or []):
+                e.set_hand_level(ht, l)
+
+    inject()
+    obs_r = r.obs()
+    assert_obs_equal(o.obs(), obs_r, f"seed {seed} initial")
+    for t in range(steps):
+        a = rh.policy_action(obs_r["action_mask"], int(obs_r["phase"]), policy, pseed, env_index, t)
+        assert o.policy_action(policy, pseed, env_index, t) == a
+        obs_r, rr, tr, _, ir = r.step(a)
+        obs_o, ro, to, _, io = o.step(a)
+        ctx = f"seed {seed} t {t} action {a}"
+        assert_obs_equal(obs_o, obs_r, ctx)
+        assert ro == rr and to == tr, f"{ctx}: reward {ro!r} vs {rr!r}"
+        if "final_score" in ir:
+            assert io.final_score == ir["final_score"] and io.hand_type == int(ir["hand_type"]), ctx
+            assert io.cards_played == ir["cards_played"], ctx
+            for i, k in enumerate(TERMS):
+                assert io.reward_terms[i] == float(ir["reward_breakdown"][k]), f"{ctx}: {k}"
+        if tr:
+            r.reset()
+            o.reset()
+            inject()
+            obs_r = r.obs()
+            assert_obs_equal(o.obs(), obs_r, ctx + " reset")
+
+
+@pytest.mark.parametrize("policy", [rh.POLICY_SMALL_ONLY, rh.POLICY_CYCLE3, rh.POLICY_UNIFORM])
+def test_env_lockstep_no_jokers(policy):
+    for s in range(12):
+        lockstep(7000 + s, 500, policy, env_index=s)
+
+
+def test_env_lockstep_scorer_jokers():
+    from oracle.gen_golden import IMPLEMENTED
+    for s in range(12):
+        lockstep(8000 + s, 500, rh.POLICY_CYCLE3, scorer=True, jokers=random.Random(s).sample(IMPLEMENTED, 5),
+                 max_ante=4, env_index=s)
+
+
+def test_env_lockstep_rich_shop_and_late_antes():
+    for s in range(10):
+        lockstep(9000 + s, 600, rh.POLICY_UNIFORM, scorer=bool(s & 1), env_index=s, max_ante=22,
+                 money=[500, 3000, 100000][s % 3], ante=[1, 2, 5, 9, 20][s % 5],
+                 jokers=random.Random(s).sample(range(1, 151), s % 6))
+
+
+def test_env_lockstep_card_states_and_levels():
+    for s in range(10):
+        rr = random.Random(40 + s)
+        cards = [(d, rr.choice([0, 0, 1, 2, 3, 4, 5, 6, 7, 8]), rr.choice([0, 0, 1, 2, 3]), rr.choice([0, 0, 1, 2, 3]))
+                 for d in range(12)]
+        levels = [(ht, rr.randint(1, 15)) for ht in range(9)]
+        lockstep(9500 + s, 400, rh.POLICY_UNIFORM, scorer=bool(s & 1), env_index=s, max_ante=20, cards=cards,
+                 levels=levels, jokers=rr.sample(range(1, 151), s % 6))
+
+
+def test_reseed_reproduces_first_shuffle():
+    """reset(seed=s) rebuilds the streams (balatro_env_2.py:507-509); reset() continues them."""
+    r = rh.RefEnv(42)
+    o = po.OracleEnv(42)
+    for e in (r, o):
+        e.step(45)
+    first = r.obs()["hand"].tolist()
+    assert o.obs()["hand"].tolist() == first
+    r.reset(); o.reset()
+    for e in (r, o):
+        e.step(45)
+    second = r.obs()["hand"].tolist()
+    assert second != first and o.obs()["hand"].tolist() == second
+    r.reset(seed=42); o.reset(seed=42)
+    for e in (r, o):
+        e.step(45)
+    assert r.obs()["hand"].tolist() == first and o.obs()["hand"].tolist() == first
