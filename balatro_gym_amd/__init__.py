@@ -1,0 +1,22 @@
+"""balatro_gym_amd -- MI355X-native vectorised Balatro environment (hand-written HIP for gfx950).
+
+Drop-in for ONE hot path of cassiusfive/balatro-gym: the reset()/step() loop of
+`balatro_gym/balatro_env_2.py::BalatroEnv`.  `BalatroEnv` keeps the single-env Gymnasium surface; `BalatroVecEnv`
+steps tens of thousands of games in lockstep on one GPU; `ShardedBalatroVecEnv` spreads them over a node's GPUs.
+"""
+from .constants import Action, Phase  # noqa: F401
+
+__all__ = ["Action", "Phase", "BalatroEnv", "BalatroVecEnv", "ShardedBalatroVecEnv", "make_balatro_env", "shard_range"]
+
+
+def __getattr__(name):  # lazy: importing the package must not need torch / the GPU
+    if name in ("BalatroVecEnv", "ObsBuffers"):
+        from . import vec_env
+        return getattr(vec_env, name)
+    if name in ("BalatroEnv", "make_balatro_env"):
+        from . import env
+        return getattr(env, name)
+    if name in ("ShardedBalatroVecEnv", "shard_range"):
+        from . import sharded
+        return getattr(sharded, name)
+    raise AttributeError(name)

@@ -1,0 +1,115 @@
+"""ctypes binding of libbalatro_mi355x.so (the C ABI in include/balatro_mi355x.h).
+
+The HIP library is the ONLY compute path: loading fails loudly if it is missing or cannot be built, and bg_create
+fails if no HIP device is visible.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+OBS_KEYS = [
+    "hand", "hand_size", "deck_size", "selected_cards", "chips_scored", "round_chips_scored", "progress_ratio",
+    "mult", "chips_needed", "money", "ante", "round", "hands_left", "discards_left", "joker_count", "joker_ids",
+    "joker_slots", "consumable_count", "consumables", "consumable_slots", "shop_items", "shop_costs",
+    "shop_rerolls", "hand_levels", "phase", "action_mask", "hands_played", "best_hand_this_ante",
+    "boss_blind_active", "boss_blind_type", "face_down_cards",
+]
+# key -> (torch/numpy dtype name, trailing shape) in the reference's dtypes (balatro_env_2.py:1488-1531)
+OBS_SPEC = {
+    "hand": ("int8", (8,)), "hand_size": ("int8", ()), "deck_size": ("int8", ()), "selected_cards": ("int64", (8,)),
+    "chips_scored": ("int64", ()), "round_chips_scored": ("int32", ()), "progress_ratio": ("float32", ()),
+    "mult": ("int32", ()), "chips_needed": ("int32", ()), "money": ("int32", ()), "ante": ("int16", ()),
+    "round": ("int8", ()), "hands_left": ("int8", ()), "discards_left": ("int8", ()), "joker_count": ("int8", ()),
+    "joker_ids": ("int16", (10,)), "joker_slots": ("int8", ()), "consumable_count": ("int8", ()),
+    "consumables": ("int16", (5,)), "consumable_slots": ("int8", ()), "shop_items": ("int16", (10,)),
+    "shop_costs": ("int16", (10,)), "shop_rerolls": ("int16", ()), "hand_levels": ("int8", (12,)),
+    "phase": ("int8", ()), "action_mask": ("int8", (60,)), "hands_played": ("int32", ()),
+    "best_hand_this_ante": ("int32", ()), "boss_blind_active": ("int8", ()), "boss_blind_type": ("int8", ()),
+    "face_down_cards": ("int64", (8,)),
+}
+OBS_BYTES = 330
+INFO_KEYS = ["final_score", "error", "flags", "aux", "hand_type", "cards_played", "reward_terms"]
+INFO_SPEC = {"final_score": ("int64", ()), "error": ("int32", ()), "flags": ("int32", ()), "aux": ("int32", ()),
+             "hand_type": ("int8", ()), "cards_played": ("int8", ()), "reward_terms": ("float64", (8,))}
+
+FLAG_SCORER_JOKERS = 1
+FLAG_AUTORESET = 2
+POLICY_UNIFORM, POLICY_SMALL_ONLY, POLICY_CYCLE3 = 0, 1, 2
+
+EXPORTS = ["bg_create", "bg_destroy", "bg_last_error", "bg_num_envs", "bg_state_bytes", "bg_seed", "bg_reset",
+           "bg_step", "bg_observe", "bg_rollout", "bg_inject", "bg_state_blob_bytes", "bg_get_state", "bg_set_state",
+           "bg_refill", "bg_check", "bg_set_profiling", "bg_get_profile"]
+
+
+class ObsPtrs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in OBS_KEYS]
+
+
+class InfoPtrs(C.Structure):
+    _fields_ = [(k, C.c_void_p) for k in INFO_KEYS]
+
+
+class RolloutStats(C.Structure):
+    _fields_ = [("steps", C.c_uint64), ("episodes", C.c_uint64), ("plays", C.c_uint64), ("score_sum", C.c_int64),
+                ("reward_bits", C.c_uint64), ("obs_hash", C.c_uint64)]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib_path() -> str:
+    return _build.LIB
+
+
+def load(build_if_missing: bool = True):
+    """Load the HIP library; raises NativeError (never falls back) when it is unavailable."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = lib_path()
+    if build_if_missing and _build.needs_build():
+        try:
+            _build.build()
+        except Exception as exc:  # no hipcc on the box and no prebuilt .so
+            if not os.path.exists(path):
+                raise NativeError(f"libbalatro_mi355x.so is missing and could not be built: {exc}") from exc
+    if not os.path.exists(path):
+        raise NativeError(f"{path} not found: build it with `python -m balatro_gym_amd.build` (no CPU fallback exists)")
+    try:
+        L = C.CDLL(path)
+    except OSError as exc:
+        raise NativeError(f"cannot load {path}: {exc}") from exc
+    for name in EXPORTS:
+        if not hasattr(L, name):
+            raise NativeError(f"{path} does not export {name}")
+    vp, i32, u32, u64, i64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_int64
+    L.bg_create.argtypes = [i32, i32, u32, i32, C.POINTER(vp)]
+    L.bg_destroy.argtypes = [vp]
+    L.bg_last_error.restype = C.c_char_p
+    L.bg_last_error.argtypes = [vp]
+    L.bg_num_envs.argtypes = [vp]
+    L.bg_state_bytes.restype = u64
+    L.bg_state_bytes.argtypes = [vp]
+    L.bg_seed.argtypes = [vp, vp, vp, i32, vp]
+    L.bg_reset.argtypes = [vp, vp, C.POINTER(ObsPtrs), vp]
+    L.bg_step.argtypes = [vp, vp, C.POINTER(ObsPtrs), vp, vp, vp, C.POINTER(InfoPtrs), vp]
+    L.bg_observe.argtypes = [vp, C.POINTER(ObsPtrs), vp]
+    L.bg_rollout.argtypes = [vp, i32, i32, u64, u64, u64, C.POINTER(ObsPtrs), i32, vp, vp, vp, vp, vp]
+    L.bg_inject.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp]
+    L.bg_state_blob_bytes.restype = u64
+    L.bg_state_blob_bytes.argtypes = [vp]
+    L.bg_get_state.argtypes = [vp, i32, vp, u64]
+    L.bg_set_state.argtypes = [vp, i32, vp, u64]
+    L.bg_refill.argtypes = [vp, vp]
+    L.bg_check.argtypes = [vp, vp]
+    L.bg_set_profiling.argtypes = [vp, i32]
+    L.bg_get_profile.argtypes = [vp, C.POINTER(C.c_double)]
+    _lib = L
+    return L

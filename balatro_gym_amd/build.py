@@ -1,0 +1,45 @@
+"""Build libbalatro_mi355x.so (hand-written HIP for gfx950) in-tree with hipcc.
+
+`python -m balatro_gym_amd.build` or `__graft_entry__.build()`.  hipcc cross-compiles without a GPU.
+-ffp-contract=off: the reference's float64 expressions must not be fused into FMAs (bit-exact rewards/scores).
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "csrc", "bg_lib.hip")
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("bg_device.h", "bg_step.h", "bg_tables.h")] + [
+    os.path.join(os.path.dirname(HERE), "include", "balatro_mi355x.h")]
+LIB = os.path.join(HERE, "libbalatro_mi355x.so")
+ARCH = "gfx950"
+
+
+def hipcc_path() -> str:
+    p = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(p):
+        raise RuntimeError("hipcc not found: the MI355X kernels cannot be built")
+    return p
+
+
+def needs_build() -> bool:
+    return not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    cmd = [hipcc_path(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
+           "-Wno-unused-value", "-o", LIB, SRC]
+    if verbose:
+        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose="-v" in sys.argv))

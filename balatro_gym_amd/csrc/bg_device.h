@@ -1,0 +1,319 @@
+// bg_device.h -- HBM data layout + per-env device functions of the MI355X Balatro step path (gfx950 only).
+//
+// Execution model: ONE LANE = ONE ENV (a wave64 steps 64 independent games in lockstep).  Every per-env array is
+// structure-of-arrays with the env index fastest, so a wave's access to any field is one coalesced request:
+//   hot   uint4[BG_NHOT ][N]   packed game state, 16 B "chunks" (global_load_dwordx4 per lane = 1 KiB per wave)
+//   deck  uint4[4       ][N]   52 card codes ((rank-2)*4+suit, cards.py:103-104), 12 B pad
+//   cold  uint4[BG_NCOLD][N]   hand_play_counts + shop inventory (touched only by the lanes that need them)
+//   tmpl  uint4[2       ][N]   reset template (harness injection: jokers / money / ante / hand levels)
+//   gblk  u32[KG][624][N]      per-env "global random" stream: ring of consecutive raw MT19937 blocks
+//   sblk  u32[KS][624][N]      ring of pre-seeded shop streams (first block of random.Random(shop_seed))
+//   ndeck uint4[KD][4][N]      ring of pre-shuffled decks (DeterministicRNG 'deck_shuffle' look-ahead)
+//   deckmt / shopgenmt u32[625][N]   authoritative MT state of streams 0 and 2 (+ index word)
+// The serial MT19937 work (seeding = 1247 dependent steps, block twist, 51-swap shuffle) is never on the step path:
+// it runs in the refill kernel, which looks AHEAD on streams whose consumption order does not depend on play
+// (stream 0 is only consumed by reset shuffles, stream 2 only by one get_int per shop visit).
+//
+// Reference semantics (file:line relative to the reference's balatro_gym/) are cited per function.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bg_tables.h"
+
+#define BG_NHOT 8
+#define BG_NDECK 4
+#define BG_NCOLD 7
+#define BG_NTMPL 2
+#define BG_MT_N 624
+#define BG_MT_M 397
+
+// device error word bits (sticky; checked by the host, which then fails loudly)
+#define BG_DEVERR_GSTREAM 1u  // global-stream ring underflow
+#define BG_DEVERR_SHOPBLK 2u  // a shop visit consumed more than one MT block
+#define BG_DEVERR_DECKRING 4u // pre-shuffled deck ring empty at reset
+#define BG_DEVERR_SHOPRING 8u // pre-seeded shop ring empty at shop generation
+
+struct BgDev {
+  int N;
+  uint32_t flags;
+  int max_ante;
+  int KG, KS, KD;
+  uint4* hot;
+  uint4* deck;
+  uint4* cold;
+  uint4* tmpl;
+  uint4* ndeck;
+  uint32_t* gblk;
+  uint32_t* sblk;
+  uint32_t* deckmt;
+  uint32_t* shopgenmt;
+  uint32_t* err;
+  const uint32_t* mt_init; // init_genrand(19650218) table, 624 words
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// Unpacked per-env state (lives in registers for the duration of a step)
+// ---------------------------------------------------------------------------------------------------------
+struct Env {
+  // chunk 0
+  int64_t chips_scored, round_chips;
+  // chunk 1
+  int64_t best_hand;
+  int32_t chips_needed, money;
+  // chunk 2
+  int32_t hp_total, hp_ante, jokers_sold, shop_reroll_state, shop_reroll_base;
+  // chunk 3 (16 x u8)
+  int32_t ante, round, phase, hands_left, discards_left, hand_size, nhand, nsel, njokers, ncons, n_magic, n_minim,
+      boss_type, boss_req, bflags, shop_n;
+  // chunk 4
+  uint64_t hand, sel; // 8 deck indexes / 8 selected positions (selection order), one byte each
+  // chunk 5
+  uint32_t highlighted, face_down, boss_hp, boss_types, cons0, cons1;
+  uint64_t jokers; // up to 5 ids, one byte each
+  int32_t shop_ante, d_head, d_ready;
+  // chunk 6
+  uint64_t boss_cards; // played-deck-index mask (stands in for id(card), boss_blinds.py:472)
+  uint64_t levels;     // 12 x 4-bit engine hand levels (scoring_engine.py:66)
+  int32_t g_cur, g_valid;
+  // chunk 7
+  int32_t g_idx, s_idx, s_cur, s_ready;
+  uint64_t excess; // 12 x 4-bit (state.hand_levels - engine level): planets used at the level-15 cap
+};
+
+#define BG_BF_FIRST_HAND 1
+#define BG_BF_SHOP_EXISTS 2
+
+__device__ __forceinline__ uint32_t bg_b(uint32_t w, int i) { return (w >> (8 * i)) & 0xffu; }
+
+__device__ __forceinline__ void bg_unpack(const uint4 c[BG_NHOT], Env& e) {
+  e.chips_scored = (int64_t)(((uint64_t)c[0].y << 32) | c[0].x);
+  e.round_chips = (int64_t)(((uint64_t)c[0].w << 32) | c[0].z);
+  e.best_hand = (int64_t)(((uint64_t)c[1].y << 32) | c[1].x);
+  e.chips_needed = (int32_t)c[1].z;
+  e.money = (int32_t)c[1].w;
+  e.hp_total = (int32_t)c[2].x;
+  e.hp_ante = (int32_t)(c[2].y & 0xffffu);
+  e.jokers_sold = (int32_t)(c[2].y >> 16);
+  e.shop_reroll_state = (int32_t)c[2].z;
+  e.shop_reroll_base = (int32_t)c[2].w;
+  e.ante = bg_b(c[3].x, 0); e.round = bg_b(c[3].x, 1); e.phase = bg_b(c[3].x, 2); e.hands_left = bg_b(c[3].x, 3);
+  e.discards_left = bg_b(c[3].y, 0); e.hand_size = bg_b(c[3].y, 1); e.nhand = bg_b(c[3].y, 2); e.nsel = bg_b(c[3].y, 3);
+  e.njokers = bg_b(c[3].z, 0); e.ncons = bg_b(c[3].z, 1); e.n_magic = bg_b(c[3].z, 2); e.n_minim = bg_b(c[3].z, 3);
+  e.boss_type = bg_b(c[3].w, 0); e.boss_req = bg_b(c[3].w, 1); e.bflags = bg_b(c[3].w, 2); e.shop_n = bg_b(c[3].w, 3);
+  e.hand = ((uint64_t)c[4].y << 32) | c[4].x;
+  e.sel = ((uint64_t)c[4].w << 32) | c[4].z;
+  e.highlighted = c[5].x & 0xffffu; e.face_down = bg_b(c[5].x, 2); e.boss_hp = bg_b(c[5].x, 3);
+  e.boss_types = c[5].y & 0xffffu; e.cons0 = bg_b(c[5].y, 2); e.cons1 = bg_b(c[5].y, 3);
+  e.jokers = (uint64_t)c[5].z | ((uint64_t)(c[5].w & 0xffu) << 32);
+  e.shop_ante = bg_b(c[5].w, 1); e.d_head = bg_b(c[5].w, 2); e.d_ready = bg_b(c[5].w, 3);
+  e.boss_cards = ((uint64_t)c[6].y << 32) | c[6].x;
+  e.levels = (uint64_t)c[6].z | ((uint64_t)(c[6].w & 0xffffu) << 32);
+  e.g_cur = bg_b(c[6].w, 2); e.g_valid = bg_b(c[6].w, 3);
+  e.g_idx = (int32_t)(c[7].x & 0xffffu); e.s_idx = (int32_t)(c[7].x >> 16);
+  e.s_cur = bg_b(c[7].y, 0); e.s_ready = bg_b(c[7].y, 1);
+  e.excess = (uint64_t)c[7].z | ((uint64_t)(c[7].w & 0xffffu) << 32);
+}
+
+__device__ __forceinline__ uint32_t bg_p4(int a, int b, int c, int d) {
+  return (uint32_t)(a & 0xff) | ((uint32_t)(b & 0xff) << 8) | ((uint32_t)(c & 0xff) << 16) | ((uint32_t)(d & 0xff) << 24);
+}
+
+__device__ __forceinline__ void bg_pack(const Env& e, uint4 c[BG_NHOT]) {
+  c[0] = make_uint4((uint32_t)e.chips_scored, (uint32_t)((uint64_t)e.chips_scored >> 32), (uint32_t)e.round_chips,
+                    (uint32_t)((uint64_t)e.round_chips >> 32));
+  c[1] = make_uint4((uint32_t)e.best_hand, (uint32_t)((uint64_t)e.best_hand >> 32), (uint32_t)e.chips_needed, (uint32_t)e.money);
+  c[2] = make_uint4((uint32_t)e.hp_total, ((uint32_t)e.hp_ante & 0xffffu) | ((uint32_t)e.jokers_sold << 16),
+                    (uint32_t)e.shop_reroll_state, (uint32_t)e.shop_reroll_base);
+  c[3] = make_uint4(bg_p4(e.ante, e.round, e.phase, e.hands_left), bg_p4(e.discards_left, e.hand_size, e.nhand, e.nsel),
+                    bg_p4(e.njokers, e.ncons, e.n_magic, e.n_minim), bg_p4(e.boss_type, e.boss_req, e.bflags, e.shop_n));
+  c[4] = make_uint4((uint32_t)e.hand, (uint32_t)(e.hand >> 32), (uint32_t)e.sel, (uint32_t)(e.sel >> 32));
+  c[5] = make_uint4((e.highlighted & 0xffffu) | ((e.face_down & 0xffu) << 16) | ((e.boss_hp & 0xffu) << 24),
+                    (e.boss_types & 0xffffu) | ((e.cons0 & 0xffu) << 16) | ((e.cons1 & 0xffu) << 24), (uint32_t)e.jokers,
+                    bg_p4((int)(e.jokers >> 32), e.shop_ante, e.d_head, e.d_ready));
+  c[6] = make_uint4((uint32_t)e.boss_cards, (uint32_t)(e.boss_cards >> 32), (uint32_t)e.levels,
+                    ((uint32_t)(e.levels >> 32) & 0xffffu) | ((uint32_t)(e.g_cur & 0xff) << 16) | ((uint32_t)(e.g_valid & 0xff) << 24));
+  c[7] = make_uint4(((uint32_t)e.g_idx & 0xffffu) | ((uint32_t)e.s_idx << 16), bg_p4(e.s_cur, e.s_ready, 0, 0),
+                    (uint32_t)e.excess, (uint32_t)(e.excess >> 32) & 0xffffu);
+}
+
+__device__ __forceinline__ void bg_load_env(const BgDev& d, int env, Env& e) {
+  uint4 c[BG_NHOT];
+#pragma unroll
+  for (int k = 0; k < BG_NHOT; k++) c[k] = d.hot[(size_t)k * d.N + env];
+  bg_unpack(c, e);
+}
+__device__ __forceinline__ void bg_store_env(const BgDev& d, int env, const Env& e) {
+  uint4 c[BG_NHOT];
+  bg_pack(e, c);
+#pragma unroll
+  for (int k = 0; k < BG_NHOT; k++) d.hot[(size_t)k * d.N + env] = c[k];
+}
+
+// byte i of a packed 8-byte list
+__device__ __forceinline__ int bg_get8(uint64_t v, int i) { return (int)((v >> (8 * i)) & 0xffull); }
+__device__ __forceinline__ uint64_t bg_set8(uint64_t v, int i, int x) {
+  return (v & ~(0xffull << (8 * i))) | ((uint64_t)(x & 0xff) << (8 * i));
+}
+// remove byte i, shifting the tail down
+__device__ __forceinline__ uint64_t bg_del8(uint64_t v, int i) {
+  uint64_t lowmask = i ? ((1ull << (8 * i)) - 1) : 0ull;
+  uint64_t lo = v & lowmask;
+  uint64_t hi = (i < 7) ? (v >> (8 * (i + 1))) << (8 * i) : 0ull;
+  return lo | hi;
+}
+__device__ __forceinline__ int bg_level(const Env& e, int ht) { return (int)((e.levels >> (4 * ht)) & 0xf); }
+
+// ---------------------------------------------------------------------------------------------------------
+// Card lookups.  deck chunk 0 (deck indexes 0..15) is held in registers; in the live reference the hand is always a
+// subset of deck[0..hand_size), so the global-memory path below is the rare general case.
+// ---------------------------------------------------------------------------------------------------------
+struct Deck0 { uint64_t lo, hi; };
+__device__ __forceinline__ Deck0 bg_load_deck0(const BgDev& d, int env) {
+  uint4 c = d.deck[env];
+  Deck0 r;
+  r.lo = ((uint64_t)c.y << 32) | c.x;
+  r.hi = ((uint64_t)c.w << 32) | c.z;
+  return r;
+}
+__device__ __forceinline__ int bg_card(const BgDev& d, int env, const Deck0& k, int idx) {
+  if (idx < 16) return (int)(((idx < 8 ? k.lo : k.hi) >> (8 * (idx & 7))) & 0xffull);
+  const uint8_t* p = (const uint8_t*)&d.deck[(size_t)(idx >> 4) * d.N + env];
+  return p[idx & 15];
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MT19937 pieces (CPython Modules/_randommodule.c)
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bg_temper(uint32_t y) {
+  y ^= (y >> 11);
+  y ^= (y << 7) & 0x9d2c5680u;
+  y ^= (y << 15) & 0xefc60000u;
+  y ^= (y >> 18);
+  return y;
+}
+__device__ __forceinline__ uint32_t bg_twist(uint32_t a, uint32_t b, uint32_t far) {
+  uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
+  return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// next raw word of the per-env "global random" stream (ring of blocks, tempered on read)
+__device__ __forceinline__ uint32_t bg_gdraw(const BgDev& d, int env, Env& e) {
+  if (e.g_idx >= BG_MT_N) { e.g_cur = (e.g_cur + 1 == d.KG) ? 0 : e.g_cur + 1; e.g_idx = 0; e.g_valid--; }
+  if (e.g_valid <= 0) { atomicOr(d.err, BG_DEVERR_GSTREAM); e.g_valid = 0; return 0u; }
+  uint32_t y = d.gblk[((size_t)e.g_cur * BG_MT_N + e.g_idx) * d.N + env];
+  e.g_idx++;
+  return bg_temper(y);
+}
+// next raw word of the current shop's random.Random(shop_seed) (shop.py:96)
+__device__ __forceinline__ uint32_t bg_sdraw(const BgDev& d, int env, Env& e) {
+  if (e.s_idx >= BG_MT_N) { atomicOr(d.err, BG_DEVERR_SHOPBLK); return 0u; }
+  uint32_t y = d.sblk[((size_t)e.s_cur * BG_MT_N + e.s_idx) * d.N + env];
+  e.s_idx++;
+  return bg_temper(y);
+}
+// Lib/random.py _randbelow_with_getrandbits (n >= 1): k = n.bit_length(); r = getrandbits(k) until r < n
+template <bool SHOP>
+__device__ __forceinline__ uint32_t bg_randbelow(const BgDev& d, int env, Env& e, uint32_t n) {
+  int k = 32 - __clz(n);
+  uint32_t r;
+  int guard = 0;
+  do {
+    r = (SHOP ? bg_sdraw(d, env, e) : bg_gdraw(d, env, e)) >> (32 - k);
+  } while (r >= n && ++guard < 4096);
+  return r < n ? r : 0u;
+}
+// random(): (a*67108864.0+b)*(1.0/9007199254740992.0) with a = u32>>5, b = u32>>6
+__device__ __forceinline__ double bg_grandom(const BgDev& d, int env, Env& e) {
+  uint32_t a = bg_gdraw(d, env, e) >> 5;
+  uint32_t b = bg_gdraw(d, env, e) >> 6;
+  return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Pure game functions
+// ---------------------------------------------------------------------------------------------------------
+// cards.py:52-60 Rank.base_chips, on a card code
+__device__ __forceinline__ int bg_card_chips(int code) {
+  int r = (code >> 2) + 2;
+  return r <= 10 ? r : (r == 14 ? 11 : 10);
+}
+// scoring_engine.py:27-40,87-101 get_hand_chips_mult
+__device__ __forceinline__ void bg_hand_base(int ht, int level, int& chips, int& mult) {
+  int bc, bm;
+  switch (ht) {
+    case 0: bc = 5; bm = 1; break;
+    case 1: bc = 10; bm = 2; break;
+    case 2: bc = 20; bm = 2; break;
+    case 3: bc = 30; bm = 3; break;
+    case 4: bc = 30; bm = 4; break;
+    case 5: bc = 35; bm = 4; break;
+    case 6: bc = 40; bm = 4; break;
+    case 7: bc = 60; bm = 7; break;
+    case 8: bc = 100; bm = 8; break;
+    case 9: bc = 120; bm = 12; break;
+    case 10: bc = 140; bm = 14; break;
+    default: bc = 160; bm = 16; break;
+  }
+  chips = bc + (level - 1) * 10;
+  mult = bm + (level - 1);
+}
+
+// balatro_game.py:40-93 _classify_hand, bit-parallel: `cards` = up to 8 card codes, n of them valid.
+// rank presence mask (13 bits) for the straight test, 4-bit-per-rank histogram for the count tests.
+__device__ __forceinline__ int bg_classify(uint64_t cards, int n) {
+  if (n <= 0) return 0;
+  uint64_t hist = 0; // 13 nibbles
+  uint32_t suits = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    if (i < n) {
+      int c = (int)((cards >> (8 * i)) & 0xff);
+      hist += 1ull << (4 * (c >> 2));
+      suits |= 1u << (c & 3);
+    }
+  }
+  uint32_t present = 0;
+  int c0 = 0, c1 = 0;
+#pragma unroll
+  for (int r = 0; r < 13; r++) {
+    int c = (int)((hist >> (4 * r)) & 0xf);
+    present |= (c ? 1u : 0u) << r;
+    if (c > c0) { c1 = c0; c0 = c; } else if (c > c1) c1 = c;
+  }
+  bool flush = (__popc(suits) == 1) && n >= 5;                                    // :60
+  uint32_t run = present & (present >> 1) & (present >> 2) & (present >> 3) & (present >> 4); // 5 consecutive ranks
+  bool straight = run != 0 || ((present & 0x100fu) == 0x100fu);                   // :66-73 (A,2,3,4,5)
+  // (>= 5 distinct ranks is implied by either pattern)
+  if (straight && flush) return 8;
+  if (c0 == 4) return 7;
+  if (c0 == 3 && c1 == 2) return 6;
+  if (flush) return 5;
+  if (straight && n >= 5) return 4;
+  if (c0 == 3) return 3;
+  if (c0 == 2 && c1 == 2) return 2;
+  if (c0 == 2) return 1;
+  return 0;
+}
+
+// balatro_game.py:95-109 _draw_cards: append the lowest deck indexes not in hand until len == hand_size
+__device__ __forceinline__ void bg_draw_cards(Env& e) {
+  uint64_t inhand = 0;
+  for (int i = 0; i < e.nhand; i++) inhand |= 1ull << bg_get8(e.hand, i);
+  while (e.nhand < e.hand_size && e.nhand < 8) {
+    uint64_t freeset = ~inhand & ((1ull << 52) - 1);
+    if (!freeset) break;
+    int dnext = __ffsll((long long)freeset) - 1;
+    e.hand = bg_set8(e.hand, e.nhand, dnext);
+    e.nhand++;
+    inhand |= 1ull << dnext;
+  }
+}
+
+// counter-hash policy: splitmix64 finaliser, high 32 bits
+__device__ __forceinline__ uint32_t bg_policy_hash(uint64_t policy_seed, uint64_t env_index, uint64_t t) {
+  uint64_t x = policy_seed + 0x9E3779B97F4A7C15ull * (env_index + 1) + 0xD1B54A32D192ED03ull * (t + 1);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (uint32_t)(x >> 32);
+}

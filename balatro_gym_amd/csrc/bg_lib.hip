@@ -1,0 +1,727 @@
+// bg_lib.hip -- kernels + C ABI of libbalatro_mi355x.so (gfx950 / CDNA4 only; see include/balatro_mi355x.h).
+//
+// Kernels (one lane = one env, env index fastest in every array => every wave access is one coalesced request):
+//   bg_step_kernel     one lockstep step() of all envs + observation / mask / reward / info
+//   bg_rollout_kernel  T fused steps with the counter-hash policy on device, state resident in registers
+//   bg_reset_kernel    masked reset() + observation
+//   bg_observe_kernel  observation only
+//   bg_seed_kernel     DeterministicRNG(seed): CPython init_by_array for streams 0, 2 and the per-env global stream
+//   bg_refill_kernel   RNG look-ahead: pre-shuffled decks, pre-seeded shop streams, next global-stream blocks
+//   bg_inject_kernel   harness injection into live state
+// There is no CPU path: every entry point needs the HIP device bg_create() opened.
+#include "../../include/balatro_mi355x.h"
+#include "bg_step.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#define BG_BLOCK 64
+
+struct InfoPtrs {
+  int64_t* final_score; int32_t* error; int32_t* flags; int32_t* aux; int8_t* hand_type; int8_t* cards_played;
+  double* reward_terms;
+};
+
+static_assert(sizeof(ObsPtrs) == sizeof(bg_obs_ptrs), "ObsPtrs must mirror bg_obs_ptrs");
+static_assert(sizeof(InfoPtrs) == sizeof(bg_info_ptrs), "InfoPtrs must mirror bg_info_ptrs");
+
+// ---------------------------------------------------------------------------------------------------------
+// step / rollout / reset / observe
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bg_emit(const BgDev& d, int env, size_t row, const StepOut& o, double* reward,
+                                        uint8_t* term, uint8_t* trunc, const InfoPtrs& info) {
+  if (reward) reward[row] = o.reward;
+  if (term) term[row] = o.terminated ? 1 : 0;
+  if (trunc) trunc[row] = 0; // the reference never truncates (balatro_env_2.py:1064)
+  if (info.final_score) info.final_score[row] = o.final_score;
+  if (info.error) info.error[row] = o.error;
+  if (info.flags) info.flags[row] = o.flags;
+  if (info.aux) info.aux[row] = o.aux;
+  if (info.hand_type) info.hand_type[row] = (int8_t)o.hand_type;
+  if (info.cards_played) info.cards_played[row] = (int8_t)o.cards_played;
+  if (info.reward_terms) {
+    double2* q = (double2*)(info.reward_terms + row * 8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = make_double2(o.terms[2 * i], o.terms[2 * i + 1]);
+  }
+}
+
+__global__ __launch_bounds__(BG_BLOCK) void bg_step_kernel(BgDev d, const int32_t* __restrict__ actions, ObsPtrs obs,
+                                                          double* reward, uint8_t* term, uint8_t* trunc, InfoPtrs info) {
+  int env = blockIdx.x * BG_BLOCK + threadIdx.x;
+  if (env >= d.N) return;
+  Env e;
+  bg_load_env(d, env, e);
+  Deck0 dk = bg_load_deck0(d, env);
+  StepOut o;
+  bg_env_step(d, env, e, dk, actions[env], o);
+  if (o.terminated && (d.flags & BG_FLAG_AUTORESET)) { bg_env_reset(d, env, e, dk); o.flags |= BG_INFO_AUTORESET; }
+  bg_store_env(d, env, e);
+  uint64_t mask = bg_action_mask(d, env, e);
+  bg_write_obs(d, env, (size_t)env, e, dk, obs, mask);
+  bg_emit(d, env, (size_t)env, o, reward, term, trunc, info);
+}
+
+__global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
+                                                             uint64_t env_index0, uint64_t t0, ObsPtrs obs,
+                                                             int obs_stride_steps, double* reward, uint8_t* term,
+                                                             int32_t* actions_out, bg_rollout_stats* stats) {
+  int env = blockIdx.x * BG_BLOCK + threadIdx.x;
+  uint64_t n_steps = 0, n_eps = 0, n_plays = 0, rbits = 0, ohash = 0;
+  int64_t ssum = 0;
+  if (env < d.N) {
+    Env e;
+    bg_load_env(d, env, e);
+    Deck0 dk = bg_load_deck0(d, env);
+    uint64_t mask = bg_action_mask(d, env, e);
+    for (int t = 0; t < T; t++) {
+      int action = bg_policy_action(e, mask, policy, policy_seed, env_index0 + (uint64_t)env, t0 + (uint64_t)t);
+      StepOut o;
+      bg_env_step(d, env, e, dk, action, o);
+      if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; } // SAME_STEP auto-reset
+      mask = bg_action_mask(d, env, e);
+      size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
+      uint64_t h = bg_write_obs(d, env, row, e, dk, obs, mask);
+      ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
+      if (reward) reward[row] = o.reward;
+      if (term) term[row] = o.terminated ? 1 : 0;
+      if (actions_out) actions_out[row] = action;
+      n_steps++;
+      rbits ^= (uint64_t)__double_as_longlong(o.reward) * (2 * (uint64_t)(t0 + t) + 1);
+      if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
+    }
+    bg_store_env(d, env, e);
+  }
+  if (stats) {
+    // wave reduction (64 lanes) with DPP/shuffle intrinsics, then one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      n_steps += __shfl_down(n_steps, off); n_eps += __shfl_down(n_eps, off); n_plays += __shfl_down(n_plays, off);
+      ssum += __shfl_down(ssum, off); rbits ^= __shfl_down(rbits, off); ohash ^= __shfl_down(ohash, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd((unsigned long long*)&stats->steps, (unsigned long long)n_steps);
+      atomicAdd((unsigned long long*)&stats->episodes, (unsigned long long)n_eps);
+      atomicAdd((unsigned long long*)&stats->plays, (unsigned long long)n_plays);
+      atomicAdd((unsigned long long*)&stats->score_sum, (unsigned long long)ssum);
+      atomicXor((unsigned long long*)&stats->reward_bits, (unsigned long long)rbits);
+      atomicXor((unsigned long long*)&stats->obs_hash, (unsigned long long)ohash);
+    }
+  }
+}
+
+__global__ __launch_bounds__(BG_BLOCK) void bg_reset_kernel(BgDev d, const uint8_t* __restrict__ mask_in, ObsPtrs obs) {
+  int env = blockIdx.x * BG_BLOCK + threadIdx.x;
+  if (env >= d.N) return;
+  Env e;
+  bg_load_env(d, env, e);
+  Deck0 dk = bg_load_deck0(d, env);
+  if (!mask_in || mask_in[env]) { bg_env_reset(d, env, e, dk); bg_store_env(d, env, e); }
+  uint64_t mask = bg_action_mask(d, env, e);
+  bg_write_obs(d, env, (size_t)env, e, dk, obs, mask);
+}
+
+__global__ __launch_bounds__(BG_BLOCK) void bg_observe_kernel(BgDev d, ObsPtrs obs) {
+  int env = blockIdx.x * BG_BLOCK + threadIdx.x;
+  if (env >= d.N) return;
+  Env e;
+  bg_load_env(d, env, e);
+  Deck0 dk = bg_load_deck0(d, env);
+  uint64_t mask = bg_action_mask(d, env, e);
+  bg_write_obs(d, env, (size_t)env, e, dk, obs, mask);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// MT19937 on structure-of-arrays state: word i of env `env` lives at p[i * N] (p already offset by env)
+// ---------------------------------------------------------------------------------------------------------
+// CPython random_seed()/init_by_array() for a ONE-word key (every stream / shop / global seed is < 2**32).
+// init_genrand(19650218) is a constant table (d.mt_init); the key-dependent passes are 1247 dependent steps.
+__device__ void bg_mt_seed_soa(const BgDev& d, uint32_t* p, uint32_t key) {
+  size_t N = d.N;
+  uint32_t prev = d.mt_init[0];
+  uint32_t mt1 = 0;
+  for (int i = 1; i < BG_MT_N; i++) { // first pass, i = 1..623 (j is always 0)
+    uint32_t v = (d.mt_init[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + key;
+    p[(size_t)i * N] = v;
+    if (i == 1) mt1 = v;
+    prev = v;
+  }
+  // wrap: mt[0] = mt[623]; 624th iteration at i = 1
+  {
+    uint32_t mt0 = prev;
+    uint32_t v = (mt1 ^ ((mt0 ^ (mt0 >> 30)) * 1664525u)) + key;
+    mt1 = v;
+    prev = v;
+  }
+  // second pass: 623 iterations starting at i = 2
+  for (int i = 2; i < BG_MT_N; i++) {
+    uint32_t cur = p[(size_t)i * N];
+    uint32_t v = (cur ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+    p[(size_t)i * N] = v;
+    prev = v;
+  }
+  {
+    uint32_t mt0 = prev; // mt[0] = mt[623]
+    uint32_t v = (mt1 ^ ((mt0 ^ (mt0 >> 30)) * 1566083941u)) - 1u;
+    p[N] = v;
+  }
+  p[0] = 0x80000000u;
+}
+
+// genrand_uint32()'s block regeneration, in place
+__device__ void bg_mt_twist_inplace(uint32_t* p, size_t N) {
+  uint32_t cur = p[0], first_new = 0;
+  for (int kk = 0; kk < BG_MT_N - BG_MT_M; kk++) {
+    uint32_t nxt = p[(size_t)(kk + 1) * N];
+    uint32_t v = bg_twist(cur, nxt, p[(size_t)(kk + BG_MT_M) * N]);
+    p[(size_t)kk * N] = v;
+    if (kk == 0) first_new = v;
+    cur = nxt;
+  }
+  for (int kk = BG_MT_N - BG_MT_M; kk < BG_MT_N - 1; kk++) {
+    uint32_t nxt = p[(size_t)(kk + 1) * N];
+    uint32_t v = bg_twist(cur, nxt, p[(size_t)(kk + BG_MT_M - BG_MT_N) * N]);
+    p[(size_t)kk * N] = v;
+    cur = nxt;
+  }
+  p[(size_t)(BG_MT_N - 1) * N] = bg_twist(cur, first_new, p[(size_t)(BG_MT_M - 1) * N]);
+}
+
+// the same, from block `src` into block `dst` (next block of a continuous stream)
+__device__ void bg_mt_twist_next(const uint32_t* src, uint32_t* dst, size_t N) {
+  uint32_t cur = src[0], first_new = 0;
+  for (int kk = 0; kk < BG_MT_N - BG_MT_M; kk++) {
+    uint32_t nxt = src[(size_t)(kk + 1) * N];
+    uint32_t v = bg_twist(cur, nxt, src[(size_t)(kk + BG_MT_M) * N]);
+    dst[(size_t)kk * N] = v;
+    if (kk == 0) first_new = v;
+    cur = nxt;
+  }
+  for (int kk = BG_MT_N - BG_MT_M; kk < BG_MT_N - 1; kk++) {
+    uint32_t nxt = src[(size_t)(kk + 1) * N];
+    uint32_t v = bg_twist(cur, nxt, dst[(size_t)(kk + BG_MT_M - BG_MT_N) * N]);
+    dst[(size_t)kk * N] = v;
+    cur = nxt;
+  }
+  dst[(size_t)(BG_MT_N - 1) * N] = bg_twist(cur, first_new, dst[(size_t)(BG_MT_M - 1) * N]);
+}
+
+// genrand_uint32() on an authoritative stream state (624 words + index word at row 624)
+__device__ __forceinline__ uint32_t bg_mt_next(uint32_t* p, size_t N, uint32_t& mti) {
+  if (mti >= BG_MT_N) { bg_mt_twist_inplace(p, N); mti = 0; }
+  uint32_t y = p[(size_t)mti * N];
+  mti++;
+  return bg_temper(y);
+}
+__device__ __forceinline__ uint32_t bg_mt_randbelow(uint32_t* p, size_t N, uint32_t& mti, uint32_t n) {
+  int k = 32 - __clz(n);
+  uint32_t r;
+  do { r = bg_mt_next(p, N, mti) >> (32 - k); } while (r >= n);
+  return r;
+}
+
+// DeterministicRNG(seed) (balatro_env_2.py:84-106) for streams 0 ('deck_shuffle') and 2 ('shop_generation'), plus the
+// per-env global stream seeded G(seed).  Streams are seeded `(master + 1000 * i) % 2**32` (:105).
+__global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_t* __restrict__ seeds,
+                                                          const uint8_t* __restrict__ mask_in, int reseed_global) {
+  int env = blockIdx.x * BG_BLOCK + threadIdx.x;
+  if (env >= d.N) return;
+  if (mask_in && !mask_in[env]) return;
+  size_t N = d.N;
+  Env e;
+  bg_load_env(d, env, e);
+  int64_t seed = seeds[env];
+  if (reseed_global) {
+    uint32_t gs = (uint32_t)((uint64_t)seed + 16000ull);
+    uint32_t* g = d.gblk + env; // slot 0
+    bg_mt_seed_soa(d, g, gs);
+    bg_mt_twist_inplace(g, N); // first block = what the first 624 getrandbits(32) read
+    e.g_cur = 0; e.g_idx = 0; e.g_valid = 1;
+  }
+  if (seed == 0) { // `master_seed or random.randint(0, 2**32 - 1)` (:88): _randbelow(2**32), k = 33 bits
+    uint64_t r;
+    int guard = 0;
+    do {
+      uint64_t lo = bg_gdraw(d, env, e);
+      uint64_t hi = bg_gdraw(d, env, e) >> 31;
+      r = lo | (hi << 32);
+    } while (r >= 4294967296ull && ++guard < 4096);
+    seed = (int64_t)(r & 0xffffffffull);
+  }
+  uint32_t base = (uint32_t)(uint64_t)seed;
+  bg_mt_seed_soa(d, d.deckmt + env, base);
+  d.deckmt[(size_t)BG_MT_N * N + env] = BG_MT_N;
+  bg_mt_seed_soa(d, d.shopgenmt + env, base + 2000u);
+  d.shopgenmt[(size_t)BG_MT_N * N + env] = BG_MT_N;
+  e.d_head = 0; e.d_ready = 0; // look-ahead rings are functions of the streams: invalidate
+  e.s_ready = 0;
+  bg_store_env(d, env, e);
+}
+
+// RNG look-ahead.  Every lane inspects its env's ring counters and tops the rings up:
+//   * ndeck: `rng.shuffle('deck_shuffle', deck)` (balatro_env_2.py:525) on stream 0
+//   * sblk : `shop_seed = rng.get_int('shop_generation', 0, 2**31 - 1)` (:1389) then `random.Random(shop_seed)`
+//            (shop.py:96) seeded + first block regenerated
+//   * gblk : next 624-word block(s) of the per-env global stream
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_kernel(BgDev d) {
+  __shared__ uint8_t sdeck[52][BG_BLOCK];
+  int env = blockIdx.x * BG_BLOCK + threadIdx.x;
+  if (env >= d.N) return;
+  size_t N = d.N;
+  uint4 c5 = d.hot[(size_t)5 * N + env], c6 = d.hot[(size_t)6 * N + env], c7 = d.hot[(size_t)7 * N + env];
+  int d_head = bg_b(c5.w, 2), d_ready = bg_b(c5.w, 3);
+  int g_cur = bg_b(c6.w, 2), g_valid = bg_b(c6.w, 3);
+  int g_idx = (int)(c7.x & 0xffffu);
+  int s_cur = bg_b(c7.y, 0), s_ready = bg_b(c7.y, 1);
+  if (g_valid > 0 && g_idx >= BG_MT_N) { g_cur = (g_cur + 1 == d.KG) ? 0 : g_cur + 1; g_idx = 0; g_valid--; }
+  bool seeded = d.deckmt[(size_t)BG_MT_N * N + env] != 0; // index word is 0 only before the first bg_seed
+  bool need = seeded && (d_ready < d.KD || s_ready < d.KS - 1 || (g_valid > 0 && g_valid < d.KG));
+  if (!need) return;
+  // ---- pre-shuffled decks
+  if (d_ready < d.KD) {
+    uint32_t* mt = d.deckmt + env;
+    uint32_t mti = mt[(size_t)BG_MT_N * N];
+    int tid = threadIdx.x;
+    while (d_ready < d.KD) {
+      int p = 0;
+      for (int s = 0; s < 4; s++) for (int r = 0; r < 13; r++) sdeck[p++][tid] = (uint8_t)(r * 4 + s); // :519-522
+      for (int i = 51; i >= 1; i--) { // random.shuffle
+        uint32_t j = bg_mt_randbelow(mt, N, mti, (uint32_t)(i + 1));
+        uint8_t a = sdeck[i][tid], b = sdeck[j][tid];
+        sdeck[i][tid] = b; sdeck[j][tid] = a;
+      }
+      int slot = d_head + d_ready; if (slot >= d.KD) slot -= d.KD;
+#pragma unroll
+      for (int k = 0; k < BG_NDECK; k++) {
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 16; b++) { int i = k * 16 + b; if (i < 52) w[b >> 2] |= (uint32_t)sdeck[i][tid] << (8 * (b & 3)); }
+        d.ndeck[((size_t)slot * BG_NDECK + k) * N + env] = make_uint4(w[0], w[1], w[2], w[3]);
+      }
+      d_ready++;
+    }
+    mt[(size_t)BG_MT_N * N] = mti;
+  }
+  // ---- pre-seeded shop streams
+  if (s_ready < d.KS - 1) {
+    uint32_t* mt = d.shopgenmt + env;
+    uint32_t mti = mt[(size_t)BG_MT_N * N];
+    while (s_ready < d.KS - 1) {
+      uint32_t shop_seed = bg_mt_randbelow(mt, N, mti, 2147483648u);
+      int slot = s_cur + 1 + s_ready; while (slot >= d.KS) slot -= d.KS;
+      uint32_t* blk = d.sblk + (size_t)slot * BG_MT_N * N + env;
+      bg_mt_seed_soa(d, blk, shop_seed);
+      bg_mt_twist_inplace(blk, N);
+      s_ready++;
+    }
+    mt[(size_t)BG_MT_N * N] = mti;
+  }
+  // ---- next blocks of the global stream
+  while (g_valid > 0 && g_valid < d.KG) {
+    int last = g_cur + g_valid - 1; if (last >= d.KG) last -= d.KG;
+    int nxt = last + 1 == d.KG ? 0 : last + 1;
+    bg_mt_twist_next(d.gblk + (size_t)last * BG_MT_N * N + env, d.gblk + (size_t)nxt * BG_MT_N * N + env, N);
+    g_valid++;
+  }
+  c5.w = (c5.w & 0x0000ffffu) | ((uint32_t)d_head << 16) | ((uint32_t)d_ready << 24);
+  c6.w = (c6.w & 0x0000ffffu) | ((uint32_t)g_cur << 16) | ((uint32_t)g_valid << 24);
+  c7.x = (c7.x & 0xffff0000u) | (uint32_t)g_idx;
+  c7.y = (c7.y & 0xffff0000u) | (uint32_t)s_cur | ((uint32_t)s_ready << 8);
+  d.hot[(size_t)5 * N + env] = c5; d.hot[(size_t)6 * N + env] = c6; d.hot[(size_t)7 * N + env] = c7;
+}
+
+// apply the reset template to the live state (bg_inject apply_now)
+__global__ __launch_bounds__(BG_BLOCK) void bg_inject_kernel(BgDev d, const uint8_t* __restrict__ mask_in) {
+  int env = blockIdx.x * BG_BLOCK + threadIdx.x;
+  if (env >= d.N) return;
+  if (mask_in && !mask_in[env]) return;
+  Env e;
+  bg_load_env(d, env, e);
+  uint4 t0 = d.tmpl[env], t1 = d.tmpl[(size_t)d.N + env];
+  if (t0.y & 0x80000000u) { e.njokers = (int)bg_b(t0.y, 1); e.jokers = (uint64_t)t0.x | ((uint64_t)(t0.y & 0xffu) << 32); }
+  if (t0.y & 0x40000000u) e.money = (int32_t)t0.z;
+  if (t0.y & 0x20000000u) e.ante = (int)bg_b(t0.y, 2);
+  if (t0.y & 0x10000000u) { e.levels = (uint64_t)t1.x | ((uint64_t)(t1.y & 0xffffu) << 32); e.excess = 0; }
+  bg_store_env(d, env, e);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------
+struct bg_handle {
+  BgDev dev;
+  int device_id;
+  bool seeded;
+  int64_t* d_seeds;
+  uint8_t* d_mask;
+  uint32_t* d_mt_init;
+  std::vector<uint4> h_tmpl;
+  uint64_t bytes;
+  std::string err;
+  // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
+  bool profiling;
+  std::vector<hipEvent_t> ev_rollout, ev_refill, ev_step; // start/stop pairs
+  std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
+};
+
+static std::string g_create_err;
+
+#define BG_HIP(call)                                                                                   \
+  do {                                                                                                 \
+    hipError_t _e = (call);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      h->err = std::string(#call) + ": " + hipGetErrorString(_e);                                      \
+      return BG_E_HIP;                                                                                 \
+    }                                                                                                  \
+  } while (0)
+
+template <typename T>
+static hipError_t bg_alloc(bg_handle* h, T** p, size_t count) {
+  size_t bytes = count * sizeof(T);
+  hipError_t e = hipMalloc((void**)p, bytes);
+  if (e != hipSuccess) return e;
+  h->bytes += bytes;
+  return hipMemset(*p, 0, bytes);
+}
+
+static int bg_grid(const bg_handle* h) { return (h->dev.N + BG_BLOCK - 1) / BG_BLOCK; }
+
+static void bg_ev_begin(bg_handle* h, std::vector<hipEvent_t>& v, hipStream_t s) {
+  if (!h->profiling) return;
+  hipEvent_t a, b;
+  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  v.push_back(a); v.push_back(b);
+  (void)hipEventRecord(a, s);
+}
+static void bg_ev_end(bg_handle* h, std::vector<hipEvent_t>& v, hipStream_t s) {
+  if (!h->profiling || v.empty()) return;
+  (void)hipEventRecord(v.back(), s);
+}
+static double bg_ev_sum(std::vector<hipEvent_t>& v) {
+  double ms = 0;
+  for (size_t i = 0; i + 1 < v.size(); i += 2) {
+    float f = 0;
+    if (hipEventElapsedTime(&f, v[i], v[i + 1]) == hipSuccess) ms += f;
+    (void)hipEventDestroy(v[i]); (void)hipEventDestroy(v[i + 1]);
+  }
+  v.clear();
+  return ms;
+}
+
+extern "C" {
+
+int bg_set_profiling(bg_handle* h, int enable) {
+  if (!h) return BG_E_ARG;
+  h->profiling = enable != 0;
+  return 0;
+}
+
+// out[0..5] = rollout kernel ms, launches, fused env-steps per env summed over launches; refill ms, launches; step ms
+int bg_get_profile(bg_handle* h, double* out8) {
+  if (!h || !out8) return BG_E_ARG;
+  BG_HIP(hipDeviceSynchronize());
+  double nr = (double)(h->ev_rollout.size() / 2), nf = (double)(h->ev_refill.size() / 2), ns = (double)(h->ev_step.size() / 2);
+  double steps = 0;
+  for (int t : h->rollout_steps) steps += t;
+  h->rollout_steps.clear();
+  out8[0] = bg_ev_sum(h->ev_rollout); out8[1] = nr; out8[2] = steps;
+  out8[3] = bg_ev_sum(h->ev_refill); out8[4] = nf;
+  out8[5] = bg_ev_sum(h->ev_step); out8[6] = ns; out8[7] = 0;
+  return 0;
+}
+
+int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle** out) {
+  if (!out || n_envs <= 0) { g_create_err = "bg_create: bad arguments"; return BG_E_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+    g_create_err = "bg_create: no HIP device visible (this library has no CPU fallback)";
+    return BG_E_NODEVICE;
+  }
+  if (device_id < 0 || device_id >= ndev) { g_create_err = "bg_create: device_id out of range"; return BG_E_ARG; }
+  bg_handle* h = new bg_handle();
+  h->device_id = device_id; h->seeded = false; h->bytes = 0; h->profiling = false;
+  h->d_seeds = nullptr; h->d_mask = nullptr; h->d_mt_init = nullptr;
+  memset(&h->dev, 0, sizeof(h->dev));
+  BgDev& d = h->dev;
+  d.N = n_envs; d.flags = flags; d.max_ante = max_ante;
+  const char* kg = getenv("BG_KG"); const char* ks = getenv("BG_KS"); const char* kd = getenv("BG_KD");
+  d.KG = kg ? atoi(kg) : 2; d.KS = ks ? atoi(ks) : 2; d.KD = kd ? atoi(kd) : 2;
+  if (d.KG < 2 || d.KS < 2 || d.KD < 1 || d.KG > 250 || d.KS > 250 || d.KD > 250) { delete h; g_create_err = "bg_create: bad ring depths"; return BG_E_ARG; }
+  size_t N = (size_t)n_envs;
+  hipError_t e = hipSetDevice(device_id);
+  if (e == hipSuccess) e = bg_alloc(h, &d.hot, BG_NHOT * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.deck, BG_NDECK * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.cold, BG_NCOLD * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.tmpl, BG_NTMPL * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.ndeck, (size_t)d.KD * BG_NDECK * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.gblk, (size_t)d.KG * BG_MT_N * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.sblk, (size_t)d.KS * BG_MT_N * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.deckmt, (size_t)(BG_MT_N + 1) * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.shopgenmt, (size_t)(BG_MT_N + 1) * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.err, 4);
+  if (e == hipSuccess) e = bg_alloc(h, &h->d_seeds, N);
+  if (e == hipSuccess) e = bg_alloc(h, &h->d_mask, N);
+  if (e == hipSuccess) e = bg_alloc(h, &h->d_mt_init, (size_t)BG_MT_N);
+  if (e == hipSuccess) {
+    std::vector<uint32_t> init(BG_MT_N);
+    init[0] = 19650218u; // init_genrand(19650218)
+    for (int i = 1; i < BG_MT_N; i++) init[i] = 1812433253u * (init[i - 1] ^ (init[i - 1] >> 30)) + (uint32_t)i;
+    e = hipMemcpy(h->d_mt_init, init.data(), BG_MT_N * sizeof(uint32_t), hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    g_create_err = std::string("bg_create: ") + hipGetErrorString(e);
+    bg_destroy(h);
+    return BG_E_HIP;
+  }
+  d.mt_init = h->d_mt_init;
+  h->h_tmpl.assign(BG_NTMPL * N, make_uint4(0, 0, 0, 0));
+  *out = h;
+  return 0;
+}
+
+int bg_destroy(bg_handle* h) {
+  if (!h) return 0;
+  BgDev& d = h->dev;
+  hipFree(d.hot); hipFree(d.deck); hipFree(d.cold); hipFree(d.tmpl); hipFree(d.ndeck); hipFree(d.gblk); hipFree(d.sblk);
+  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(h->d_mt_init);
+  delete h;
+  return 0;
+}
+
+const char* bg_last_error(const bg_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+int bg_num_envs(const bg_handle* h) { return h ? h->dev.N : 0; }
+uint64_t bg_state_bytes(const bg_handle* h) { return h ? h->bytes : 0; }
+
+int bg_refill(bg_handle* h, void* stream) {
+  if (!h) return BG_E_ARG;
+  bg_ev_begin(h, h->ev_refill, (hipStream_t)stream);
+  hipLaunchKernelGGL(bg_refill_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev);
+  bg_ev_end(h, h->ev_refill, (hipStream_t)stream);
+  BG_HIP(hipGetLastError());
+  return 0;
+}
+
+int bg_check(bg_handle* h, void* stream) {
+  if (!h) return BG_E_ARG;
+  uint32_t w = 0;
+  BG_HIP(hipMemcpyAsync(&w, h->dev.err, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream));
+  BG_HIP(hipStreamSynchronize((hipStream_t)stream));
+  if (w) {
+    char buf[160];
+    snprintf(buf, sizeof(buf), "device invariant violated: error word 0x%x (1 global-stream underflow, 2 shop block, 4 deck ring, 8 shop ring)", w);
+    h->err = buf;
+    return BG_E_INTERNAL;
+  }
+  return 0;
+}
+
+int bg_seed(bg_handle* h, const int64_t* seeds_host, const uint8_t* mask_host, int reseed_global, void* stream) {
+  if (!h || !seeds_host) return BG_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  size_t N = h->dev.N;
+  BG_HIP(hipMemcpyAsync(h->d_seeds, seeds_host, N * sizeof(int64_t), hipMemcpyHostToDevice, s));
+  if (mask_host) BG_HIP(hipMemcpyAsync(h->d_mask, mask_host, N, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(bg_seed_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, h->dev, (const int64_t*)h->d_seeds,
+                     mask_host ? (const uint8_t*)h->d_mask : (const uint8_t*)nullptr, reseed_global);
+  BG_HIP(hipGetLastError());
+  // the copies above read pageable host memory: make sure they are done before the caller reuses the buffers
+  BG_HIP(hipStreamSynchronize(s));
+  h->seeded = true;
+  return bg_refill(h, stream);
+}
+
+static int bg_require_seeded(bg_handle* h) {
+  if (!h) return BG_E_ARG;
+  if (!h->seeded) { h->err = "bg_seed must be called before reset/step (streams are unseeded)"; return BG_E_ARG; }
+  return 0;
+}
+
+static ObsPtrs bg_obs(const bg_obs_ptrs* o) {
+  ObsPtrs p;
+  if (o) memcpy(&p, o, sizeof(p)); else memset(&p, 0, sizeof(p));
+  return p;
+}
+static InfoPtrs bg_info(const bg_info_ptrs* o) {
+  InfoPtrs p;
+  if (o) memcpy(&p, o, sizeof(p)); else memset(&p, 0, sizeof(p));
+  return p;
+}
+
+int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void* stream) {
+  int rc = bg_require_seeded(h);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bg_reset_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev, mask_dev, bg_obs(obs));
+  BG_HIP(hipGetLastError());
+  return bg_refill(h, stream);
+}
+
+int bg_step(bg_handle* h, const int32_t* actions_dev, const bg_obs_ptrs* obs, double* reward_dev, uint8_t* terminated_dev,
+            uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream) {
+  int rc = bg_require_seeded(h);
+  if (rc) return rc;
+  if (!actions_dev) return BG_E_ARG;
+  bg_ev_begin(h, h->ev_step, (hipStream_t)stream);
+  hipLaunchKernelGGL(bg_step_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev, actions_dev,
+                     bg_obs(obs), reward_dev, terminated_dev, truncated_dev, bg_info(info));
+  bg_ev_end(h, h->ev_step, (hipStream_t)stream);
+  BG_HIP(hipGetLastError());
+  return bg_refill(h, stream);
+}
+
+int bg_observe(bg_handle* h, const bg_obs_ptrs* obs, void* stream) {
+  if (!h) return BG_E_ARG;
+  hipLaunchKernelGGL(bg_observe_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev, bg_obs(obs));
+  BG_HIP(hipGetLastError());
+  return 0;
+}
+
+int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t env_index0, uint64_t t0,
+               const bg_obs_ptrs* obs, int obs_stride_steps, double* reward_dev, uint8_t* terminated_dev,
+               int32_t* actions_out_dev, bg_rollout_stats* stats_dev, void* stream) {
+  int rc = bg_require_seeded(h);
+  if (rc) return rc;
+  if (T <= 0) return BG_E_ARG;
+  // The look-ahead rings bound how many steps may be fused between two refills.  An env consumes at most one
+  // pre-shuffled deck and one pre-seeded shop stream per 3 steps (reset -> 45/47 -> select -> failing play;
+  // shop generated -> 31 -> select -> winning play), so R ready entries cover 3*R steps.  The global stream has
+  // (KG-1) full blocks of 624 words ahead; a step draws < 24 words without and < 110 with the scorer-level joker
+  // chain (8 cards x 5 jokers x 2 + 5 x randint, accepted plays are >= 2 steps apart).
+  int ring = h->dev.KD < h->dev.KS - 1 ? h->dev.KD : h->dev.KS - 1;
+  int max_chunk = 3 * ring;
+  int gchunk = ((h->dev.KG - 1) * BG_MT_N) / ((h->dev.flags & BG_FLAG_SCORER_JOKERS) ? 110 : 24);
+  if (gchunk < max_chunk) max_chunk = gchunk;
+  if (max_chunk < 1) max_chunk = 1;
+  int done = 0;
+  while (done < T) {
+    int chunk = T - done < max_chunk ? T - done : max_chunk;
+    ObsPtrs o = bg_obs(obs);
+    size_t off = obs_stride_steps ? (size_t)done * (size_t)h->dev.N : 0;
+    if (off) {
+      // advance every non-null pointer by `off` rows
+      if (o.hand) o.hand += off * 8; if (o.hand_size) o.hand_size += off; if (o.deck_size) o.deck_size += off;
+      if (o.selected_cards) o.selected_cards += off * 8; if (o.chips_scored) o.chips_scored += off;
+      if (o.round_chips_scored) o.round_chips_scored += off; if (o.progress_ratio) o.progress_ratio += off;
+      if (o.mult) o.mult += off; if (o.chips_needed) o.chips_needed += off; if (o.money) o.money += off;
+      if (o.ante) o.ante += off; if (o.round) o.round += off; if (o.hands_left) o.hands_left += off;
+      if (o.discards_left) o.discards_left += off; if (o.joker_count) o.joker_count += off;
+      if (o.joker_ids) o.joker_ids += off * 10; if (o.joker_slots) o.joker_slots += off;
+      if (o.consumable_count) o.consumable_count += off; if (o.consumables) o.consumables += off * 5;
+      if (o.consumable_slots) o.consumable_slots += off; if (o.shop_items) o.shop_items += off * 10;
+      if (o.shop_costs) o.shop_costs += off * 10; if (o.shop_rerolls) o.shop_rerolls += off;
+      if (o.hand_levels) o.hand_levels += off * 12; if (o.phase) o.phase += off; if (o.action_mask) o.action_mask += off * 60;
+      if (o.hands_played) o.hands_played += off; if (o.best_hand_this_ante) o.best_hand_this_ante += off;
+      if (o.boss_blind_active) o.boss_blind_active += off; if (o.boss_blind_type) o.boss_blind_type += off;
+      if (o.face_down_cards) o.face_down_cards += off * 8;
+    }
+    bg_ev_begin(h, h->ev_rollout, (hipStream_t)stream);
+    if (h->profiling) h->rollout_steps.push_back(chunk);
+    hipLaunchKernelGGL(bg_rollout_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev, chunk, policy,
+                       policy_seed, env_index0, t0 + (uint64_t)done, o, obs_stride_steps,
+                       reward_dev ? reward_dev + off : nullptr, terminated_dev ? terminated_dev + off : nullptr,
+                       actions_out_dev ? actions_out_dev + off : nullptr, stats_dev);
+    bg_ev_end(h, h->ev_rollout, (hipStream_t)stream);
+    BG_HIP(hipGetLastError());
+    rc = bg_refill(h, stream);
+    if (rc) return rc;
+    done += chunk;
+  }
+  return 0;
+}
+
+int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_host, const int64_t* money_host,
+              const int32_t* ante_host, const uint8_t* levels_host, const uint8_t* mask_host, int apply_now, void* stream) {
+  if (!h) return BG_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  size_t N = h->dev.N;
+  for (size_t i = 0; i < N; i++) {
+    if (mask_host && !mask_host[i]) continue;
+    uint4& t0 = h->h_tmpl[i];
+    uint4& t1 = h->h_tmpl[N + i];
+    uint32_t fl = t0.y >> 24;
+    uint32_t j4 = t0.y & 0xffu, nj = (t0.y >> 8) & 0xffu, an = (t0.y >> 16) & 0xffu;
+    if (jokers_host && njokers_host) {
+      int n = njokers_host[i];
+      if (n < 0 || n > 5) { h->err = "bg_inject: njokers must be in [0,5]"; return BG_E_ARG; }
+      uint32_t lo = 0; j4 = 0;
+      for (int k = 0; k < n; k++) {
+        int id = jokers_host[i * 5 + k];
+        if (id < 1 || id > 150) { h->err = "bg_inject: joker id out of range"; return BG_E_ARG; }
+        if (k < 4) lo |= (uint32_t)id << (8 * k); else j4 = (uint32_t)id;
+      }
+      t0.x = lo; nj = (uint32_t)n; fl |= 0x80u;
+    }
+    if (money_host) { if (money_host[i] >= 0) { t0.z = (uint32_t)(int32_t)money_host[i]; fl |= 0x40u; } else fl &= ~0x40u; }
+    if (ante_host) { if (ante_host[i] > 0) { an = (uint32_t)ante_host[i] & 0xffu; fl |= 0x20u; } else fl &= ~0x20u; }
+    if (levels_host) {
+      uint64_t lv = 0; bool any = false;
+      for (int k = 0; k < 12; k++) { int l = levels_host[i * 12 + k]; if (l) any = true; if (l < 1) l = 1; if (l > 15) l = 15; lv |= (uint64_t)l << (4 * k); }
+      if (any) { t1.x = (uint32_t)lv; t1.y = (uint32_t)(lv >> 32); fl |= 0x10u; } else fl &= ~0x10u;
+    }
+    t0.y = j4 | (nj << 8) | (an << 16) | (fl << 24);
+  }
+  BG_HIP(hipMemcpyAsync(h->dev.tmpl, h->h_tmpl.data(), BG_NTMPL * N * sizeof(uint4), hipMemcpyHostToDevice, s));
+  if (apply_now) {
+    if (mask_host) BG_HIP(hipMemcpyAsync(h->d_mask, mask_host, N, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(bg_inject_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, h->dev,
+                       mask_host ? (const uint8_t*)h->d_mask : (const uint8_t*)nullptr);
+    BG_HIP(hipGetLastError());
+  }
+  BG_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
+// ---- save_state / load_state: raw per-env slices of every array, in a fixed order ----
+struct BgSlice { void* base; size_t rows; size_t elem; };
+static void bg_slices(bg_handle* h, std::vector<BgSlice>& v) {
+  BgDev& d = h->dev;
+  v.push_back({d.hot, BG_NHOT, 16}); v.push_back({d.deck, BG_NDECK, 16}); v.push_back({d.cold, BG_NCOLD, 16});
+  v.push_back({d.tmpl, BG_NTMPL, 16}); v.push_back({d.ndeck, (size_t)d.KD * BG_NDECK, 16});
+  v.push_back({d.gblk, (size_t)d.KG * BG_MT_N, 4}); v.push_back({d.sblk, (size_t)d.KS * BG_MT_N, 4});
+  v.push_back({d.deckmt, BG_MT_N + 1, 4}); v.push_back({d.shopgenmt, BG_MT_N + 1, 4});
+}
+uint64_t bg_state_blob_bytes(const bg_handle* h) {
+  if (!h) return 0;
+  std::vector<BgSlice> v;
+  bg_slices(const_cast<bg_handle*>(h), v);
+  uint64_t b = 16; // header: magic, version, KG, KS/KD
+  for (auto& s : v) b += s.rows * s.elem;
+  return b;
+}
+#define BG_BLOB_MAGIC 0x42474d58u
+int bg_get_state(bg_handle* h, int env_index, void* blob_host, uint64_t blob_bytes) {
+  if (!h || !blob_host || env_index < 0 || env_index >= h->dev.N || blob_bytes < bg_state_blob_bytes(h)) return BG_E_ARG;
+  BG_HIP(hipDeviceSynchronize());
+  uint8_t* out = (uint8_t*)blob_host;
+  uint32_t hdr[4] = {BG_BLOB_MAGIC, 1u, (uint32_t)h->dev.KG, (uint32_t)h->dev.KS | ((uint32_t)h->dev.KD << 16)};
+  memcpy(out, hdr, 16); out += 16;
+  std::vector<BgSlice> v;
+  bg_slices(h, v);
+  size_t N = h->dev.N;
+  for (auto& s : v) {
+    BG_HIP(hipMemcpy2D(out, s.elem, (uint8_t*)s.base + (size_t)env_index * s.elem, N * s.elem, s.elem, s.rows, hipMemcpyDeviceToHost));
+    out += s.rows * s.elem;
+  }
+  return 0;
+}
+int bg_set_state(bg_handle* h, int env_index, const void* blob_host, uint64_t blob_bytes) {
+  if (!h || !blob_host || env_index < 0 || env_index >= h->dev.N || blob_bytes < bg_state_blob_bytes(h)) return BG_E_ARG;
+  const uint8_t* in = (const uint8_t*)blob_host;
+  uint32_t hdr[4];
+  memcpy(hdr, in, 16); in += 16;
+  if (hdr[0] != BG_BLOB_MAGIC || hdr[1] != 1u || hdr[2] != (uint32_t)h->dev.KG ||
+      hdr[3] != ((uint32_t)h->dev.KS | ((uint32_t)h->dev.KD << 16))) { h->err = "bg_set_state: blob header mismatch"; return BG_E_ARG; }
+  BG_HIP(hipDeviceSynchronize());
+  std::vector<BgSlice> v;
+  bg_slices(h, v);
+  size_t N = h->dev.N;
+  for (auto& s : v) {
+    BG_HIP(hipMemcpy2D((uint8_t*)s.base + (size_t)env_index * s.elem, N * s.elem, in, s.elem, s.elem, s.rows, hipMemcpyHostToDevice));
+    in += s.rows * s.elem;
+  }
+  h->seeded = true;
+  return 0;
+}
+
+} // extern "C"

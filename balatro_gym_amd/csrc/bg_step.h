@@ -1,0 +1,793 @@
+// bg_step.h -- the per-env step state machine (device).  One lane = one env; see bg_device.h for the layout.
+// Reference: balatro_env_2.py::BalatroEnv.step and everything it calls; file:line cited per function.
+#pragma once
+#include "bg_device.h"
+
+// what a step reports besides the state change
+struct StepOut {
+  double reward;
+  int64_t final_score;
+  double terms[8];
+  int32_t error, flags, aux;
+  int32_t hand_type, cards_played;
+  bool terminated;
+};
+
+// ---------------------------------------------------------------------------------------------------------
+// shop inventory storage (cold chunks 3..6): cost i32[9], (type | payload << 8) u16[9]
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int32_t* bg_shop_cost_ptr(const BgDev& d, int env, int i) {
+  return ((int32_t*)&d.cold[(size_t)(3 + (i >> 2)) * d.N + env]) + (i & 3);
+}
+__device__ __forceinline__ uint16_t* bg_shop_tp_ptr(const BgDev& d, int env, int i) {
+  return i < 6 ? ((uint16_t*)&d.cold[(size_t)5 * d.N + env]) + 2 + i : ((uint16_t*)&d.cold[(size_t)6 * d.N + env]) + (i - 6);
+}
+enum { IT_PACK = 1, IT_CARD = 2, IT_JOKER = 3, IT_VOUCHER = 4 }; // shop.py:17-21 ItemType (auto())
+enum { PK_STANDARD = 0, PK_JOKER = 1, PK_TAROT = 2, PK_PLANET = 3, PK_SPECTRAL = 4 };
+
+// balatro_env_2.py:1426-1471 _get_action_mask as a 60-bit set
+__device__ __forceinline__ uint64_t bg_action_mask(const BgDev& d, int env, const Env& e) {
+  uint64_t m = 0;
+  if (e.phase == 0) {
+    int n = e.nhand < 8 ? e.nhand : 8;
+    m |= ((1ull << n) - 1) << 2;
+    if (e.nsel > 0) { m |= 1ull; if (e.discards_left > 0) m |= 2ull; }
+    m |= ((1ull << e.ncons) - 1) << 10;
+  } else if (e.phase == 1) {
+    if (e.bflags & BG_BF_SHOP_EXISTS) {
+      for (int i = 0; i < e.shop_n; i++)
+        if (e.money >= *bg_shop_cost_ptr(d, env, i)) m |= 1ull << (20 + i);
+      if (e.money >= e.shop_reroll_state) m |= 1ull << 30;
+    }
+    m |= 1ull << 31;
+    m |= ((1ull << e.njokers) - 1) << 32;
+  } else if (e.phase == 2) {
+    m |= 0xfull << 45;
+  }
+  return m;
+}
+
+__device__ __forceinline__ bool bg_owns(const Env& e, int id) {
+  bool r = false;
+  for (int i = 0; i < e.njokers; i++) r |= bg_get8(e.jokers, i) == id;
+  return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// reset (balatro_env_2.py:505-558).  The shuffled deck comes from the look-ahead ring filled by the refill kernel
+// (`rng.shuffle('deck_shuffle', deck)` :525 depends on nothing but stream 0).
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, Deck0& dk) {
+  e.ante = 1; e.round = 1; e.phase = 2; e.chips_needed = 300; e.chips_scored = 0; e.round_chips = 0; e.money = 4;
+  e.hand = 0; e.nhand = 0; e.sel = 0; e.nsel = 0; e.hands_left = 4; e.discards_left = 3; e.hand_size = 8;
+  e.njokers = 0; e.jokers = 0; e.ncons = 0; e.cons0 = 0; e.cons1 = 0; e.n_magic = 0; e.n_minim = 0;
+  e.shop_reroll_state = 5; e.hp_total = 0; e.hp_ante = 0; e.best_hand = 0; e.jokers_sold = 0;
+  e.boss_type = 0; e.boss_types = 0; e.boss_cards = 0; e.boss_hp = 0; e.boss_req = 5; e.face_down = 0;
+  e.bflags = (e.bflags & BG_BF_SHOP_EXISTS) | BG_BF_FIRST_HAND;
+  e.highlighted = 0;
+  e.levels = 0x111111111111ull; // ScoreEngine(): every level 1
+  e.excess = 0;
+  // hand_play_counts = 0 (cold chunks 0..2)
+#pragma unroll
+  for (int k = 0; k < 3; k++) d.cold[(size_t)k * d.N + env] = make_uint4(0, 0, 0, 0);
+  // consume one pre-shuffled deck
+  if (e.d_ready <= 0) atomicOr(d.err, BG_DEVERR_DECKRING);
+  else {
+#pragma unroll
+    for (int k = 0; k < BG_NDECK; k++) {
+      uint4 c = d.ndeck[((size_t)e.d_head * BG_NDECK + k) * d.N + env];
+      d.deck[(size_t)k * d.N + env] = c;
+      if (k == 0) { dk.lo = ((uint64_t)c.y << 32) | c.x; dk.hi = ((uint64_t)c.w << 32) | c.z; }
+    }
+    e.d_head = (e.d_head + 1 == d.KD) ? 0 : e.d_head + 1;
+    e.d_ready--;
+  }
+  // reset template (harness injection, applied after every reset)
+  uint4 t0 = d.tmpl[env], t1 = d.tmpl[(size_t)d.N + env];
+  int tnj = (int)bg_b(t0.y, 1);
+  if (t0.y & 0x80000000u) { e.njokers = tnj; e.jokers = (uint64_t)t0.x | ((uint64_t)(t0.y & 0xffu) << 32); }
+  if (t0.y & 0x40000000u) e.money = (int32_t)t0.z;
+  if (t0.y & 0x20000000u) e.ante = (int)bg_b(t0.y, 2);
+  if (t0.y & 0x10000000u) e.levels = (uint64_t)t1.x | ((uint64_t)(t1.y & 0xffffu) << 32);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// shop.py:104-139 + balatro_env_2.py:1383-1392
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double bg_shop_cost_mult(const Env& e) { // shop.py:104-108
+  int k = e.shop_ante - 1;
+  k = k < 0 ? 0 : (k > 100 ? 100 : k);
+  double m = BG_POW115[k];
+  if (e.n_magic > 0) m *= 0.9;
+  return m;
+}
+
+// candid[j] = j-th id (0-based) of {1..145} \ owned, in library order (shop.py:123)
+__device__ __forceinline__ int bg_candidate(const Env& e, int j) {
+  int id = j + 1;
+  for (int it = 0; it < 12; it++) {
+    int c = 0;
+    for (int q = 0; q < e.njokers; q++) { int o = bg_get8(e.jokers, q); c += (o <= id && o <= 145) ? 1 : 0; }
+    int nid = j + 1 + c;
+    if (nid == id) break;
+    id = nid;
+  }
+  return id;
+}
+
+__device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& e) { // shop.py:111-139
+  double mult = bg_shop_cost_mult(e);
+  int third = PK_TAROT + (int)bg_randbelow<true>(d, env, e, 3u); // rng.choice([...]) is evaluated before the loop
+  int c_pack2 = third == PK_TAROT ? 600 : (third == PK_PLANET ? 900 : 1300);
+  int32_t cost[9];
+  uint32_t tp[9];
+  cost[0] = (int32_t)(250.0 * mult); tp[0] = IT_PACK | (PK_STANDARD << 8);
+  cost[1] = (int32_t)(500.0 * mult); tp[1] = IT_PACK | (PK_JOKER << 8);
+  cost[2] = (int32_t)((double)c_pack2 * mult); tp[2] = IT_PACK | ((uint32_t)third << 8);
+  int owned145 = 0;
+  for (int q = 0; q < e.njokers; q++) owned145 += bg_get8(e.jokers, q) <= 145 ? 1 : 0;
+  uint32_t nc = (uint32_t)(145 - owned145);
+  // random.sample(candid, 3): n > 21 -> selection-set method (Lib/random.py sample())
+  int p0, p1, p2, guard = 0;
+  p0 = (int)bg_randbelow<true>(d, env, e, nc);
+  do { p1 = (int)bg_randbelow<true>(d, env, e, nc); } while (p1 == p0 && ++guard < 4096);
+  do { p2 = (int)bg_randbelow<true>(d, env, e, nc); } while ((p2 == p0 || p2 == p1) && ++guard < 4096);
+  int j0 = bg_candidate(e, p0), j1 = bg_candidate(e, p1), j2 = bg_candidate(e, p2);
+  cost[3] = (int32_t)((double)BG_JOKER_COST[j0] * mult); tp[3] = IT_JOKER | ((uint32_t)j0 << 8);
+  cost[4] = (int32_t)((double)BG_JOKER_COST[j1] * mult); tp[4] = IT_JOKER | ((uint32_t)j1 << 8);
+  cost[5] = (int32_t)((double)BG_JOKER_COST[j2] * mult); tp[5] = IT_JOKER | ((uint32_t)j2 << 8);
+  int v = (int)bg_randbelow<true>(d, env, e, 2u); // 0 'Voucher: Magic Trick' 600, 1 'Voucher: Minimalist' 750
+  cost[6] = (int32_t)((v ? 750.0 : 600.0) * mult); tp[6] = IT_VOUCHER | ((uint32_t)v << 8);
+  int ca = (int)bg_randbelow<true>(d, env, e, 52u), cb = (int)bg_randbelow<true>(d, env, e, 52u); // randint(0, 51)
+  cost[7] = 40; tp[7] = IT_CARD | ((uint32_t)ca << 8);
+  cost[8] = 40; tp[8] = IT_CARD | ((uint32_t)cb << 8);
+  size_t N = d.N;
+  d.cold[3 * N + env] = make_uint4(cost[0], cost[1], cost[2], cost[3]);
+  d.cold[4 * N + env] = make_uint4(cost[4], cost[5], cost[6], cost[7]);
+  d.cold[5 * N + env] = make_uint4(cost[8], tp[0] | (tp[1] << 16), tp[2] | (tp[3] << 16), tp[4] | (tp[5] << 16));
+  d.cold[6 * N + env] = make_uint4(tp[6] | (tp[7] << 16), tp[8], 0, 0);
+  e.shop_n = 9;
+}
+
+// balatro_env_2.py:1383-1392: the shop seed (one get_int on stream 2) and random.Random(seed) were produced ahead of
+// time by the refill kernel; switching to the next ring slot IS "Shop(ante, player, seed=shop_seed)".
+__device__ __forceinline__ void bg_generate_shop(const BgDev& d, int env, Env& e) {
+  if (e.s_ready <= 0) { atomicOr(d.err, BG_DEVERR_SHOPRING); return; }
+  e.s_cur = (e.s_cur + 1 == d.KS) ? 0 : e.s_cur + 1;
+  e.s_ready--;
+  e.s_idx = 0;
+  e.bflags |= BG_BF_SHOP_EXISTS;
+  e.shop_ante = e.ante;
+  e.shop_reroll_base = 50;
+  bg_shop_inventory(d, env, e);
+  e.shop_reroll_state = (int32_t)(50.0 * bg_shop_cost_mult(e));
+}
+
+// balatro_env_2.py:1326-1381 (card-state gold money needs card states: not on this path)
+__device__ __forceinline__ void bg_advance_round(const BgDev& d, int env, Env& e) {
+  if (e.boss_type) { e.money += 5; e.boss_type = 0; e.boss_types = 0; e.boss_cards = 0; e.face_down = 0; }
+  e.round_chips = 0; e.best_hand = 0; e.hp_ante = 0;
+  if (e.round == 3) {
+    e.ante += 1; e.round = 1;
+    if (e.ante > 100) return; // :1366-1367
+  } else e.round += 1;
+  e.money += 25 * e.round + (e.round == 3 ? 10 : 0);
+  e.hands_left = 4; e.discards_left = 3;
+  e.phase = 1;
+  bg_generate_shop(d, env, e);
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Joker chain (unified_scoring.py:111-299 + complete_joker_effects.py:35-184), jokers by jokers.py id.
+// Played cards are (rank, suit, chips) packed per card: rank | suit << 4 | chips << 8.
+// ---------------------------------------------------------------------------------------------------------
+struct JEff { int chips, mult, money; double x; };
+
+// complete_joker_effects.py:35-129; the dict at :39-53 is rebuilt per call => one randint(0,23) per joker (Q13)
+__device__ __forceinline__ JEff bg_joker_main(const BgDev& d, int env, Env& e, int id, const uint32_t* pc, int n, int ht) {
+  JEff r = {0, 0, 0, 1.0};
+  uint32_t mis = bg_randbelow<false>(d, env, e, 24u);
+  uint32_t suits = 0; int kings = 0, queens = 0;
+  for (int i = 0; i < n; i++) { int rk = pc[i] & 0xf; suits |= 1u << ((pc[i] >> 4) & 0xf); kings += rk == 13; queens += rk == 12; }
+  switch (id) {
+    case 27: r.mult = (int)mis; break;                                  // Misprint
+    case 1: r.mult = 4; break;                                          // Joker
+    case 136: r.chips = 250; break;                                     // Stuntman
+    case 38: r.mult = 15; break;                                        // Gros Michel
+    case 61: r.x = 3.0; break;                                          // Cavendish
+    case 16: if (n <= 3) r.mult = 20; break;                            // Half Joker
+    case 34: r.mult = 3 * e.njokers; break;                             // Abstract Joker
+    case 108: if (e.hands_left == 1) r.x = 3.0; break;                  // Acrobat
+    case 23: if (e.discards_left == 0) r.mult = 15; break;              // Mystic Summit
+    case 22: r.chips = 30 * e.discards_left; break;                     // Banner
+    case 53: r.chips = 104; break;                                      // Blue Joker: 2 * len(deck)
+    case 97: r.mult = 20; break;                                        // Popcorn
+    case 50: r.chips = 100; break;                                      // Ice Cream
+    case 2: if (suits & 2u) r.mult = 3; break;                          // Greedy (Diamonds)
+    case 3: if (suits & 4u) r.mult = 3; break;                          // Lusty (Hearts)
+    case 4: if (suits & 8u) r.mult = 3; break;                          // Wrathful (Spades)
+    case 5: if (suits & 1u) r.mult = 3; break;                          // Gluttonous (Clubs)
+    // hand-type jokers: the env passes 'One Pair'/'Three Kind'/'Four Kind' (balatro_env_2.py:674), so only
+    // 'Two Pair' / 'Straight' / 'Flush' ever match
+    case 8: if (ht == 2) r.mult = 10; break;
+    case 9: if (ht == 4) r.mult = 12; break;
+    case 10: if (ht == 5) r.mult = 10; break;
+    case 13: if (ht == 2) r.chips = 80; break;
+    case 14: if (ht == 4) r.chips = 100; break;
+    case 15: if (ht == 5) r.chips = 80; break;
+    case 134: if (ht == 4) r.x = 3.0; break;
+    case 135: if (ht == 5) r.x = 2.0; break;
+    case 48: if ((suits & ~9u) == 0) r.x = 3.0; break;                  // Blackboard: all Spades/Clubs
+    case 128: if ((suits & 1u) && __popc(suits) > 1) r.x = 2.0; break;  // Seeing Double
+    case 122: if (__popc(suits) == 4) r.x = 3.0; break;                 // Flower Pot ('Stone' is a suit string)
+    case 72: if (kings > 0) r.x = BG_POW15[kings]; break;               // Baron
+    case 140: if (queens > 0) r.mult = 13 * queens; break;              // Shoot the Moon
+    default: break;
+  }
+  return r;
+}
+
+// complete_joker_effects.py:131-184; suit_effects (:157-162) is rebuilt per call => one random() per (card, joker)
+__device__ __forceinline__ JEff bg_joker_individual(const BgDev& d, int env, Env& e, int id, uint32_t card) {
+  JEff r = {0, 0, 0, 1.0};
+  double blood = bg_grandom(d, env, e);
+  int rk = card & 0xf, su = (card >> 4) & 0xf;
+  switch (id) {
+    case 31: if (rk == 2 || rk == 3 || rk == 5 || rk == 8 || rk == 14) r.mult = 8; break;      // Fibonacci
+    case 39: if (rk == 2 || rk == 4 || rk == 6 || rk == 8 || rk == 10) r.mult = 4; break;      // Even Steven
+    case 40: if (rk == 3 || rk == 5 || rk == 7 || rk == 9 || rk == 14) r.chips = 31; break;    // Odd Todd
+    case 41: if (rk == 14) { r.chips = 20; r.mult = 4; } break;                                 // Scholar
+    case 101: if (rk == 4 || rk == 10) { r.chips = 10; r.mult = 4; } break;                     // Walkie Talkie
+    case 124: if (rk == 2) r.chips = 8; break;                                                  // Wee Joker
+    case 26: if (rk == 8) (void)bg_grandom(d, env, e); break;                                   // 8 Ball :167
+    case 33: if (rk >= 11 && rk <= 13) r.chips = 30; break;                                     // Scary Face
+    case 104: if (rk >= 11 && rk <= 13) r.mult = 5; break;                                      // Smiley Face
+    case 147: if (rk == 12 || rk == 13) r.x = 2.0; break;                                       // Triboulet
+    case 118: if (su == 3) r.chips = 50; break;                                                 // Arrowhead
+    case 119: if (su == 0) r.mult = 7; break;                                                   // Onyx Agate
+    case 116: if (su == 1) r.money = 1; break;                                                  // Rough Gem
+    case 117: if (su == 2 && blood < 0.5) r.x = 2.0; break;                                     // Bloodstone
+    default: break;
+  }
+  return r;
+}
+
+// boss_blinds.py:343-378 on_hand_drawn as applied by balatro_env_2.py:936-948
+__device__ __forceinline__ void bg_boss_on_hand_drawn(const BgDev& d, int env, Env& e, const Deck0& dk) {
+  uint32_t fd = 0;
+  int n = e.nhand;
+  int h0 = -1, h1 = -1;
+  switch (e.boss_type) {
+    case 1: // The Hook: random.sample(range(n), 2), n <= 21 -> pool method
+      if (n >= 2) {
+        int j0 = (int)bg_randbelow<false>(d, env, e, (uint32_t)n);
+        int j1 = (int)bg_randbelow<false>(d, env, e, (uint32_t)(n - 1));
+        h0 = j0;                                  // pool[j] = j initially
+        h1 = (j1 == j0) ? (n - 1) : j1;           // pool[j0] was overwritten with pool[n-1]
+      }
+      break;
+    case 3: // The Wheel
+      for (int i = 0; i < n; i++) if (bg_grandom(d, env, e) < 1.0 / 7.0) fd |= 1u << i;
+      break;
+    case 4: if (e.bflags & BG_BF_FIRST_HAND) fd = (1u << n) - 1; break;  // The House
+    case 5: // The Mark
+      for (int i = 0; i < n; i++) { int rk = (bg_card(d, env, dk, bg_get8(e.hand, i)) >> 2) + 2; if (rk >= 11 && rk <= 13) fd |= 1u << i; }
+      break;
+    case 6: if (!(e.bflags & BG_BF_FIRST_HAND)) fd = (1u << n) - 1; break; // The Fish
+    default: break;
+  }
+  e.face_down = fd & 0xffu;
+  if (h0 >= 0) { // pop in descending position order (:946-948)
+    int a = h0 > h1 ? h0 : h1, b = h0 > h1 ? h1 : h0;
+    if (a < e.nhand) { e.hand = bg_del8(e.hand, a); e.nhand--; }
+    if (b < e.nhand) { e.hand = bg_del8(e.hand, b); e.nhand--; }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// PLAY_HAND  balatro_env_2.py:645-960
+// ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& e, const Deck0& dk, StepOut& o) {
+  // :650-660 selected cards in selection order
+  uint32_t pc[8]; // rank | suit<<4 | chips<<8 per played card (static indexing only: loops are fully unrolled)
+  int didx[8];
+  int n = 0;
+  int chip_sum = 0, faces = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    pc[i] = 0; didx[i] = 0;
+    if (i < e.nsel) {
+      int pos = bg_get8(e.sel, i);
+      if (pos < e.nhand) {
+        int ci = bg_get8(e.hand, pos);
+        int code = bg_card(d, env, dk, ci);
+        int rk = (code >> 2) + 2, su = code & 3, ch = bg_card_chips(code);
+        // all valid selections are contiguous from 0 because positions are validated at selection time
+        pc[i] = (uint32_t)rk | ((uint32_t)su << 4) | ((uint32_t)ch << 8);
+        didx[i] = ci;
+        chip_sum += ch;
+        faces += rk >= 11;
+        n++;
+        e.highlighted |= 1u << pos; // :663-666 highlights are never cleared by a play
+      }
+    }
+  }
+  // :669-671 classify deck[p] for highlighted POSITIONS p
+  uint64_t hc = 0; int nh = 0;
+  for (int p = 0; p < 16; p++)
+    if (e.highlighted & (1u << p)) { if (nh < 8) hc |= (uint64_t)bg_card(d, env, dk, p) << (8 * nh); nh++; }
+  int ht = bg_classify(hc, nh < 8 ? nh : 8);
+  // :677-680 boss restrictions (boss_blinds.py:380-407)
+  if (e.boss_type) {
+    int err = 0;
+    if (e.boss_type == 7 && n != 5) err = 2;
+    else if (e.boss_type == 12 && (e.boss_types & (1u << ht))) err = 3;
+    else if (e.boss_type == 13 && e.boss_types && !(e.boss_types & (1u << ht))) err = 4;
+    else if (e.boss_type == 25 && n < e.boss_req) err = 5;
+    if (err) { o.reward = -1.0; o.error = err; return; }
+  }
+  // :683-692 UnifiedScorer.score_hand
+  int level = bg_level(e, ht);
+  int bchips, bmult;
+  bg_hand_base(ht, level, bchips, bmult);
+  int64_t chips = bchips + chip_sum, mult = bmult;
+  double x_mult = 1.0;
+  if ((d.flags & 1u) && e.njokers > 0) { // scorer-level joker names (BG_FLAG_SCORER_JOKERS); dict jokers are inert (Q6)
+    int64_t ic = 0, im = 0; double ix = 1.0;
+    for (int c = 0; c < n; c++) {
+      uint32_t card = 0;
+#pragma unroll
+      for (int q = 0; q < 8; q++) if (q == c) card = pc[q];
+      for (int j = 0; j < e.njokers; j++) {
+        JEff f = bg_joker_individual(d, env, e, bg_get8(e.jokers, j), card);
+        ic += f.chips; im += f.mult; ix *= f.x;
+      }
+    }
+    chips += ic; mult += im; x_mult *= ix;
+    for (int j = 0; j < e.njokers; j++) {
+      JEff f = bg_joker_main(d, env, e, bg_get8(e.jokers, j), pc, n, ht);
+      chips += f.chips; mult += f.mult; x_mult *= f.x;
+    }
+  }
+  int64_t final_score = (int64_t)((double)(chips * mult) * x_mult); // unified_scoring.py:286
+  // :741-742 steel needs card states (not on this path): int(score * 1.0)
+  // :745-755 boss scoring ratio (boss_blinds.py:409-445)
+  if (e.boss_type) {
+    int64_t mc = bchips, mm = bmult;
+    if (e.boss_type == 21) { mc = mc / 2; mm = mm / 2; }
+    else if (e.boss_type == 22) mc = 0;
+    else if (e.boss_type == 23) { mc = (int64_t)((double)mc * 0.75); mm = (int64_t)((double)mm * 0.75); }
+    int deb = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+      if (i < n) {
+        int rk = pc[i] & 0xf;
+        if (e.boss_type == 14 && rk >= 11 && rk <= 13) deb++;
+        else if (e.boss_type == 24) deb++;
+        else if (e.boss_type == 16 && ((e.boss_cards >> didx[i]) & 1ull)) deb++;
+      }
+    if (deb > 0) {
+      double pen = BG_POW08[deb];
+      mc = (int64_t)((double)mc * pen);
+      mm = (int64_t)((double)mm * pen);
+    }
+    double cr = (double)mc / (double)bchips, mr = (double)mm / (double)bmult;
+    final_score = (int64_t)((double)final_score * cr * mr);
+  }
+  // :758-759 int(final * (1 + 0.5 * red seals)) with no card states is the identity
+  // :775-786
+  int64_t need1 = e.chips_needed > 1 ? e.chips_needed : 1;
+  double old_progress = (double)e.round_chips / (double)need1;
+  if (old_progress > 1.0) old_progress = 1.0;
+  e.round_chips += final_score;
+  e.chips_scored += final_score;
+  e.hp_total++; e.hp_ante++;
+  if (final_score > e.best_hand) e.best_hand = final_score;
+  { // engine.hand_play_counts[hand_type] += 1
+    uint32_t* pcnt = ((uint32_t*)&d.cold[(size_t)(ht >> 2) * d.N + env]) + (ht & 3);
+    *pcnt = *pcnt + 1;
+  }
+  // :789-794 boss on_hand_scored (boss_blinds.py:480-507); Tooth/Serpent mutate a throw-away dict
+  if (e.boss_type) {
+    e.boss_types |= 1u << ht;
+    e.bflags &= ~BG_BF_FIRST_HAND;
+    e.boss_hp++;
+    if (e.boss_type == 16) {
+#pragma unroll
+      for (int i = 0; i < 8; i++) if (i < n) e.boss_cards |= 1ull << didx[i];
+    }
+    if (e.boss_type == 25) e.boss_req = e.boss_req + 1 > 7 ? 7 : e.boss_req + 1;
+  }
+  e.nsel = 0; e.sel = 0; // :797
+  // :799-892 reward shaping (float64, left to right)
+  double new_progress = (double)e.round_chips / (double)need1;
+  if (new_progress > 1.0) new_progress = 1.0;
+  double progress_reward = 15.0 * new_progress;
+  double milestone = 0.0;
+  if (old_progress < 0.25 && 0.25 <= new_progress) milestone = 5.0;
+  else if (old_progress < 0.5 && 0.5 <= new_progress) milestone = 10.0;
+  else if (old_progress < 0.75 && 0.75 <= new_progress) milestone = 15.0;
+  else if (old_progress < 1.0 && 1.0 <= new_progress) milestone = 25.0;
+  double score_reward;
+  if (e.ante <= 3) { score_reward = (double)final_score / 100.0; if (score_reward > 10.0) score_reward = 10.0; }
+  else {
+    int64_t s = final_score > 1 ? final_score : 1;
+    score_reward = s >= BG_LOG10_N ? 10.0 : 3.0 * BG_LOG10[s]; // 3.0 * np.log10(s), table pinned on the reference platform
+    if (score_reward > 10.0) score_reward = 10.0;
+  }
+  double hq;
+  switch (ht) {
+    case 0: hq = 0.1; break; case 1: hq = 0.5; break; case 2: hq = 1.0; break; case 3: hq = 2.0; break;
+    case 4: hq = 2.5; break; case 5: hq = 2.5; break; case 6: hq = 3.5; break; case 7: hq = 5.0; break;
+    case 8: hq = 7.0; break; case 9: hq = 10.0; break; default: hq = 0.0; break;
+  }
+  double eff = 0.0;
+  if (ht >= 3 && n <= 3) eff = 2.0;
+  else if (ht >= 5 && n == 5) eff = 1.0;
+  else if (n <= 4 && e.hands_left <= 2) eff = 1.5;
+  double syn = 0.0;
+  if (e.njokers > 0) {
+    if (ht == 5 && (bg_owns(e, 113) || bg_owns(e, 18) || bg_owns(e, 69))) syn += 2.0;
+    if ((ht == 1 || ht == 2 || ht == 3) && (bg_owns(e, 40) || bg_owns(e, 39) || bg_owns(e, 6) || bg_owns(e, 7))) syn += 1.5;
+    if (faces > 0 && (bg_owns(e, 33) || bg_owns(e, 104) || bg_owns(e, 42))) syn += 0.5 * (double)faces;
+  }
+  double strat = 0.0;
+  if (new_progress > 0.7 && e.hands_left >= 3) strat = 2.0;
+  else if (new_progress < 0.3 && ht >= 5) strat = 3.0;
+  double ante_bonus = 0.0;
+  if (e.ante >= 4) { ante_bonus = (double)(e.ante - 3) * 0.5; if (ante_bonus > 5.0) ante_bonus = 5.0; }
+  double r = progress_reward + milestone;
+  r = r + score_reward;
+  r = r + hq * 2.0;
+  r = r + eff * 1.5;
+  r = r + syn * 3.0;
+  r = r + strat * 2.0;
+  r = r + ante_bonus;
+  if (r > 100.0) r = 100.0;
+  o.terms[0] = progress_reward; o.terms[1] = milestone; o.terms[2] = score_reward; o.terms[3] = hq;
+  o.terms[4] = eff; o.terms[5] = syn; o.terms[6] = strat; o.terms[7] = ante_bonus;
+  o.final_score = final_score; o.hand_type = ht; o.cards_played = n;
+  // :914-960 outcome
+  if (e.round_chips >= (int64_t)e.chips_needed) {
+    double bonus = 25.0 + 10.0 * (double)e.ante;
+    r += bonus < 50.0 ? bonus : 50.0;
+    bg_advance_round(d, env, e);
+    o.flags |= 1; // beat_blind
+  } else if (e.hands_left <= 1) {
+    r += -50.0 * (1.0 - new_progress);
+    o.terminated = true;
+    o.flags |= 2; // failed
+  } else {
+    e.hands_left -= 1;
+    bg_draw_cards(e);
+    if (e.boss_type) bg_boss_on_hand_drawn(d, env, e, dk);
+  }
+  o.reward = r;
+}
+
+// DISCARD  balatro_env_2.py:962-1050
+__device__ __forceinline__ void bg_step_discard(const BgDev& d, int env, Env& e, const Deck0& dk, StepOut& o) {
+  int n = 0, nfaces = 0;
+  for (int i = 0; i < e.nsel; i++) {
+    int pos = bg_get8(e.sel, i);
+    if (pos < e.nhand) {
+      int rk = (bg_card(d, env, dk, bg_get8(e.hand, pos)) >> 2) + 2;
+      nfaces += (rk >= 11 && rk <= 13);
+      n++;
+      e.highlighted |= 1u << pos; // :1011-1013 on top of stale play highlights
+    }
+  }
+  bool first = e.discards_left == 3; // == game.discards (balatro_game.py:25)
+  int money = 0, ndj = 0;
+  for (int j = 0; j < e.njokers; j++) { // complete_joker_effects.py:186-209
+    int id = bg_get8(e.jokers, j);
+    if (id == 95 && first && n == 1) money += 3;        // Trading Card
+    else if (id == 57 && nfaces >= 3) money += 5;       // Faceless Joker
+    ndj += (id == 57 || id == 130 || id == 82 || id == 77) ? 1 : 0;
+  }
+  e.money += money;
+  // balatro_game.py:111-127 discard_hand: drop every highlighted position, clear highlights, refill
+  uint64_t nh = 0; int k = 0;
+  for (int p = 0; p < e.nhand; p++)
+    if (!(e.highlighted & (1u << p))) { nh |= (uint64_t)bg_get8(e.hand, p) << (8 * k); k++; }
+  e.hand = nh; e.nhand = k;
+  e.highlighted = 0;
+  e.discards_left -= 1;
+  bg_draw_cards(e);
+  e.nsel = 0; e.sel = 0;
+  double r = 0.2;
+  if (ndj) r += 0.5 * (double)ndj;
+  if (money > 0) r += (double)money / 5.0;
+  int64_t need1 = e.chips_needed > 1 ? e.chips_needed : 1;
+  double progress = (double)e.round_chips / (double)need1;
+  if (progress < 0.5 && e.discards_left > 1) r += 0.5;
+  else if (progress > 0.8 && e.discards_left > 1) r -= 0.3;
+  o.reward = r;
+}
+
+// SHOP  balatro_env_2.py:1174-1253 + shop.py:160-205
+__device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, int action, StepOut& o) {
+  if (action >= 32 && action < 37) { // sell joker :1202-1215
+    int ji = action - 32;
+    int id = bg_get8(e.jokers, ji);
+    e.jokers = bg_del8(e.jokers, ji);
+    e.njokers--;
+    int v = BG_JOKER_COST[id] / 2;
+    if (v < 3) v = 3;
+    e.money += v;
+    e.jokers_sold++;
+    o.reward = (double)v / 5.0;
+    o.flags |= 128; o.aux = id;
+    return;
+  }
+  if (action == 31) { // SKIP -> PLAY :1247-1251
+    e.phase = 0;
+    bg_draw_cards(e);
+    o.reward = 0.0;
+    return;
+  }
+  if (action == 30) { // REROLL shop.py:170-177
+    int32_t cost = (int32_t)((double)e.shop_reroll_base * bg_shop_cost_mult(e));
+    if (e.money < cost) { o.reward = -1.0; o.error = 6; return; }
+    e.money -= cost;
+    e.shop_reroll_base = (int32_t)((double)e.shop_reroll_base * 1.35);
+    bg_shop_inventory(d, env, e);
+    o.reward = 0.0;
+    return;
+  }
+  // buy 20..28: the mask guarantees index < shop_n and money >= cost (shop.py:179-203)
+  int idx = action - 20;
+  int32_t cost = *bg_shop_cost_ptr(d, env, idx);
+  uint32_t tp = *bg_shop_tp_ptr(d, env, idx);
+  e.money -= cost;
+  for (int i = idx; i + 1 < e.shop_n; i++) {
+    *bg_shop_cost_ptr(d, env, i) = *bg_shop_cost_ptr(d, env, i + 1);
+    *bg_shop_tp_ptr(d, env, i) = *bg_shop_tp_ptr(d, env, i + 1);
+  }
+  e.shop_n--;
+  int type = tp & 0xff, payload = (tp >> 8) & 0xff;
+  if (type == IT_PACK) {
+    int count = payload == PK_STANDARD ? 3 : 1; // shop.py:150-157 _open_pack draws from the shop stream
+    for (int i = 0; i < count; i++) { int c = (int)bg_randbelow<true>(d, env, e, 52u); if (i == 0) o.aux = c; }
+    o.reward = 5.0; o.flags |= 8;
+  } else if (type == IT_CARD) {
+    o.reward = 3.0; o.flags |= 16;
+  } else if (type == IT_JOKER) {
+    if (e.njokers >= 5) { o.reward = -1.0; o.error = 7; return; } // chips already deducted (shop.py:187-197)
+    e.jokers = bg_set8(e.jokers, e.njokers, payload);
+    e.njokers++;
+    o.reward = 15.0; o.flags |= 64; o.aux = payload;
+  } else {
+    if (payload == 0) e.n_magic++; else e.n_minim++;
+    o.reward = 10.0; o.flags |= 32; o.aux = payload;
+  }
+}
+
+// BLIND_SELECT  balatro_env_2.py:1255-1318
+__device__ __forceinline__ void bg_step_blind(const BgDev& d, int env, Env& e, int action, StepOut& o) {
+  if (action < 48) {
+    int b = action - 45;
+    e.round = b + 1;
+    int64_t need;
+    {
+      int a = e.ante;
+      // balatro_env_2.py:55-74
+      const int T[8][3] = {{300, 450, 600},    {450, 675, 900},    {600, 900, 1200},   {900, 1350, 1800},
+                           {1350, 2025, 2700}, {2100, 3150, 4200}, {3300, 4950, 6600}, {5250, 7875, 10500}};
+      if (a <= 8) need = T[a - 1][b];
+      else { int k = a - 8; if (k > 92) k = 92; need = (int64_t)((double)T[7][b] * BG_POW15[k]); }
+    }
+    o.reward = 0.0;
+    if (b == 2) {
+      int boss = 1 + (int)bg_randbelow<false>(d, env, e, 28u); // boss_blinds.py:522-532 random.choice(list(BossBlindType))
+      e.boss_type = boss; e.boss_types = 0; e.boss_cards = 0; e.boss_hp = 0; e.boss_req = 5;
+      e.bflags |= BG_BF_FIRST_HAND;
+      need = (int64_t)((double)need * (boss == 2 ? 2.0 : 1.0)); // The Wall
+      if (boss == 9) e.discards_left = 0;   // The Water
+      if (boss == 11) e.hand_size -= 1;     // The Manacle
+      if (boss == 17) e.hands_left = 1;     // The Needle
+      o.aux = boss;
+      o.reward = 10.0;
+    }
+    e.chips_needed = (int32_t)need;
+    e.phase = 0;
+    bg_draw_cards(e);
+  } else { // 48 SKIP_BLIND :1305-1316
+    o.reward = -5.0;
+    bg_advance_round(d, env, e);
+    o.flags |= 4;
+  }
+}
+
+// balatro_env_2.py:616-637 step()
+__device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, const Deck0& dk, int action, StepOut& o) {
+  o.reward = 0.0; o.final_score = 0; o.error = 0; o.flags = 0; o.aux = 0; o.hand_type = -1; o.cards_played = 0;
+  o.terminated = false;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o.terms[i] = 0.0;
+  if (e.ante > 100) { o.terminated = true; o.error = 9; return; }
+  if (e.chips_scored > 1000000000ll) { o.terminated = true; o.error = 10; return; }
+  uint64_t mask = bg_action_mask(d, env, e);
+  if (action < 0 || action >= 60 || !((mask >> action) & 1ull)) { o.reward = -1.0; o.error = 1; return; }
+  if (e.phase == 0) {
+    if (action == 0) bg_step_play_hand(d, env, e, dk, o);
+    else if (action == 1) bg_step_discard(d, env, e, dk, o);
+    else if (action < 10) { // :1052-1058 toggle, selection ORDER kept
+      int pos = action - 2;
+      int at = -1;
+      for (int i = 0; i < e.nsel; i++) if (bg_get8(e.sel, i) == pos) at = i;
+      if (at >= 0) { e.sel = bg_del8(e.sel, at); e.nsel--; }
+      else { e.sel = bg_set8(e.sel, e.nsel, pos); e.nsel++; }
+    } else { // 10..14 _use_consumable :1066-1172, planets only (consumables.py:644-652)
+      int ci = action - 10;
+      int id = ci == 0 ? (int)e.cons0 : (int)e.cons1;
+      if (id >= 30 && id <= 41) {
+        const int PLANET_HT[12] = {1, 2, 3, 4, 5, 6, 7, 8, 0, 9, 10, 11};
+        int ht = PLANET_HT[id - 30];
+        if (ci == 0) e.cons0 = e.cons1;
+        e.cons1 = 0; e.ncons--;
+        int lv = bg_level(e, ht);
+        if (lv < 15) e.levels += 1ull << (4 * ht);          // engine.apply_planet (scoring_engine.py:82-85)
+        else e.excess += 1ull << (4 * ht);                  // state.hand_levels[...] += 1 is uncapped (:1119)
+        o.reward = 10.0;
+      } else { o.reward = -1.0; o.error = 8; }
+      e.nsel = 0; e.sel = 0;
+    }
+  } else if (e.phase == 1) bg_step_shop(d, env, e, action, o);
+  else if (e.phase == 2) bg_step_blind(d, env, e, action, o);
+  if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Observation writer (balatro_env_2.py:1473-1541), reference dtypes, one array per key, row `env`.
+// ---------------------------------------------------------------------------------------------------------
+struct ObsPtrs {
+  int8_t* hand; int8_t* hand_size; int8_t* deck_size; int64_t* selected_cards; int64_t* chips_scored;
+  int32_t* round_chips_scored; float* progress_ratio; int32_t* mult; int32_t* chips_needed; int32_t* money;
+  int16_t* ante; int8_t* round; int8_t* hands_left; int8_t* discards_left; int8_t* joker_count; int16_t* joker_ids;
+  int8_t* joker_slots; int8_t* consumable_count; int16_t* consumables; int8_t* consumable_slots; int16_t* shop_items;
+  int16_t* shop_costs; int16_t* shop_rerolls; int8_t* hand_levels; int8_t* phase; int8_t* action_mask;
+  int32_t* hands_played; int32_t* best_hand_this_ante; int8_t* boss_blind_active; int8_t* boss_blind_type;
+  int64_t* face_down_cards;
+};
+
+// `row` = env + t * N for [T, N, ...] rollout buffers.  Returns a 64-bit hash of the row (rollout checksum).
+__device__ __forceinline__ uint64_t bg_write_obs(const BgDev& d, int env, size_t row, const Env& e, const Deck0& dk,
+                                                const ObsPtrs& p, uint64_t mask) {
+  uint64_t hsh = 0x9E3779B97F4A7C15ull;
+#define BG_MIX(v) do { hsh ^= (uint64_t)(v); hsh *= 0xBF58476D1CE4E5B9ull; hsh ^= hsh >> 29; } while (0)
+  uint64_t handb = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    int v = 0xff;
+    if (i < e.nhand) v = bg_card(d, env, dk, bg_get8(e.hand, i));
+    handb |= (uint64_t)(v & 0xff) << (8 * i);
+  }
+  BG_MIX(handb);
+  if (p.hand) ((uint64_t*)p.hand)[row] = handb;
+  if (p.hand_size) p.hand_size[row] = (int8_t)e.nhand;
+  if (p.deck_size) p.deck_size[row] = 52;
+  uint32_t selm = 0;
+  for (int i = 0; i < e.nsel; i++) selm |= 1u << bg_get8(e.sel, i);
+  BG_MIX(selm | ((uint64_t)e.face_down << 8) | ((uint64_t)e.nhand << 16));
+  if (p.selected_cards) {
+    ulonglong2* q = (ulonglong2*)(p.selected_cards + row * 8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = make_ulonglong2((selm >> (2 * i)) & 1u, (selm >> (2 * i + 1)) & 1u);
+  }
+  BG_MIX(e.chips_scored); BG_MIX(e.round_chips);
+  if (p.chips_scored) p.chips_scored[row] = e.chips_scored;
+  if (p.round_chips_scored) p.round_chips_scored[row] = (int32_t)e.round_chips;
+  int64_t need1 = e.chips_needed > 1 ? e.chips_needed : 1;
+  double pr = (double)e.round_chips / (double)need1;
+  float prf = (float)(pr < 2.0 ? pr : 2.0);
+  BG_MIX(__float_as_uint(prf));
+  if (p.progress_ratio) p.progress_ratio[row] = prf;
+  if (p.mult) p.mult[row] = 1;
+  BG_MIX(((uint64_t)(uint32_t)e.chips_needed << 32) | (uint32_t)e.money);
+  if (p.chips_needed) p.chips_needed[row] = e.chips_needed;
+  if (p.money) p.money[row] = e.money;
+  BG_MIX((uint64_t)e.ante | ((uint64_t)e.round << 8) | ((uint64_t)e.hands_left << 16) | ((uint64_t)e.discards_left << 24) |
+         ((uint64_t)e.njokers << 32) | ((uint64_t)e.ncons << 40) | ((uint64_t)e.phase << 48));
+  if (p.ante) p.ante[row] = (int16_t)e.ante;
+  if (p.round) p.round[row] = (int8_t)e.round;
+  if (p.hands_left) p.hands_left[row] = (int8_t)e.hands_left;
+  if (p.discards_left) p.discards_left[row] = (int8_t)e.discards_left;
+  if (p.joker_count) p.joker_count[row] = (int8_t)e.njokers;
+  BG_MIX(e.jokers);
+  if (p.joker_ids) {
+    uint32_t* q = (uint32_t*)(p.joker_ids + row * 10);
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+      uint32_t a = (2 * i < e.njokers) ? (uint32_t)bg_get8(e.jokers, 2 * i) : 0u;
+      uint32_t b = (2 * i + 1 < e.njokers && 2 * i + 1 < 8) ? (uint32_t)bg_get8(e.jokers, (2 * i + 1) & 7) : 0u;
+      q[i] = a | (b << 16);
+    }
+  }
+  if (p.joker_slots) p.joker_slots[row] = 5;
+  if (p.consumable_count) p.consumable_count[row] = (int8_t)e.ncons;
+  BG_MIX(e.cons0 | (e.cons1 << 8));
+  if (p.consumables) {
+    int16_t* q = p.consumables + row * 5;
+    q[0] = (int16_t)(e.ncons > 0 ? e.cons0 : 0); q[1] = (int16_t)(e.ncons > 1 ? e.cons1 : 0); q[2] = 0; q[3] = 0; q[4] = 0;
+  }
+  if (p.consumable_slots) p.consumable_slots[row] = 2;
+  // shop rows only in SHOP phase (:1534-1539)
+  {
+    uint32_t it[5] = {0, 0, 0, 0, 0}, co[5] = {0, 0, 0, 0, 0};
+    if (e.phase == 1 && (e.bflags & BG_BF_SHOP_EXISTS)) {
+#pragma unroll
+      for (int i = 0; i < 9; i++)
+        if (i < e.shop_n) {
+          uint32_t tp = *bg_shop_tp_ptr(d, env, i);
+          uint32_t c = (uint32_t)(*bg_shop_cost_ptr(d, env, i)) & 0xffffu;
+          it[i >> 1] |= (tp & 0xffu) << (16 * (i & 1));
+          co[i >> 1] |= c << (16 * (i & 1));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 5; i++) { BG_MIX(((uint64_t)it[i] << 32) | co[i]); }
+    if (p.shop_items) { uint32_t* q = (uint32_t*)(p.shop_items + row * 10);
+#pragma unroll
+      for (int i = 0; i < 5; i++) q[i] = it[i]; }
+    if (p.shop_costs) { uint32_t* q = (uint32_t*)(p.shop_costs + row * 10);
+#pragma unroll
+      for (int i = 0; i < 5; i++) q[i] = co[i]; }
+  }
+  BG_MIX(e.shop_reroll_state);
+  if (p.shop_rerolls) p.shop_rerolls[row] = (int16_t)e.shop_reroll_state;
+  {
+    uint32_t lv[3];
+#pragma unroll
+    for (int w = 0; w < 3; w++) {
+      uint32_t x = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        int ht = w * 4 + b;
+        uint32_t l = (uint32_t)((e.levels >> (4 * ht)) & 0xf) + (uint32_t)((e.excess >> (4 * ht)) & 0xf);
+        x |= (l & 0xffu) << (8 * b);
+      }
+      lv[w] = x;
+      BG_MIX(x);
+    }
+    if (p.hand_levels) { uint32_t* q = (uint32_t*)(p.hand_levels + row * 12); q[0] = lv[0]; q[1] = lv[1]; q[2] = lv[2]; }
+  }
+  if (p.phase) p.phase[row] = (int8_t)e.phase;
+  BG_MIX(mask);
+  if (p.action_mask) {
+    uint32_t* q = (uint32_t*)(p.action_mask + row * 60);
+#pragma unroll
+    for (int w = 0; w < 15; w++) {
+      uint32_t bits = (uint32_t)(mask >> (4 * w)) & 0xfu;
+      q[w] = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
+    }
+  }
+  BG_MIX(((uint64_t)(uint32_t)e.hp_total << 32) | (uint32_t)e.best_hand);
+  if (p.hands_played) p.hands_played[row] = e.hp_total;
+  if (p.best_hand_this_ante) p.best_hand_this_ante[row] = (int32_t)e.best_hand;
+  BG_MIX(e.boss_type);
+  if (p.boss_blind_active) p.boss_blind_active[row] = e.boss_type ? 1 : 0;
+  if (p.boss_blind_type) p.boss_blind_type[row] = (int8_t)e.boss_type;
+  if (p.face_down_cards) {
+    ulonglong2* q = (ulonglong2*)(p.face_down_cards + row * 8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = make_ulonglong2((e.face_down >> (2 * i)) & 1u, (e.face_down >> (2 * i + 1)) & 1u);
+  }
+#undef BG_MIX
+  return hsh;
+}
+
+// counter-hash policy on a 60-bit action mask; phase overrides for the scripted policies
+__device__ __forceinline__ int bg_policy_action(const Env& e, uint64_t mask, int policy, uint64_t policy_seed,
+                                                uint64_t env_index, uint64_t t) {
+  if (policy != 0) {
+    if (e.phase == 2) return policy == 2 ? 45 + (int)(env_index % 3) : 45;
+    if (e.phase == 1) return 31;
+  }
+  int nv = __popcll(mask);
+  if (!nv) return 0;
+  uint32_t k = bg_policy_hash(policy_seed, env_index, t) % (uint32_t)nv;
+  uint64_t m = mask;
+  for (uint32_t i = 0; i < k; i++) m &= m - 1; // clear the k lowest set bits
+  return __ffsll((long long)m) - 1;
+}

@@ -1,0 +1,246 @@
+"""BalatroVecEnv -- N lockstep Balatro envs on one MI355X behind the reference's reset()/step() surface.
+
+Host-side mirror of `balatro_gym/balatro_env_2.py::BalatroEnv` (observation keys/dtypes, Discrete(60) actions, reward
+/ terminated / truncated / info semantics), vectorised: every quantity gains a leading [N] axis and lives in HBM as a
+torch tensor.  All game logic runs in libbalatro_mi355x.so (hand-written HIP); torch only owns device buffers and the
+stream.  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import random as _pyrandom
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _native as nat
+
+_TORCH_DT = {"int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64,
+             "float32": torch.float32, "float64": torch.float64, "uint8": torch.uint8}
+
+
+def _align(n: int, a: int = 256) -> int:
+    return (n + a - 1) // a * a
+
+
+class ObsBuffers:
+    """The 31 observation arrays as views into ONE flat device byte buffer (one collective gathers all keys)."""
+
+    def __init__(self, n: int, device: torch.device, steps: int = 1):
+        self.n, self.steps = n, steps
+        rows = n * steps
+        off = 0
+        self.layout = {}
+        for k in nat.OBS_KEYS:
+            dt, shape = nat.OBS_SPEC[k]
+            nbytes = rows * int(np.prod(shape, dtype=np.int64)) * np.dtype(dt).itemsize
+            self.layout[k] = (off, nbytes)
+            off = _align(off + nbytes)
+        self.flat = torch.zeros(off, dtype=torch.uint8, device=device)
+        self.tensors: Dict[str, torch.Tensor] = {}
+        for k in nat.OBS_KEYS:
+            dt, shape = nat.OBS_SPEC[k]
+            o, nb = self.layout[k]
+            lead = (steps, n) if steps > 1 else (n,)
+            self.tensors[k] = self.flat[o:o + nb].view(_TORCH_DT[dt]).view(*lead, *shape)
+        self.ptrs = nat.ObsPtrs(**{k: self.tensors[k].data_ptr() for k in nat.OBS_KEYS})
+
+
+class BalatroVecEnv:
+    """N independent Balatro games stepped in lockstep on one GPU.
+
+    seeds[i] plays the role of `BalatroEnv(seed=seeds[i])` (balatro_env_2.py:359): it seeds the 16 named streams
+    (`(seed + 1000*i) % 2**32`, :105) and -- harness convention -- a per-env stand-in for the process-global
+    `random` module with G(seed) = (seed + 16000) % 2**32.  Like the reference constructor, __init__ ends with reset().
+    """
+
+    num_actions = 60
+
+    def __init__(self, num_envs: int, seeds: Optional[Sequence[int]] = None, *, device: int | str | torch.device = 0,
+                 scorer_jokers: bool = False, autoreset: bool = True, max_ante: int = 0, info_terms: bool = True):
+        if not torch.cuda.is_available():
+            raise nat.NativeError("BalatroVecEnv needs a HIP device (torch.cuda.is_available() is False); "
+                                  "there is no CPU fallback")
+        self._L = nat.load()
+        self.device = torch.device(device if not isinstance(device, int) else f"cuda:{device}")
+        self.num_envs = int(num_envs)
+        self.autoreset = bool(autoreset)
+        self.scorer_jokers = bool(scorer_jokers)
+        self.max_ante = int(max_ante)
+        flags = (nat.FLAG_SCORER_JOKERS if scorer_jokers else 0) | (nat.FLAG_AUTORESET if autoreset else 0)
+        self._h = C.c_void_p()
+        rc = self._L.bg_create(self.num_envs, self.device.index or 0, flags, self.max_ante, C.byref(self._h))
+        if rc != 0:
+            raise nat.NativeError(f"bg_create failed ({rc}): {self._L.bg_last_error(None).decode()}")
+        n, dev = self.num_envs, self.device
+        with torch.cuda.device(dev):
+            self._obs = ObsBuffers(n, dev)
+            self.reward = torch.zeros(n, dtype=torch.float64, device=dev)
+            self.terminated = torch.zeros(n, dtype=torch.uint8, device=dev)
+            self.truncated = torch.zeros(n, dtype=torch.uint8, device=dev)
+            self.info = {k: torch.zeros((n,) + nat.INFO_SPEC[k][1], dtype=_TORCH_DT[nat.INFO_SPEC[k][0]], device=dev)
+                         for k in nat.INFO_KEYS if info_terms or k != "reward_terms"}
+            self._info_ptrs = nat.InfoPtrs(**{k: (self.info[k].data_ptr() if k in self.info else None)
+                                              for k in nat.INFO_KEYS})
+            self._stats = torch.zeros(6, dtype=torch.int64, device=dev)
+        self.seed(seeds)
+        self.reset()
+
+    # ------------------------------------------------------------------ plumbing
+    def _check(self, rc: int, what: str):
+        if rc != 0:
+            raise nat.NativeError(f"{what} failed ({rc}): {self._L.bg_last_error(self._h).decode()}")
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    @property
+    def obs(self) -> Dict[str, torch.Tensor]:
+        """The live observation tensors (updated in place by reset/step; clone() to keep a copy)."""
+        return self._obs.tensors
+
+    @property
+    def obs_flat(self) -> torch.Tensor:
+        return self._obs.flat
+
+    def state_bytes(self) -> int:
+        return int(self._L.bg_state_bytes(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            torch.cuda.synchronize(self.device)
+            self._L.bg_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------ reference surface
+    def seed(self, seeds: Optional[Sequence[int]] = None, mask: Optional[Sequence[bool]] = None, reseed_global: bool = True):
+        """`DeterministicRNG(seed)` per env (balatro_env_2.py:84-106).  None -> `random.randint(0, 2**32-1)` (:88)."""
+        n = self.num_envs
+        if seeds is None:
+            seeds = [_pyrandom.randint(0, 2 ** 32 - 1) for _ in range(n)]
+        arr = np.ascontiguousarray(np.asarray(seeds, dtype=np.int64))
+        if arr.shape != (n,):
+            raise ValueError(f"seeds must have shape ({n},)")
+        m = None if mask is None else np.ascontiguousarray(np.asarray(mask, dtype=np.uint8))
+        with torch.cuda.device(self.device):
+            self._check(self._L.bg_seed(self._h, arr.ctypes.data_as(C.c_void_p),
+                                        None if m is None else m.ctypes.data_as(C.c_void_p),
+                                        1 if reseed_global else 0, self._stream()), "bg_seed")
+        self.seeds = arr.copy() if mask is None else np.where(np.asarray(mask, bool), arr, getattr(self, "seeds", arr))
+
+    def reset(self, *, seed: Optional[Sequence[int]] = None, mask: Optional[torch.Tensor] = None):
+        """`reset(seed=...)` for the masked envs (all when mask is None); returns the observation dict of ALL envs."""
+        if seed is not None:
+            hm = None if mask is None else mask.to("cpu").numpy().astype(np.uint8)
+            self.seed(seed, hm, reseed_global=False)  # reset(seed=s) rebuilds the streams, not the global module (:507-509)
+        mptr = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            mptr = C.c_void_p(mask.data_ptr())
+        with torch.cuda.device(self.device):
+            self._check(self._L.bg_reset(self._h, mptr, C.byref(self._obs.ptrs), self._stream()), "bg_reset")
+        return self.obs
+
+    def step(self, actions: torch.Tensor):
+        """One lockstep `step(action)` (balatro_env_2.py:616).  actions: int32 [N] on this device."""
+        if actions.dtype != torch.int32 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        with torch.cuda.device(self.device):
+            self._check(self._L.bg_step(self._h, C.c_void_p(actions.data_ptr()), C.byref(self._obs.ptrs),
+                                        C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.terminated.data_ptr()),
+                                        C.c_void_p(self.truncated.data_ptr()), C.byref(self._info_ptrs),
+                                        self._stream()), "bg_step")
+        return self.obs, self.reward, self.terminated, self.truncated, self.info
+
+    def observe(self):
+        with torch.cuda.device(self.device):
+            self._check(self._L.bg_observe(self._h, C.byref(self._obs.ptrs), self._stream()), "bg_observe")
+        return self.obs
+
+    # ------------------------------------------------------------------ extras
+    def rollout(self, steps: int, policy: int = nat.POLICY_UNIFORM, policy_seed: int = 0, env_index0: int = 0,
+                t0: int = 0, obs_buffers: Optional[ObsBuffers] = None, reward: Optional[torch.Tensor] = None,
+                terminated: Optional[torch.Tensor] = None, actions: Optional[torch.Tensor] = None,
+                zero_stats: bool = True):
+        """Fused random-policy rollout (bg_rollout).  With obs_buffers of `steps` rows every step's observation is
+        kept ([T, N, ...]); otherwise the live observation tensors are overwritten each step."""
+        ob = obs_buffers or self._obs
+        stride = 1 if (obs_buffers is not None and obs_buffers.steps > 1) else 0
+        if stride and obs_buffers.steps < steps:
+            raise ValueError("obs_buffers has fewer rows than steps")
+        if zero_stats:
+            self._stats.zero_()
+        with torch.cuda.device(self.device):
+            self._check(self._L.bg_rollout(
+                self._h, int(steps), int(policy), C.c_uint64(policy_seed), C.c_uint64(env_index0), C.c_uint64(t0),
+                C.byref(ob.ptrs), stride,
+                None if reward is None else C.c_void_p(reward.data_ptr()),
+                None if terminated is None else C.c_void_p(terminated.data_ptr()),
+                None if actions is None else C.c_void_p(actions.data_ptr()),
+                C.c_void_p(self._stats.data_ptr()), self._stream()), "bg_rollout")
+        return self._stats
+
+    def stats(self) -> Dict[str, int]:
+        s = self._stats.cpu().numpy()
+        u = s.view(np.uint64)
+        return {"steps": int(u[0]), "episodes": int(u[1]), "plays": int(u[2]), "score_sum": int(s[3]),
+                "reward_bits": int(u[4]), "obs_hash": int(u[5])}
+
+    def inject(self, jokers=None, money=None, ante=None, levels=None, mask=None, apply_now: bool = True):
+        """Harness injection (reset template + optionally the live state): jokers = list of id lists per env."""
+        n = self.num_envs
+        jptr = nptr = mptr = aptr = lptr = kptr = None
+        keep = []
+        if jokers is not None:
+            ja = np.zeros((n, 5), np.int32)
+            na = np.zeros(n, np.int32)
+            for i, js in enumerate(jokers):
+                na[i] = len(js)
+                ja[i, :len(js)] = js
+            keep += [ja, na]
+            jptr, nptr = ja.ctypes.data_as(C.c_void_p), na.ctypes.data_as(C.c_void_p)
+        if money is not None:
+            ma = np.ascontiguousarray(np.asarray(money, np.int64)); keep.append(ma); mptr = ma.ctypes.data_as(C.c_void_p)
+        if ante is not None:
+            aa = np.ascontiguousarray(np.asarray(ante, np.int32)); keep.append(aa); aptr = aa.ctypes.data_as(C.c_void_p)
+        if levels is not None:
+            la = np.ascontiguousarray(np.asarray(levels, np.uint8)); keep.append(la); lptr = la.ctypes.data_as(C.c_void_p)
+        if mask is not None:
+            ka = np.ascontiguousarray(np.asarray(mask, np.uint8)); keep.append(ka); kptr = ka.ctypes.data_as(C.c_void_p)
+        with torch.cuda.device(self.device):
+            self._check(self._L.bg_inject(self._h, jptr, nptr, mptr, aptr, lptr, kptr, 1 if apply_now else 0,
+                                          self._stream()), "bg_inject")
+
+    def get_state(self, env_index: int) -> bytes:
+        """save_state() (balatro_env_2.py:1575-1593) as a versioned binary blob."""
+        nb = int(self._L.bg_state_blob_bytes(self._h))
+        buf = (C.c_uint8 * nb)()
+        self._check(self._L.bg_get_state(self._h, int(env_index), buf, nb), "bg_get_state")
+        return bytes(buf)
+
+    def set_state(self, env_index: int, blob: bytes):
+        """load_state() (balatro_env_2.py:1595-1615)."""
+        buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
+        self._check(self._L.bg_set_state(self._h, int(env_index), buf, len(blob)), "bg_set_state")
+
+    def set_profiling(self, enable: bool):
+        self._check(self._L.bg_set_profiling(self._h, 1 if enable else 0), "bg_set_profiling")
+
+    def get_profile(self) -> Dict[str, float]:
+        """Per-kernel HIP-event timings since the last call (synchronises)."""
+        out = (C.c_double * 8)()
+        self._check(self._L.bg_get_profile(self._h, out), "bg_get_profile")
+        return {"rollout_ms": out[0], "rollout_launches": int(out[1]), "rollout_fused_steps": int(out[2]),
+                "refill_ms": out[3], "refill_launches": int(out[4]), "step_ms": out[5], "step_launches": int(out[6])}
+
+    def check(self):
+        """Raise if the device reported an internal invariant violation (RNG look-ahead underflow)."""
+        with torch.cuda.device(self.device):
+            self._check(self._L.bg_check(self._h, self._stream()), "bg_check")

@@ -1,0 +1,189 @@
+/* balatro_mi355x.h -- C ABI of the MI355X-native vectorised Balatro environment (libbalatro_mi355x.so).
+ *
+ * This is the drop-in boundary for ONE hot path of cassiusfive/balatro-gym: the step()/reset() loop of
+ * `balatro_gym/balatro_env_2.py::BalatroEnv` (deck shuffle/draw -> hand classification -> chip/mult accumulation ->
+ * joker chain -> planet-level / boss-blind multipliers -> blind outcome -> observation + action mask).  The reference
+ * is pure Python with no FFI; the entry points below are what a ctypes binding on the reference side would call
+ * (see INTEGRATION.md).  Each entry point cites the reference interface it replaces (paths relative to the
+ * reference's balatro_gym/ directory).
+ *
+ * Conventions: plain C, no torch types; every function returns 0 on success and a negative BG_E_* code on failure
+ * (bg_last_error() gives the text); all `*_dev` pointers are DEVICE pointers into buffers the CALLER owns (e.g.
+ * torch tensors' data_ptr()); `stream` is a hipStream_t passed as void* (NULL = default stream); the library owns
+ * the per-env game/RNG state (structure-of-arrays in HBM) and never synchronises the host inside bg_step /
+ * bg_rollout.  One handle drives one GPU; a handle is not thread-safe, different handles are independent.
+ * There is NO CPU fallback: without a HIP device bg_create fails.
+ */
+#ifndef BALATRO_MI355X_H
+#define BALATRO_MI355X_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BG_NUM_ACTIONS 60 /* constants.py:117 ACTION_SPACE_SIZE */
+#define BG_OBS_BYTES 330  /* bytes of one observation in the reference's dtypes */
+
+/* bg_create flags */
+#define BG_FLAG_SCORER_JOKERS 1u /* hand the scorer joker NAMES (unified_scoring.py:313-351) so the joker chain is live */
+#define BG_FLAG_AUTORESET 2u     /* SAME_STEP auto-reset: a terminated env is reset() inside the same bg_step call */
+
+/* error codes */
+#define BG_E_ARG (-1)
+#define BG_E_HIP (-2)
+#define BG_E_NODEVICE (-3)
+#define BG_E_INTERNAL (-4) /* device-side invariant violated (RNG look-ahead ring underflow); sticky */
+
+/* info.error values (device side) -- reference error strings in brackets */
+#define BG_ERR_NONE 0
+#define BG_ERR_INVALID_ACTION 1 /* balatro_env_2.py:627 'Invalid action' */
+#define BG_ERR_PSYCHIC 2        /* boss_blinds.py:388 'Must play exactly 5 cards' */
+#define BG_ERR_EYE 3            /* boss_blinds.py:393 'Cannot play <type> again' */
+#define BG_ERR_MOUTH 4          /* boss_blinds.py:399 'Can only play <type>' */
+#define BG_ERR_VERDANT 5        /* boss_blinds.py:405 'Must play at least <n> cards' */
+#define BG_ERR_REROLL_FUNDS 6   /* shop.py:173 'Insufficient chips for reroll' */
+#define BG_ERR_JOKER_SLOTS 7    /* shop.py:196 'Joker slots full' */
+#define BG_ERR_CONSUMABLE 8     /* tarot / spectral use is outside the accelerated path */
+#define BG_ERR_MAX_ANTE 9       /* balatro_env_2.py:620 terminated 'max_ante_reached' */
+#define BG_ERR_MAX_SCORE 10     /* balatro_env_2.py:623 terminated 'max_score_reached' */
+
+/* info.flags bits */
+#define BG_INFO_BEAT_BLIND 1     /* info['beat_blind'] */
+#define BG_INFO_FAILED 2         /* info['failed'] */
+#define BG_INFO_SKIPPED_BLIND 4  /* info['skipped_blind'] */
+#define BG_INFO_OPENED_PACK 8    /* info['opened_pack'] */
+#define BG_INFO_BOUGHT_CARD 16   /* info['bought_card'] */
+#define BG_INFO_BOUGHT_VOUCHER 32
+#define BG_INFO_BOUGHT_JOKER 64
+#define BG_INFO_SOLD_JOKER 128   /* info['sold_joker'] (aux = joker id) */
+#define BG_INFO_CURRICULUM 256   /* info['curriculum_limit_reached'] (train_balatro_agent.py:146-152) */
+#define BG_INFO_AUTORESET 512    /* the env was reset inside this step (BG_FLAG_AUTORESET) */
+
+/* policies of bg_rollout (counter-hash random policy) */
+#define BG_POLICY_UNIFORM 0    /* k-th valid action, k = hash(seed, env, t) mod n_valid */
+#define BG_POLICY_SMALL_ONLY 1 /* BLIND_SELECT->45, SHOP->31, else uniform (balatro_env_2.py:1841-1849) */
+#define BG_POLICY_CYCLE3 2     /* BLIND_SELECT->45+env%3, SHOP->31, else uniform */
+
+typedef struct bg_handle bg_handle;
+
+/* Observation: one device pointer per key of BalatroEnv._get_observation() (balatro_env_2.py:1488-1531), each a
+ * contiguous [n_envs, ...] array in the REFERENCE's dtype.  A NULL pointer skips that key. */
+typedef struct bg_obs_ptrs {
+  int8_t* hand;                 /* [N,8]  int8, -1 padded */
+  int8_t* hand_size;            /* [N] */
+  int8_t* deck_size;            /* [N] */
+  int64_t* selected_cards;      /* [N,8]  int64 0/1 (the reference emits int64 here) */
+  int64_t* chips_scored;        /* [N] */
+  int32_t* round_chips_scored;  /* [N] */
+  float* progress_ratio;        /* [N] */
+  int32_t* mult;                /* [N] always 1 */
+  int32_t* chips_needed;        /* [N] */
+  int32_t* money;               /* [N] */
+  int16_t* ante;                /* [N] */
+  int8_t* round;                /* [N] */
+  int8_t* hands_left;           /* [N] */
+  int8_t* discards_left;        /* [N] */
+  int8_t* joker_count;          /* [N] */
+  int16_t* joker_ids;           /* [N,10] */
+  int8_t* joker_slots;          /* [N] */
+  int8_t* consumable_count;     /* [N] */
+  int16_t* consumables;         /* [N,5] */
+  int8_t* consumable_slots;     /* [N] */
+  int16_t* shop_items;          /* [N,10] */
+  int16_t* shop_costs;          /* [N,10] */
+  int16_t* shop_rerolls;        /* [N] */
+  int8_t* hand_levels;          /* [N,12] */
+  int8_t* phase;                /* [N] */
+  int8_t* action_mask;          /* [N,60] */
+  int32_t* hands_played;        /* [N] */
+  int32_t* best_hand_this_ante; /* [N] */
+  int8_t* boss_blind_active;    /* [N] */
+  int8_t* boss_blind_type;      /* [N] */
+  int64_t* face_down_cards;     /* [N,8] int64 0/1 */
+} bg_obs_ptrs;
+
+/* Per-step info (the numeric content of the reference's info dict, balatro_env_2.py:895-925).  NULL skips. */
+typedef struct bg_info_ptrs {
+  int64_t* final_score;  /* [N] info['final_score'] on an accepted play, else 0 */
+  int32_t* error;        /* [N] BG_ERR_* */
+  int32_t* flags;        /* [N] BG_INFO_* */
+  int32_t* aux;          /* [N] boss type on action 47 / joker id bought or sold / first pack card */
+  int8_t* hand_type;     /* [N] info['hand_type'] on an accepted play, else -1 */
+  int8_t* cards_played;  /* [N] info['cards_played'] */
+  double* reward_terms;  /* [N,8] info['reward_breakdown'] without 'total' */
+} bg_info_ptrs;
+
+/* Aggregate counters of a rollout (device, one struct per call; all ranks of a sharded job sum them on the host). */
+typedef struct bg_rollout_stats {
+  uint64_t steps;        /* env-steps executed */
+  uint64_t episodes;     /* terminated episodes */
+  uint64_t plays;        /* accepted PLAY_HAND steps */
+  int64_t score_sum;     /* sum of final_score over accepted plays */
+  uint64_t reward_bits;  /* XOR of the IEEE bit patterns of all rewards (order-independent checksum) */
+  uint64_t obs_hash;     /* XOR over (env,t) of a 64-bit hash of each observation row */
+} bg_rollout_stats;
+
+/* Replaces: constructing n_envs `BalatroEnv` objects (balatro_env_2.py:359-384) + SB3 SubprocVecEnv (hpc_train.py:60-65).
+ * max_ante > 0 applies the CurriculumBalatroEnv cap (train_balatro_agent.py:146-152). */
+int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle** out);
+int bg_destroy(bg_handle* h);
+const char* bg_last_error(const bg_handle* h); /* also valid with h == NULL after a failed bg_create */
+int bg_num_envs(const bg_handle* h);
+uint64_t bg_state_bytes(const bg_handle* h); /* HBM held by the library for this handle */
+
+/* Replaces: `DeterministicRNG(seed)` (balatro_env_2.py:84-106) for the masked envs; seeds_host[i] is env i's master seed,
+ * mask_host (nullable = all) selects envs.  reseed_global != 0 also seeds the per-env stand-in for the process-global
+ * `random` module with G(seed) = (seed + 16000) mod 2**32 (harness convention).  Does NOT reset the game. */
+int bg_seed(bg_handle* h, const int64_t* seeds_host, const uint8_t* mask_host, int reseed_global, void* stream);
+
+/* Replaces: `BalatroEnv.reset()` without a seed (balatro_env_2.py:505-558) for the envs with mask_dev[i] != 0
+ * (NULL = all) and writes the observation of EVERY env. */
+int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void* stream);
+
+/* Replaces: `BalatroEnv.step(action)` (balatro_env_2.py:616-637) for all envs in lockstep.  Invalid actions give
+ * reward -1.0 / info.error exactly like the reference; nothing raises. */
+int bg_step(bg_handle* h, const int32_t* actions_dev, const bg_obs_ptrs* obs, double* reward_dev,
+            uint8_t* terminated_dev, uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream);
+
+/* Replaces: `_get_observation()` / `_get_action_mask()` (balatro_env_2.py:1426-1541) without stepping. */
+int bg_observe(bg_handle* h, const bg_obs_ptrs* obs, void* stream);
+
+/* Fused random-policy rollout: T lockstep steps with the counter-hash policy computed on device and SAME_STEP
+ * auto-reset, observations of step t written to row t of [T, N, ...] buffers when obs_stride_steps != 0 (or
+ * overwritten in place when 0).  env_index0 = global index of this handle's env 0 (sharding); t0 = first step number.
+ * Replaces the driver loop of balatro_env_2.py:1835-1859 / SB3 rollout collection. */
+int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t env_index0, uint64_t t0,
+               const bg_obs_ptrs* obs, int obs_stride_steps, double* reward_dev, uint8_t* terminated_dev,
+               int32_t* actions_out_dev, bg_rollout_stats* stats_dev, void* stream);
+
+/* Harness injection (configs 3-4): per-env "reset template" applied by every reset of that env -- owned jokers (ids
+ * from jokers.py), money, ante and hand levels; -1 / NULL leaves a field at its reset default.  apply_now != 0 also
+ * writes them into the live state.  Replaces direct writes to env.state.* (e.g. train_balatro_agent.py:150). */
+int bg_inject(bg_handle* h, const int32_t* jokers_host /*[N,5] or NULL*/, const int32_t* njokers_host /*[N]*/,
+              const int64_t* money_host /*[N] or NULL*/, const int32_t* ante_host /*[N] or NULL*/,
+              const uint8_t* levels_host /*[N,12] or NULL*/, const uint8_t* mask_host, int apply_now, void* stream);
+
+/* Replaces: save_state()/load_state() (balatro_env_2.py:1575-1615).  Blob = versioned raw copy of one env's state
+ * (game + all RNG streams + look-ahead rings).  bg_state_blob_bytes gives the size. */
+uint64_t bg_state_blob_bytes(const bg_handle* h);
+int bg_get_state(bg_handle* h, int env_index, void* blob_host, uint64_t blob_bytes);
+int bg_set_state(bg_handle* h, int env_index, const void* blob_host, uint64_t blob_bytes);
+
+/* Top up the RNG look-ahead rings (pre-shuffled decks, pre-seeded shop streams, global-stream blocks).  bg_step /
+ * bg_reset / bg_rollout call it themselves; exposed for tests and for overlapping it on a side stream. */
+int bg_refill(bg_handle* h, void* stream);
+
+/* Measurement hooks (bench.py): when enabled every kernel launch is bracketed by HIP events on its own stream.
+ * bg_get_profile synchronises and returns out8 = {rollout kernel ms, rollout launches, fused steps summed over
+ * launches, refill kernel ms, refill launches, step kernel ms, step launches, 0} since the last call. */
+int bg_set_profiling(bg_handle* h, int enable);
+int bg_get_profile(bg_handle* h, double* out8);
+
+/* Check the sticky device error word (synchronises the stream). */
+int bg_check(bg_handle* h, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

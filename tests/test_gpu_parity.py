@@ -1,0 +1,290 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI (ctypes ->
+libbalatro_mi355x.so), against (1) the committed golden traces generated from the Python reference and (2) the CPU
+oracle on fresh seeds.  Integer / byte / index results and float64 rewards must be BIT-exact (tolerance 0).
+"""
+import random
+
+import numpy as np
+import pytest
+
+from tests.helpers import OBS_KEYS, load_trace, trace_injection
+
+pytestmark = pytest.mark.gpu
+
+GPU_TRACES = ["c1_small_only", "c2_cycle3", "c3_jokers", "c5_uniform", "c5_uniform_rich"]
+TERMS = 8
+
+
+def _vec(n, seeds, **kw):
+    from balatro_gym_amd import BalatroVecEnv
+    return BalatroVecEnv(n, seeds, device=0, **kw)
+
+
+def _obs_np(env):
+    return {k: v.cpu().numpy() for k, v in env.obs.items()}
+
+
+def _assert_obs(got, want_rows, ctx):
+    for k in OBS_KEYS:
+        g, w = got[k], want_rows[k]
+        if not np.array_equal(g, w):
+            bad = np.argwhere(g.reshape(len(g), -1) != w.reshape(len(w), -1))[0][0]
+            raise AssertionError(f"{ctx}: obs[{k}] differs for env {bad}: got {g[bad]} want {w[bad]}")
+
+
+@pytest.mark.parametrize("name", GPU_TRACES)
+def test_golden_trace(name):
+    """Replay a reference trace: all of its seeds in parallel, same actions, compare everything every step."""
+    import torch
+    tr = load_trace(name)
+    S, T = tr["actions"].shape
+    seeds = [int(s) for s in tr["seeds"]]
+    env = _vec(S, seeds, scorer_jokers=bool(tr["scorer_jokers"]), autoreset=False, max_ante=int(tr["max_ante"]))
+    inj = [trace_injection(tr, si) for si in range(S)]
+    assert not any(i["cards"] for i in inj)
+    if any(i["jokers"] or i["money"] is not None or i["ante"] is not None or i["levels"] for i in inj):
+        levels = np.zeros((S, 12), np.uint8)
+        for si, i in enumerate(inj):
+            for ht, l in i["levels"]:
+                levels[si, ht] = l
+        env.inject(jokers=[i["jokers"] for i in inj],
+                   money=[-1 if i["money"] is None else i["money"] for i in inj],
+                   ante=[0 if i["ante"] is None else i["ante"] for i in inj],
+                   levels=levels if levels.any() else None, apply_now=True)
+        env.observe()
+    _assert_obs(_obs_np(env), {k: tr["obs0_" + k] for k in OBS_KEYS}, f"{name} initial")
+    for t in range(T):
+        a = torch.from_numpy(tr["actions"][:, t].astype(np.int32)).to(env.device)
+        _, reward, term, trunc, info = env.step(a)
+        ctx = f"{name} t {t}"
+        r = reward.cpu().numpy()
+        assert np.array_equal(r.view(np.uint64), tr["rewards"][:, t].view(np.uint64)), \
+            f"{ctx}: rewards {r} vs {tr['rewards'][:, t]}"
+        tm = term.cpu().numpy()
+        assert np.array_equal(tm, tr["terminated"][:, t]), ctx
+        assert not trunc.cpu().numpy().any()
+        assert np.array_equal(info["final_score"].cpu().numpy(), tr["final_score"][:, t]), ctx
+        assert np.array_equal(info["hand_type"].cpu().numpy(), tr["hand_type"][:, t]), ctx
+        err = info["error"].cpu().numpy()
+        assert np.array_equal((err != 0) & (err < 9), tr["error"][:, t].astype(bool) & (err < 9)), ctx
+        _assert_obs(_obs_np(env), {k: tr["obs_" + k][:, t] for k in OBS_KEYS}, ctx)
+        if tm.any():
+            env.reset(mask=torch.from_numpy(tm).to(env.device))  # un-seeded reset() + reset template
+    env.check()
+    env.close()
+
+
+def _oracle_envs(n, seeds, scorer, max_ante, jokers=None):
+    from oracle import pyoracle as po
+    envs = [po.OracleEnv(seeds[i], scorer_jokers=scorer, max_ante=max_ante) for i in range(n)]
+    if jokers:
+        for e, js in zip(envs, jokers):
+            e.set_jokers(js)
+    return envs
+
+
+@pytest.mark.parametrize("policy,scorer", [(0, False), (2, False), (2, True), (0, True)])
+def test_step_vs_oracle_fresh_seeds(policy, scorer):
+    """512 fresh seeds x 250 steps in lockstep with the CPU oracle (actions from the oracle's counter-hash policy)."""
+    import torch
+    from oracle import pyoracle as po
+    from oracle.gen_golden import IMPLEMENTED
+    n, T = 512, 250
+    seeds = [910_000 + 7 * i for i in range(n)]
+    jokers = [random.Random(i).sample(IMPLEMENTED if i % 2 else list(range(1, 151)), i % 6) for i in range(n)] if scorer else None
+    max_ante = 4 if scorer else 0
+    env = _vec(n, seeds, scorer_jokers=scorer, autoreset=False, max_ante=max_ante)
+    if jokers:
+        env.inject(jokers=jokers, apply_now=True)
+        env.observe()
+    orc = _oracle_envs(n, seeds, scorer, max_ante, jokers)
+    want0 = [o.obs() for o in orc]
+    _assert_obs(_obs_np(env), {k: np.stack([w[k] for w in want0]) for k in OBS_KEYS}, "initial")
+    for t in range(T):
+        acts = np.array([o.policy_action(policy, 99, i, t) for i, o in enumerate(orc)], dtype=np.int32)
+        res = [o.step(int(a)) for o, a in zip(orc, acts)]
+        _, reward, term, _, info = env.step(torch.from_numpy(acts).to(env.device))
+        ctx = f"policy {policy} scorer {scorer} t {t}"
+        wr = np.array([r[1] for r in res])
+        assert np.array_equal(reward.cpu().numpy().view(np.uint64), wr.view(np.uint64)), ctx
+        wt = np.array([r[2] for r in res], dtype=np.uint8)
+        assert np.array_equal(term.cpu().numpy(), wt), ctx
+        assert np.array_equal(info["final_score"].cpu().numpy(), np.array([r[4].final_score for r in res])), ctx
+        assert np.array_equal(info["hand_type"].cpu().numpy(), np.array([r[4].hand_type for r in res], dtype=np.int8)), ctx
+        assert np.array_equal(info["cards_played"].cpu().numpy(), np.array([r[4].cards_played for r in res], dtype=np.int8)), ctx
+        assert np.array_equal(info["error"].cpu().numpy(), np.array([r[4].error for r in res], dtype=np.int32)), ctx
+        assert np.array_equal(info["flags"].cpu().numpy() & 511, np.array([r[4].flags for r in res], dtype=np.int32)), ctx
+        wterms = np.array([[r[4].reward_terms[i] for i in range(TERMS)] for r in res])
+        assert np.array_equal(info["reward_terms"].cpu().numpy().view(np.uint64), wterms.view(np.uint64)), ctx
+        _assert_obs(_obs_np(env), {k: np.stack([r[0][k] for r in res]) for k in OBS_KEYS}, ctx)
+        if wt.any():
+            for i in np.nonzero(wt)[0]:
+                orc[i].reset()
+                if jokers:
+                    orc[i].set_jokers(jokers[i])
+            env.reset(mask=torch.from_numpy(wt).to(env.device))
+    env.check()
+    env.close()
+
+
+def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_index0=0, t0=0):
+    """SAME_STEP auto-reset rollout on the oracle; returns per-step obs/rewards/terminated and the stats dict."""
+    orc = _oracle_envs(n, seeds, scorer, max_ante, jokers)
+    obs = {k: [] for k in OBS_KEYS}
+    rewards = np.zeros((T, n)); terms = np.zeros((T, n), np.uint8); acts = np.zeros((T, n), np.int32)
+    stats = {"steps": 0, "episodes": 0, "plays": 0, "score_sum": 0, "reward_bits": 0}
+    for t in range(T):
+        row = []
+        for i, o in enumerate(orc):
+            a = o.policy_action(policy, pseed, env_index0 + i, t0 + t)
+            ob, r, term, _, info = o.step(a)
+            if term:
+                ob = o.reset()
+                if jokers:
+                    o.set_jokers(jokers[i])
+                    ob = o.obs()
+                stats["episodes"] += 1
+            rewards[t, i] = r; terms[t, i] = term; acts[t, i] = a
+            stats["steps"] += 1
+            stats["reward_bits"] ^= (int(np.float64(r).view(np.uint64)) * (2 * (t0 + t) + 1)) & (2 ** 64 - 1)
+            if info.hand_type >= 0:
+                stats["plays"] += 1
+                stats["score_sum"] += info.final_score
+            row.append(ob)
+        for k in OBS_KEYS:
+            obs[k].append(np.stack([r[k] for r in row]))
+    return {k: np.stack(v) for k, v in obs.items()}, rewards, terms, acts, stats
+
+
+@pytest.mark.parametrize("policy,scorer", [(2, False), (0, False), (2, True)])
+def test_fused_rollout_vs_oracle(policy, scorer):
+    """bg_rollout (policy on device, SAME_STEP auto-reset, every step's observation kept) against the oracle."""
+    import torch
+    from balatro_gym_amd.vec_env import ObsBuffers
+    from oracle.gen_golden import IMPLEMENTED
+    n, T = 256, 96
+    seeds = [55_000 + 3 * i for i in range(n)]
+    jokers = [random.Random(1000 + i).sample(IMPLEMENTED, 5) for i in range(n)] if scorer else None
+    max_ante = 4 if scorer else 0
+    env = _vec(n, seeds, scorer_jokers=scorer, autoreset=True, max_ante=max_ante)
+    if jokers:
+        env.inject(jokers=jokers, apply_now=True)
+    ob = ObsBuffers(n, env.device, steps=T)
+    reward = torch.zeros((T, n), dtype=torch.float64, device=env.device)
+    term = torch.zeros((T, n), dtype=torch.uint8, device=env.device)
+    acts = torch.zeros((T, n), dtype=torch.int32, device=env.device)
+    env.rollout(T, policy=policy, policy_seed=4242, env_index0=17, t0=5, obs_buffers=ob, reward=reward, terminated=term,
+                actions=acts)
+    env.check()
+    got_stats = env.stats()
+    wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, T, policy, 4242, scorer, max_ante, jokers, env_index0=17, t0=5)
+    assert np.array_equal(acts.cpu().numpy(), wa)
+    assert np.array_equal(term.cpu().numpy(), wt)
+    assert np.array_equal(reward.cpu().numpy().view(np.uint64), wr.view(np.uint64))
+    for k in OBS_KEYS:
+        g = ob.tensors[k].cpu().numpy()
+        assert np.array_equal(g, wobs[k]), f"rollout obs[{k}] differs at {np.argwhere(g != wobs[k])[0]}"
+    for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
+        assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
+    env.close()
+
+
+def test_rollout_properties_full_size():
+    """Size-independent properties at BASELINE.json's N = 65 536: determinism, chunking invariance (one T=48 call ==
+    48 T=1 calls), sharding invariance (two half-size handles with env_index0 offsets == one full handle)."""
+    import torch
+    n, T = 65536, 48
+    seeds = [1000 + i for i in range(n)]
+
+    def run(count, seeds_, index0, chunks):
+        env = _vec(count, seeds_, autoreset=True)
+        tot = None
+        t0 = 0
+        for c in chunks:
+            env.rollout(c, policy=2, policy_seed=7, env_index0=index0, t0=t0, zero_stats=(t0 == 0))
+            t0 += c
+        env.check()
+        st = env.stats()
+        final = {k: v.clone() for k, v in env.obs.items()}
+        env.close()
+        return st, final
+
+    a, fa = run(n, seeds, 0, [T])
+    b, fb = run(n, seeds, 0, [T])
+    assert a == b, "rollout is not deterministic"
+    assert a["steps"] == n * T and a["episodes"] > 0 and a["plays"] > 0
+    c, fc = run(n, seeds, 0, [1] * T)
+    assert a == c, "chunking changed the result"
+    for k in OBS_KEYS:
+        assert torch.equal(fa[k], fc[k]), k
+    h = n // 2
+    s0, f0 = run(h, seeds[:h], 0, [T])
+    s1, f1 = run(h, seeds[h:], h, [T])
+    for k in ("steps", "episodes", "plays", "score_sum"):
+        assert s0[k] + s1[k] == a[k], k
+    assert s0["reward_bits"] ^ s1["reward_bits"] == a["reward_bits"]
+    assert s0["obs_hash"] ^ s1["obs_hash"] == a["obs_hash"]
+    for k in OBS_KEYS:
+        assert torch.equal(torch.cat([f0[k], f1[k]]), fa[k]), k
+
+
+def test_single_env_gym_surface():
+    """BalatroEnv (N = 1) keeps the reference surface: config 1 of BASELINE.json against the golden trace."""
+    from balatro_gym_amd import BalatroEnv
+    tr = load_trace("c1_small_only")
+    si = 0
+    env = BalatroEnv(seed=int(tr["seeds"][si]))
+    assert env.action_space.n == 60
+    assert set(env.observation_space.spaces.keys()) == set(OBS_KEYS)
+    obs = env._np_obs()
+    for k in OBS_KEYS:
+        assert np.array_equal(obs[k], tr["obs0_" + k][si]) and np.asarray(obs[k]).dtype == tr["obs0_" + k].dtype, k
+    for t in range(200):
+        obs, r, term, trunc, info = env.step(int(tr["actions"][si, t]))
+        assert isinstance(r, float) and r == tr["rewards"][si, t]
+        assert term == bool(tr["terminated"][si, t]) and trunc is False
+        for k in OBS_KEYS:
+            assert np.array_equal(obs[k], tr["obs_" + k][si, t]), (t, k)
+        if "final_score" in info:
+            assert info["final_score"] == tr["final_score"][si, t]
+        if term:
+            obs, inf = env.reset()
+            assert inf == {}
+    # reset(seed=s) reproduces shuffle #1
+    obs, _ = env.reset(seed=int(tr["seeds"][si]))
+    env.step(45)
+    first = env._np_obs()["hand"].tolist()
+    env2 = BalatroEnv(seed=int(tr["seeds"][si]))
+    env2.step(45)
+    assert env2._np_obs()["hand"].tolist() == first
+    env.close(); env2.close()
+
+
+def test_save_load_state_roundtrip():
+    import torch
+    n = 64
+    env = _vec(n, [300 + i for i in range(n)], autoreset=True)
+    env.rollout(40, policy=0, policy_seed=3)
+    blob = env.get_state(5)
+    env.rollout(25, policy=0, policy_seed=3, t0=40)
+    after = {k: v[5].clone() for k, v in env.obs.items()}
+    env.set_state(5, blob)
+    env.rollout(25, policy=0, policy_seed=3, t0=40)
+    for k in OBS_KEYS:
+        assert torch.equal(env.obs[k][5], after[k]), k
+    env.check()
+    env.close()
+
+
+def test_invalid_actions_and_no_raise():
+    """Invalid actions never raise: reward -1.0, state unchanged (balatro_env_2.py:626-627)."""
+    import torch
+    n = 128
+    env = _vec(n, [77 + i for i in range(n)], autoreset=False)
+    before = {k: v.clone() for k, v in env.obs.items()}
+    for bad in (0, 1, 31, 59, -1, 60, 1000):
+        _, r, term, _, info = env.step(torch.full((n,), bad, dtype=torch.int32, device=env.device))
+        assert (r == -1.0).all() and not term.any() and (info["error"] == 1).all()
+        for k in OBS_KEYS:
+            assert torch.equal(env.obs[k], before[k]), (bad, k)
+    env.close()
