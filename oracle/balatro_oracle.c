@@ -439,6 +439,12 @@ void bo_set_jokers(bo_env* e, const int32_t* ids, int n) {
   for (int i = 0; i < e->njokers; i++) e->jokers[i] = ids[i];
 }
 void bo_set_card_state(bo_env* e, int idx, int enh, int edi, int seal) { e->enh[idx] = (uint8_t)enh; e->edi[idx] = (uint8_t)edi; e->seal[idx] = (uint8_t)seal; }
+/* harness convention: jokers re-injected after every reset of a batched rollout (bench config 3) */
+void bo_set_template_jokers(bo_env* e, const int32_t* ids, int n) {
+  e->tmpl_njokers = n > 5 ? 5 : n;
+  for (int i = 0; i < e->tmpl_njokers; i++) e->tmpl_jokers[i] = ids[i];
+  bo_set_jokers(e, ids, e->tmpl_njokers);
+}
 void bo_set_money(bo_env* e, int64_t money) { e->money = money; }
 void bo_set_ante(bo_env* e, int ante) { e->ante = ante; }
 void bo_set_hand_level(bo_env* e, int ht, int level) { e->hand_levels[ht] = (uint8_t)(level < 1 ? 1 : level > 15 ? 15 : level); e->obs_levels[ht] = e->hand_levels[ht]; }
@@ -1063,7 +1069,11 @@ int64_t bo_rollout(bo_env** envs, int n, int64_t env_index0, int T, int policy, 
       int a = bo_policy_action(e, policy, policy_seed, (uint64_t)(env_index0 + i), t0 + (uint64_t)t);
       double r; uint8_t term; bo_info info; bo_obs obs;
       bo_step(e, a, &r, &term, &info);
-      if (term) { bo_reset(e, 0, 0); eps++; }
+      if (term) {
+        bo_reset(e, 0, 0);
+        if (e->tmpl_njokers > 0) bo_set_jokers(e, e->tmpl_jokers, e->tmpl_njokers);
+        eps++;
+      }
       bo_get_obs(e, &obs); /* the reference builds the observation on every step (:1064) */
       rs += r; sc += info.final_score; steps++;
     }

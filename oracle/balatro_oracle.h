@@ -153,6 +153,9 @@ typedef struct bo_env {
   bo_item shop_items[BO_MAX_ITEMS];
   int64_t shop_reroll_base; /* Shop.reroll_cost */
   bo_mt shop_rng;
+  /* harness: reset template used by bo_rollout */
+  int32_t tmpl_jokers[5];
+  int32_t tmpl_njokers;
 } bo_env;
 
 /* ---- CPython random.Random restated (Appendix B of SURVEY.md) ---- */
@@ -190,6 +193,7 @@ void bo_step(bo_env* e, int action, double* reward, uint8_t* terminated, bo_info
 void bo_set_jokers(bo_env* e, const int32_t* ids, int n);          /* harness injection (config 3) */
 void bo_set_card_state(bo_env* e, int deck_idx, int enh, int edi, int seal);
 void bo_set_hand_level(bo_env* e, int hand_type, int level);
+void bo_set_template_jokers(bo_env* e, const int32_t* ids, int n); /* jokers now + after every reset in bo_rollout */
 void bo_set_money(bo_env* e, int64_t money);   /* harness injection: state.money */
 void bo_set_ante(bo_env* e, int ante);         /* harness injection: state.ante */
 int bo_policy_action(const bo_env* e, int policy, uint64_t policy_seed, uint64_t env_index, uint64_t t);
