@@ -6,10 +6,12 @@
 //   deck  uint4[4       ][N]   52 card codes ((rank-2)*4+suit, cards.py:103-104), 12 B pad
 //   cold  uint4[BG_NCOLD][N]   hand_play_counts + shop inventory (touched only by the lanes that need them)
 //   tmpl  uint4[2       ][N]   reset template (harness injection: jokers / money / ante / hand levels)
-//   gblk  u32[KG][624][N]      per-env "global random" stream: ring of consecutive raw MT19937 blocks
-//   sblk  u32[KS][624][N]      ring of pre-seeded shop streams (first block of random.Random(shop_seed))
 //   ndeck uint4[KD][4][N]      ring of pre-shuffled decks (DeterministicRNG 'deck_shuffle' look-ahead)
-//   deckmt / shopgenmt u32[625][N]   authoritative MT state of streams 0 and 2 (+ index word)
+// MT19937 state is the exception: a stream is produced AND consumed by one lane walking consecutive words, so each env
+// owns contiguous 2560-byte blocks (array-of-structures; sparse lanes then write whole lines instead of 4 bytes/line):
+//   gblk  u32[N][KG][640]      per-env "global random" stream: ring of consecutive raw MT19937 blocks (624 words used)
+//   sblk  u32[N][KS][640]      ring of pre-seeded shop streams (first block of random.Random(shop_seed))
+//   deckmt / shopgenmt u32[N][640]   authoritative MT state of streams 0 and 2 (word 624 = index)
 // The serial MT19937 work (seeding = 1247 dependent steps, block twist, 51-swap shuffle) is never on the step path:
 // it runs in the refill kernel, which looks AHEAD on streams whose consumption order does not depend on play
 // (stream 0 is only consumed by reset shuffles, stream 2 only by one get_int per shop visit).
@@ -26,6 +28,8 @@
 #define BG_NTMPL 2
 #define BG_MT_N 624
 #define BG_MT_M 397
+#define BG_MTS 640 // words per stored MT block (624 + index word, padded to 20 x 128 B)
+#define BG_BLOCK 64 // threads per block = one wave64
 
 // device error word bits (sticky; checked by the host, which then fails loudly)
 #define BG_DEVERR_GSTREAM 1u  // global-stream ring underflow
@@ -48,7 +52,8 @@ struct BgDev {
   uint32_t* deckmt;
   uint32_t* shopgenmt;
   uint32_t* err;
-  const uint32_t* mt_init; // init_genrand(19650218) table, 624 words
+  uint32_t* wl_count; // [4] refill work-list lengths: decks, shops, global blocks
+  uint32_t* wl;       // [3][N] env indexes needing a refill of each kind
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -167,6 +172,11 @@ __device__ __forceinline__ int bg_level(const Env& e, int ht) { return (int)((e.
 // Card lookups.  deck chunk 0 (deck indexes 0..15) is held in registers; in the live reference the hand is always a
 // subset of deck[0..hand_size), so the global-memory path below is the rare general case.
 // ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t* bg_gblock(const BgDev& d, int env, int slot) { return d.gblk + ((size_t)env * d.KG + slot) * BG_MTS; }
+__device__ __forceinline__ uint32_t* bg_sblock(const BgDev& d, int env, int slot) { return d.sblk + ((size_t)env * d.KS + slot) * BG_MTS; }
+__device__ __forceinline__ uint32_t* bg_deckmt(const BgDev& d, int env) { return d.deckmt + (size_t)env * BG_MTS; }
+__device__ __forceinline__ uint32_t* bg_shopgenmt(const BgDev& d, int env) { return d.shopgenmt + (size_t)env * BG_MTS; }
+
 struct Deck0 { uint64_t lo, hi; };
 __device__ __forceinline__ Deck0 bg_load_deck0(const BgDev& d, int env) {
   uint4 c = d.deck[env];
@@ -196,36 +206,94 @@ __device__ __forceinline__ uint32_t bg_twist(uint32_t a, uint32_t b, uint32_t fa
   return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
 }
 
+// Per-lane LDS window over the next raw words of an RNG block.  The draws of a play (joker chain: ~2 words per
+// (card, joker) pair) or of a shop generation are consecutive words of ONE block, so they are fetched with
+// independent loads up front and then consumed from LDS: the serial chain of dependent HBM round trips (one per
+// draw, ~1 us each at one wave per SIMD) becomes one batch.  Layout [word][lane] (bank = lane: conflict-free).
+#define BG_WIN 112
+struct RngWin {
+  uint32_t* lds;   // &win[0][lane]
+  int g_blk, g_start, g_len; // window over the global stream: block, first index, words
+  int s_start, s_len;        // window over the current shop stream
+};
+__device__ __forceinline__ void bg_win_init(RngWin& w, uint32_t* lds_lane) {
+  w.lds = lds_lane; w.g_blk = -1; w.g_start = 0; w.g_len = 0; w.s_start = 0; w.s_len = 0;
+}
+__device__ __forceinline__ void bg_win_fill(uint32_t* lds, const uint32_t* src, int len) {
+  for (int base = 0; base < len; base += 8) {
+    uint32_t v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (base + j < len) ? src[base + j] : 0u;
+#pragma unroll
+    for (int j = 0; j < 8; j++) if (base + j < len) lds[(base + j) * BG_BLOCK] = v[j];
+  }
+}
+
 // next raw word of the per-env "global random" stream (ring of blocks, tempered on read)
-__device__ __forceinline__ uint32_t bg_gdraw(const BgDev& d, int env, Env& e) {
-  if (e.g_idx >= BG_MT_N) { e.g_cur = (e.g_cur + 1 == d.KG) ? 0 : e.g_cur + 1; e.g_idx = 0; e.g_valid--; }
+// block switch; g_idx may have been advanced past the end by bg_gskip (words consumed without being read)
+__device__ __forceinline__ void bg_gnorm(const BgDev& d, Env& e) {
+  if (e.g_idx >= BG_MT_N) { e.g_cur = (e.g_cur + 1 == d.KG) ? 0 : e.g_cur + 1; e.g_idx -= BG_MT_N; e.g_valid--; }
+}
+// consume `count` (< 624) words whose values nobody looks at (complete_joker_effects.py draws them eagerly)
+__device__ __forceinline__ void bg_gskip(const BgDev& d, Env& e, int count) {
+  bg_gnorm(d, e);
+  e.g_idx += count;
+}
+__device__ __forceinline__ uint32_t bg_gdraw(const BgDev& d, int env, Env& e, RngWin& w) {
+  bg_gnorm(d, e);
   if (e.g_valid <= 0) { atomicOr(d.err, BG_DEVERR_GSTREAM); e.g_valid = 0; return 0u; }
-  uint32_t y = d.gblk[((size_t)e.g_cur * BG_MT_N + e.g_idx) * d.N + env];
+  uint32_t off = (uint32_t)(e.g_idx - w.g_start);
+  uint32_t y;
+  if (w.g_blk == e.g_cur && off < (uint32_t)w.g_len) y = w.lds[off * BG_BLOCK];
+  else y = bg_gblock(d, env, e.g_cur)[e.g_idx];
   e.g_idx++;
   return bg_temper(y);
 }
+// fetch the next `count` words of the global stream into the window (stops at the block end)
+__device__ __forceinline__ void bg_gprefetch(const BgDev& d, int env, Env& e, RngWin& w, int count) {
+  bg_gnorm(d, e);
+  if (e.g_valid <= 0) return;
+  int len = BG_MT_N - e.g_idx;
+  if (len > count) len = count;
+  if (len > BG_WIN) len = BG_WIN;
+  bg_win_fill(w.lds, bg_gblock(d, env, e.g_cur) + e.g_idx, len);
+  w.g_blk = e.g_cur; w.g_start = e.g_idx; w.g_len = len;
+  w.s_len = 0; // the window storage is shared with the shop stream
+}
 // next raw word of the current shop's random.Random(shop_seed) (shop.py:96)
-__device__ __forceinline__ uint32_t bg_sdraw(const BgDev& d, int env, Env& e) {
+__device__ __forceinline__ uint32_t bg_sdraw(const BgDev& d, int env, Env& e, RngWin& w) {
   if (e.s_idx >= BG_MT_N) { atomicOr(d.err, BG_DEVERR_SHOPBLK); return 0u; }
-  uint32_t y = d.sblk[((size_t)e.s_cur * BG_MT_N + e.s_idx) * d.N + env];
+  uint32_t off = (uint32_t)(e.s_idx - w.s_start);
+  uint32_t y;
+  if (off < (uint32_t)w.s_len) y = w.lds[off * BG_BLOCK];
+  else y = bg_sblock(d, env, e.s_cur)[e.s_idx];
   e.s_idx++;
   return bg_temper(y);
 }
+__device__ __forceinline__ void bg_sprefetch(const BgDev& d, int env, Env& e, RngWin& w, int count) {
+  int len = BG_MT_N - e.s_idx;
+  if (len > count) len = count;
+  if (len > BG_WIN) len = BG_WIN;
+  if (len < 0) len = 0;
+  bg_win_fill(w.lds, bg_sblock(d, env, e.s_cur) + e.s_idx, len);
+  w.s_start = e.s_idx; w.s_len = len;
+  w.g_len = 0; w.g_blk = -1;
+}
 // Lib/random.py _randbelow_with_getrandbits (n >= 1): k = n.bit_length(); r = getrandbits(k) until r < n
 template <bool SHOP>
-__device__ __forceinline__ uint32_t bg_randbelow(const BgDev& d, int env, Env& e, uint32_t n) {
+__device__ __forceinline__ uint32_t bg_randbelow(const BgDev& d, int env, Env& e, RngWin& w, uint32_t n) {
   int k = 32 - __clz(n);
   uint32_t r;
   int guard = 0;
   do {
-    r = (SHOP ? bg_sdraw(d, env, e) : bg_gdraw(d, env, e)) >> (32 - k);
+    r = (SHOP ? bg_sdraw(d, env, e, w) : bg_gdraw(d, env, e, w)) >> (32 - k);
   } while (r >= n && ++guard < 4096);
   return r < n ? r : 0u;
 }
 // random(): (a*67108864.0+b)*(1.0/9007199254740992.0) with a = u32>>5, b = u32>>6
-__device__ __forceinline__ double bg_grandom(const BgDev& d, int env, Env& e) {
-  uint32_t a = bg_gdraw(d, env, e) >> 5;
-  uint32_t b = bg_gdraw(d, env, e) >> 6;
+__device__ __forceinline__ double bg_grandom(const BgDev& d, int env, Env& e, RngWin& w) {
+  uint32_t a = bg_gdraw(d, env, e, w) >> 5;
+  uint32_t b = bg_gdraw(d, env, e, w) >> 6;
   return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
 }
 

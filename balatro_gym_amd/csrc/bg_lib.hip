@@ -17,7 +17,6 @@
 #include <string>
 #include <vector>
 
-#define BG_BLOCK 64
 
 struct InfoPtrs {
   int64_t* final_score; int32_t* error; int32_t* flags; int32_t* aux; int8_t* hand_type; int8_t* cards_played;
@@ -52,11 +51,14 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_step_kernel(BgDev d, const int32_
                                                           double* reward, uint8_t* term, uint8_t* trunc, InfoPtrs info) {
   int env = blockIdx.x * BG_BLOCK + threadIdx.x;
   if (env >= d.N) return;
+  __shared__ uint32_t win[BG_WIN][BG_BLOCK];
+  RngWin w;
+  bg_win_init(w, &win[0][threadIdx.x]);
   Env e;
   bg_load_env(d, env, e);
   Deck0 dk = bg_load_deck0(d, env);
   StepOut o;
-  bg_env_step(d, env, e, dk, actions[env], o);
+  bg_env_step(d, env, e, w, dk, actions[env], o);
   if (o.terminated && (d.flags & BG_FLAG_AUTORESET)) { bg_env_reset(d, env, e, dk); o.flags |= BG_INFO_AUTORESET; }
   bg_store_env(d, env, e);
   uint64_t mask = bg_action_mask(d, env, e);
@@ -71,7 +73,10 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, in
   int env = blockIdx.x * BG_BLOCK + threadIdx.x;
   uint64_t n_steps = 0, n_eps = 0, n_plays = 0, rbits = 0, ohash = 0;
   int64_t ssum = 0;
+  __shared__ uint32_t win[BG_WIN][BG_BLOCK];
   if (env < d.N) {
+    RngWin w;
+    bg_win_init(w, &win[0][threadIdx.x]);
     Env e;
     bg_load_env(d, env, e);
     Deck0 dk = bg_load_deck0(d, env);
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, in
     for (int t = 0; t < T; t++) {
       int action = bg_policy_action(e, mask, policy, policy_seed, env_index0 + (uint64_t)env, t0 + (uint64_t)t);
       StepOut o;
-      bg_env_step(d, env, e, dk, action, o);
+      bg_env_step(d, env, e, w, dk, action, o);
       if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; } // SAME_STEP auto-reset
       mask = bg_action_mask(d, env, e);
       size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
@@ -134,91 +139,93 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_observe_kernel(BgDev d, ObsPtrs o
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// MT19937 on structure-of-arrays state: word i of env `env` lives at p[i * N] (p already offset by env)
+// MT19937 on a lane-private contiguous state block (word i at p[i]; see bg_device.h for why this is not SoA)
 // ---------------------------------------------------------------------------------------------------------
 // CPython random_seed()/init_by_array() for a ONE-word key (every stream / shop / global seed is < 2**32).
-// init_genrand(19650218) is a constant table (d.mt_init); the key-dependent passes are 1247 dependent steps.
-__device__ void bg_mt_seed_soa(const BgDev& d, uint32_t* p, uint32_t key) {
-  size_t N = d.N;
-  uint32_t prev = d.mt_init[0];
+// The key-dependent passes are 1247 DEPENDENT steps per stream; the only way to make them cheap is to keep memory out
+// of the dependency chain: pass 1 regenerates init_genrand(19650218) in a second register chain (no loads at all),
+// pass 2 and the block twist fetch their operands in batches of BG_MTB independent loads before running the chain.
+#define BG_MTB 16
+#define BG_RWIN 96 // words of the deck stream prefetched per shuffle (refill kernel)
+__device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) {
+  uint32_t g = 19650218u; // init_genrand seed; g tracks init_genrand's mt[i]
+  uint32_t prev = g;      // mt[0]
   uint32_t mt1 = 0;
-  for (int i = 1; i < BG_MT_N; i++) { // first pass, i = 1..623 (j is always 0)
-    uint32_t v = (d.mt_init[i] ^ ((prev ^ (prev >> 30)) * 1664525u)) + key;
-    p[(size_t)i * N] = v;
+  for (int i = 1; i < BG_MT_N; i++) { // first pass, i = 1..623 (key index j is always 0)
+    g = 1812433253u * (g ^ (g >> 30)) + (uint32_t)i;
+    uint32_t v = (g ^ ((prev ^ (prev >> 30)) * 1664525u)) + key;
+    p[i] = v;
     if (i == 1) mt1 = v;
     prev = v;
   }
-  // wrap: mt[0] = mt[623]; 624th iteration at i = 1
-  {
+  { // wrap: mt[0] = mt[623]; 624th iteration at i = 1
     uint32_t mt0 = prev;
     uint32_t v = (mt1 ^ ((mt0 ^ (mt0 >> 30)) * 1664525u)) + key;
     mt1 = v;
     prev = v;
   }
-  // second pass: 623 iterations starting at i = 2
-  for (int i = 2; i < BG_MT_N; i++) {
-    uint32_t cur = p[(size_t)i * N];
-    uint32_t v = (cur ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
-    p[(size_t)i * N] = v;
-    prev = v;
+  // second pass: 622 iterations i = 2..623, then the wrapped one at i = 1
+  for (int base = 2; base < BG_MT_N; base += BG_MTB) {
+    uint32_t buf[BG_MTB];
+#pragma unroll
+    for (int j = 0; j < BG_MTB; j++) { int i = base + j; buf[j] = (i < BG_MT_N) ? p[i] : 0u; }
+#pragma unroll
+    for (int j = 0; j < BG_MTB; j++) {
+      int i = base + j;
+      if (i < BG_MT_N) {
+        uint32_t v = (buf[j] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+        p[i] = v;
+        prev = v;
+      }
+    }
   }
   {
     uint32_t mt0 = prev; // mt[0] = mt[623]
-    uint32_t v = (mt1 ^ ((mt0 ^ (mt0 >> 30)) * 1566083941u)) - 1u;
-    p[N] = v;
+    p[1] = (mt1 ^ ((mt0 ^ (mt0 >> 30)) * 1566083941u)) - 1u;
   }
   p[0] = 0x80000000u;
 }
 
-// genrand_uint32()'s block regeneration, in place
-__device__ void bg_mt_twist_inplace(uint32_t* p, size_t N) {
-  uint32_t cur = p[0], first_new = 0;
-  for (int kk = 0; kk < BG_MT_N - BG_MT_M; kk++) {
-    uint32_t nxt = p[(size_t)(kk + 1) * N];
-    uint32_t v = bg_twist(cur, nxt, p[(size_t)(kk + BG_MT_M) * N]);
-    p[(size_t)kk * N] = v;
-    if (kk == 0) first_new = v;
-    cur = nxt;
-  }
-  for (int kk = BG_MT_N - BG_MT_M; kk < BG_MT_N - 1; kk++) {
-    uint32_t nxt = p[(size_t)(kk + 1) * N];
-    uint32_t v = bg_twist(cur, nxt, p[(size_t)(kk + BG_MT_M - BG_MT_N) * N]);
-    p[(size_t)kk * N] = v;
-    cur = nxt;
-  }
-  p[(size_t)(BG_MT_N - 1) * N] = bg_twist(cur, first_new, p[(size_t)(BG_MT_M - 1) * N]);
-}
-
-// the same, from block `src` into block `dst` (next block of a continuous stream)
-__device__ void bg_mt_twist_next(const uint32_t* src, uint32_t* dst, size_t N) {
+// genrand_uint32()'s block regeneration: dst[kk] = twist(src[kk], src[kk+1], kk < 227 ? src[kk+397] : dst[kk-227]),
+// last element uses the NEW dst[0].  dst == src gives CPython's in-place update (operands are loaded per batch before
+// any element of the batch is stored; BG_MTB < 227 keeps the kk-227 operands already written).
+__device__ void bg_mt_twist(const uint32_t* src, uint32_t* dst) {
   uint32_t cur = src[0], first_new = 0;
-  for (int kk = 0; kk < BG_MT_N - BG_MT_M; kk++) {
-    uint32_t nxt = src[(size_t)(kk + 1) * N];
-    uint32_t v = bg_twist(cur, nxt, src[(size_t)(kk + BG_MT_M) * N]);
-    dst[(size_t)kk * N] = v;
-    if (kk == 0) first_new = v;
-    cur = nxt;
+  for (int base = 0; base < BG_MT_N - 1; base += BG_MTB) {
+    uint32_t nxt[BG_MTB], far[BG_MTB];
+#pragma unroll
+    for (int j = 0; j < BG_MTB; j++) {
+      int kk = base + j;
+      if (kk < BG_MT_N - 1) {
+        nxt[j] = src[kk + 1];
+        far[j] = (kk < BG_MT_N - BG_MT_M) ? src[kk + BG_MT_M] : dst[kk + BG_MT_M - BG_MT_N];
+      } else { nxt[j] = 0; far[j] = 0; }
+    }
+#pragma unroll
+    for (int j = 0; j < BG_MTB; j++) {
+      int kk = base + j;
+      if (kk < BG_MT_N - 1) {
+        uint32_t v = bg_twist(cur, nxt[j], far[j]);
+        dst[kk] = v;
+        if (kk == 0) first_new = v;
+        cur = nxt[j];
+      }
+    }
   }
-  for (int kk = BG_MT_N - BG_MT_M; kk < BG_MT_N - 1; kk++) {
-    uint32_t nxt = src[(size_t)(kk + 1) * N];
-    uint32_t v = bg_twist(cur, nxt, dst[(size_t)(kk + BG_MT_M - BG_MT_N) * N]);
-    dst[(size_t)kk * N] = v;
-    cur = nxt;
-  }
-  dst[(size_t)(BG_MT_N - 1) * N] = bg_twist(cur, first_new, dst[(size_t)(BG_MT_M - 1) * N]);
+  dst[BG_MT_N - 1] = bg_twist(cur, first_new, dst[BG_MT_M - 1]);
 }
 
-// genrand_uint32() on an authoritative stream state (624 words + index word at row 624)
-__device__ __forceinline__ uint32_t bg_mt_next(uint32_t* p, size_t N, uint32_t& mti) {
-  if (mti >= BG_MT_N) { bg_mt_twist_inplace(p, N); mti = 0; }
-  uint32_t y = p[(size_t)mti * N];
+// genrand_uint32() on an authoritative stream state (624 words + index word at [624])
+__device__ __forceinline__ uint32_t bg_mt_next(uint32_t* p, uint32_t& mti) {
+  if (mti >= BG_MT_N) { bg_mt_twist(p, p); mti = 0; }
+  uint32_t y = p[mti];
   mti++;
   return bg_temper(y);
 }
-__device__ __forceinline__ uint32_t bg_mt_randbelow(uint32_t* p, size_t N, uint32_t& mti, uint32_t n) {
+__device__ __forceinline__ uint32_t bg_mt_randbelow(uint32_t* p, uint32_t& mti, uint32_t n) {
   int k = 32 - __clz(n);
   uint32_t r;
-  do { r = bg_mt_next(p, N, mti) >> (32 - k); } while (r >= n);
+  do { r = bg_mt_next(p, mti) >> (32 - k); } while (r >= n);
   return r;
 }
 
@@ -229,107 +236,158 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_
   int env = blockIdx.x * BG_BLOCK + threadIdx.x;
   if (env >= d.N) return;
   if (mask_in && !mask_in[env]) return;
-  size_t N = d.N;
+  RngWin w;
+  bg_win_init(w, nullptr);
   Env e;
   bg_load_env(d, env, e);
   int64_t seed = seeds[env];
   if (reseed_global) {
     uint32_t gs = (uint32_t)((uint64_t)seed + 16000ull);
-    uint32_t* g = d.gblk + env; // slot 0
-    bg_mt_seed_soa(d, g, gs);
-    bg_mt_twist_inplace(g, N); // first block = what the first 624 getrandbits(32) read
+    uint32_t* g = bg_gblock(d, env, 0);
+    bg_mt_seed(g, gs);
+    bg_mt_twist(g, g); // first block = what the first 624 getrandbits(32) read
     e.g_cur = 0; e.g_idx = 0; e.g_valid = 1;
   }
   if (seed == 0) { // `master_seed or random.randint(0, 2**32 - 1)` (:88): _randbelow(2**32), k = 33 bits
     uint64_t r;
     int guard = 0;
     do {
-      uint64_t lo = bg_gdraw(d, env, e);
-      uint64_t hi = bg_gdraw(d, env, e) >> 31;
+      uint64_t lo = bg_gdraw(d, env, e, w);
+      uint64_t hi = bg_gdraw(d, env, e, w) >> 31;
       r = lo | (hi << 32);
     } while (r >= 4294967296ull && ++guard < 4096);
     seed = (int64_t)(r & 0xffffffffull);
   }
   uint32_t base = (uint32_t)(uint64_t)seed;
-  bg_mt_seed_soa(d, d.deckmt + env, base);
-  d.deckmt[(size_t)BG_MT_N * N + env] = BG_MT_N;
-  bg_mt_seed_soa(d, d.shopgenmt + env, base + 2000u);
-  d.shopgenmt[(size_t)BG_MT_N * N + env] = BG_MT_N;
+  bg_mt_seed(bg_deckmt(d, env), base);
+  bg_deckmt(d, env)[BG_MT_N] = BG_MT_N;
+  bg_mt_seed(bg_shopgenmt(d, env), base + 2000u);
+  bg_shopgenmt(d, env)[BG_MT_N] = BG_MT_N;
   e.d_head = 0; e.d_ready = 0; // look-ahead rings are functions of the streams: invalidate
   e.s_ready = 0;
   bg_store_env(d, env, e);
 }
 
-// RNG look-ahead.  Every lane inspects its env's ring counters and tops the rings up:
-//   * ndeck: `rng.shuffle('deck_shuffle', deck)` (balatro_env_2.py:525) on stream 0
-//   * sblk : `shop_seed = rng.get_int('shop_generation', 0, 2**31 - 1)` (:1389) then `random.Random(shop_seed)`
-//            (shop.py:96) seeded + first block regenerated
-//   * gblk : next 624-word block(s) of the per-env global stream
-__global__ __launch_bounds__(BG_BLOCK) void bg_refill_kernel(BgDev d) {
-  __shared__ uint8_t sdeck[52][BG_BLOCK];
+// ---------------------------------------------------------------------------------------------------------
+// RNG look-ahead (refill).  Only ~2% of the envs need a new deck / shop stream / global block after a step, and each
+// such item is a long SERIAL computation, so the work is compacted first: a scan kernel (lane = env, three 16-byte
+// loads) appends the needy envs to per-kind work lists with wave-aggregated atomics; dense kernels (lane = work item)
+// then run the serial MT19937 code with every lane busy.
+//   * decks : `rng.shuffle('deck_shuffle', deck)` (balatro_env_2.py:525) on stream 0
+//   * shops : `shop_seed = rng.get_int('shop_generation', 0, 2**31 - 1)` (:1389), `random.Random(shop_seed)` (shop.py:96)
+//   * gblk  : next 624-word block(s) of the per-env global stream
+// ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
   int env = blockIdx.x * BG_BLOCK + threadIdx.x;
   if (env >= d.N) return;
   size_t N = d.N;
-  uint4 c5 = d.hot[(size_t)5 * N + env], c6 = d.hot[(size_t)6 * N + env], c7 = d.hot[(size_t)7 * N + env];
-  int d_head = bg_b(c5.w, 2), d_ready = bg_b(c5.w, 3);
-  int g_cur = bg_b(c6.w, 2), g_valid = bg_b(c6.w, 3);
-  int g_idx = (int)(c7.x & 0xffffu);
-  int s_cur = bg_b(c7.y, 0), s_ready = bg_b(c7.y, 1);
-  if (g_valid > 0 && g_idx >= BG_MT_N) { g_cur = (g_cur + 1 == d.KG) ? 0 : g_cur + 1; g_idx = 0; g_valid--; }
-  bool seeded = d.deckmt[(size_t)BG_MT_N * N + env] != 0; // index word is 0 only before the first bg_seed
-  bool need = seeded && (d_ready < d.KD || s_ready < d.KS - 1 || (g_valid > 0 && g_valid < d.KG));
-  if (!need) return;
-  // ---- pre-shuffled decks
-  if (d_ready < d.KD) {
-    uint32_t* mt = d.deckmt + env;
-    uint32_t mti = mt[(size_t)BG_MT_N * N];
-    int tid = threadIdx.x;
+  uint32_t w5 = ((const uint32_t*)&d.hot[(size_t)5 * N + env])[3];
+  uint32_t w6 = ((const uint32_t*)&d.hot[(size_t)6 * N + env])[3];
+  uint2 w7 = *((const uint2*)&d.hot[(size_t)7 * N + env]);
+  int d_ready = bg_b(w5, 3);
+  int g_cur = bg_b(w6, 2), g_valid = bg_b(w6, 3);
+  int g_idx = (int)(w7.x & 0xffffu);
+  int s_ready = bg_b(w7.y, 1);
+  bool seeded = bg_deckmt(d, env)[BG_MT_N] != 0; // index word is 0 only before the first bg_seed
+  if (!seeded) return;
+  if (g_valid > 0 && g_idx >= BG_MT_N) { // finish a pending block switch so the exhausted block can be reused
+    g_cur = (g_cur + 1 == d.KG) ? 0 : g_cur + 1; g_idx -= BG_MT_N; g_valid--;
+    ((uint32_t*)&d.hot[(size_t)6 * N + env])[3] = (w6 & 0x0000ffffu) | ((uint32_t)g_cur << 16) | ((uint32_t)g_valid << 24);
+    ((uint32_t*)&d.hot[(size_t)7 * N + env])[0] = (w7.x & 0xffff0000u) | (uint32_t)g_idx;
+    if (g_valid <= 0) atomicOr(d.err, BG_DEVERR_GSTREAM);
+  }
+  if (d_ready < d.KD) { uint32_t i = atomicAdd(&d.wl_count[0], 1u); d.wl[i] = (uint32_t)env; }
+  if (s_ready < d.KS - 1) { uint32_t i = atomicAdd(&d.wl_count[1], 1u); d.wl[N + i] = (uint32_t)env; }
+  if (g_valid > 0 && g_valid < d.KG) { uint32_t i = atomicAdd(&d.wl_count[2], 1u); d.wl[2 * N + i] = (uint32_t)env; }
+}
+
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
+  __shared__ uint8_t sdeck[52][BG_BLOCK];
+  __shared__ uint32_t rwin[BG_RWIN][BG_BLOCK];
+  size_t N = d.N;
+  int tid = threadIdx.x;
+  uint32_t count = d.wl_count[0];
+  for (uint32_t item = blockIdx.x * BG_BLOCK + tid; item < count; item += gridDim.x * BG_BLOCK) {
+    int env = (int)d.wl[item];
+    uint32_t* w5p = ((uint32_t*)&d.hot[(size_t)5 * N + env]) + 3;
+    uint32_t w5 = *w5p;
+    int d_head = bg_b(w5, 2), d_ready = bg_b(w5, 3);
+    uint32_t* mt = bg_deckmt(d, env);
+    uint32_t mti = mt[BG_MT_N];
     while (d_ready < d.KD) {
+      // the ~51-70 words a shuffle consumes are consecutive words of the stream: fetch them with independent loads
+      if (mti >= BG_MT_N) { bg_mt_twist(mt, mt); mti = 0; }
+      int wl = BG_MT_N - (int)mti; if (wl > BG_RWIN) wl = BG_RWIN;
+      bg_win_fill(&rwin[0][tid], mt + mti, wl);
+      int wpos = 0;
       int p = 0;
       for (int s = 0; s < 4; s++) for (int r = 0; r < 13; r++) sdeck[p++][tid] = (uint8_t)(r * 4 + s); // :519-522
-      for (int i = 51; i >= 1; i--) { // random.shuffle
-        uint32_t j = bg_mt_randbelow(mt, N, mti, (uint32_t)(i + 1));
+      for (int i = 51; i >= 1; i--) { // random.shuffle: j = _randbelow(i + 1)
+        int k = 32 - __clz((uint32_t)(i + 1));
+        uint32_t j;
+        do {
+          uint32_t y;
+          if (wpos < wl) { y = bg_temper(rwin[wpos][tid]); wpos++; mti++; }
+          else y = bg_mt_next(mt, mti);
+          j = y >> (32 - k);
+        } while (j >= (uint32_t)(i + 1));
         uint8_t a = sdeck[i][tid], b = sdeck[j][tid];
         sdeck[i][tid] = b; sdeck[j][tid] = a;
       }
       int slot = d_head + d_ready; if (slot >= d.KD) slot -= d.KD;
 #pragma unroll
       for (int k = 0; k < BG_NDECK; k++) {
-        uint32_t w[4] = {0, 0, 0, 0};
+        uint32_t wv[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int b = 0; b < 16; b++) { int i = k * 16 + b; if (i < 52) w[b >> 2] |= (uint32_t)sdeck[i][tid] << (8 * (b & 3)); }
-        d.ndeck[((size_t)slot * BG_NDECK + k) * N + env] = make_uint4(w[0], w[1], w[2], w[3]);
+        for (int b = 0; b < 16; b++) { int i = k * 16 + b; if (i < 52) wv[b >> 2] |= (uint32_t)sdeck[i][tid] << (8 * (b & 3)); }
+        d.ndeck[((size_t)slot * BG_NDECK + k) * N + env] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
       }
       d_ready++;
     }
-    mt[(size_t)BG_MT_N * N] = mti;
+    mt[BG_MT_N] = mti;
+    *w5p = (w5 & 0x00ffffffu) | ((uint32_t)d_ready << 24);
   }
-  // ---- pre-seeded shop streams
-  if (s_ready < d.KS - 1) {
-    uint32_t* mt = d.shopgenmt + env;
-    uint32_t mti = mt[(size_t)BG_MT_N * N];
+}
+
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop_kernel(BgDev d) {
+  size_t N = d.N;
+  uint32_t count = d.wl_count[1];
+  for (uint32_t item = blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
+    int env = (int)d.wl[N + item];
+    uint32_t* w7p = ((uint32_t*)&d.hot[(size_t)7 * N + env]) + 1;
+    uint32_t w7 = *w7p;
+    int s_cur = bg_b(w7, 0), s_ready = bg_b(w7, 1);
+    uint32_t* mt = bg_shopgenmt(d, env);
+    uint32_t mti = mt[BG_MT_N];
     while (s_ready < d.KS - 1) {
-      uint32_t shop_seed = bg_mt_randbelow(mt, N, mti, 2147483648u);
+      uint32_t shop_seed = bg_mt_randbelow(mt, mti, 2147483648u);
       int slot = s_cur + 1 + s_ready; while (slot >= d.KS) slot -= d.KS;
-      uint32_t* blk = d.sblk + (size_t)slot * BG_MT_N * N + env;
-      bg_mt_seed_soa(d, blk, shop_seed);
-      bg_mt_twist_inplace(blk, N);
+      uint32_t* blk = bg_sblock(d, env, slot);
+      bg_mt_seed(blk, shop_seed);
+      bg_mt_twist(blk, blk);
       s_ready++;
     }
-    mt[(size_t)BG_MT_N * N] = mti;
+    mt[BG_MT_N] = mti;
+    *w7p = (w7 & 0xffff00ffu) | ((uint32_t)s_ready << 8);
   }
-  // ---- next blocks of the global stream
-  while (g_valid > 0 && g_valid < d.KG) {
-    int last = g_cur + g_valid - 1; if (last >= d.KG) last -= d.KG;
-    int nxt = last + 1 == d.KG ? 0 : last + 1;
-    bg_mt_twist_next(d.gblk + (size_t)last * BG_MT_N * N + env, d.gblk + (size_t)nxt * BG_MT_N * N + env, N);
-    g_valid++;
+}
+
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_gblk_kernel(BgDev d) {
+  size_t N = d.N;
+  uint32_t count = d.wl_count[2];
+  for (uint32_t item = blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
+    int env = (int)d.wl[2 * N + item];
+    uint32_t* w6p = ((uint32_t*)&d.hot[(size_t)6 * N + env]) + 3;
+    uint32_t w6 = *w6p;
+    int g_cur = bg_b(w6, 2), g_valid = bg_b(w6, 3);
+    while (g_valid > 0 && g_valid < d.KG) {
+      int last = g_cur + g_valid - 1; if (last >= d.KG) last -= d.KG;
+      int nxt = last + 1 == d.KG ? 0 : last + 1;
+      bg_mt_twist(bg_gblock(d, env, last), bg_gblock(d, env, nxt));
+      g_valid++;
+    }
+    *w6p = (w6 & 0x00ffffffu) | ((uint32_t)g_valid << 24);
   }
-  c5.w = (c5.w & 0x0000ffffu) | ((uint32_t)d_head << 16) | ((uint32_t)d_ready << 24);
-  c6.w = (c6.w & 0x0000ffffu) | ((uint32_t)g_cur << 16) | ((uint32_t)g_valid << 24);
-  c7.x = (c7.x & 0xffff0000u) | (uint32_t)g_idx;
-  c7.y = (c7.y & 0xffff0000u) | (uint32_t)s_cur | ((uint32_t)s_ready << 8);
-  d.hot[(size_t)5 * N + env] = c5; d.hot[(size_t)6 * N + env] = c6; d.hot[(size_t)7 * N + env] = c7;
 }
 
 // apply the reset template to the live state (bg_inject apply_now)
@@ -356,7 +414,6 @@ struct bg_handle {
   bool seeded;
   int64_t* d_seeds;
   uint8_t* d_mask;
-  uint32_t* d_mt_init;
   std::vector<uint4> h_tmpl;
   uint64_t bytes;
   std::string err;
@@ -442,7 +499,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (device_id < 0 || device_id >= ndev) { g_create_err = "bg_create: device_id out of range"; return BG_E_ARG; }
   bg_handle* h = new bg_handle();
   h->device_id = device_id; h->seeded = false; h->bytes = 0; h->profiling = false;
-  h->d_seeds = nullptr; h->d_mask = nullptr; h->d_mt_init = nullptr;
+  h->d_seeds = nullptr; h->d_mask = nullptr;
   memset(&h->dev, 0, sizeof(h->dev));
   BgDev& d = h->dev;
   d.N = n_envs; d.flags = flags; d.max_ante = max_ante;
@@ -456,26 +513,20 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (e == hipSuccess) e = bg_alloc(h, &d.cold, BG_NCOLD * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.tmpl, BG_NTMPL * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.ndeck, (size_t)d.KD * BG_NDECK * N);
-  if (e == hipSuccess) e = bg_alloc(h, &d.gblk, (size_t)d.KG * BG_MT_N * N);
-  if (e == hipSuccess) e = bg_alloc(h, &d.sblk, (size_t)d.KS * BG_MT_N * N);
-  if (e == hipSuccess) e = bg_alloc(h, &d.deckmt, (size_t)(BG_MT_N + 1) * N);
-  if (e == hipSuccess) e = bg_alloc(h, &d.shopgenmt, (size_t)(BG_MT_N + 1) * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.gblk, (size_t)d.KG * BG_MTS * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.sblk, (size_t)d.KS * BG_MTS * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.deckmt, (size_t)BG_MTS * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.shopgenmt, (size_t)BG_MTS * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.wl_count, 4);
+  if (e == hipSuccess) e = bg_alloc(h, &d.wl, 3 * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.err, 4);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_seeds, N);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_mask, N);
-  if (e == hipSuccess) e = bg_alloc(h, &h->d_mt_init, (size_t)BG_MT_N);
-  if (e == hipSuccess) {
-    std::vector<uint32_t> init(BG_MT_N);
-    init[0] = 19650218u; // init_genrand(19650218)
-    for (int i = 1; i < BG_MT_N; i++) init[i] = 1812433253u * (init[i - 1] ^ (init[i - 1] >> 30)) + (uint32_t)i;
-    e = hipMemcpy(h->d_mt_init, init.data(), BG_MT_N * sizeof(uint32_t), hipMemcpyHostToDevice);
-  }
   if (e != hipSuccess) {
     g_create_err = std::string("bg_create: ") + hipGetErrorString(e);
     bg_destroy(h);
     return BG_E_HIP;
   }
-  d.mt_init = h->d_mt_init;
   h->h_tmpl.assign(BG_NTMPL * N, make_uint4(0, 0, 0, 0));
   *out = h;
   return 0;
@@ -485,7 +536,7 @@ int bg_destroy(bg_handle* h) {
   if (!h) return 0;
   BgDev& d = h->dev;
   hipFree(d.hot); hipFree(d.deck); hipFree(d.cold); hipFree(d.tmpl); hipFree(d.ndeck); hipFree(d.gblk); hipFree(d.sblk);
-  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(h->d_mt_init);
+  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl);
   delete h;
   return 0;
 }
@@ -496,9 +547,15 @@ uint64_t bg_state_bytes(const bg_handle* h) { return h ? h->bytes : 0; }
 
 int bg_refill(bg_handle* h, void* stream) {
   if (!h) return BG_E_ARG;
-  bg_ev_begin(h, h->ev_refill, (hipStream_t)stream);
-  hipLaunchKernelGGL(bg_refill_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev);
-  bg_ev_end(h, h->ev_refill, (hipStream_t)stream);
+  hipStream_t s = (hipStream_t)stream;
+  bg_ev_begin(h, h->ev_refill, s);
+  BG_HIP(hipMemsetAsync(h->dev.wl_count, 0, 4 * sizeof(uint32_t), s));
+  hipLaunchKernelGGL(bg_refill_scan_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, h->dev);
+  int dense = bg_grid(h) < 1024 ? bg_grid(h) : 1024; // grid-stride over the compacted work lists
+  hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, h->dev);
+  hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, h->dev);
+  hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, h->dev);
+  bg_ev_end(h, h->ev_refill, s);
   BG_HIP(hipGetLastError());
   return 0;
 }
@@ -678,8 +735,9 @@ static void bg_slices(bg_handle* h, std::vector<BgSlice>& v) {
   BgDev& d = h->dev;
   v.push_back({d.hot, BG_NHOT, 16}); v.push_back({d.deck, BG_NDECK, 16}); v.push_back({d.cold, BG_NCOLD, 16});
   v.push_back({d.tmpl, BG_NTMPL, 16}); v.push_back({d.ndeck, (size_t)d.KD * BG_NDECK, 16});
-  v.push_back({d.gblk, (size_t)d.KG * BG_MT_N, 4}); v.push_back({d.sblk, (size_t)d.KS * BG_MT_N, 4});
-  v.push_back({d.deckmt, BG_MT_N + 1, 4}); v.push_back({d.shopgenmt, BG_MT_N + 1, 4});
+  // per-env contiguous MT blocks: one "row" of KG*2560 / KS*2560 / 2560 bytes at base + env * elem
+  v.push_back({d.gblk, 1, (size_t)d.KG * BG_MTS * 4}); v.push_back({d.sblk, 1, (size_t)d.KS * BG_MTS * 4});
+  v.push_back({d.deckmt, 1, (size_t)BG_MTS * 4}); v.push_back({d.shopgenmt, 1, (size_t)BG_MTS * 4});
 }
 uint64_t bg_state_blob_bytes(const bg_handle* h) {
   if (!h) return 0;

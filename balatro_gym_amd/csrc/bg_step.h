@@ -115,9 +115,10 @@ __device__ __forceinline__ int bg_candidate(const Env& e, int j) {
   return id;
 }
 
-__device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& e) { // shop.py:111-139
+__device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& e, RngWin& w) {
+  bg_sprefetch(d, env, e, w, 24); // shop.py:111-139
   double mult = bg_shop_cost_mult(e);
-  int third = PK_TAROT + (int)bg_randbelow<true>(d, env, e, 3u); // rng.choice([...]) is evaluated before the loop
+  int third = PK_TAROT + (int)bg_randbelow<true>(d, env, e, w, 3u); // rng.choice([...]) is evaluated before the loop
   int c_pack2 = third == PK_TAROT ? 600 : (third == PK_PLANET ? 900 : 1300);
   int32_t cost[9];
   uint32_t tp[9];
@@ -129,16 +130,16 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
   uint32_t nc = (uint32_t)(145 - owned145);
   // random.sample(candid, 3): n > 21 -> selection-set method (Lib/random.py sample())
   int p0, p1, p2, guard = 0;
-  p0 = (int)bg_randbelow<true>(d, env, e, nc);
-  do { p1 = (int)bg_randbelow<true>(d, env, e, nc); } while (p1 == p0 && ++guard < 4096);
-  do { p2 = (int)bg_randbelow<true>(d, env, e, nc); } while ((p2 == p0 || p2 == p1) && ++guard < 4096);
+  p0 = (int)bg_randbelow<true>(d, env, e, w, nc);
+  do { p1 = (int)bg_randbelow<true>(d, env, e, w, nc); } while (p1 == p0 && ++guard < 4096);
+  do { p2 = (int)bg_randbelow<true>(d, env, e, w, nc); } while ((p2 == p0 || p2 == p1) && ++guard < 4096);
   int j0 = bg_candidate(e, p0), j1 = bg_candidate(e, p1), j2 = bg_candidate(e, p2);
   cost[3] = (int32_t)((double)BG_JOKER_COST[j0] * mult); tp[3] = IT_JOKER | ((uint32_t)j0 << 8);
   cost[4] = (int32_t)((double)BG_JOKER_COST[j1] * mult); tp[4] = IT_JOKER | ((uint32_t)j1 << 8);
   cost[5] = (int32_t)((double)BG_JOKER_COST[j2] * mult); tp[5] = IT_JOKER | ((uint32_t)j2 << 8);
-  int v = (int)bg_randbelow<true>(d, env, e, 2u); // 0 'Voucher: Magic Trick' 600, 1 'Voucher: Minimalist' 750
+  int v = (int)bg_randbelow<true>(d, env, e, w, 2u); // 0 'Voucher: Magic Trick' 600, 1 'Voucher: Minimalist' 750
   cost[6] = (int32_t)((v ? 750.0 : 600.0) * mult); tp[6] = IT_VOUCHER | ((uint32_t)v << 8);
-  int ca = (int)bg_randbelow<true>(d, env, e, 52u), cb = (int)bg_randbelow<true>(d, env, e, 52u); // randint(0, 51)
+  int ca = (int)bg_randbelow<true>(d, env, e, w, 52u), cb = (int)bg_randbelow<true>(d, env, e, w, 52u); // randint(0, 51)
   cost[7] = 40; tp[7] = IT_CARD | ((uint32_t)ca << 8);
   cost[8] = 40; tp[8] = IT_CARD | ((uint32_t)cb << 8);
   size_t N = d.N;
@@ -151,7 +152,7 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
 
 // balatro_env_2.py:1383-1392: the shop seed (one get_int on stream 2) and random.Random(seed) were produced ahead of
 // time by the refill kernel; switching to the next ring slot IS "Shop(ante, player, seed=shop_seed)".
-__device__ __forceinline__ void bg_generate_shop(const BgDev& d, int env, Env& e) {
+__device__ __forceinline__ void bg_generate_shop(const BgDev& d, int env, Env& e, RngWin& w) {
   if (e.s_ready <= 0) { atomicOr(d.err, BG_DEVERR_SHOPRING); return; }
   e.s_cur = (e.s_cur + 1 == d.KS) ? 0 : e.s_cur + 1;
   e.s_ready--;
@@ -159,12 +160,12 @@ __device__ __forceinline__ void bg_generate_shop(const BgDev& d, int env, Env& e
   e.bflags |= BG_BF_SHOP_EXISTS;
   e.shop_ante = e.ante;
   e.shop_reroll_base = 50;
-  bg_shop_inventory(d, env, e);
+  bg_shop_inventory(d, env, e, w);
   e.shop_reroll_state = (int32_t)(50.0 * bg_shop_cost_mult(e));
 }
 
 // balatro_env_2.py:1326-1381 (card-state gold money needs card states: not on this path)
-__device__ __forceinline__ void bg_advance_round(const BgDev& d, int env, Env& e) {
+__device__ __forceinline__ void bg_advance_round(const BgDev& d, int env, Env& e, RngWin& w) {
   if (e.boss_type) { e.money += 5; e.boss_type = 0; e.boss_types = 0; e.boss_cards = 0; e.face_down = 0; }
   e.round_chips = 0; e.best_hand = 0; e.hp_ante = 0;
   if (e.round == 3) {
@@ -174,21 +175,20 @@ __device__ __forceinline__ void bg_advance_round(const BgDev& d, int env, Env& e
   e.money += 25 * e.round + (e.round == 3 ? 10 : 0);
   e.hands_left = 4; e.discards_left = 3;
   e.phase = 1;
-  bg_generate_shop(d, env, e);
+  bg_generate_shop(d, env, e, w);
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // Joker chain (unified_scoring.py:111-299 + complete_joker_effects.py:35-184), jokers by jokers.py id.
 // Played cards are (rank, suit, chips) packed per card: rank | suit << 4 | chips << 8.
 // ---------------------------------------------------------------------------------------------------------
-struct JEff { int chips, mult, money; double x; };
+struct JEff { int chips, mult; double x; };
 
-// complete_joker_effects.py:35-129; the dict at :39-53 is rebuilt per call => one randint(0,23) per joker (Q13)
-__device__ __forceinline__ JEff bg_joker_main(const BgDev& d, int env, Env& e, int id, const uint32_t* pc, int n, int ht) {
-  JEff r = {0, 0, 0, 1.0};
-  uint32_t mis = bg_randbelow<false>(d, env, e, 24u);
-  uint32_t suits = 0; int kings = 0, queens = 0;
-  for (int i = 0; i < n; i++) { int rk = pc[i] & 0xf; suits |= 1u << ((pc[i] >> 4) & 0xf); kings += rk == 13; queens += rk == 12; }
+// complete_joker_effects.py:35-129 (main 'scoring' phase).  The dict literal at :39-53 is rebuilt on every call, so one
+// random.randint(0, 23) is drawn per joker whatever its name; `mis` is that draw.
+__device__ __forceinline__ JEff bg_joker_main(const Env& e, int id, uint32_t mis, uint32_t suits, int kings, int queens,
+                                              int n, int ht) {
+  JEff r = {0, 0, 1.0};
   switch (id) {
     case 27: r.mult = (int)mis; break;                                  // Misprint
     case 1: r.mult = 4; break;                                          // Joker
@@ -227,47 +227,51 @@ __device__ __forceinline__ JEff bg_joker_main(const BgDev& d, int env, Env& e, i
   return r;
 }
 
-// complete_joker_effects.py:131-184; suit_effects (:157-162) is rebuilt per call => one random() per (card, joker)
-__device__ __forceinline__ JEff bg_joker_individual(const BgDev& d, int env, Env& e, int id, uint32_t card) {
-  JEff r = {0, 0, 0, 1.0};
-  double blood = bg_grandom(d, env, e);
-  int rk = card & 0xf, su = (card >> 4) & 0xf;
+// complete_joker_effects.py:131-184 (per-card 'individual_scoring' phase) as a descriptor per joker:
+//   bits 0..14 ranks that trigger, 16..20 suits that trigger (C,D,H,S,'Stone'), 21..22 special (1 = 8 Ball: one more
+//   random() when the card is an 8, :167; 2 = Bloodstone: the effect needs the random() value, :161), 23 = x2,
+//   24..39 chips, 40..47 mult.  An effect fires iff rank AND suit bits are set; every (card, joker) pair consumes one
+//   random() = 2 words because suit_effects (:157-162) is rebuilt per call.
+#define BG_JD(ranks, suits, special, x2, chips, mult) \
+  ((uint64_t)(ranks) | ((uint64_t)(suits) << 16) | ((uint64_t)(special) << 21) | ((uint64_t)(x2) << 23) | ((uint64_t)(chips) << 24) | ((uint64_t)(mult) << 40))
+#define BG_R(r) (1u << (r))
+__device__ __forceinline__ uint64_t bg_jdesc(int id) {
+  const uint32_t ALLR = 0x7fffu, ALLS = 0x1fu, FACES = BG_R(11) | BG_R(12) | BG_R(13);
   switch (id) {
-    case 31: if (rk == 2 || rk == 3 || rk == 5 || rk == 8 || rk == 14) r.mult = 8; break;      // Fibonacci
-    case 39: if (rk == 2 || rk == 4 || rk == 6 || rk == 8 || rk == 10) r.mult = 4; break;      // Even Steven
-    case 40: if (rk == 3 || rk == 5 || rk == 7 || rk == 9 || rk == 14) r.chips = 31; break;    // Odd Todd
-    case 41: if (rk == 14) { r.chips = 20; r.mult = 4; } break;                                 // Scholar
-    case 101: if (rk == 4 || rk == 10) { r.chips = 10; r.mult = 4; } break;                     // Walkie Talkie
-    case 124: if (rk == 2) r.chips = 8; break;                                                  // Wee Joker
-    case 26: if (rk == 8) (void)bg_grandom(d, env, e); break;                                   // 8 Ball :167
-    case 33: if (rk >= 11 && rk <= 13) r.chips = 30; break;                                     // Scary Face
-    case 104: if (rk >= 11 && rk <= 13) r.mult = 5; break;                                      // Smiley Face
-    case 147: if (rk == 12 || rk == 13) r.x = 2.0; break;                                       // Triboulet
-    case 118: if (su == 3) r.chips = 50; break;                                                 // Arrowhead
-    case 119: if (su == 0) r.mult = 7; break;                                                   // Onyx Agate
-    case 116: if (su == 1) r.money = 1; break;                                                  // Rough Gem
-    case 117: if (su == 2 && blood < 0.5) r.x = 2.0; break;                                     // Bloodstone
-    default: break;
+    case 31: return BG_JD(BG_R(2) | BG_R(3) | BG_R(5) | BG_R(8) | BG_R(14), ALLS, 0, 0, 0, 8);   // Fibonacci
+    case 39: return BG_JD(BG_R(2) | BG_R(4) | BG_R(6) | BG_R(8) | BG_R(10), ALLS, 0, 0, 0, 4);   // Even Steven
+    case 40: return BG_JD(BG_R(3) | BG_R(5) | BG_R(7) | BG_R(9) | BG_R(14), ALLS, 0, 0, 31, 0);  // Odd Todd
+    case 41: return BG_JD(BG_R(14), ALLS, 0, 0, 20, 4);                                          // Scholar
+    case 101: return BG_JD(BG_R(4) | BG_R(10), ALLS, 0, 0, 10, 4);                               // Walkie Talkie
+    case 124: return BG_JD(BG_R(2), ALLS, 0, 0, 8, 0);                                           // Wee Joker
+    case 26: return BG_JD(0, 0, 1, 0, 0, 0);                                                     // 8 Ball
+    case 33: return BG_JD(FACES, ALLS, 0, 0, 30, 0);                                             // Scary Face
+    case 104: return BG_JD(FACES, ALLS, 0, 0, 0, 5);                                             // Smiley Face
+    case 147: return BG_JD(BG_R(12) | BG_R(13), ALLS, 0, 1, 0, 0);                               // Triboulet
+    case 118: return BG_JD(ALLR, 1u << 3, 0, 0, 50, 0);                                          // Arrowhead (Spades)
+    case 119: return BG_JD(ALLR, 1u << 0, 0, 0, 0, 7);                                           // Onyx Agate (Clubs)
+    case 117: return BG_JD(ALLR, 1u << 2, 2, 1, 0, 0);                                           // Bloodstone (Hearts, p = .5)
+    default: return 0ull;                                                                        // incl. Rough Gem ($ only)
   }
-  return r;
 }
 
 // boss_blinds.py:343-378 on_hand_drawn as applied by balatro_env_2.py:936-948
-__device__ __forceinline__ void bg_boss_on_hand_drawn(const BgDev& d, int env, Env& e, const Deck0& dk) {
+__device__ __forceinline__ void bg_boss_on_hand_drawn(const BgDev& d, int env, Env& e, RngWin& w, const Deck0& dk) {
   uint32_t fd = 0;
   int n = e.nhand;
   int h0 = -1, h1 = -1;
   switch (e.boss_type) {
     case 1: // The Hook: random.sample(range(n), 2), n <= 21 -> pool method
       if (n >= 2) {
-        int j0 = (int)bg_randbelow<false>(d, env, e, (uint32_t)n);
-        int j1 = (int)bg_randbelow<false>(d, env, e, (uint32_t)(n - 1));
+        int j0 = (int)bg_randbelow<false>(d, env, e, w, (uint32_t)n);
+        int j1 = (int)bg_randbelow<false>(d, env, e, w, (uint32_t)(n - 1));
         h0 = j0;                                  // pool[j] = j initially
         h1 = (j1 == j0) ? (n - 1) : j1;           // pool[j0] was overwritten with pool[n-1]
       }
       break;
     case 3: // The Wheel
-      for (int i = 0; i < n; i++) if (bg_grandom(d, env, e) < 1.0 / 7.0) fd |= 1u << i;
+      bg_gprefetch(d, env, e, w, 2 * n);
+      for (int i = 0; i < n; i++) if (bg_grandom(d, env, e, w) < 1.0 / 7.0) fd |= 1u << i;
       break;
     case 4: if (e.bflags & BG_BF_FIRST_HAND) fd = (1u << n) - 1; break;  // The House
     case 5: // The Mark
@@ -287,7 +291,7 @@ __device__ __forceinline__ void bg_boss_on_hand_drawn(const BgDev& d, int env, E
 // ---------------------------------------------------------------------------------------------------------
 // PLAY_HAND  balatro_env_2.py:645-960
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& e, const Deck0& dk, StepOut& o) {
+__device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& e, RngWin& w, const Deck0& dk, StepOut& o) {
   // :650-660 selected cards in selection order
   uint32_t pc[8]; // rank | suit<<4 | chips<<8 per played card (static indexing only: loops are fully unrolled)
   int didx[8];
@@ -333,20 +337,56 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   int64_t chips = bchips + chip_sum, mult = bmult;
   double x_mult = 1.0;
   if ((d.flags & 1u) && e.njokers > 0) { // scorer-level joker names (BG_FLAG_SCORER_JOKERS); dict jokers are inert (Q6)
-    int64_t ic = 0, im = 0; double ix = 1.0;
-    for (int c = 0; c < n; c++) {
-      uint32_t card = 0;
+    // unified_scoring.py:174-209 individual phase, card-major / joker-minor.  Every x factor is 2.0 or a small exact
+    // product, so the order of the float multiplications cannot change the (exact) result.
+    uint64_t jd[5];
+    int jid[5];
+    bool blood = false;
 #pragma unroll
-      for (int q = 0; q < 8; q++) if (q == c) card = pc[q];
-      for (int j = 0; j < e.njokers; j++) {
-        JEff f = bg_joker_individual(d, env, e, bg_get8(e.jokers, j), card);
-        ic += f.chips; im += f.mult; ix *= f.x;
+    for (int j = 0; j < 5; j++) {
+      jid[j] = j < e.njokers ? bg_get8(e.jokers, j) : 0;
+      jd[j] = bg_jdesc(jid[j]);
+      blood |= ((jd[j] >> 21) & 3u) == 2u;
+    }
+    if (blood) bg_gprefetch(d, env, e, w, n * e.njokers * 2 + 16 + e.njokers * 2 + 6);
+    int ic = 0, im = 0, xexp = 0, pend = 0;
+    uint32_t suits = 0; int kings = 0, queens = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      if (c < n) {
+        uint32_t rk = pc[c] & 0xfu, su = (pc[c] >> 4) & 0xfu;
+        suits |= 1u << su; kings += rk == 13; queens += rk == 12;
+#pragma unroll
+        for (int j = 0; j < 5; j++) {
+          if (j < e.njokers) {
+            uint64_t dsc = jd[j];
+            bool hit = ((dsc >> rk) & (dsc >> (16 + su)) & 1ull) != 0;
+            uint32_t sp = (uint32_t)(dsc >> 21) & 3u;
+            if (sp == 2u) { // Bloodstone: the random() value decides
+              bg_gskip(d, e, pend); pend = 0;
+              double b = bg_grandom(d, env, e, w);
+              hit = hit && b < 0.5;
+            } else {
+              pend += 2;
+              if (sp == 1u && rk == 8u) pend += 2; // 8 Ball's extra random() on an 8
+            }
+            if (hit) { ic += (int)((dsc >> 24) & 0xffffu); im += (int)((dsc >> 40) & 0xffu); xexp += (int)((dsc >> 23) & 1u); }
+          }
+        }
       }
     }
-    chips += ic; mult += im; x_mult *= ix;
-    for (int j = 0; j < e.njokers; j++) {
-      JEff f = bg_joker_main(d, env, e, bg_get8(e.jokers, j), pc, n, ht);
-      chips += f.chips; mult += f.mult; x_mult *= f.x;
+    bg_gskip(d, e, pend);
+    chips += ic; mult += im;
+    x_mult *= (double)(1ull << xexp);
+    // :216-244 main phase, joker order; one randint(0, 23) per joker
+    bg_gprefetch(d, env, e, w, e.njokers * 2 + 6);
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      if (j < e.njokers) {
+        uint32_t mis = bg_randbelow<false>(d, env, e, w, 24u);
+        JEff f = bg_joker_main(e, jid[j], mis, suits, kings, queens, n, ht);
+        chips += f.chips; mult += f.mult; x_mult *= f.x;
+      }
     }
   }
   int64_t final_score = (int64_t)((double)(chips * mult) * x_mult); // unified_scoring.py:286
@@ -451,7 +491,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   if (e.round_chips >= (int64_t)e.chips_needed) {
     double bonus = 25.0 + 10.0 * (double)e.ante;
     r += bonus < 50.0 ? bonus : 50.0;
-    bg_advance_round(d, env, e);
+    bg_advance_round(d, env, e, w);
     o.flags |= 1; // beat_blind
   } else if (e.hands_left <= 1) {
     r += -50.0 * (1.0 - new_progress);
@@ -460,7 +500,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   } else {
     e.hands_left -= 1;
     bg_draw_cards(e);
-    if (e.boss_type) bg_boss_on_hand_drawn(d, env, e, dk);
+    if (e.boss_type) bg_boss_on_hand_drawn(d, env, e, w, dk);
   }
   o.reward = r;
 }
@@ -506,7 +546,7 @@ __device__ __forceinline__ void bg_step_discard(const BgDev& d, int env, Env& e,
 }
 
 // SHOP  balatro_env_2.py:1174-1253 + shop.py:160-205
-__device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, int action, StepOut& o) {
+__device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, RngWin& w, int action, StepOut& o) {
   if (action >= 32 && action < 37) { // sell joker :1202-1215
     int ji = action - 32;
     int id = bg_get8(e.jokers, ji);
@@ -531,7 +571,7 @@ __device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, in
     if (e.money < cost) { o.reward = -1.0; o.error = 6; return; }
     e.money -= cost;
     e.shop_reroll_base = (int32_t)((double)e.shop_reroll_base * 1.35);
-    bg_shop_inventory(d, env, e);
+    bg_shop_inventory(d, env, e, w);
     o.reward = 0.0;
     return;
   }
@@ -548,7 +588,7 @@ __device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, in
   int type = tp & 0xff, payload = (tp >> 8) & 0xff;
   if (type == IT_PACK) {
     int count = payload == PK_STANDARD ? 3 : 1; // shop.py:150-157 _open_pack draws from the shop stream
-    for (int i = 0; i < count; i++) { int c = (int)bg_randbelow<true>(d, env, e, 52u); if (i == 0) o.aux = c; }
+    for (int i = 0; i < count; i++) { int c = (int)bg_randbelow<true>(d, env, e, w, 52u); if (i == 0) o.aux = c; }
     o.reward = 5.0; o.flags |= 8;
   } else if (type == IT_CARD) {
     o.reward = 3.0; o.flags |= 16;
@@ -564,7 +604,7 @@ __device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, in
 }
 
 // BLIND_SELECT  balatro_env_2.py:1255-1318
-__device__ __forceinline__ void bg_step_blind(const BgDev& d, int env, Env& e, int action, StepOut& o) {
+__device__ __forceinline__ void bg_step_blind(const BgDev& d, int env, Env& e, RngWin& w, int action, StepOut& o) {
   if (action < 48) {
     int b = action - 45;
     e.round = b + 1;
@@ -579,7 +619,7 @@ __device__ __forceinline__ void bg_step_blind(const BgDev& d, int env, Env& e, i
     }
     o.reward = 0.0;
     if (b == 2) {
-      int boss = 1 + (int)bg_randbelow<false>(d, env, e, 28u); // boss_blinds.py:522-532 random.choice(list(BossBlindType))
+      int boss = 1 + (int)bg_randbelow<false>(d, env, e, w, 28u); // boss_blinds.py:522-532 random.choice(list(BossBlindType))
       e.boss_type = boss; e.boss_types = 0; e.boss_cards = 0; e.boss_hp = 0; e.boss_req = 5;
       e.bflags |= BG_BF_FIRST_HAND;
       need = (int64_t)((double)need * (boss == 2 ? 2.0 : 1.0)); // The Wall
@@ -594,13 +634,13 @@ __device__ __forceinline__ void bg_step_blind(const BgDev& d, int env, Env& e, i
     bg_draw_cards(e);
   } else { // 48 SKIP_BLIND :1305-1316
     o.reward = -5.0;
-    bg_advance_round(d, env, e);
+    bg_advance_round(d, env, e, w);
     o.flags |= 4;
   }
 }
 
 // balatro_env_2.py:616-637 step()
-__device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, const Deck0& dk, int action, StepOut& o) {
+__device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, RngWin& w, const Deck0& dk, int action, StepOut& o) {
   o.reward = 0.0; o.final_score = 0; o.error = 0; o.flags = 0; o.aux = 0; o.hand_type = -1; o.cards_played = 0;
   o.terminated = false;
 #pragma unroll
@@ -610,7 +650,7 @@ __device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, con
   uint64_t mask = bg_action_mask(d, env, e);
   if (action < 0 || action >= 60 || !((mask >> action) & 1ull)) { o.reward = -1.0; o.error = 1; return; }
   if (e.phase == 0) {
-    if (action == 0) bg_step_play_hand(d, env, e, dk, o);
+    if (action == 0) bg_step_play_hand(d, env, e, w, dk, o);
     else if (action == 1) bg_step_discard(d, env, e, dk, o);
     else if (action < 10) { // :1052-1058 toggle, selection ORDER kept
       int pos = action - 2;
@@ -633,8 +673,8 @@ __device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, con
       } else { o.reward = -1.0; o.error = 8; }
       e.nsel = 0; e.sel = 0;
     }
-  } else if (e.phase == 1) bg_step_shop(d, env, e, action, o);
-  else if (e.phase == 2) bg_step_blind(d, env, e, action, o);
+  } else if (e.phase == 1) bg_step_shop(d, env, e, w, action, o);
+  else if (e.phase == 2) bg_step_blind(d, env, e, w, action, o);
   if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
 }
 
