@@ -220,12 +220,12 @@ __device__ __forceinline__ void bg_win_init(RngWin& w, uint32_t* lds_lane) {
   w.lds = lds_lane; w.g_blk = -1; w.g_start = 0; w.g_len = 0; w.s_start = 0; w.s_len = 0;
 }
 __device__ __forceinline__ void bg_win_fill(uint32_t* lds, const uint32_t* src, int len) {
-  for (int base = 0; base < len; base += 8) {
-    uint32_t v[8];
+  for (int base = 0; base < len; base += 24) { // 24 independent loads in flight, then one wait
+    uint32_t v[24];
 #pragma unroll
-    for (int j = 0; j < 8; j++) v[j] = (base + j < len) ? src[base + j] : 0u;
+    for (int j = 0; j < 24; j++) v[j] = (base + j < len) ? src[base + j] : 0u;
 #pragma unroll
-    for (int j = 0; j < 8; j++) if (base + j < len) lds[(base + j) * BG_BLOCK] = v[j];
+    for (int j = 0; j < 24; j++) if (base + j < len) lds[(base + j) * BG_BLOCK] = v[j];
   }
 }
 

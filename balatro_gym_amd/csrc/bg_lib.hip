@@ -57,15 +57,18 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_step_kernel(BgDev d, const int32_
   Env e;
   bg_load_env(d, env, e);
   Deck0 dk = bg_load_deck0(d, env);
+  ShopRegs sr; sr.valid = false;
   StepOut o;
-  bg_env_step(d, env, e, w, dk, actions[env], o);
+  uint64_t mask = bg_action_mask(d, env, e, sr);
+  bg_env_step(d, env, e, w, sr, dk, mask, actions[env], o);
   if (o.terminated && (d.flags & BG_FLAG_AUTORESET)) { bg_env_reset(d, env, e, dk); o.flags |= BG_INFO_AUTORESET; }
   bg_store_env(d, env, e);
-  uint64_t mask = bg_action_mask(d, env, e);
-  bg_write_obs(d, env, (size_t)env, e, dk, obs, mask);
+  mask = bg_action_mask(d, env, e, sr);
+  bg_write_obs<false>(d, env, (size_t)env, e, dk, obs, mask, sr);
   bg_emit(d, env, (size_t)env, o, reward, term, trunc, info);
 }
 
+template <bool HASH>
 __global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
                                                              uint64_t env_index0, uint64_t t0, ObsPtrs obs,
                                                              int obs_stride_steps, double* reward, uint8_t* term,
@@ -80,16 +83,17 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, in
     Env e;
     bg_load_env(d, env, e);
     Deck0 dk = bg_load_deck0(d, env);
-    uint64_t mask = bg_action_mask(d, env, e);
+    ShopRegs sr; sr.valid = false;
+    uint64_t mask = bg_action_mask(d, env, e, sr);
     for (int t = 0; t < T; t++) {
       int action = bg_policy_action(e, mask, policy, policy_seed, env_index0 + (uint64_t)env, t0 + (uint64_t)t);
       StepOut o;
-      bg_env_step(d, env, e, w, dk, action, o);
+      bg_env_step(d, env, e, w, sr, dk, mask, action, o);
       if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; } // SAME_STEP auto-reset
-      mask = bg_action_mask(d, env, e);
+      mask = bg_action_mask(d, env, e, sr);
       size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
-      uint64_t h = bg_write_obs(d, env, row, e, dk, obs, mask);
-      ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
+      uint64_t h = bg_write_obs<HASH>(d, env, row, e, dk, obs, mask, sr);
+      if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
       if (reward) reward[row] = o.reward;
       if (term) term[row] = o.terminated ? 1 : 0;
       if (actions_out) actions_out[row] = action;
@@ -124,8 +128,9 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_reset_kernel(BgDev d, const uint8
   bg_load_env(d, env, e);
   Deck0 dk = bg_load_deck0(d, env);
   if (!mask_in || mask_in[env]) { bg_env_reset(d, env, e, dk); bg_store_env(d, env, e); }
-  uint64_t mask = bg_action_mask(d, env, e);
-  bg_write_obs(d, env, (size_t)env, e, dk, obs, mask);
+  ShopRegs sr; sr.valid = false;
+  uint64_t mask = bg_action_mask(d, env, e, sr);
+  bg_write_obs<false>(d, env, (size_t)env, e, dk, obs, mask, sr);
 }
 
 __global__ __launch_bounds__(BG_BLOCK) void bg_observe_kernel(BgDev d, ObsPtrs obs) {
@@ -134,8 +139,9 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_observe_kernel(BgDev d, ObsPtrs o
   Env e;
   bg_load_env(d, env, e);
   Deck0 dk = bg_load_deck0(d, env);
-  uint64_t mask = bg_action_mask(d, env, e);
-  bg_write_obs(d, env, (size_t)env, e, dk, obs, mask);
+  ShopRegs sr; sr.valid = false;
+  uint64_t mask = bg_action_mask(d, env, e, sr);
+  bg_write_obs<false>(d, env, (size_t)env, e, dk, obs, mask, sr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -147,43 +153,60 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_observe_kernel(BgDev d, ObsPtrs o
 // pass 2 and the block twist fetch their operands in batches of BG_MTB independent loads before running the chain.
 #define BG_MTB 16
 #define BG_RWIN 96 // words of the deck stream prefetched per shuffle (refill kernel)
+// All stores/loads of the state are 16-byte vectors on 16-byte aligned groups: a lane walks its own block, so a
+// wave-level access touches 64 different lines whatever the width -- 4x fewer instructions = 4x less TA time.
 __device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) {
+  uint4* p4 = (uint4*)p;
   uint32_t g = 19650218u; // init_genrand seed; g tracks init_genrand's mt[i]
   uint32_t prev = g;      // mt[0]
   uint32_t mt1 = 0;
-  for (int i = 1; i < BG_MT_N; i++) { // first pass, i = 1..623 (key index j is always 0)
-    g = 1812433253u * (g ^ (g >> 30)) + (uint32_t)i;
-    uint32_t v = (g ^ ((prev ^ (prev >> 30)) * 1664525u)) + key;
-    p[i] = v;
-    if (i == 1) mt1 = v;
-    prev = v;
+  // first pass, i = 1..623 (key index j is always 0); group q = words 4q..4q+3
+  for (int q = 0; q < BG_MT_N / 4; q++) {
+    uint32_t v[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      int i = 4 * q + c;
+      if (i == 0) { v[c] = 0u; continue; }
+      g = 1812433253u * (g ^ (g >> 30)) + (uint32_t)i;
+      uint32_t x = (g ^ ((prev ^ (prev >> 30)) * 1664525u)) + key;
+      v[c] = x;
+      if (i == 1) mt1 = x;
+      prev = x;
+    }
+    p4[q] = make_uint4(v[0], v[1], v[2], v[3]);
   }
   { // wrap: mt[0] = mt[623]; 624th iteration at i = 1
     uint32_t mt0 = prev;
-    uint32_t v = (mt1 ^ ((mt0 ^ (mt0 >> 30)) * 1664525u)) + key;
-    mt1 = v;
-    prev = v;
+    uint32_t x = (mt1 ^ ((mt0 ^ (mt0 >> 30)) * 1664525u)) + key;
+    mt1 = x;
+    prev = x;
   }
-  // second pass: 622 iterations i = 2..623, then the wrapped one at i = 1
-  for (int base = 2; base < BG_MT_N; base += BG_MTB) {
-    uint32_t buf[BG_MTB];
+  // second pass: 622 iterations i = 2..623, then the wrapped one at i = 1; words 0 and 1 are finalised at the end
+  uint32_t w2 = 0, w3 = 0;
+  for (int base = 0; base < BG_MT_N / 4; base += BG_MTB / 4) {
+    uint4 buf[BG_MTB / 4];
 #pragma unroll
-    for (int j = 0; j < BG_MTB; j++) { int i = base + j; buf[j] = (i < BG_MT_N) ? p[i] : 0u; }
+    for (int j = 0; j < BG_MTB / 4; j++) buf[j] = p4[base + j];
 #pragma unroll
-    for (int j = 0; j < BG_MTB; j++) {
-      int i = base + j;
-      if (i < BG_MT_N) {
-        uint32_t v = (buf[j] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
-        p[i] = v;
-        prev = v;
+    for (int j = 0; j < BG_MTB / 4; j++) {
+      int q = base + j;
+      uint32_t v[4] = {buf[j].x, buf[j].y, buf[j].z, buf[j].w};
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        int i = 4 * q + c;
+        if (i >= 2) {
+          uint32_t x = (v[c] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
+          v[c] = x;
+          prev = x;
+        }
       }
+      if (q == 0) { w2 = v[2]; w3 = v[3]; }
+      else p4[q] = make_uint4(v[0], v[1], v[2], v[3]);
     }
   }
-  {
-    uint32_t mt0 = prev; // mt[0] = mt[623]
-    p[1] = (mt1 ^ ((mt0 ^ (mt0 >> 30)) * 1566083941u)) - 1u;
-  }
-  p[0] = 0x80000000u;
+  uint32_t mt0 = prev; // mt[0] = mt[623]
+  uint32_t w1 = (mt1 ^ ((mt0 ^ (mt0 >> 30)) * 1566083941u)) - 1u;
+  p4[0] = make_uint4(0x80000000u, w1, w2, w3);
 }
 
 // genrand_uint32()'s block regeneration: dst[kk] = twist(src[kk], src[kk+1], kk < 227 ? src[kk+397] : dst[kk-227]),
@@ -191,7 +214,8 @@ __device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) {
 // any element of the batch is stored; BG_MTB < 227 keeps the kk-227 operands already written).
 __device__ void bg_mt_twist(const uint32_t* src, uint32_t* dst) {
   uint32_t cur = src[0], first_new = 0;
-  for (int base = 0; base < BG_MT_N - 1; base += BG_MTB) {
+  uint4* d4 = (uint4*)dst;
+  for (int base = 0; base < BG_MT_N; base += BG_MTB) {
     uint32_t nxt[BG_MTB], far[BG_MTB];
 #pragma unroll
     for (int j = 0; j < BG_MTB; j++) {
@@ -199,20 +223,18 @@ __device__ void bg_mt_twist(const uint32_t* src, uint32_t* dst) {
       if (kk < BG_MT_N - 1) {
         nxt[j] = src[kk + 1];
         far[j] = (kk < BG_MT_N - BG_MT_M) ? src[kk + BG_MT_M] : dst[kk + BG_MT_M - BG_MT_N];
-      } else { nxt[j] = 0; far[j] = 0; }
+      } else { nxt[j] = first_new; far[j] = dst[BG_MT_M - 1]; } // kk == 623: new dst[0], new dst[396]
     }
+    uint32_t v[BG_MTB];
 #pragma unroll
     for (int j = 0; j < BG_MTB; j++) {
-      int kk = base + j;
-      if (kk < BG_MT_N - 1) {
-        uint32_t v = bg_twist(cur, nxt[j], far[j]);
-        dst[kk] = v;
-        if (kk == 0) first_new = v;
-        cur = nxt[j];
-      }
+      v[j] = bg_twist(cur, nxt[j], far[j]);
+      if (base + j == 0) first_new = v[j];
+      cur = nxt[j];
     }
+#pragma unroll
+    for (int j = 0; j < BG_MTB / 4; j++) d4[base / 4 + j] = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
   }
-  dst[BG_MT_N - 1] = bg_twist(cur, first_new, dst[BG_MT_M - 1]);
 }
 
 // genrand_uint32() on an authoritative stream state (624 words + index word at [624])
@@ -674,10 +696,16 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
     }
     bg_ev_begin(h, h->ev_rollout, (hipStream_t)stream);
     if (h->profiling) h->rollout_steps.push_back(chunk);
-    hipLaunchKernelGGL(bg_rollout_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev, chunk, policy,
-                       policy_seed, env_index0, t0 + (uint64_t)done, o, obs_stride_steps,
-                       reward_dev ? reward_dev + off : nullptr, terminated_dev ? terminated_dev + off : nullptr,
-                       actions_out_dev ? actions_out_dev + off : nullptr, stats_dev);
+    if (policy & BG_POLICY_HASH_OBS)
+      hipLaunchKernelGGL(bg_rollout_kernel<true>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev, chunk,
+                         policy & 0xff, policy_seed, env_index0, t0 + (uint64_t)done, o, obs_stride_steps,
+                         reward_dev ? reward_dev + off : nullptr, terminated_dev ? terminated_dev + off : nullptr,
+                         actions_out_dev ? actions_out_dev + off : nullptr, stats_dev);
+    else
+      hipLaunchKernelGGL(bg_rollout_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev, chunk,
+                         policy & 0xff, policy_seed, env_index0, t0 + (uint64_t)done, o, obs_stride_steps,
+                         reward_dev ? reward_dev + off : nullptr, terminated_dev ? terminated_dev + off : nullptr,
+                         actions_out_dev ? actions_out_dev + off : nullptr, stats_dev);
     bg_ev_end(h, h->ev_rollout, (hipStream_t)stream);
     BG_HIP(hipGetLastError());
     rc = bg_refill(h, stream);

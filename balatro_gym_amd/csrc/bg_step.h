@@ -16,17 +16,38 @@ struct StepOut {
 // ---------------------------------------------------------------------------------------------------------
 // shop inventory storage (cold chunks 3..6): cost i32[9], (type | payload << 8) u16[9]
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int32_t* bg_shop_cost_ptr(const BgDev& d, int env, int i) {
-  return ((int32_t*)&d.cold[(size_t)(3 + (i >> 2)) * d.N + env]) + (i & 3);
+// The inventory is kept in registers while an env is in the shop (ShopRegs = cold chunks 3..6): the action mask and the
+// observation read it every step, and fetching it item by item would put ~9 dependent HBM round trips on every step of
+// every wave that has one lane in SHOP phase.
+struct ShopRegs { uint4 c3, c4, c5, c6; bool valid; };
+__device__ __forceinline__ void bg_shop_load(const BgDev& d, int env, ShopRegs& sr) {
+  if (sr.valid) return;
+  size_t N = d.N;
+  sr.c3 = d.cold[3 * N + env]; sr.c4 = d.cold[4 * N + env]; sr.c5 = d.cold[5 * N + env]; sr.c6 = d.cold[6 * N + env];
+  sr.valid = true;
 }
-__device__ __forceinline__ uint16_t* bg_shop_tp_ptr(const BgDev& d, int env, int i) {
-  return i < 6 ? ((uint16_t*)&d.cold[(size_t)5 * d.N + env]) + 2 + i : ((uint16_t*)&d.cold[(size_t)6 * d.N + env]) + (i - 6);
+__device__ __forceinline__ void bg_shop_store(const BgDev& d, int env, const ShopRegs& sr) {
+  size_t N = d.N;
+  d.cold[3 * N + env] = sr.c3; d.cold[4 * N + env] = sr.c4; d.cold[5 * N + env] = sr.c5; d.cold[6 * N + env] = sr.c6;
+}
+__device__ __forceinline__ void bg_shop_unpack(const ShopRegs& sr, int32_t cost[9], uint32_t tp[9]) {
+  cost[0] = sr.c3.x; cost[1] = sr.c3.y; cost[2] = sr.c3.z; cost[3] = sr.c3.w;
+  cost[4] = sr.c4.x; cost[5] = sr.c4.y; cost[6] = sr.c4.z; cost[7] = sr.c4.w; cost[8] = sr.c5.x;
+  tp[0] = sr.c5.y & 0xffffu; tp[1] = sr.c5.y >> 16; tp[2] = sr.c5.z & 0xffffu; tp[3] = sr.c5.z >> 16;
+  tp[4] = sr.c5.w & 0xffffu; tp[5] = sr.c5.w >> 16; tp[6] = sr.c6.x & 0xffffu; tp[7] = sr.c6.x >> 16; tp[8] = sr.c6.y & 0xffffu;
+}
+__device__ __forceinline__ void bg_shop_pack(ShopRegs& sr, const int32_t cost[9], const uint32_t tp[9]) {
+  sr.c3 = make_uint4(cost[0], cost[1], cost[2], cost[3]);
+  sr.c4 = make_uint4(cost[4], cost[5], cost[6], cost[7]);
+  sr.c5 = make_uint4(cost[8], tp[0] | (tp[1] << 16), tp[2] | (tp[3] << 16), tp[4] | (tp[5] << 16));
+  sr.c6 = make_uint4(tp[6] | (tp[7] << 16), tp[8], 0, 0);
+  sr.valid = true;
 }
 enum { IT_PACK = 1, IT_CARD = 2, IT_JOKER = 3, IT_VOUCHER = 4 }; // shop.py:17-21 ItemType (auto())
 enum { PK_STANDARD = 0, PK_JOKER = 1, PK_TAROT = 2, PK_PLANET = 3, PK_SPECTRAL = 4 };
 
 // balatro_env_2.py:1426-1471 _get_action_mask as a 60-bit set
-__device__ __forceinline__ uint64_t bg_action_mask(const BgDev& d, int env, const Env& e) {
+__device__ __forceinline__ uint64_t bg_action_mask(const BgDev& d, int env, const Env& e, ShopRegs& sr) {
   uint64_t m = 0;
   if (e.phase == 0) {
     int n = e.nhand < 8 ? e.nhand : 8;
@@ -35,8 +56,12 @@ __device__ __forceinline__ uint64_t bg_action_mask(const BgDev& d, int env, cons
     m |= ((1ull << e.ncons) - 1) << 10;
   } else if (e.phase == 1) {
     if (e.bflags & BG_BF_SHOP_EXISTS) {
-      for (int i = 0; i < e.shop_n; i++)
-        if (e.money >= *bg_shop_cost_ptr(d, env, i)) m |= 1ull << (20 + i);
+      bg_shop_load(d, env, sr);
+      int32_t cost[9]; uint32_t tp[9];
+      bg_shop_unpack(sr, cost, tp);
+#pragma unroll
+      for (int i = 0; i < 9; i++)
+        if (i < e.shop_n && e.money >= cost[i]) m |= 1ull << (20 + i);
       if (e.money >= e.shop_reroll_state) m |= 1ull << 30;
     }
     m |= 1ull << 31;
@@ -115,7 +140,7 @@ __device__ __forceinline__ int bg_candidate(const Env& e, int j) {
   return id;
 }
 
-__device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& e, RngWin& w) {
+__device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr) {
   bg_sprefetch(d, env, e, w, 24); // shop.py:111-139
   double mult = bg_shop_cost_mult(e);
   int third = PK_TAROT + (int)bg_randbelow<true>(d, env, e, w, 3u); // rng.choice([...]) is evaluated before the loop
@@ -142,17 +167,14 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
   int ca = (int)bg_randbelow<true>(d, env, e, w, 52u), cb = (int)bg_randbelow<true>(d, env, e, w, 52u); // randint(0, 51)
   cost[7] = 40; tp[7] = IT_CARD | ((uint32_t)ca << 8);
   cost[8] = 40; tp[8] = IT_CARD | ((uint32_t)cb << 8);
-  size_t N = d.N;
-  d.cold[3 * N + env] = make_uint4(cost[0], cost[1], cost[2], cost[3]);
-  d.cold[4 * N + env] = make_uint4(cost[4], cost[5], cost[6], cost[7]);
-  d.cold[5 * N + env] = make_uint4(cost[8], tp[0] | (tp[1] << 16), tp[2] | (tp[3] << 16), tp[4] | (tp[5] << 16));
-  d.cold[6 * N + env] = make_uint4(tp[6] | (tp[7] << 16), tp[8], 0, 0);
+  bg_shop_pack(sr, cost, tp);
+  bg_shop_store(d, env, sr);
   e.shop_n = 9;
 }
 
 // balatro_env_2.py:1383-1392: the shop seed (one get_int on stream 2) and random.Random(seed) were produced ahead of
 // time by the refill kernel; switching to the next ring slot IS "Shop(ante, player, seed=shop_seed)".
-__device__ __forceinline__ void bg_generate_shop(const BgDev& d, int env, Env& e, RngWin& w) {
+__device__ __forceinline__ void bg_generate_shop(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr) {
   if (e.s_ready <= 0) { atomicOr(d.err, BG_DEVERR_SHOPRING); return; }
   e.s_cur = (e.s_cur + 1 == d.KS) ? 0 : e.s_cur + 1;
   e.s_ready--;
@@ -160,12 +182,12 @@ __device__ __forceinline__ void bg_generate_shop(const BgDev& d, int env, Env& e
   e.bflags |= BG_BF_SHOP_EXISTS;
   e.shop_ante = e.ante;
   e.shop_reroll_base = 50;
-  bg_shop_inventory(d, env, e, w);
+  bg_shop_inventory(d, env, e, w, sr);
   e.shop_reroll_state = (int32_t)(50.0 * bg_shop_cost_mult(e));
 }
 
 // balatro_env_2.py:1326-1381 (card-state gold money needs card states: not on this path)
-__device__ __forceinline__ void bg_advance_round(const BgDev& d, int env, Env& e, RngWin& w) {
+__device__ __forceinline__ void bg_advance_round(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr) {
   if (e.boss_type) { e.money += 5; e.boss_type = 0; e.boss_types = 0; e.boss_cards = 0; e.face_down = 0; }
   e.round_chips = 0; e.best_hand = 0; e.hp_ante = 0;
   if (e.round == 3) {
@@ -175,7 +197,7 @@ __device__ __forceinline__ void bg_advance_round(const BgDev& d, int env, Env& e
   e.money += 25 * e.round + (e.round == 3 ? 10 : 0);
   e.hands_left = 4; e.discards_left = 3;
   e.phase = 1;
-  bg_generate_shop(d, env, e, w);
+  bg_generate_shop(d, env, e, w, sr);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -291,7 +313,7 @@ __device__ __forceinline__ void bg_boss_on_hand_drawn(const BgDev& d, int env, E
 // ---------------------------------------------------------------------------------------------------------
 // PLAY_HAND  balatro_env_2.py:645-960
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& e, RngWin& w, const Deck0& dk, StepOut& o) {
+__device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, const Deck0& dk, StepOut& o) {
   // :650-660 selected cards in selection order
   uint32_t pc[8]; // rank | suit<<4 | chips<<8 per played card (static indexing only: loops are fully unrolled)
   int didx[8];
@@ -423,10 +445,8 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   e.chips_scored += final_score;
   e.hp_total++; e.hp_ante++;
   if (final_score > e.best_hand) e.best_hand = final_score;
-  { // engine.hand_play_counts[hand_type] += 1
-    uint32_t* pcnt = ((uint32_t*)&d.cold[(size_t)(ht >> 2) * d.N + env]) + (ht & 3);
-    *pcnt = *pcnt + 1;
-  }
+  // engine.hand_play_counts[hand_type] += 1 (write-only statistic: a no-return atomic keeps it off the wait path)
+  atomicAdd(((uint32_t*)&d.cold[(size_t)(ht >> 2) * d.N + env]) + (ht & 3), 1u);
   // :789-794 boss on_hand_scored (boss_blinds.py:480-507); Tooth/Serpent mutate a throw-away dict
   if (e.boss_type) {
     e.boss_types |= 1u << ht;
@@ -491,7 +511,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   if (e.round_chips >= (int64_t)e.chips_needed) {
     double bonus = 25.0 + 10.0 * (double)e.ante;
     r += bonus < 50.0 ? bonus : 50.0;
-    bg_advance_round(d, env, e, w);
+    bg_advance_round(d, env, e, w, sr);
     o.flags |= 1; // beat_blind
   } else if (e.hands_left <= 1) {
     r += -50.0 * (1.0 - new_progress);
@@ -546,7 +566,7 @@ __device__ __forceinline__ void bg_step_discard(const BgDev& d, int env, Env& e,
 }
 
 // SHOP  balatro_env_2.py:1174-1253 + shop.py:160-205
-__device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, RngWin& w, int action, StepOut& o) {
+__device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, int action, StepOut& o) {
   if (action >= 32 && action < 37) { // sell joker :1202-1215
     int ji = action - 32;
     int id = bg_get8(e.jokers, ji);
@@ -571,19 +591,23 @@ __device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, Rn
     if (e.money < cost) { o.reward = -1.0; o.error = 6; return; }
     e.money -= cost;
     e.shop_reroll_base = (int32_t)((double)e.shop_reroll_base * 1.35);
-    bg_shop_inventory(d, env, e, w);
+    bg_shop_inventory(d, env, e, w, sr);
     o.reward = 0.0;
     return;
   }
   // buy 20..28: the mask guarantees index < shop_n and money >= cost (shop.py:179-203)
   int idx = action - 20;
-  int32_t cost = *bg_shop_cost_ptr(d, env, idx);
-  uint32_t tp = *bg_shop_tp_ptr(d, env, idx);
+  bg_shop_load(d, env, sr);
+  int32_t costs[9]; uint32_t tps[9];
+  bg_shop_unpack(sr, costs, tps);
+  int32_t cost = 0; uint32_t tp = 0;
+#pragma unroll
+  for (int i = 0; i < 9; i++) if (i == idx) { cost = costs[i]; tp = tps[i]; }
   e.money -= cost;
-  for (int i = idx; i + 1 < e.shop_n; i++) {
-    *bg_shop_cost_ptr(d, env, i) = *bg_shop_cost_ptr(d, env, i + 1);
-    *bg_shop_tp_ptr(d, env, i) = *bg_shop_tp_ptr(d, env, i + 1);
-  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) if (i >= idx) { costs[i] = costs[i + 1]; tps[i] = tps[i + 1]; } // inventory.pop(idx)
+  bg_shop_pack(sr, costs, tps);
+  bg_shop_store(d, env, sr);
   e.shop_n--;
   int type = tp & 0xff, payload = (tp >> 8) & 0xff;
   if (type == IT_PACK) {
@@ -604,7 +628,7 @@ __device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, Rn
 }
 
 // BLIND_SELECT  balatro_env_2.py:1255-1318
-__device__ __forceinline__ void bg_step_blind(const BgDev& d, int env, Env& e, RngWin& w, int action, StepOut& o) {
+__device__ __forceinline__ void bg_step_blind(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, int action, StepOut& o) {
   if (action < 48) {
     int b = action - 45;
     e.round = b + 1;
@@ -634,23 +658,23 @@ __device__ __forceinline__ void bg_step_blind(const BgDev& d, int env, Env& e, R
     bg_draw_cards(e);
   } else { // 48 SKIP_BLIND :1305-1316
     o.reward = -5.0;
-    bg_advance_round(d, env, e, w);
+    bg_advance_round(d, env, e, w, sr);
     o.flags |= 4;
   }
 }
 
 // balatro_env_2.py:616-637 step()
-__device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, RngWin& w, const Deck0& dk, int action, StepOut& o) {
+__device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, const Deck0& dk, uint64_t mask,
+                                            int action, StepOut& o) {
   o.reward = 0.0; o.final_score = 0; o.error = 0; o.flags = 0; o.aux = 0; o.hand_type = -1; o.cards_played = 0;
   o.terminated = false;
 #pragma unroll
   for (int i = 0; i < 8; i++) o.terms[i] = 0.0;
   if (e.ante > 100) { o.terminated = true; o.error = 9; return; }
   if (e.chips_scored > 1000000000ll) { o.terminated = true; o.error = 10; return; }
-  uint64_t mask = bg_action_mask(d, env, e);
   if (action < 0 || action >= 60 || !((mask >> action) & 1ull)) { o.reward = -1.0; o.error = 1; return; }
   if (e.phase == 0) {
-    if (action == 0) bg_step_play_hand(d, env, e, w, dk, o);
+    if (action == 0) bg_step_play_hand(d, env, e, w, sr, dk, o);
     else if (action == 1) bg_step_discard(d, env, e, dk, o);
     else if (action < 10) { // :1052-1058 toggle, selection ORDER kept
       int pos = action - 2;
@@ -673,8 +697,8 @@ __device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, Rng
       } else { o.reward = -1.0; o.error = 8; }
       e.nsel = 0; e.sel = 0;
     }
-  } else if (e.phase == 1) bg_step_shop(d, env, e, w, action, o);
-  else if (e.phase == 2) bg_step_blind(d, env, e, w, action, o);
+  } else if (e.phase == 1) bg_step_shop(d, env, e, w, sr, action, o);
+  else if (e.phase == 2) bg_step_blind(d, env, e, w, sr, action, o);
   if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
 }
 
@@ -692,10 +716,11 @@ struct ObsPtrs {
 };
 
 // `row` = env + t * N for [T, N, ...] rollout buffers.  Returns a 64-bit hash of the row (rollout checksum).
+template <bool HASH>
 __device__ __forceinline__ uint64_t bg_write_obs(const BgDev& d, int env, size_t row, const Env& e, const Deck0& dk,
-                                                const ObsPtrs& p, uint64_t mask) {
+                                                const ObsPtrs& p, uint64_t mask, ShopRegs& sr) {
   uint64_t hsh = 0x9E3779B97F4A7C15ull;
-#define BG_MIX(v) do { hsh ^= (uint64_t)(v); hsh *= 0xBF58476D1CE4E5B9ull; hsh ^= hsh >> 29; } while (0)
+#define BG_MIX(v) do { if (HASH) { hsh ^= (uint64_t)(v); hsh *= 0xBF58476D1CE4E5B9ull; hsh ^= hsh >> 29; } } while (0)
   uint64_t handb = 0;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
@@ -756,13 +781,14 @@ __device__ __forceinline__ uint64_t bg_write_obs(const BgDev& d, int env, size_t
   {
     uint32_t it[5] = {0, 0, 0, 0, 0}, co[5] = {0, 0, 0, 0, 0};
     if (e.phase == 1 && (e.bflags & BG_BF_SHOP_EXISTS)) {
+      bg_shop_load(d, env, sr);
+      int32_t costs[9]; uint32_t tps[9];
+      bg_shop_unpack(sr, costs, tps);
 #pragma unroll
       for (int i = 0; i < 9; i++)
         if (i < e.shop_n) {
-          uint32_t tp = *bg_shop_tp_ptr(d, env, i);
-          uint32_t c = (uint32_t)(*bg_shop_cost_ptr(d, env, i)) & 0xffffu;
-          it[i >> 1] |= (tp & 0xffu) << (16 * (i & 1));
-          co[i >> 1] |= c << (16 * (i & 1));
+          it[i >> 1] |= (tps[i] & 0xffu) << (16 * (i & 1));
+          co[i >> 1] |= ((uint32_t)costs[i] & 0xffffu) << (16 * (i & 1));
         }
     }
 #pragma unroll

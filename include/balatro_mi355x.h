@@ -64,6 +64,7 @@ extern "C" {
 #define BG_POLICY_UNIFORM 0    /* k-th valid action, k = hash(seed, env, t) mod n_valid */
 #define BG_POLICY_SMALL_ONLY 1 /* BLIND_SELECT->45, SHOP->31, else uniform (balatro_env_2.py:1841-1849) */
 #define BG_POLICY_CYCLE3 2     /* BLIND_SELECT->45+env%3, SHOP->31, else uniform */
+#define BG_POLICY_HASH_OBS 0x100 /* OR into `policy`: also fold every observation row into stats.obs_hash (tests) */
 
 typedef struct bg_handle bg_handle;
 
@@ -121,7 +122,7 @@ typedef struct bg_rollout_stats {
   uint64_t plays;        /* accepted PLAY_HAND steps */
   int64_t score_sum;     /* sum of final_score over accepted plays */
   uint64_t reward_bits;  /* XOR of the IEEE bit patterns of all rewards (order-independent checksum) */
-  uint64_t obs_hash;     /* XOR over (env,t) of a 64-bit hash of each observation row */
+  uint64_t obs_hash;     /* XOR over (env,t) of a 64-bit hash of each observation row (only with BG_POLICY_HASH_OBS) */
 } bg_rollout_stats;
 
 /* Replaces: constructing n_envs `BalatroEnv` objects (balatro_env_2.py:359-384) + SB3 SubprocVecEnv (hpc_train.py:60-65).

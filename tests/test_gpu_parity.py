@@ -201,7 +201,7 @@ def test_rollout_properties_full_size():
         tot = None
         t0 = 0
         for c in chunks:
-            env.rollout(c, policy=2, policy_seed=7, env_index0=index0, t0=t0, zero_stats=(t0 == 0))
+            env.rollout(c, policy=2 | 0x100, policy_seed=7, env_index0=index0, t0=t0, zero_stats=(t0 == 0))
             t0 += c
         env.check()
         st = env.stats()

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Ablation timings of the fused rollout kernel on one GPU (development tool, not part of the product)."""
+import ctypes as C
+import os
+import random
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+from balatro_gym_amd import BalatroVecEnv  # noqa: E402
+from balatro_gym_amd import _native as nat  # noqa: E402
+from balatro_gym_amd.vec_env import ObsBuffers  # noqa: E402
+from bench import IMPLEMENTED, jokers_for  # noqa: E402
+
+
+def run(n, scorer, policy, chunk, steps, obs_mode, max_ante=4, label=""):
+    env = BalatroVecEnv(n, [1000 + i for i in range(n)], device=0, scorer_jokers=scorer, autoreset=True, max_ante=max_ante)
+    if scorer:
+        env.inject(jokers=[jokers_for(i) for i in range(n)], apply_now=True)
+    ob = None
+    if obs_mode == "keep":
+        ob = ObsBuffers(n, env.device, steps=chunk)
+    elif obs_mode == "none":
+        ob = ObsBuffers(1, env.device)
+        ob.ptrs = nat.ObsPtrs()  # all NULL
+        ob.steps = 1
+    def go(k, t0):
+        done = 0
+        while done < k:
+            env.rollout(chunk, policy=policy, policy_seed=7, t0=t0 + done, obs_buffers=ob, zero_stats=False)
+            done += chunk
+    go(chunk * 2, 0)
+    env.check()
+    env.set_profiling(True)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    go(steps, chunk * 2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t
+    p = env.get_profile()
+    env.check()
+    fused = p["rollout_fused_steps"]
+    print(f"{label:34s} n={n:7d} chunk={chunk:3d} obs={obs_mode:5s} | rollout {p['rollout_ms']*1e3/fused:7.2f} us/step "
+          f"| refill {p['refill_ms']*1e3/fused:7.2f} us/step | wall {dt*1e6/steps:7.2f} us/step | {n*steps/dt/1e6:8.1f} M steps/s",
+          flush=True)
+    env.close()
+
+
+if __name__ == "__main__":
+    chunk = int(os.environ.get("CHUNK", "16"))
+    steps = chunk * 8
+    run(65536, True, 2, chunk, steps, "keep", label="C3 baseline")
+    run(65536, True, 2, chunk, steps, "live", label="C3 obs overwritten in place")
+    run(65536, True, 2, chunk, steps, "none", label="C3 no obs writes")
+    run(65536, False, 2, chunk, steps, "keep", max_ante=0, label="C2 no jokers")
+    run(65536, False, 1, chunk, steps, "keep", max_ante=0, label="C1 small-only policy")
+    run(65536, False, 0, chunk, steps, "keep", max_ante=0, label="C5 uniform policy")
+    run(131072, True, 2, chunk, steps, "keep", label="C3 2x envs")
+    run(262144, True, 2, chunk, steps, "keep", label="C3 4x envs")
+    run(16384, True, 2, chunk, steps, "keep", label="C3 1/4 envs")
