@@ -54,6 +54,7 @@ struct BgDev {
   uint32_t* err;
   uint32_t* wl_count; // [4] refill work-list lengths: decks, shops, global blocks
   uint32_t* wl;       // [3][N] env indexes needing a refill of each kind
+  unsigned long long* dbg; // [16] phase cycle counters (development builds, -DBG_TIMING)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -177,6 +178,17 @@ __device__ __forceinline__ uint32_t* bg_sblock(const BgDev& d, int env, int slot
 __device__ __forceinline__ uint32_t* bg_deckmt(const BgDev& d, int env) { return d.deckmt + (size_t)env * BG_MTS; }
 __device__ __forceinline__ uint32_t* bg_shopgenmt(const BgDev& d, int env) { return d.shopgenmt + (size_t)env * BG_MTS; }
 
+// development cycle probes (-DBG_TIMING): the first active lane of the wave adds the cycles since the previous probe
+#ifdef BG_TIMING
+#define BG_PROBE_BEGIN() unsigned long long _pt = __builtin_readcyclecounter()
+#define BG_PROBE(k) do { unsigned long long _n = __builtin_readcyclecounter(); \
+    if (d.dbg && (int)threadIdx.x == __ffsll((long long)__ballot(1)) - 1 + (int)(threadIdx.x & ~63u)) atomicAdd(&d.dbg[k], _n - _pt); \
+    _pt = __builtin_readcyclecounter(); } while (0)
+#else
+#define BG_PROBE_BEGIN() do {} while (0)
+#define BG_PROBE(k) do {} while (0)
+#endif
+
 struct Deck0 { uint64_t lo, hi; };
 __device__ __forceinline__ Deck0 bg_load_deck0(const BgDev& d, int env) {
   uint4 c = d.deck[env];
@@ -211,15 +223,29 @@ __device__ __forceinline__ uint32_t bg_twist(uint32_t a, uint32_t b, uint32_t fa
 // independent loads up front and then consumed from LDS: the serial chain of dependent HBM round trips (one per
 // draw, ~1 us each at one wave per SIMD) becomes one batch.  Layout [word][lane] (bank = lane: conflict-free).
 #define BG_WIN 112
+// Per-workgroup lookup tables in LDS (filled once per launch by bg_tables_init): per-lane-different joker ids make
+// `switch` statements fully divergent (a wave walks every case some lane takes) and constant-memory tables cost an HBM
+// round trip per lookup at one wave per SIMD; an LDS read is ~100 cycles and never diverges.
+struct JTables {
+  uint64_t jd[152];    // individual-phase descriptor per joker id (bg_jdesc)
+  uint32_t jm[152];    // main-phase descriptor per joker id (bg_jmain_desc)
+  uint8_t jf[152];     // name-group flags used by reward shaping / discard hooks
+  uint8_t cost[152];   // JokerInfo.base_cost (jokers.py)
+  double pow115[101];  // 1.15 ** k  (shop.py:105)
+  double pow15[16];    // 1.5 ** k   (Baron)
+  double pow08[16];    // 0.8 ** k   (boss_blinds.py:436)
+};
 struct RngWin {
+  const JTables* jt;
   uint32_t* lds;   // &win[0][lane]
   int g_blk, g_start, g_len; // window over the global stream: block, first index, words
   int s_start, s_len;        // window over the current shop stream
 };
-__device__ __forceinline__ void bg_win_init(RngWin& w, uint32_t* lds_lane) {
-  w.lds = lds_lane; w.g_blk = -1; w.g_start = 0; w.g_len = 0; w.s_start = 0; w.s_len = 0;
+__device__ __forceinline__ void bg_win_init(RngWin& w, uint32_t* lds_lane, const JTables* jt = nullptr) {
+  w.jt = jt; w.lds = lds_lane; w.g_blk = -1; w.g_start = 0; w.g_len = 0; w.s_start = 0; w.s_len = 0;
 }
-__device__ __forceinline__ void bg_win_fill(uint32_t* lds, const uint32_t* src, int len) {
+__device__ __noinline__ void bg_win_fill(uint32_t* lds, const uint32_t* src, int len) {
+#pragma unroll 1
   for (int base = 0; base < len; base += 24) { // 24 independent loads in flight, then one wait
     uint32_t v[24];
 #pragma unroll
@@ -248,6 +274,14 @@ __device__ __forceinline__ uint32_t bg_gdraw(const BgDev& d, int env, Env& e, Rn
   else y = bg_gblock(d, env, e.g_cur)[e.g_idx];
   e.g_idx++;
   return bg_temper(y);
+}
+// raw word `off` (< 624) positions ahead of the next draw, without consuming anything
+__device__ __forceinline__ uint32_t bg_gpeek(const BgDev& d, int env, const Env& e, int off) {
+  int idx = e.g_idx + off, blk = e.g_cur, need = 1;
+  if (idx >= BG_MT_N) { idx -= BG_MT_N; blk = (blk + 1 == d.KG) ? 0 : blk + 1; need = 2; }
+  if (idx >= BG_MT_N) { idx -= BG_MT_N; blk = (blk + 1 == d.KG) ? 0 : blk + 1; need = 3; }
+  if (e.g_valid < need) { atomicOr(d.err, BG_DEVERR_GSTREAM); return 0u; }
+  return bg_temper(bg_gblock(d, env, blk)[idx]);
 }
 // fetch the next `count` words of the global stream into the window (stops at the block end)
 __device__ __forceinline__ void bg_gprefetch(const BgDev& d, int env, Env& e, RngWin& w, int count) {
@@ -366,7 +400,9 @@ __device__ __forceinline__ int bg_classify(uint64_t cards, int n) {
 // balatro_game.py:95-109 _draw_cards: append the lowest deck indexes not in hand until len == hand_size
 __device__ __forceinline__ void bg_draw_cards(Env& e) {
   uint64_t inhand = 0;
+#pragma unroll 1
   for (int i = 0; i < e.nhand; i++) inhand |= 1ull << bg_get8(e.hand, i);
+#pragma unroll 1
   while (e.nhand < e.hand_size && e.nhand < 8) {
     uint64_t freeset = ~inhand & ((1ull << 52) - 1);
     if (!freeset) break;

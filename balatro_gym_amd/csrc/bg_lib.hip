@@ -49,11 +49,13 @@ __device__ __forceinline__ void bg_emit(const BgDev& d, int env, size_t row, con
 
 __global__ __launch_bounds__(BG_BLOCK) void bg_step_kernel(BgDev d, const int32_t* __restrict__ actions, ObsPtrs obs,
                                                           double* reward, uint8_t* term, uint8_t* trunc, InfoPtrs info) {
+  __shared__ uint32_t win[BG_WIN][BG_BLOCK];
+  __shared__ JTables jt;
+  bg_tables_init(&jt);
   int env = blockIdx.x * BG_BLOCK + threadIdx.x;
   if (env >= d.N) return;
-  __shared__ uint32_t win[BG_WIN][BG_BLOCK];
   RngWin w;
-  bg_win_init(w, &win[0][threadIdx.x]);
+  bg_win_init(w, &win[0][threadIdx.x], &jt);
   Env e;
   bg_load_env(d, env, e);
   Deck0 dk = bg_load_deck0(d, env);
@@ -77,9 +79,11 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, in
   uint64_t n_steps = 0, n_eps = 0, n_plays = 0, rbits = 0, ohash = 0;
   int64_t ssum = 0;
   __shared__ uint32_t win[BG_WIN][BG_BLOCK];
+  __shared__ JTables jt;
+  bg_tables_init(&jt);
   if (env < d.N) {
     RngWin w;
-    bg_win_init(w, &win[0][threadIdx.x]);
+    bg_win_init(w, &win[0][threadIdx.x], &jt);
     Env e;
     bg_load_env(d, env, e);
     Deck0 dk = bg_load_deck0(d, env);
@@ -105,6 +109,172 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, in
   }
   if (stats) {
     // wave reduction (64 lanes) with DPP/shuffle intrinsics, then one atomic per wave
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      n_steps += __shfl_down(n_steps, off); n_eps += __shfl_down(n_eps, off); n_plays += __shfl_down(n_plays, off);
+      ssum += __shfl_down(ssum, off); rbits ^= __shfl_down(rbits, off); ohash ^= __shfl_down(ohash, off);
+    }
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd((unsigned long long*)&stats->steps, (unsigned long long)n_steps);
+      atomicAdd((unsigned long long*)&stats->episodes, (unsigned long long)n_eps);
+      atomicAdd((unsigned long long*)&stats->plays, (unsigned long long)n_plays);
+      atomicAdd((unsigned long long*)&stats->score_sum, (unsigned long long)ssum);
+      atomicXor((unsigned long long*)&stats->reward_bits, (unsigned long long)rbits);
+      atomicXor((unsigned long long*)&stats->obs_hash, (unsigned long long)ohash);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused rollout, block-compacted (the bench path).
+//
+// A step of the lane-per-env kernel above costs a wave the UNION of every branch some lane takes (a random policy
+// plays a hand on 8% of the steps, so practically every wave pays for the whole play path at ~13% lane utilisation),
+// and at 65 536 envs = 1 wave per SIMD nothing hides it.  Here a workgroup owns 256 envs and each step runs in three
+// phases separated by workgroup barriers:
+//   A  lane = env (4 waves): action mask, counter-hash policy, guards; the cheap, common actions (card-select toggles,
+//      shop end, small/big blind) are applied in registers; everything else (PLAY_HAND, DISCARD, boss blind, skip, shop
+//      buy/reroll/sell, consumables) is DEFERRED: the env's packed state goes to LDS and its index to an LDS work list
+//   B  lane = work item (dense): the deferred envs are stepped from / back to LDS by as few waves as needed
+//   C  lane = env: merge, curriculum cap, SAME_STEP auto-reset, observation / reward / terminated stores, statistics
+// State stays in registers (lane = env) across the T fused steps; LDS is only the exchange between the two lane maps.
+// ---------------------------------------------------------------------------------------------------------
+#define BG_RB 256 // envs per workgroup
+struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags; }; // misc: hand_type+1 | terminated<<8 | has_shop<<9
+
+template <bool HASH>
+__global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
+                                                              uint64_t env_index0, uint64_t t0, ObsPtrs obs,
+                                                              int obs_stride_steps, double* reward, uint8_t* term,
+                                                              int32_t* actions_out, bg_rollout_stats* stats) {
+  __shared__ uint4 s_state[BG_NHOT][BG_RB];
+  __shared__ uint4 s_shop[4][BG_RB];
+  __shared__ OutLds s_out[BG_RB];
+  __shared__ uint32_t s_items[BG_RB];
+  __shared__ uint32_t s_nitems;
+  __shared__ uint32_t win[BG_WIN][BG_BLOCK];
+  __shared__ JTables jt;
+  bg_tables_init(&jt);
+  const int local = threadIdx.x;
+  const int env = blockIdx.x * BG_RB + local;
+  const bool live = env < d.N;
+  uint64_t n_steps = 0, n_eps = 0, n_plays = 0, rbits = 0, ohash = 0;
+  int64_t ssum = 0;
+  Env e;
+  Deck0 dk;
+  ShopRegs sr; sr.valid = false;
+  uint64_t mask = 0;
+  if (live) {
+    bg_load_env(d, env, e);
+    dk = bg_load_deck0(d, env);
+    mask = bg_action_mask(d, env, e, sr);
+  }
+#ifdef BG_TIMING
+  unsigned long long tA = 0, tB = 0, tC = 0, tBitems = 0;
+#define BG_TICK() __builtin_readcyclecounter()
+#endif
+  for (int t = 0; t < T; t++) {
+    if (local == 0) s_nitems = 0;
+    __syncthreads();
+#ifdef BG_TIMING
+    unsigned long long c0 = BG_TICK();
+#endif
+    // ---------------- phase A
+    StepOut o;
+    bg_step_init(o);
+    int action = 0;
+    bool deferred = false;
+    if (live) {
+      action = bg_policy_action(e, mask, policy, policy_seed, env_index0 + (uint64_t)env, t0 + (uint64_t)t);
+      if (bg_step_guards(e, mask, action, o)) {
+        if (e.phase == 0 && action >= 2 && action < 10) bg_toggle_select(e, action - 2);
+        else if (e.phase == 1 && action == 31) { e.phase = 0; bg_draw_cards(e); }              // shop end :1247-1251
+        else deferred = true;
+      }
+      if (deferred) {
+        uint32_t slot = atomicAdd(&s_nitems, 1u);
+        s_items[slot] = (uint32_t)local | ((uint32_t)action << 16);
+        uint4 c[BG_NHOT];
+        bg_pack(e, c);
+#pragma unroll
+        for (int k = 0; k < BG_NHOT; k++) s_state[k][local] = c[k];
+      }
+    }
+    __syncthreads();
+#ifdef BG_TIMING
+    unsigned long long c1 = BG_TICK();
+#endif
+    // ---------------- phase B: dense over the work list (wave 0, 64 items per round)
+    {
+      uint32_t nitems = s_nitems;
+      if (local < BG_BLOCK) for (uint32_t it = (uint32_t)local; it < nitems; it += BG_BLOCK) { // one wave owns the RNG window
+        uint32_t item = s_items[it];
+        int l = (int)(item & 0xffffu), a = (int)(item >> 16);
+        int benv = blockIdx.x * BG_RB + l;
+        uint4 c[BG_NHOT];
+#pragma unroll
+        for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][l];
+        Env be;
+        bg_unpack(c, be);
+        Deck0 bdk = bg_load_deck0(d, benv);
+        ShopRegs bsr; bsr.valid = false;
+        RngWin w;
+        bg_win_init(w, &win[0][local & (BG_BLOCK - 1)], &jt);
+        StepOut bo;
+        bg_step_init(bo);
+        bg_env_dispatch(d, benv, be, w, bsr, bdk, a, bo);
+        bg_pack(be, c);
+#pragma unroll
+        for (int k = 0; k < BG_NHOT; k++) s_state[k][l] = c[k];
+        if (bsr.valid) { s_shop[0][l] = bsr.c3; s_shop[1][l] = bsr.c4; s_shop[2][l] = bsr.c5; s_shop[3][l] = bsr.c6; }
+        OutLds ol;
+        ol.reward = bo.reward; ol.final_score = bo.final_score;
+        ol.misc = (bo.hand_type + 1) | (bo.terminated ? 0x100 : 0) | (bsr.valid ? 0x200 : 0) | (bo.error << 16);
+        ol.flags = bo.flags;
+        s_out[l] = ol;
+      }
+    }
+    __syncthreads();
+#ifdef BG_TIMING
+    unsigned long long c2 = BG_TICK();
+    tBitems += s_nitems;
+#endif
+    // ---------------- phase C
+    if (live) {
+      if (deferred) {
+        uint4 c[BG_NHOT];
+#pragma unroll
+        for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][local];
+        bg_unpack(c, e);
+        OutLds ol = s_out[local];
+        o.reward = ol.reward; o.final_score = ol.final_score; o.flags = ol.flags;
+        o.hand_type = (ol.misc & 0xff) - 1; o.terminated = (ol.misc & 0x100) != 0; o.error = ol.misc >> 16;
+        if (ol.misc & 0x200) { sr.c3 = s_shop[0][local]; sr.c4 = s_shop[1][local]; sr.c5 = s_shop[2][local]; sr.c6 = s_shop[3][local]; sr.valid = true; }
+      }
+      if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
+      if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; } // SAME_STEP auto-reset
+      mask = bg_action_mask(d, env, e, sr);
+      size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
+      uint64_t h = bg_write_obs<HASH>(d, env, row, e, dk, obs, mask, sr);
+      if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
+      if (reward) reward[row] = o.reward;
+      if (term) term[row] = o.terminated ? 1 : 0;
+      if (actions_out) actions_out[row] = action;
+      n_steps++;
+      rbits ^= (uint64_t)__double_as_longlong(o.reward) * (2 * (uint64_t)(t0 + t) + 1);
+      if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
+    }
+#ifdef BG_TIMING
+    __syncthreads();
+    unsigned long long c3 = BG_TICK();
+    tA += c1 - c0; tB += c2 - c1; tC += c3 - c2;
+#endif
+  }
+#ifdef BG_TIMING
+  if (local == 0 && d.dbg) { atomicAdd(&d.dbg[0], tA); atomicAdd(&d.dbg[1], tB); atomicAdd(&d.dbg[2], tC); atomicAdd(&d.dbg[3], tBitems); atomicAdd(&d.dbg[4], (unsigned long long)T); }
+#endif
+  if (live) bg_store_env(d, env, e);
+  if (stats) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
       n_steps += __shfl_down(n_steps, off); n_eps += __shfl_down(n_eps, off); n_plays += __shfl_down(n_plays, off);
@@ -441,6 +611,7 @@ struct bg_handle {
   std::string err;
   // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
   bool profiling;
+  int rollout_version; // 1 = lane-per-env kernel, 2 = block-compacted kernel (BG_ROLLOUT_V)
   std::vector<hipEvent_t> ev_rollout, ev_refill, ev_step; // start/stop pairs
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
 };
@@ -491,6 +662,15 @@ static double bg_ev_sum(std::vector<hipEvent_t>& v) {
 
 extern "C" {
 
+// development hook: copy (and clear) the 16 phase counters written by -DBG_TIMING builds
+int bg_debug_counters(bg_handle* h, unsigned long long* out16) {
+  if (!h || !out16) return BG_E_ARG;
+  BG_HIP(hipDeviceSynchronize());
+  BG_HIP(hipMemcpy(out16, h->dev.dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  BG_HIP(hipMemset(h->dev.dbg, 0, 16 * sizeof(unsigned long long)));
+  return 0;
+}
+
 int bg_set_profiling(bg_handle* h, int enable) {
   if (!h) return BG_E_ARG;
   h->profiling = enable != 0;
@@ -521,12 +701,13 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (device_id < 0 || device_id >= ndev) { g_create_err = "bg_create: device_id out of range"; return BG_E_ARG; }
   bg_handle* h = new bg_handle();
   h->device_id = device_id; h->seeded = false; h->bytes = 0; h->profiling = false;
+  { const char* rv = getenv("BG_ROLLOUT_V"); h->rollout_version = rv ? atoi(rv) : 2; }
   h->d_seeds = nullptr; h->d_mask = nullptr;
   memset(&h->dev, 0, sizeof(h->dev));
   BgDev& d = h->dev;
   d.N = n_envs; d.flags = flags; d.max_ante = max_ante;
   const char* kg = getenv("BG_KG"); const char* ks = getenv("BG_KS"); const char* kd = getenv("BG_KD");
-  d.KG = kg ? atoi(kg) : 2; d.KS = ks ? atoi(ks) : 2; d.KD = kd ? atoi(kd) : 2;
+  d.KG = kg ? atoi(kg) : 6; d.KS = ks ? atoi(ks) : 12; d.KD = kd ? atoi(kd) : 11; // ~46 KB of look-ahead per env
   if (d.KG < 2 || d.KS < 2 || d.KD < 1 || d.KG > 250 || d.KS > 250 || d.KD > 250) { delete h; g_create_err = "bg_create: bad ring depths"; return BG_E_ARG; }
   size_t N = (size_t)n_envs;
   hipError_t e = hipSetDevice(device_id);
@@ -541,6 +722,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (e == hipSuccess) e = bg_alloc(h, &d.shopgenmt, (size_t)BG_MTS * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.wl_count, 4);
   if (e == hipSuccess) e = bg_alloc(h, &d.wl, 3 * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.dbg, 16);
   if (e == hipSuccess) e = bg_alloc(h, &d.err, 4);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_seeds, N);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_mask, N);
@@ -558,7 +740,7 @@ int bg_destroy(bg_handle* h) {
   if (!h) return 0;
   BgDev& d = h->dev;
   hipFree(d.hot); hipFree(d.deck); hipFree(d.cold); hipFree(d.tmpl); hipFree(d.ndeck); hipFree(d.gblk); hipFree(d.sblk);
-  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl);
+  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.dbg);
   delete h;
   return 0;
 }
@@ -696,16 +878,23 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
     }
     bg_ev_begin(h, h->ev_rollout, (hipStream_t)stream);
     if (h->profiling) h->rollout_steps.push_back(chunk);
-    if (policy & BG_POLICY_HASH_OBS)
-      hipLaunchKernelGGL(bg_rollout_kernel<true>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev, chunk,
-                         policy & 0xff, policy_seed, env_index0, t0 + (uint64_t)done, o, obs_stride_steps,
-                         reward_dev ? reward_dev + off : nullptr, terminated_dev ? terminated_dev + off : nullptr,
-                         actions_out_dev ? actions_out_dev + off : nullptr, stats_dev);
-    else
-      hipLaunchKernelGGL(bg_rollout_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev, chunk,
-                         policy & 0xff, policy_seed, env_index0, t0 + (uint64_t)done, o, obs_stride_steps,
-                         reward_dev ? reward_dev + off : nullptr, terminated_dev ? terminated_dev + off : nullptr,
-                         actions_out_dev ? actions_out_dev + off : nullptr, stats_dev);
+    {
+      const bool hash = (policy & BG_POLICY_HASH_OBS) != 0;
+      const int pol = policy & 0xff;
+      double* rw = reward_dev ? reward_dev + off : nullptr;
+      uint8_t* tm = terminated_dev ? terminated_dev + off : nullptr;
+      int32_t* ac = actions_out_dev ? actions_out_dev + off : nullptr;
+      hipStream_t st = (hipStream_t)stream;
+      uint64_t tt = t0 + (uint64_t)done;
+      if (h->rollout_version == 1) {
+        if (hash) hipLaunchKernelGGL(bg_rollout_kernel<true>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, h->dev, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
+        else hipLaunchKernelGGL(bg_rollout_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, h->dev, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
+      } else {
+        dim3 g2((h->dev.N + BG_RB - 1) / BG_RB);
+        if (hash) hipLaunchKernelGGL(bg_rollout2_kernel<true>, g2, dim3(BG_RB), 0, st, h->dev, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
+        else hipLaunchKernelGGL(bg_rollout2_kernel<false>, g2, dim3(BG_RB), 0, st, h->dev, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
+      }
+    }
     bg_ev_end(h, h->ev_rollout, (hipStream_t)stream);
     BG_HIP(hipGetLastError());
     rc = bg_refill(h, stream);

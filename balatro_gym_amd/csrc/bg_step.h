@@ -72,12 +72,6 @@ __device__ __forceinline__ uint64_t bg_action_mask(const BgDev& d, int env, cons
   return m;
 }
 
-__device__ __forceinline__ bool bg_owns(const Env& e, int id) {
-  bool r = false;
-  for (int i = 0; i < e.njokers; i++) r |= bg_get8(e.jokers, i) == id;
-  return r;
-}
-
 // ---------------------------------------------------------------------------------------------------------
 // reset (balatro_env_2.py:505-558).  The shuffled deck comes from the look-ahead ring filled by the refill kernel
 // (`rng.shuffle('deck_shuffle', deck)` :525 depends on nothing but stream 0).
@@ -119,30 +113,38 @@ __device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, De
 // ---------------------------------------------------------------------------------------------------------
 // shop.py:104-139 + balatro_env_2.py:1383-1392
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double bg_shop_cost_mult(const Env& e) { // shop.py:104-108
+__device__ __forceinline__ double bg_shop_cost_mult(const Env& e, const JTables* jt) { // shop.py:104-108
   int k = e.shop_ante - 1;
   k = k < 0 ? 0 : (k > 100 ? 100 : k);
-  double m = BG_POW115[k];
+  double m = jt->pow115[k];
   if (e.n_magic > 0) m *= 0.9;
   return m;
 }
 
-// candid[j] = j-th id (0-based) of {1..145} \ owned, in library order (shop.py:123)
-__device__ __forceinline__ int bg_candidate(const Env& e, int j) {
-  int id = j + 1;
-  for (int it = 0; it < 12; it++) {
-    int c = 0;
-    for (int q = 0; q < e.njokers; q++) { int o = bg_get8(e.jokers, q); c += (o <= id && o <= 145) ? 1 : 0; }
-    int nid = j + 1 + c;
-    if (nid == id) break;
-    id = nid;
+// candid[j] = j-th id (0-based) of {1..145} \ owned, in library order (shop.py:123): walk the owned ids in ASCENDING
+// order and step over each one that is <= the running id.
+__device__ __forceinline__ uint64_t bg_sorted_jokers(const Env& e) {
+  uint64_t v = e.jokers | (e.njokers < 8 ? (~0ull << (8 * e.njokers)) : 0ull); // pad with 0xff
+#pragma unroll 1
+  for (int pass = 0; pass < 4; pass++) { // bubble passes over 5 bytes (jokers <= 5)
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint32_t a = (uint32_t)(v >> (8 * i)) & 0xffu, b2 = (uint32_t)(v >> (8 * (i + 1))) & 0xffu;
+      if (a > b2) v = (v & ~(0xffffull << (8 * i))) | ((uint64_t)b2 << (8 * i)) | ((uint64_t)a << (8 * (i + 1)));
+    }
   }
+  return v;
+}
+__device__ __forceinline__ int bg_candidate(uint64_t sorted, int j) {
+  int id = j + 1;
+#pragma unroll
+  for (int q = 0; q < 5; q++) { int o = (int)((sorted >> (8 * q)) & 0xff); if (o <= id && o <= 145) id++; }
   return id;
 }
 
 __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr) {
   bg_sprefetch(d, env, e, w, 24); // shop.py:111-139
-  double mult = bg_shop_cost_mult(e);
+  double mult = bg_shop_cost_mult(e, w.jt);
   int third = PK_TAROT + (int)bg_randbelow<true>(d, env, e, w, 3u); // rng.choice([...]) is evaluated before the loop
   int c_pack2 = third == PK_TAROT ? 600 : (third == PK_PLANET ? 900 : 1300);
   int32_t cost[9];
@@ -151,6 +153,7 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
   cost[1] = (int32_t)(500.0 * mult); tp[1] = IT_PACK | (PK_JOKER << 8);
   cost[2] = (int32_t)((double)c_pack2 * mult); tp[2] = IT_PACK | ((uint32_t)third << 8);
   int owned145 = 0;
+#pragma unroll 1
   for (int q = 0; q < e.njokers; q++) owned145 += bg_get8(e.jokers, q) <= 145 ? 1 : 0;
   uint32_t nc = (uint32_t)(145 - owned145);
   // random.sample(candid, 3): n > 21 -> selection-set method (Lib/random.py sample())
@@ -158,10 +161,11 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
   p0 = (int)bg_randbelow<true>(d, env, e, w, nc);
   do { p1 = (int)bg_randbelow<true>(d, env, e, w, nc); } while (p1 == p0 && ++guard < 4096);
   do { p2 = (int)bg_randbelow<true>(d, env, e, w, nc); } while ((p2 == p0 || p2 == p1) && ++guard < 4096);
-  int j0 = bg_candidate(e, p0), j1 = bg_candidate(e, p1), j2 = bg_candidate(e, p2);
-  cost[3] = (int32_t)((double)BG_JOKER_COST[j0] * mult); tp[3] = IT_JOKER | ((uint32_t)j0 << 8);
-  cost[4] = (int32_t)((double)BG_JOKER_COST[j1] * mult); tp[4] = IT_JOKER | ((uint32_t)j1 << 8);
-  cost[5] = (int32_t)((double)BG_JOKER_COST[j2] * mult); tp[5] = IT_JOKER | ((uint32_t)j2 << 8);
+  uint64_t sj = bg_sorted_jokers(e);
+  int j0 = bg_candidate(sj, p0), j1 = bg_candidate(sj, p1), j2 = bg_candidate(sj, p2);
+  cost[3] = (int32_t)((double)w.jt->cost[j0] * mult); tp[3] = IT_JOKER | ((uint32_t)j0 << 8);
+  cost[4] = (int32_t)((double)w.jt->cost[j1] * mult); tp[4] = IT_JOKER | ((uint32_t)j1 << 8);
+  cost[5] = (int32_t)((double)w.jt->cost[j2] * mult); tp[5] = IT_JOKER | ((uint32_t)j2 << 8);
   int v = (int)bg_randbelow<true>(d, env, e, w, 2u); // 0 'Voucher: Magic Trick' 600, 1 'Voucher: Minimalist' 750
   cost[6] = (int32_t)((v ? 750.0 : 600.0) * mult); tp[6] = IT_VOUCHER | ((uint32_t)v << 8);
   int ca = (int)bg_randbelow<true>(d, env, e, w, 52u), cb = (int)bg_randbelow<true>(d, env, e, w, 52u); // randint(0, 51)
@@ -183,7 +187,7 @@ __device__ __forceinline__ void bg_generate_shop(const BgDev& d, int env, Env& e
   e.shop_ante = e.ante;
   e.shop_reroll_base = 50;
   bg_shop_inventory(d, env, e, w, sr);
-  e.shop_reroll_state = (int32_t)(50.0 * bg_shop_cost_mult(e));
+  e.shop_reroll_state = (int32_t)(50.0 * bg_shop_cost_mult(e, w.jt));
 }
 
 // balatro_env_2.py:1326-1381 (card-state gold money needs card states: not on this path)
@@ -206,75 +210,109 @@ __device__ __forceinline__ void bg_advance_round(const BgDev& d, int env, Env& e
 // ---------------------------------------------------------------------------------------------------------
 struct JEff { int chips, mult; double x; };
 
-// complete_joker_effects.py:35-129 (main 'scoring' phase).  The dict literal at :39-53 is rebuilt on every call, so one
-// random.randint(0, 23) is drawn per joker whatever its name; `mis` is that draw.
-__device__ __forceinline__ JEff bg_joker_main(const Env& e, int id, uint32_t mis, uint32_t suits, int kings, int queens,
-                                              int n, int ht) {
-  JEff r = {0, 0, 1.0};
+// complete_joker_effects.py:35-129 (main 'scoring' phase) as a descriptor per joker id:
+//   bits 0..4 condition index into a per-play condition bit set, 5..7 value kind, 8..23 constant.
+// conditions: 0 always | 1 <= 3 scoring cards | 2 hands_left == 1 | 3 discards_left == 0 | 4..7 a scoring card of suit
+//   C,D,H,S | 8 Blackboard | 9 Seeing Double | 10 Flower Pot | 11 a King played | 12 a Queen played | 16+t hand type == t
+//   (the env's names 'One Pair'/'Three Kind'/'Four Kind' never match 'Pair'/'Three of a Kind'/'Four of a Kind', SURVEY
+//   Q11, so only Two Pair / Straight / Flush jokers get a type condition) | 31 never.
+// values: 0 +mult c | 1 +chips c | 2 x c | 3 +mult randint(0,23) (Misprint) | 4 +mult 3*len(jokers) | 5 +chips 30*discards
+//   | 6 x 1.5**kings | 7 +mult 13*queens.
+#define BG_JM(cond, vk, c) ((uint32_t)(cond) | ((uint32_t)(vk) << 5) | ((uint32_t)(c) << 8))
+__device__ __forceinline__ uint32_t bg_jmain_desc(int id) {
   switch (id) {
-    case 27: r.mult = (int)mis; break;                                  // Misprint
-    case 1: r.mult = 4; break;                                          // Joker
-    case 136: r.chips = 250; break;                                     // Stuntman
-    case 38: r.mult = 15; break;                                        // Gros Michel
-    case 61: r.x = 3.0; break;                                          // Cavendish
-    case 16: if (n <= 3) r.mult = 20; break;                            // Half Joker
-    case 34: r.mult = 3 * e.njokers; break;                             // Abstract Joker
-    case 108: if (e.hands_left == 1) r.x = 3.0; break;                  // Acrobat
-    case 23: if (e.discards_left == 0) r.mult = 15; break;              // Mystic Summit
-    case 22: r.chips = 30 * e.discards_left; break;                     // Banner
-    case 53: r.chips = 104; break;                                      // Blue Joker: 2 * len(deck)
-    case 97: r.mult = 20; break;                                        // Popcorn
-    case 50: r.chips = 100; break;                                      // Ice Cream
-    case 2: if (suits & 2u) r.mult = 3; break;                          // Greedy (Diamonds)
-    case 3: if (suits & 4u) r.mult = 3; break;                          // Lusty (Hearts)
-    case 4: if (suits & 8u) r.mult = 3; break;                          // Wrathful (Spades)
-    case 5: if (suits & 1u) r.mult = 3; break;                          // Gluttonous (Clubs)
-    // hand-type jokers: the env passes 'One Pair'/'Three Kind'/'Four Kind' (balatro_env_2.py:674), so only
-    // 'Two Pair' / 'Straight' / 'Flush' ever match
-    case 8: if (ht == 2) r.mult = 10; break;
-    case 9: if (ht == 4) r.mult = 12; break;
-    case 10: if (ht == 5) r.mult = 10; break;
-    case 13: if (ht == 2) r.chips = 80; break;
-    case 14: if (ht == 4) r.chips = 100; break;
-    case 15: if (ht == 5) r.chips = 80; break;
-    case 134: if (ht == 4) r.x = 3.0; break;
-    case 135: if (ht == 5) r.x = 2.0; break;
-    case 48: if ((suits & ~9u) == 0) r.x = 3.0; break;                  // Blackboard: all Spades/Clubs
-    case 128: if ((suits & 1u) && __popc(suits) > 1) r.x = 2.0; break;  // Seeing Double
-    case 122: if (__popc(suits) == 4) r.x = 3.0; break;                 // Flower Pot ('Stone' is a suit string)
-    case 72: if (kings > 0) r.x = BG_POW15[kings]; break;               // Baron
-    case 140: if (queens > 0) r.mult = 13 * queens; break;              // Shoot the Moon
-    default: break;
+    case 1: return BG_JM(0, 0, 4);      // Joker
+    case 136: return BG_JM(0, 1, 250);  // Stuntman
+    case 27: return BG_JM(0, 3, 0);     // Misprint
+    case 38: return BG_JM(0, 0, 15);    // Gros Michel
+    case 61: return BG_JM(0, 2, 3);     // Cavendish
+    case 16: return BG_JM(1, 0, 20);    // Half Joker
+    case 34: return BG_JM(0, 4, 0);     // Abstract Joker
+    case 108: return BG_JM(2, 2, 3);    // Acrobat
+    case 23: return BG_JM(3, 0, 15);    // Mystic Summit
+    case 22: return BG_JM(0, 5, 0);     // Banner
+    case 53: return BG_JM(0, 1, 104);   // Blue Joker: 2 * len(deck)
+    case 97: return BG_JM(0, 0, 20);    // Popcorn
+    case 50: return BG_JM(0, 1, 100);   // Ice Cream
+    case 2: return BG_JM(5, 0, 3);      // Greedy (Diamonds)
+    case 3: return BG_JM(6, 0, 3);      // Lusty (Hearts)
+    case 4: return BG_JM(7, 0, 3);      // Wrathful (Spades)
+    case 5: return BG_JM(4, 0, 3);      // Gluttonous (Clubs)
+    case 8: return BG_JM(16 + 2, 0, 10);   // Mad Joker (Two Pair)
+    case 9: return BG_JM(16 + 4, 0, 12);   // Crazy Joker (Straight)
+    case 10: return BG_JM(16 + 5, 0, 10);  // Droll Joker (Flush)
+    case 13: return BG_JM(16 + 2, 1, 80);  // Clever Joker
+    case 14: return BG_JM(16 + 4, 1, 100); // Devious Joker
+    case 15: return BG_JM(16 + 5, 1, 80);  // Crafty Joker
+    case 134: return BG_JM(16 + 4, 2, 3);  // The Order
+    case 135: return BG_JM(16 + 5, 2, 2);  // The Tribe
+    case 48: return BG_JM(8, 2, 3);     // Blackboard
+    case 128: return BG_JM(9, 2, 2);    // Seeing Double
+    case 122: return BG_JM(10, 2, 3);   // Flower Pot
+    case 72: return BG_JM(11, 6, 0);    // Baron
+    case 140: return BG_JM(12, 7, 0);   // Shoot the Moon
+    default: return BG_JM(31, 0, 0);
   }
-  return r;
+}
+// name groups: 1 flush synergy (:853) | 2 pair/set synergy (:857-858) | 4 face synergy (:863) | 8 Trading Card | 16 Faceless
+// Joker | 32 "discard joker" names (:1006)
+__device__ __forceinline__ uint32_t bg_jflags(int id) {
+  uint32_t f = 0;
+  if (id == 113 || id == 18 || id == 69) f |= 1;
+  if (id == 40 || id == 39 || id == 6 || id == 7) f |= 2;
+  if (id == 33 || id == 104 || id == 42) f |= 4;
+  if (id == 95) f |= 8;
+  if (id == 57) f |= 16;
+  if (id == 57 || id == 130 || id == 82 || id == 77) f |= 32;
+  return f;
 }
 
-// complete_joker_effects.py:131-184 (per-card 'individual_scoring' phase) as a descriptor per joker:
-//   bits 0..14 ranks that trigger, 16..20 suits that trigger (C,D,H,S,'Stone'), 21..22 special (1 = 8 Ball: one more
-//   random() when the card is an 8, :167; 2 = Bloodstone: the effect needs the random() value, :161), 23 = x2,
-//   24..39 chips, 40..47 mult.  An effect fires iff rank AND suit bits are set; every (card, joker) pair consumes one
-//   random() = 2 words because suit_effects (:157-162) is rebuilt per call.
-#define BG_JD(ranks, suits, special, x2, chips, mult) \
-  ((uint64_t)(ranks) | ((uint64_t)(suits) << 16) | ((uint64_t)(special) << 21) | ((uint64_t)(x2) << 23) | ((uint64_t)(chips) << 24) | ((uint64_t)(mult) << 40))
+// complete_joker_effects.py:131-184 (per-card 'individual_scoring' phase).  Every effect is "rank in R" (any suit)
+// or "suit == s" (any rank), so a joker's total over the played cards is (number of matching cards) x (chips, mult):
+// the descriptor is  bits 0..14 ranks R | 16..18 suit+1 (0 = rank type) | 20..21 special (1 = 8 Ball: one more random()
+// per played 8, :167; 2 = Bloodstone: needs the random() value, :161) | 22 x2 | 24..31 chips | 32..39 mult.
+// Each (card, joker) pair consumes one random() = 2 words whatever the joker, because suit_effects (:157-162) is
+// rebuilt on every call.
+#define BG_JD(ranks, suit1, special, x2, chips, mult) \
+  ((uint64_t)(ranks) | ((uint64_t)(suit1) << 16) | ((uint64_t)(special) << 20) | ((uint64_t)(x2) << 22) | ((uint64_t)(chips) << 24) | ((uint64_t)(mult) << 32))
 #define BG_R(r) (1u << (r))
 __device__ __forceinline__ uint64_t bg_jdesc(int id) {
-  const uint32_t ALLR = 0x7fffu, ALLS = 0x1fu, FACES = BG_R(11) | BG_R(12) | BG_R(13);
+  const uint32_t FACES = BG_R(11) | BG_R(12) | BG_R(13);
   switch (id) {
-    case 31: return BG_JD(BG_R(2) | BG_R(3) | BG_R(5) | BG_R(8) | BG_R(14), ALLS, 0, 0, 0, 8);   // Fibonacci
-    case 39: return BG_JD(BG_R(2) | BG_R(4) | BG_R(6) | BG_R(8) | BG_R(10), ALLS, 0, 0, 0, 4);   // Even Steven
-    case 40: return BG_JD(BG_R(3) | BG_R(5) | BG_R(7) | BG_R(9) | BG_R(14), ALLS, 0, 0, 31, 0);  // Odd Todd
-    case 41: return BG_JD(BG_R(14), ALLS, 0, 0, 20, 4);                                          // Scholar
-    case 101: return BG_JD(BG_R(4) | BG_R(10), ALLS, 0, 0, 10, 4);                               // Walkie Talkie
-    case 124: return BG_JD(BG_R(2), ALLS, 0, 0, 8, 0);                                           // Wee Joker
-    case 26: return BG_JD(0, 0, 1, 0, 0, 0);                                                     // 8 Ball
-    case 33: return BG_JD(FACES, ALLS, 0, 0, 30, 0);                                             // Scary Face
-    case 104: return BG_JD(FACES, ALLS, 0, 0, 0, 5);                                             // Smiley Face
-    case 147: return BG_JD(BG_R(12) | BG_R(13), ALLS, 0, 1, 0, 0);                               // Triboulet
-    case 118: return BG_JD(ALLR, 1u << 3, 0, 0, 50, 0);                                          // Arrowhead (Spades)
-    case 119: return BG_JD(ALLR, 1u << 0, 0, 0, 0, 7);                                           // Onyx Agate (Clubs)
-    case 117: return BG_JD(ALLR, 1u << 2, 2, 1, 0, 0);                                           // Bloodstone (Hearts, p = .5)
-    default: return 0ull;                                                                        // incl. Rough Gem ($ only)
+    case 31: return BG_JD(BG_R(2) | BG_R(3) | BG_R(5) | BG_R(8) | BG_R(14), 0, 0, 0, 0, 8);   // Fibonacci
+    case 39: return BG_JD(BG_R(2) | BG_R(4) | BG_R(6) | BG_R(8) | BG_R(10), 0, 0, 0, 0, 4);   // Even Steven
+    case 40: return BG_JD(BG_R(3) | BG_R(5) | BG_R(7) | BG_R(9) | BG_R(14), 0, 0, 0, 31, 0);  // Odd Todd
+    case 41: return BG_JD(BG_R(14), 0, 0, 0, 20, 4);                                          // Scholar
+    case 101: return BG_JD(BG_R(4) | BG_R(10), 0, 0, 0, 10, 4);                               // Walkie Talkie
+    case 124: return BG_JD(BG_R(2), 0, 0, 0, 8, 0);                                           // Wee Joker
+    case 26: return BG_JD(0, 0, 1, 0, 0, 0);                                                  // 8 Ball
+    case 33: return BG_JD(FACES, 0, 0, 0, 30, 0);                                             // Scary Face
+    case 104: return BG_JD(FACES, 0, 0, 0, 0, 5);                                             // Smiley Face
+    case 147: return BG_JD(BG_R(12) | BG_R(13), 0, 0, 1, 0, 0);                               // Triboulet
+    case 118: return BG_JD(0, 3 + 1, 0, 0, 50, 0);                                            // Arrowhead (Spades)
+    case 119: return BG_JD(0, 0 + 1, 0, 0, 0, 7);                                             // Onyx Agate (Clubs)
+    case 117: return BG_JD(0, 2 + 1, 2, 1, 0, 0);                                             // Bloodstone (Hearts, p = .5)
+    default: return 0ull;                                                                     // incl. Rough Gem ($ only)
   }
+}
+
+// fill the workgroup's LDS tables (every thread of the block must call it; ends with a barrier)
+__device__ __forceinline__ void bg_tables_init(JTables* t) {
+  for (int id = threadIdx.x; id < 152; id += blockDim.x) {
+    t->jd[id] = bg_jdesc(id);
+    t->jm[id] = bg_jmain_desc(id);
+    t->jf[id] = (uint8_t)bg_jflags(id);
+    t->cost[id] = id < 151 ? BG_JOKER_COST[id] : 0;
+    if (id < 101) t->pow115[id] = BG_POW115[id];
+    if (id < 16) { t->pow15[id] = BG_POW15[id]; t->pow08[id] = id < 9 ? BG_POW08[id] : 0.0; }
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ uint32_t bg_joker_flags(const Env& e, const JTables* jt) {
+  uint32_t f = 0;
+#pragma unroll 1
+  for (int j = 0; j < e.njokers; j++) f |= jt->jf[bg_get8(e.jokers, j)];
+  return f;
 }
 
 // boss_blinds.py:343-378 on_hand_drawn as applied by balatro_env_2.py:936-948
@@ -293,10 +331,12 @@ __device__ __forceinline__ void bg_boss_on_hand_drawn(const BgDev& d, int env, E
       break;
     case 3: // The Wheel
       bg_gprefetch(d, env, e, w, 2 * n);
+#pragma unroll 1
       for (int i = 0; i < n; i++) if (bg_grandom(d, env, e, w) < 1.0 / 7.0) fd |= 1u << i;
       break;
     case 4: if (e.bflags & BG_BF_FIRST_HAND) fd = (1u << n) - 1; break;  // The House
     case 5: // The Mark
+#pragma unroll 1
       for (int i = 0; i < n; i++) { int rk = (bg_card(d, env, dk, bg_get8(e.hand, i)) >> 2) + 2; if (rk >= 11 && rk <= 13) fd |= 1u << i; }
       break;
     case 6: if (!(e.bflags & BG_BF_FIRST_HAND)) fd = (1u << n) - 1; break; // The Fish
@@ -314,35 +354,41 @@ __device__ __forceinline__ void bg_boss_on_hand_drawn(const BgDev& d, int env, E
 // PLAY_HAND  balatro_env_2.py:645-960
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, const Deck0& dk, StepOut& o) {
-  // :650-660 selected cards in selection order
-  uint32_t pc[8]; // rank | suit<<4 | chips<<8 per played card (static indexing only: loops are fully unrolled)
-  int didx[8];
-  int n = 0;
-  int chip_sum = 0, faces = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    pc[i] = 0; didx[i] = 0;
-    if (i < e.nsel) {
-      int pos = bg_get8(e.sel, i);
-      if (pos < e.nhand) {
-        int ci = bg_get8(e.hand, pos);
-        int code = bg_card(d, env, dk, ci);
-        int rk = (code >> 2) + 2, su = code & 3, ch = bg_card_chips(code);
-        // all valid selections are contiguous from 0 because positions are validated at selection time
-        pc[i] = (uint32_t)rk | ((uint32_t)su << 4) | ((uint32_t)ch << 8);
-        didx[i] = ci;
-        chip_sum += ch;
-        faces += rk >= 11;
-        n++;
-        e.highlighted |= 1u << pos; // :663-666 highlights are never cleared by a play
-      }
+  BG_PROBE_BEGIN();
+  // :650-660 selected cards in selection order.  Everything the scorer needs is kept as small histograms:
+  //   phist  15 x 4-bit counts per rank (2..14), scnt 4 x 4-bit counts per suit, pcodes the card codes by play index,
+  //   pmask  bit per played DECK index (boss_blinds.py:472 id(card)), chip_sum (cards.py:52-60)
+  uint64_t phist = 0, pcodes = 0, pmask = 0;
+  uint32_t scnt = 0;
+  int n = 0, chip_sum = 0;
+#pragma unroll 1
+  for (int i = 0; i < e.nsel; i++) {
+    int pos = bg_get8(e.sel, i);
+    if (pos < e.nhand) {
+      int ci = bg_get8(e.hand, pos);
+      int code = bg_card(d, env, dk, ci);
+      phist += 1ull << (4 * ((code >> 2) + 2));
+      scnt += 1u << (4 * (code & 3));
+      pcodes |= (uint64_t)code << (8 * n);
+      pmask |= 1ull << ci;
+      chip_sum += bg_card_chips(code);
+      n++;
+      e.highlighted |= 1u << pos; // :663-666 highlights are never cleared by a play
     }
   }
+  int jacks = (int)((phist >> 44) & 0xf), queens = (int)((phist >> 48) & 0xf), kings = (int)((phist >> 52) & 0xf);
+  int faces = jacks + queens + kings + (int)((phist >> 56) & 0xf); // rank >= 11 counts the ace (:862)
+  BG_PROBE(5);
   // :669-671 classify deck[p] for highlighted POSITIONS p
   uint64_t hc = 0; int nh = 0;
-  for (int p = 0; p < 16; p++)
-    if (e.highlighted & (1u << p)) { if (nh < 8) hc |= (uint64_t)bg_card(d, env, dk, p) << (8 * nh); nh++; }
+#pragma unroll 1
+  for (uint32_t hm = e.highlighted & 0xffffu; hm; hm &= hm - 1) {
+    int p = __ffs((int)hm) - 1;
+    if (nh < 8) hc |= (uint64_t)bg_card(d, env, dk, p) << (8 * nh);
+    nh++;
+  }
   int ht = bg_classify(hc, nh < 8 ? nh : 8);
+  BG_PROBE(6);
   // :677-680 boss restrictions (boss_blinds.py:380-407)
   if (e.boss_type) {
     int err = 0;
@@ -359,56 +405,72 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   int64_t chips = bchips + chip_sum, mult = bmult;
   double x_mult = 1.0;
   if ((d.flags & 1u) && e.njokers > 0) { // scorer-level joker names (BG_FLAG_SCORER_JOKERS); dict jokers are inert (Q6)
-    // unified_scoring.py:174-209 individual phase, card-major / joker-minor.  Every x factor is 2.0 or a small exact
-    // product, so the order of the float multiplications cannot change the (exact) result.
-    uint64_t jd[5];
-    int jid[5];
-    bool blood = false;
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      jid[j] = j < e.njokers ? bg_get8(e.jokers, j) : 0;
-      jd[j] = bg_jdesc(jid[j]);
-      blood |= ((jd[j] >> 21) & 3u) == 2u;
+    // unified_scoring.py:174-209 individual phase.  Totals do not depend on the (card-major, joker-minor) order: chips
+    // and mult add up, and every x factor is exactly 2.0.
+    const int nj = e.njokers;
+    int ic = 0, im = 0, xexp = 0, j8 = -1, jb = -1;
+#pragma unroll 1
+    for (int j = 0; j < nj; j++) {
+      uint64_t dsc = w.jt->jd[bg_get8(e.jokers, j)];
+      uint32_t sp = (uint32_t)(dsc >> 20) & 3u;
+      if (sp == 1u) j8 = j;
+      if (sp == 2u) { jb = j; continue; } // Bloodstone is settled card by card below
+      int cnt = 0;
+      uint32_t suit1 = (uint32_t)(dsc >> 16) & 7u;
+      if (suit1) cnt = (int)((scnt >> (4 * (suit1 - 1))) & 0xfu);
+      else {
+#pragma unroll 1
+        for (uint32_t rm = (uint32_t)dsc & 0x7fffu; rm; rm &= rm - 1) cnt += (int)((phist >> (4 * (__ffs((int)rm) - 1))) & 0xf);
+      }
+      ic += cnt * (int)((dsc >> 24) & 0xffu); im += cnt * (int)((dsc >> 32) & 0xffu);
+      if ((dsc >> 22) & 1u) xexp += cnt;
     }
-    if (blood) bg_gprefetch(d, env, e, w, n * e.njokers * 2 + 16 + e.njokers * 2 + 6);
-    int ic = 0, im = 0, xexp = 0, pend = 0;
-    uint32_t suits = 0; int kings = 0, queens = 0;
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-      if (c < n) {
-        uint32_t rk = pc[c] & 0xfu, su = (pc[c] >> 4) & 0xfu;
-        suits |= 1u << su; kings += rk == 13; queens += rk == 12;
-#pragma unroll
-        for (int j = 0; j < 5; j++) {
-          if (j < e.njokers) {
-            uint64_t dsc = jd[j];
-            bool hit = ((dsc >> rk) & (dsc >> (16 + su)) & 1ull) != 0;
-            uint32_t sp = (uint32_t)(dsc >> 21) & 3u;
-            if (sp == 2u) { // Bloodstone: the random() value decides
-              bg_gskip(d, e, pend); pend = 0;
-              double b = bg_grandom(d, env, e, w);
-              hit = hit && b < 0.5;
-            } else {
-              pend += 2;
-              if (sp == 1u && rk == 8u) pend += 2; // 8 Ball's extra random() on an 8
-            }
-            if (hit) { ic += (int)((dsc >> 24) & 0xffffu); im += (int)((dsc >> 40) & 0xffu); xexp += (int)((dsc >> 23) & 1u); }
-          }
+    BG_PROBE(7);
+    bg_gnorm(d, e);
+    int n8 = j8 >= 0 ? (int)((phist >> 32) & 0xf) : 0; // 8 Ball: one extra random() per played 8 (:167)
+    int consumed = 2 * n * nj + 2 * n8;
+    if (jb >= 0 && ((scnt >> 8) & 0xfu)) {
+      // Bloodstone on a Heart: x2 iff the pair's random() < 0.5.  Pair (c, jb) sits 2*(c*nj + jb) words ahead, plus 2
+      // for every extra 8-Ball draw that precedes it in card-major order.
+      bg_gprefetch(d, env, e, w, consumed);
+      int eights = 0;
+#pragma unroll 1
+      for (int c = 0; c < n; c++) {
+        int code = (int)((pcodes >> (8 * c)) & 0xff);
+        int rk = (code >> 2) + 2;
+        if ((code & 3) == 2) {
+          int off = 2 * (c * nj + jb) + 2 * (eights + ((j8 >= 0 && j8 < jb && rk == 8) ? 1 : 0));
+          uint32_t ra, rb;
+          if (off + 1 < w.g_len) { ra = bg_temper(w.lds[off * BG_BLOCK]); rb = bg_temper(w.lds[(off + 1) * BG_BLOCK]); }
+          else { ra = bg_gpeek(d, env, e, off); rb = bg_gpeek(d, env, e, off + 1); }
+          double b = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
+          if (b < 0.5) xexp++;
         }
+        if (j8 >= 0 && rk == 8) eights++;
       }
     }
-    bg_gskip(d, e, pend);
+    bg_gskip(d, e, consumed);
     chips += ic; mult += im;
     x_mult *= (double)(1ull << xexp);
+    BG_PROBE(8);
     // :216-244 main phase, joker order; one randint(0, 23) per joker
-    bg_gprefetch(d, env, e, w, e.njokers * 2 + 6);
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      if (j < e.njokers) {
-        uint32_t mis = bg_randbelow<false>(d, env, e, w, 24u);
-        JEff f = bg_joker_main(e, jid[j], mis, suits, kings, queens, n, ht);
-        chips += f.chips; mult += f.mult; x_mult *= f.x;
-      }
+    uint32_t suits = ((scnt & 0xfu) ? 1u : 0u) | ((scnt & 0xf0u) ? 2u : 0u) | ((scnt & 0xf00u) ? 4u : 0u) | ((scnt & 0xf000u) ? 8u : 0u);
+    uint32_t cond = 1u | (n <= 3 ? 2u : 0u) | (e.hands_left == 1 ? 4u : 0u) | (e.discards_left == 0 ? 8u : 0u) | (suits << 4) |
+                    ((suits & ~9u) == 0 ? 1u << 8 : 0u) | (((suits & 1u) && __popc(suits) > 1) ? 1u << 9 : 0u) |
+                    (__popc(suits) == 4 ? 1u << 10 : 0u) | (kings > 0 ? 1u << 11 : 0u) | (queens > 0 ? 1u << 12 : 0u) | (1u << (16 + ht));
+    double baron = w.jt->pow15[kings];
+    bg_gprefetch(d, env, e, w, nj * 2 + 6);
+#pragma unroll 1
+    for (int j = 0; j < nj; j++) {
+      uint32_t mis = bg_randbelow<false>(d, env, e, w, 24u);
+      uint32_t dm = w.jt->jm[bg_get8(e.jokers, j)];
+      bool ok = (cond >> (dm & 31u)) & 1u;
+      uint32_t vk = (dm >> 5) & 7u;
+      int c = (int)(dm >> 8);
+      int madd = vk == 0 ? c : (vk == 3 ? (int)mis : (vk == 4 ? 3 * nj : (vk == 7 ? 13 * queens : 0)));
+      int cadd = vk == 1 ? c : (vk == 5 ? 30 * e.discards_left : 0);
+      double xf = vk == 2 ? (double)c : (vk == 6 ? baron : 1.0);
+      if (ok) { chips += cadd; mult += madd; x_mult *= xf; }
     }
   }
   int64_t final_score = (int64_t)((double)(chips * mult) * x_mult); // unified_scoring.py:286
@@ -420,16 +482,11 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     else if (e.boss_type == 22) mc = 0;
     else if (e.boss_type == 23) { mc = (int64_t)((double)mc * 0.75); mm = (int64_t)((double)mm * 0.75); }
     int deb = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++)
-      if (i < n) {
-        int rk = pc[i] & 0xf;
-        if (e.boss_type == 14 && rk >= 11 && rk <= 13) deb++;
-        else if (e.boss_type == 24) deb++;
-        else if (e.boss_type == 16 && ((e.boss_cards >> didx[i]) & 1ull)) deb++;
-      }
+    if (e.boss_type == 14) deb = jacks + queens + kings;                        // The Plant: face cards
+    else if (e.boss_type == 24) deb = n;                                        // The Violet: every card
+    else if (e.boss_type == 16) deb = __popcll(e.boss_cards & pmask);           // The Pillar: played before
     if (deb > 0) {
-      double pen = BG_POW08[deb];
+      double pen = w.jt->pow08[deb];
       mc = (int64_t)((double)mc * pen);
       mm = (int64_t)((double)mm * pen);
     }
@@ -452,13 +509,11 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     e.boss_types |= 1u << ht;
     e.bflags &= ~BG_BF_FIRST_HAND;
     e.boss_hp++;
-    if (e.boss_type == 16) {
-#pragma unroll
-      for (int i = 0; i < 8; i++) if (i < n) e.boss_cards |= 1ull << didx[i];
-    }
+    if (e.boss_type == 16) e.boss_cards |= pmask;
     if (e.boss_type == 25) e.boss_req = e.boss_req + 1 > 7 ? 7 : e.boss_req + 1;
   }
   e.nsel = 0; e.sel = 0; // :797
+  BG_PROBE(10);
   // :799-892 reward shaping (float64, left to right)
   double new_progress = (double)e.round_chips / (double)need1;
   if (new_progress > 1.0) new_progress = 1.0;
@@ -487,9 +542,10 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   else if (n <= 4 && e.hands_left <= 2) eff = 1.5;
   double syn = 0.0;
   if (e.njokers > 0) {
-    if (ht == 5 && (bg_owns(e, 113) || bg_owns(e, 18) || bg_owns(e, 69))) syn += 2.0;
-    if ((ht == 1 || ht == 2 || ht == 3) && (bg_owns(e, 40) || bg_owns(e, 39) || bg_owns(e, 6) || bg_owns(e, 7))) syn += 1.5;
-    if (faces > 0 && (bg_owns(e, 33) || bg_owns(e, 104) || bg_owns(e, 42))) syn += 0.5 * (double)faces;
+    uint32_t jf = bg_joker_flags(e, w.jt);
+    if (ht == 5 && (jf & 1u)) syn += 2.0;
+    if ((ht == 1 || ht == 2 || ht == 3) && (jf & 2u)) syn += 1.5;
+    if (faces > 0 && (jf & 4u)) syn += 0.5 * (double)faces;
   }
   double strat = 0.0;
   if (new_progress > 0.7 && e.hands_left >= 3) strat = 2.0;
@@ -507,6 +563,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   o.terms[0] = progress_reward; o.terms[1] = milestone; o.terms[2] = score_reward; o.terms[3] = hq;
   o.terms[4] = eff; o.terms[5] = syn; o.terms[6] = strat; o.terms[7] = ante_bonus;
   o.final_score = final_score; o.hand_type = ht; o.cards_played = n;
+  BG_PROBE(11);
   // :914-960 outcome
   if (e.round_chips >= (int64_t)e.chips_needed) {
     double bonus = 25.0 + 10.0 * (double)e.ante;
@@ -522,12 +579,14 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     bg_draw_cards(e);
     if (e.boss_type) bg_boss_on_hand_drawn(d, env, e, w, dk);
   }
+  BG_PROBE(12);
   o.reward = r;
 }
 
 // DISCARD  balatro_env_2.py:962-1050
-__device__ __forceinline__ void bg_step_discard(const BgDev& d, int env, Env& e, const Deck0& dk, StepOut& o) {
+__device__ __forceinline__ void bg_step_discard(const BgDev& d, int env, Env& e, const RngWin& w, const Deck0& dk, StepOut& o) {
   int n = 0, nfaces = 0;
+#pragma unroll 1
   for (int i = 0; i < e.nsel; i++) {
     int pos = bg_get8(e.sel, i);
     if (pos < e.nhand) {
@@ -539,15 +598,17 @@ __device__ __forceinline__ void bg_step_discard(const BgDev& d, int env, Env& e,
   }
   bool first = e.discards_left == 3; // == game.discards (balatro_game.py:25)
   int money = 0, ndj = 0;
+#pragma unroll 1
   for (int j = 0; j < e.njokers; j++) { // complete_joker_effects.py:186-209
-    int id = bg_get8(e.jokers, j);
-    if (id == 95 && first && n == 1) money += 3;        // Trading Card
-    else if (id == 57 && nfaces >= 3) money += 5;       // Faceless Joker
-    ndj += (id == 57 || id == 130 || id == 82 || id == 77) ? 1 : 0;
+    uint32_t f = w.jt->jf[bg_get8(e.jokers, j)];
+    if ((f & 8u) && first && n == 1) money += 3;        // Trading Card
+    else if ((f & 16u) && nfaces >= 3) money += 5;      // Faceless Joker
+    ndj += (f & 32u) ? 1 : 0;
   }
   e.money += money;
   // balatro_game.py:111-127 discard_hand: drop every highlighted position, clear highlights, refill
   uint64_t nh = 0; int k = 0;
+#pragma unroll 1
   for (int p = 0; p < e.nhand; p++)
     if (!(e.highlighted & (1u << p))) { nh |= (uint64_t)bg_get8(e.hand, p) << (8 * k); k++; }
   e.hand = nh; e.nhand = k;
@@ -572,7 +633,7 @@ __device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, Rn
     int id = bg_get8(e.jokers, ji);
     e.jokers = bg_del8(e.jokers, ji);
     e.njokers--;
-    int v = BG_JOKER_COST[id] / 2;
+    int v = w.jt->cost[id] / 2;
     if (v < 3) v = 3;
     e.money += v;
     e.jokers_sold++;
@@ -587,7 +648,7 @@ __device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, Rn
     return;
   }
   if (action == 30) { // REROLL shop.py:170-177
-    int32_t cost = (int32_t)((double)e.shop_reroll_base * bg_shop_cost_mult(e));
+    int32_t cost = (int32_t)((double)e.shop_reroll_base * bg_shop_cost_mult(e, w.jt));
     if (e.money < cost) { o.reward = -1.0; o.error = 6; return; }
     e.money -= cost;
     e.shop_reroll_base = (int32_t)((double)e.shop_reroll_base * 1.35);
@@ -663,26 +724,30 @@ __device__ __forceinline__ void bg_step_blind(const BgDev& d, int env, Env& e, R
   }
 }
 
-// balatro_env_2.py:616-637 step()
-__device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, const Deck0& dk, uint64_t mask,
-                                            int action, StepOut& o) {
+__device__ __forceinline__ void bg_step_init(StepOut& o) {
   o.reward = 0.0; o.final_score = 0; o.error = 0; o.flags = 0; o.aux = 0; o.hand_type = -1; o.cards_played = 0;
   o.terminated = false;
 #pragma unroll
   for (int i = 0; i < 8; i++) o.terms[i] = 0.0;
-  if (e.ante > 100) { o.terminated = true; o.error = 9; return; }
-  if (e.chips_scored > 1000000000ll) { o.terminated = true; o.error = 10; return; }
-  if (action < 0 || action >= 60 || !((mask >> action) & 1ull)) { o.reward = -1.0; o.error = 1; return; }
+}
+
+// :1052-1058 SELECT_CARD toggle; the selection ORDER is kept (it is the scoring / RNG order of a later play)
+__device__ __forceinline__ void bg_toggle_select(Env& e, int pos) {
+  int at = -1;
+#pragma unroll 1
+  for (int i = 0; i < e.nsel; i++) if (bg_get8(e.sel, i) == pos) at = i;
+  if (at >= 0) { e.sel = bg_del8(e.sel, at); e.nsel--; }
+  else { e.sel = bg_set8(e.sel, e.nsel, pos); e.nsel++; }
+}
+
+// dispatch of a VALID action (balatro_env_2.py:629-637)
+__device__ __forceinline__ void bg_env_dispatch(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, const Deck0& dk,
+                                                int action, StepOut& o) {
   if (e.phase == 0) {
     if (action == 0) bg_step_play_hand(d, env, e, w, sr, dk, o);
-    else if (action == 1) bg_step_discard(d, env, e, dk, o);
-    else if (action < 10) { // :1052-1058 toggle, selection ORDER kept
-      int pos = action - 2;
-      int at = -1;
-      for (int i = 0; i < e.nsel; i++) if (bg_get8(e.sel, i) == pos) at = i;
-      if (at >= 0) { e.sel = bg_del8(e.sel, at); e.nsel--; }
-      else { e.sel = bg_set8(e.sel, e.nsel, pos); e.nsel++; }
-    } else { // 10..14 _use_consumable :1066-1172, planets only (consumables.py:644-652)
+    else if (action == 1) bg_step_discard(d, env, e, w, dk, o);
+    else if (action < 10) bg_toggle_select(e, action - 2);
+    else { // 10..14 _use_consumable :1066-1172, planets only (consumables.py:644-652)
       int ci = action - 10;
       int id = ci == 0 ? (int)e.cons0 : (int)e.cons1;
       if (id >= 30 && id <= 41) {
@@ -699,6 +764,21 @@ __device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, Rng
     }
   } else if (e.phase == 1) bg_step_shop(d, env, e, w, sr, action, o);
   else if (e.phase == 2) bg_step_blind(d, env, e, w, sr, action, o);
+}
+
+// the guards in front of the dispatch (balatro_env_2.py:619-627); returns true when the action must be dispatched
+__device__ __forceinline__ bool bg_step_guards(const Env& e, uint64_t mask, int action, StepOut& o) {
+  if (e.ante > 100) { o.terminated = true; o.error = 9; return false; }
+  if (e.chips_scored > 1000000000ll) { o.terminated = true; o.error = 10; return false; }
+  if (action < 0 || action >= 60 || !((mask >> action) & 1ull)) { o.reward = -1.0; o.error = 1; return false; }
+  return true;
+}
+
+// balatro_env_2.py:616-637 step()
+__device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, const Deck0& dk, uint64_t mask,
+                                            int action, StepOut& o) {
+  bg_step_init(o);
+  if (bg_step_guards(e, mask, action, o)) bg_env_dispatch(d, env, e, w, sr, dk, action, o);
   if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
 }
 
@@ -733,6 +813,7 @@ __device__ __forceinline__ uint64_t bg_write_obs(const BgDev& d, int env, size_t
   if (p.hand_size) p.hand_size[row] = (int8_t)e.nhand;
   if (p.deck_size) p.deck_size[row] = 52;
   uint32_t selm = 0;
+#pragma unroll 1
   for (int i = 0; i < e.nsel; i++) selm |= 1u << bg_get8(e.sel, i);
   BG_MIX(selm | ((uint64_t)e.face_down << 8) | ((uint64_t)e.nhand << 16));
   if (p.selected_cards) {
@@ -854,6 +935,7 @@ __device__ __forceinline__ int bg_policy_action(const Env& e, uint64_t mask, int
   if (!nv) return 0;
   uint32_t k = bg_policy_hash(policy_seed, env_index, t) % (uint32_t)nv;
   uint64_t m = mask;
+#pragma unroll 1
   for (uint32_t i = 0; i < k; i++) m &= m - 1; // clear the k lowest set bits
   return __ffsll((long long)m) - 1;
 }

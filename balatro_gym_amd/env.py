@@ -189,7 +189,7 @@ class BalatroEnv(_EnvBase):
     def close(self):
         self._vec.close()
 
-    # harness helpers used by tests (mirror oracle.OracleEnv)
+    # harness helper used by the parity tests
     def inject(self, **kw):
         self._vec.inject(**kw)
 

@@ -54,26 +54,20 @@ class ShardedBalatroVecEnv:
         return self.local.rollout(steps, **kw)
 
     def gather_obs(self) -> torch.Tensor:
-        """all_gather of the flat observation buffer -> uint8 [world, shard_bytes] (shards padded to the largest)."""
+        """all_gather of the flat observation buffer -> uint8 [world, shard_bytes] (smaller shards are zero padded)."""
         flat = self.local.obs_flat
-        sizes = [shard_range(self.total_envs, self.world, r) for r in range(self.world)]
-        maxn = max(hi - lo for lo, hi in sizes)
-        if (self.hi - self.lo) != maxn:
-            per_env = flat.numel() // max(1, self.hi - self.lo)
-            pad = torch.zeros(maxn * per_env + 8192, dtype=torch.uint8, device=flat.device)
-            pad[:flat.numel()] = flat
-            flat = pad[:max(flat.numel(), 1)]
         nbytes = torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)
-        dist.all_reduce(nbytes, op=dist.ReduceOp.MAX, group=self.group)
+        if self.total_envs % self.world:
+            dist.all_reduce(nbytes, op=dist.ReduceOp.MAX, group=self.group)
         n = int(nbytes.item())
         if flat.numel() != n:
             buf = torch.zeros(n, dtype=torch.uint8, device=flat.device)
             buf[:flat.numel()] = flat
             flat = buf
-        if self._gathered is None or self._gathered.shape != (self.world, n):
-            self._gathered = torch.empty((self.world, n), dtype=torch.uint8, device=flat.device)
+        if self._gathered is None or self._gathered.numel() != self.world * n:
+            self._gathered = torch.empty(self.world * n, dtype=torch.uint8, device=flat.device)
         dist.all_gather_into_tensor(self._gathered, flat.contiguous(), group=self.group)
-        return self._gathered
+        return self._gathered.view(self.world, n)
 
     def close(self):
         self.local.close()

@@ -110,7 +110,7 @@ def main():
                         max_ante=MAX_ANTE)
     env.inject(jokers=[jokers_for(g) for g in range(lo, hi)], apply_now=True)
     # ring depths come from BG_KG / BG_KS / BG_KD (bg_create); chunk = what the library fuses per launch
-    chunk = args.chunk or int(os.environ.get("BG_BENCH_CHUNK", "0")) or 3
+    chunk = args.chunk or int(os.environ.get("BG_BENCH_CHUNK", "0")) or 16
     ob = ObsBuffers(n, dev, steps=chunk) if args.keep_obs and chunk > 1 else None
 
     def run(nsteps, t0):
@@ -120,7 +120,7 @@ def main():
             env.rollout(c, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, env_index0=lo, t0=t0 + done,
                         obs_buffers=ob if (ob is not None and c == chunk) else None, zero_stats=False)
             if args.gather_obs and world > 1:
-                gathered = torch.empty((world, env.obs_flat.numel()), dtype=torch.uint8, device=dev)
+                gathered = torch.empty(world * env.obs_flat.numel(), dtype=torch.uint8, device=dev)
                 dist.all_gather_into_tensor(gathered, env.obs_flat)
             done += c
 

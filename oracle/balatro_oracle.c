@@ -1006,12 +1006,11 @@ void bo_step(bo_env* e, int action, double* reward, uint8_t* terminated, bo_info
   info->hand_type = -1;
   *reward = 0.0;
   *terminated = 0;
-  if (e->ante > 100) { *terminated = 1; info->error = BO_ERR_MAX_ANTE; return; }                 /* :619-620 */
-  if (e->chips_scored > 1000000000ll) { *terminated = 1; info->error = BO_ERR_MAX_SCORE; return; } /* :622-623 */
   int8_t mask[BO_NACT];
-  bo_action_mask(e, mask);
-  if (action < 0 || action >= BO_NACT || !mask[action]) { *reward = -1.0; info->error = BO_ERR_INVALID_ACTION; return; }
-  if (e->phase == BO_PHASE_PLAY) {
+  if (e->ante > 100) { *terminated = 1; info->error = BO_ERR_MAX_ANTE; }                          /* :619-620 */
+  else if (e->chips_scored > 1000000000ll) { *terminated = 1; info->error = BO_ERR_MAX_SCORE; }  /* :622-623 */
+  else if (bo_action_mask(e, mask), (action < 0 || action >= BO_NACT || !mask[action])) { *reward = -1.0; info->error = BO_ERR_INVALID_ACTION; }
+  else if (e->phase == BO_PHASE_PLAY) {
     if (action == 0) step_play_hand(e, reward, terminated, info);
     else if (action == 1) step_discard(e, reward, info);
     else if (action >= 2 && action < 10) { /* :1052-1058 toggle, selection ORDER is kept */
@@ -1041,6 +1040,7 @@ void bo_step(bo_env* e, int action, double* reward, uint8_t* terminated, bo_info
     }
   } else if (e->phase == BO_PHASE_SHOP) step_shop(e, action, reward, info);
   else if (e->phase == BO_PHASE_BLIND_SELECT) step_blind_select(e, action, reward, info);
+  /* CurriculumBalatroEnv.step (train_balatro_agent.py:146-152) wraps EVERY step, also the guarded ones */
   if (e->max_ante > 0 && e->ante > e->max_ante) { *terminated = 1; info->flags |= BO_INFO_CURRICULUM; }
 }
 

@@ -45,6 +45,17 @@ def run(n, scorer, policy, chunk, steps, obs_mode, max_ante=4, label=""):
     print(f"{label:34s} n={n:7d} chunk={chunk:3d} obs={obs_mode:5s} | rollout {p['rollout_ms']*1e3/fused:7.2f} us/step "
           f"| refill {p['refill_ms']*1e3/fused:7.2f} us/step | wall {dt*1e6/steps:7.2f} us/step | {n*steps/dt/1e6:8.1f} M steps/s",
           flush=True)
+    if os.environ.get("BG_TIMING"):
+        import ctypes as C2
+        out = (C2.c_ulonglong * 16)()
+        L = nat.load()
+        L.bg_debug_counters.argtypes = [C2.c_void_p, C2.POINTER(C2.c_ulonglong)]
+        L.bg_debug_counters(env._h, out)
+        blocks = (n + 255) // 256
+        T = max(1, out[4] // blocks)
+        print(f"    phase cycles per block-step: A {out[0]/blocks/T:9.0f}  B {out[1]/blocks/T:9.0f}  C {out[2]/blocks/T:9.0f}  items/block-step {out[3]/blocks/T:6.1f}")
+        names = {5: "gather", 6: "classify", 7: "boss-check+joker-individual", 8: "bloodstone+skip", 9: "joker-main", 10: "boss-ratio+state", 11: "reward", 12: "outcome"}
+        print("    play path cycles per block-step: " + " | ".join(f"{names[i]} {out[i]/blocks/T:.0f}" for i in range(5, 13)))
     env.close()
 
 
@@ -52,6 +63,9 @@ if __name__ == "__main__":
     chunk = int(os.environ.get("CHUNK", "16"))
     steps = chunk * 8
     run(65536, True, 2, chunk, steps, "keep", label="C3 baseline")
+    if os.environ.get("BG_TIMING"):
+        run(65536, False, 2, chunk, steps, "keep", max_ante=0, label="C2 no jokers")
+        sys.exit(0)
     run(65536, True, 2, chunk, steps, "live", label="C3 obs overwritten in place")
     run(65536, True, 2, chunk, steps, "none", label="C3 no obs writes")
     run(65536, False, 2, chunk, steps, "keep", max_ante=0, label="C2 no jokers")
