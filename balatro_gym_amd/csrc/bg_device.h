@@ -52,8 +52,11 @@ struct BgDev {
   uint32_t* deckmt;
   uint32_t* shopgenmt;
   uint32_t* err;
-  uint32_t* wl_count; // [4] refill work-list lengths: decks, shops, global blocks
-  uint32_t* wl;       // [3][N] env indexes needing a refill of each kind
+  uint32_t* wl_count; // [4] refill work-list lengths: decks, seed rings, global blocks, shop items
+  uint32_t* wl;       // [3][N] env indexes needing a refill of each kind (0 decks, 1 shop-seed rings, 2 global blocks)
+  uint32_t* wl_shop;  // [N*(KS-1)][2] shop work items: env | slot << 24, shop seed
+  uint32_t* sseed;    // [N][32] pre-drawn shop seeds (stream 2 is consumed by nothing else, balatro_env_2.py:1389)
+  uint32_t* smeta;    // [N] seed ring: head | count << 8
   unsigned long long* dbg; // [16] phase cycle counters (development builds, -DBG_TIMING)
 };
 

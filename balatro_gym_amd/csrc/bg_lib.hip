@@ -384,23 +384,29 @@ __device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) {
 // any element of the batch is stored; BG_MTB < 227 keeps the kk-227 operands already written).
 __device__ void bg_mt_twist(const uint32_t* src, uint32_t* dst) {
   uint32_t cur = src[0], first_new = 0;
+  const uint4* s4 = (const uint4*)src;
   uint4* d4 = (uint4*)dst;
+#pragma unroll 1
   for (int base = 0; base < BG_MT_N; base += BG_MTB) {
-    uint32_t nxt[BG_MTB], far[BG_MTB];
+    uint32_t nx[BG_MTB + 4], fr[BG_MTB + 4];
+    // words base .. base+19 of src: nxt[j] = src[base + j + 1]  (src[624] is the unused index word of the 640-word block)
 #pragma unroll
-    for (int j = 0; j < BG_MTB; j++) {
-      int kk = base + j;
-      if (kk < BG_MT_N - 1) {
-        nxt[j] = src[kk + 1];
-        far[j] = (kk < BG_MT_N - BG_MT_M) ? src[kk + BG_MT_M] : dst[kk + BG_MT_M - BG_MT_N];
-      } else { nxt[j] = first_new; far[j] = dst[BG_MT_M - 1]; } // kk == 623: new dst[0], new dst[396]
+    for (int g = 0; g < BG_MTB / 4 + 1; g++) { uint4 v = s4[base / 4 + g]; nx[4 * g] = v.x; nx[4 * g + 1] = v.y; nx[4 * g + 2] = v.z; nx[4 * g + 3] = v.w; }
+    if (base == 224) { // the batch that straddles kk = 227: old src[kk+397] below, new dst[kk-227] from there on
+#pragma unroll
+      for (int j = 0; j < BG_MTB; j++) { int kk = base + j; fr[j + 1] = (kk < BG_MT_N - BG_MT_M) ? src[kk + BG_MT_M] : dst[kk + BG_MT_M - BG_MT_N]; }
+    } else {
+      const uint4* f4 = base < 224 ? s4 + (base + BG_MT_M - 1) / 4 : (const uint4*)dst + (base + BG_MT_M - BG_MT_N - 1) / 4;
+#pragma unroll
+      for (int g = 0; g < BG_MTB / 4 + 1; g++) { uint4 v = f4[g]; fr[4 * g] = v.x; fr[4 * g + 1] = v.y; fr[4 * g + 2] = v.z; fr[4 * g + 3] = v.w; }
     }
     uint32_t v[BG_MTB];
 #pragma unroll
     for (int j = 0; j < BG_MTB; j++) {
-      v[j] = bg_twist(cur, nxt[j], far[j]);
+      uint32_t nxt = (base + j == BG_MT_N - 1) ? first_new : nx[j + 1]; // kk == 623 pairs with the NEW dst[0]
+      v[j] = bg_twist(cur, nxt, fr[j + 1]);
       if (base + j == 0) first_new = v[j];
-      cur = nxt[j];
+      cur = nxt;
     }
 #pragma unroll
     for (int j = 0; j < BG_MTB / 4; j++) d4[base / 4 + j] = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
@@ -457,6 +463,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_
   bg_shopgenmt(d, env)[BG_MT_N] = BG_MT_N;
   e.d_head = 0; e.d_ready = 0; // look-ahead rings are functions of the streams: invalidate
   e.s_ready = 0;
+  d.smeta[env] = 0;
   bg_store_env(d, env, e);
 }
 
@@ -489,7 +496,26 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
     if (g_valid <= 0) atomicOr(d.err, BG_DEVERR_GSTREAM);
   }
   if (d_ready < d.KD) { uint32_t i = atomicAdd(&d.wl_count[0], 1u); d.wl[i] = (uint32_t)env; }
-  if (s_ready < d.KS - 1) { uint32_t i = atomicAdd(&d.wl_count[1], 1u); d.wl[N + i] = (uint32_t)env; }
+  if (s_ready < d.KS - 1) {
+    // one work item per missing slot (balanced: every lane of the dense kernel seeds exactly one stream); the shop
+    // seeds were drawn ahead from stream 2 into a small per-env ring
+    uint32_t sm = d.smeta[env];
+    int head = (int)(sm & 0xffu), cnt = (int)((sm >> 8) & 0xffu);
+    int s_cur = bg_b(w7.y, 0);
+    int emitted = 0;
+    while (s_ready + emitted < d.KS - 1 && cnt > 0) {
+      int slot = s_cur + 1 + s_ready + emitted; while (slot >= d.KS) slot -= d.KS;
+      uint32_t i = atomicAdd(&d.wl_count[3], 1u);
+      d.wl_shop[2 * (size_t)i] = (uint32_t)env | ((uint32_t)slot << 24);
+      d.wl_shop[2 * (size_t)i + 1] = d.sseed[(size_t)env * 32 + head];
+      head = (head + 1) & 31; cnt--; emitted++;
+    }
+    if (emitted) {
+      d.smeta[env] = (uint32_t)head | ((uint32_t)cnt << 8);
+      ((uint32_t*)&d.hot[(size_t)7 * N + env])[1] = (w7.y & 0xffff00ffu) | ((uint32_t)(s_ready + emitted) << 8);
+    }
+    if (cnt < 16) { uint32_t i = atomicAdd(&d.wl_count[1], 1u); d.wl[N + i] = (uint32_t)env; }
+  }
   if (g_valid > 0 && g_valid < d.KG) { uint32_t i = atomicAdd(&d.wl_count[2], 1u); d.wl[2 * N + i] = (uint32_t)env; }
 }
 
@@ -541,26 +567,33 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
   }
 }
 
-__global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop_kernel(BgDev d) {
+// top up the per-env ring of pre-drawn shop seeds: `rng.get_int('shop_generation', 0, 2**31 - 1)` (:1389) in stream order
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_seedring_kernel(BgDev d) {
   size_t N = d.N;
   uint32_t count = d.wl_count[1];
   for (uint32_t item = blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
     int env = (int)d.wl[N + item];
-    uint32_t* w7p = ((uint32_t*)&d.hot[(size_t)7 * N + env]) + 1;
-    uint32_t w7 = *w7p;
-    int s_cur = bg_b(w7, 0), s_ready = bg_b(w7, 1);
+    uint32_t sm = d.smeta[env];
+    int head = (int)(sm & 0xffu), cnt = (int)((sm >> 8) & 0xffu);
     uint32_t* mt = bg_shopgenmt(d, env);
     uint32_t mti = mt[BG_MT_N];
-    while (s_ready < d.KS - 1) {
-      uint32_t shop_seed = bg_mt_randbelow(mt, mti, 2147483648u);
-      int slot = s_cur + 1 + s_ready; while (slot >= d.KS) slot -= d.KS;
-      uint32_t* blk = bg_sblock(d, env, slot);
-      bg_mt_seed(blk, shop_seed);
-      bg_mt_twist(blk, blk);
-      s_ready++;
+    while (cnt < 32) {
+      d.sseed[(size_t)env * 32 + ((head + cnt) & 31)] = bg_mt_randbelow(mt, mti, 2147483648u);
+      cnt++;
     }
     mt[BG_MT_N] = mti;
-    *w7p = (w7 & 0xffff00ffu) | ((uint32_t)s_ready << 8);
+    d.smeta[env] = (uint32_t)head | ((uint32_t)cnt << 8);
+  }
+}
+
+// `random.Random(shop_seed)` (shop.py:96): seed + first block, one stream per lane
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop_kernel(BgDev d) {
+  uint32_t count = d.wl_count[3];
+  for (uint32_t item = blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
+    uint32_t es = d.wl_shop[2 * (size_t)item], seed = d.wl_shop[2 * (size_t)item + 1];
+    uint32_t* blk = bg_sblock(d, (int)(es & 0xffffffu), (int)(es >> 24));
+    bg_mt_seed(blk, seed);
+    bg_mt_twist(blk, blk);
   }
 }
 
@@ -722,6 +755,9 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (e == hipSuccess) e = bg_alloc(h, &d.shopgenmt, (size_t)BG_MTS * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.wl_count, 4);
   if (e == hipSuccess) e = bg_alloc(h, &d.wl, 3 * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.wl_shop, 2 * N * (size_t)(d.KS - 1));
+  if (e == hipSuccess) e = bg_alloc(h, &d.sseed, 32 * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.smeta, N);
   if (e == hipSuccess) e = bg_alloc(h, &d.dbg, 16);
   if (e == hipSuccess) e = bg_alloc(h, &d.err, 4);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_seeds, N);
@@ -740,7 +776,7 @@ int bg_destroy(bg_handle* h) {
   if (!h) return 0;
   BgDev& d = h->dev;
   hipFree(d.hot); hipFree(d.deck); hipFree(d.cold); hipFree(d.tmpl); hipFree(d.ndeck); hipFree(d.gblk); hipFree(d.sblk);
-  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.dbg);
+  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.wl_shop); hipFree(d.sseed); hipFree(d.smeta); hipFree(d.dbg);
   delete h;
   return 0;
 }
@@ -758,6 +794,7 @@ int bg_refill(bg_handle* h, void* stream) {
   int dense = bg_grid(h) < 1024 ? bg_grid(h) : 1024; // grid-stride over the compacted work lists
   hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, h->dev);
   hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, h->dev);
+  hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, h->dev);
   hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, h->dev);
   bg_ev_end(h, h->ev_refill, s);
   BG_HIP(hipGetLastError());
@@ -790,7 +827,9 @@ int bg_seed(bg_handle* h, const int64_t* seeds_host, const uint8_t* mask_host, i
   // the copies above read pageable host memory: make sure they are done before the caller reuses the buffers
   BG_HIP(hipStreamSynchronize(s));
   h->seeded = true;
-  return bg_refill(h, stream);
+  int rc = bg_refill(h, stream); // fills the deck ring and the shop-seed ring ...
+  if (rc) return rc;
+  return bg_refill(h, stream);   // ... then the shop streams from those seeds
 }
 
 static int bg_require_seeded(bg_handle* h) {
@@ -955,6 +994,7 @@ static void bg_slices(bg_handle* h, std::vector<BgSlice>& v) {
   // per-env contiguous MT blocks: one "row" of KG*2560 / KS*2560 / 2560 bytes at base + env * elem
   v.push_back({d.gblk, 1, (size_t)d.KG * BG_MTS * 4}); v.push_back({d.sblk, 1, (size_t)d.KS * BG_MTS * 4});
   v.push_back({d.deckmt, 1, (size_t)BG_MTS * 4}); v.push_back({d.shopgenmt, 1, (size_t)BG_MTS * 4});
+  v.push_back({d.sseed, 1, 32 * 4}); v.push_back({d.smeta, 1, 4});
 }
 uint64_t bg_state_blob_bytes(const bg_handle* h) {
   if (!h) return 0;
