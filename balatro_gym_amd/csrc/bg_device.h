@@ -57,6 +57,12 @@ struct BgDev {
   uint32_t* wl_shop;  // [N*(KS-1)][2] shop work items: env | slot << 24, shop seed
   uint32_t* sseed;    // [N][32] pre-drawn shop seeds (stream 2 is consumed by nothing else, balatro_env_2.py:1389)
   uint32_t* smeta;    // [N] seed ring: head | count << 8
+  // Ring PRODUCER counters (decks | shop streams << 8 | global blocks << 16, each mod 256) live apart from the consumer
+  // counters (hot chunks) and are double-buffered, so a refill can run on a side stream while the next rollout runs:
+  // the rollout reads `prod_view` (written by a refill that has completed), a refill reads prod_in and writes prod_out.
+  const uint32_t* prod_view;
+  const uint32_t* prod_in;
+  uint32_t* prod_out;
   unsigned long long* dbg; // [16] phase cycle counters (development builds, -DBG_TIMING)
 };
 
@@ -79,13 +85,13 @@ struct Env {
   // chunk 5
   uint32_t highlighted, face_down, boss_hp, boss_types, cons0, cons1;
   uint64_t jokers; // up to 5 ids, one byte each
-  int32_t shop_ante, d_head, d_ready;
+  int32_t shop_ante, d_head, d_cons, d_ready; // d_ready (like s_ready, g_valid) is derived: producer - consumer counter
   // chunk 6
   uint64_t boss_cards; // played-deck-index mask (stands in for id(card), boss_blinds.py:472)
   uint64_t levels;     // 12 x 4-bit engine hand levels (scoring_engine.py:66)
-  int32_t g_cur, g_valid;
+  int32_t g_cur, g_cons, g_valid;
   // chunk 7
-  int32_t g_idx, s_idx, s_cur, s_ready;
+  int32_t g_idx, s_idx, s_cur, s_cons, s_ready;
   uint64_t excess; // 12 x 4-bit (state.hand_levels - engine level): planets used at the level-15 cap
 };
 
@@ -114,12 +120,12 @@ __device__ __forceinline__ void bg_unpack(const uint4 c[BG_NHOT], Env& e) {
   e.highlighted = c[5].x & 0xffffu; e.face_down = bg_b(c[5].x, 2); e.boss_hp = bg_b(c[5].x, 3);
   e.boss_types = c[5].y & 0xffffu; e.cons0 = bg_b(c[5].y, 2); e.cons1 = bg_b(c[5].y, 3);
   e.jokers = (uint64_t)c[5].z | ((uint64_t)(c[5].w & 0xffu) << 32);
-  e.shop_ante = bg_b(c[5].w, 1); e.d_head = bg_b(c[5].w, 2); e.d_ready = bg_b(c[5].w, 3);
+  e.shop_ante = bg_b(c[5].w, 1); e.d_head = bg_b(c[5].w, 2); e.d_cons = bg_b(c[5].w, 3); e.d_ready = 0;
   e.boss_cards = ((uint64_t)c[6].y << 32) | c[6].x;
   e.levels = (uint64_t)c[6].z | ((uint64_t)(c[6].w & 0xffffu) << 32);
-  e.g_cur = bg_b(c[6].w, 2); e.g_valid = bg_b(c[6].w, 3);
+  e.g_cur = bg_b(c[6].w, 2); e.g_cons = bg_b(c[6].w, 3); e.g_valid = 0;
   e.g_idx = (int32_t)(c[7].x & 0xffffu); e.s_idx = (int32_t)(c[7].x >> 16);
-  e.s_cur = bg_b(c[7].y, 0); e.s_ready = bg_b(c[7].y, 1);
+  e.s_cur = bg_b(c[7].y, 0); e.s_cons = bg_b(c[7].y, 1); e.s_ready = 0;
   e.excess = (uint64_t)c[7].z | ((uint64_t)(c[7].w & 0xffffu) << 32);
 }
 
@@ -138,18 +144,25 @@ __device__ __forceinline__ void bg_pack(const Env& e, uint4 c[BG_NHOT]) {
   c[4] = make_uint4((uint32_t)e.hand, (uint32_t)(e.hand >> 32), (uint32_t)e.sel, (uint32_t)(e.sel >> 32));
   c[5] = make_uint4((e.highlighted & 0xffffu) | ((e.face_down & 0xffu) << 16) | ((e.boss_hp & 0xffu) << 24),
                     (e.boss_types & 0xffffu) | ((e.cons0 & 0xffu) << 16) | ((e.cons1 & 0xffu) << 24), (uint32_t)e.jokers,
-                    bg_p4((int)(e.jokers >> 32), e.shop_ante, e.d_head, e.d_ready));
+                    bg_p4((int)(e.jokers >> 32), e.shop_ante, e.d_head, e.d_cons));
   c[6] = make_uint4((uint32_t)e.boss_cards, (uint32_t)(e.boss_cards >> 32), (uint32_t)e.levels,
-                    ((uint32_t)(e.levels >> 32) & 0xffffu) | ((uint32_t)(e.g_cur & 0xff) << 16) | ((uint32_t)(e.g_valid & 0xff) << 24));
-  c[7] = make_uint4(((uint32_t)e.g_idx & 0xffffu) | ((uint32_t)e.s_idx << 16), bg_p4(e.s_cur, e.s_ready, 0, 0),
+                    ((uint32_t)(e.levels >> 32) & 0xffffu) | ((uint32_t)(e.g_cur & 0xff) << 16) | ((uint32_t)(e.g_cons & 0xff) << 24));
+  c[7] = make_uint4(((uint32_t)e.g_idx & 0xffffu) | ((uint32_t)e.s_idx << 16), bg_p4(e.s_cur, e.s_cons, 0, 0),
                     (uint32_t)e.excess, (uint32_t)(e.excess >> 32) & 0xffffu);
 }
 
+// ring fill levels as this kernel may see them: producer counters of a COMPLETED refill minus own consumer counters
+__device__ __forceinline__ void bg_derive_ready(Env& e, uint32_t prod) {
+  e.d_ready = (int)((prod - (uint32_t)e.d_cons) & 0xffu);
+  e.s_ready = (int)(((prod >> 8) - (uint32_t)e.s_cons) & 0xffu);
+  e.g_valid = (int)(((prod >> 16) - (uint32_t)e.g_cons) & 0xffu);
+}
 __device__ __forceinline__ void bg_load_env(const BgDev& d, int env, Env& e) {
   uint4 c[BG_NHOT];
 #pragma unroll
   for (int k = 0; k < BG_NHOT; k++) c[k] = d.hot[(size_t)k * d.N + env];
   bg_unpack(c, e);
+  bg_derive_ready(e, d.prod_view ? d.prod_view[env] : 0u);
 }
 __device__ __forceinline__ void bg_store_env(const BgDev& d, int env, const Env& e) {
   uint4 c[BG_NHOT];
@@ -261,7 +274,7 @@ __device__ __noinline__ void bg_win_fill(uint32_t* lds, const uint32_t* src, int
 // next raw word of the per-env "global random" stream (ring of blocks, tempered on read)
 // block switch; g_idx may have been advanced past the end by bg_gskip (words consumed without being read)
 __device__ __forceinline__ void bg_gnorm(const BgDev& d, Env& e) {
-  if (e.g_idx >= BG_MT_N) { e.g_cur = (e.g_cur + 1 == d.KG) ? 0 : e.g_cur + 1; e.g_idx -= BG_MT_N; e.g_valid--; }
+  if (e.g_idx >= BG_MT_N) { e.g_cur = (e.g_cur + 1 == d.KG) ? 0 : e.g_cur + 1; e.g_idx -= BG_MT_N; e.g_valid--; e.g_cons = (e.g_cons + 1) & 0xff; }
 }
 // consume `count` (< 624) words whose values nobody looks at (complete_joker_effects.py draws them eagerly)
 __device__ __forceinline__ void bg_gskip(const BgDev& d, Env& e, int count) {

@@ -152,6 +152,7 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
   __shared__ OutLds s_out[BG_RB];
   __shared__ uint32_t s_items[BG_RB];
   __shared__ uint32_t s_nitems;
+  __shared__ uint32_t s_prod[BG_RB];
   __shared__ uint32_t win[BG_WIN][BG_BLOCK];
   __shared__ JTables jt;
   bg_tables_init(&jt);
@@ -164,6 +165,7 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
   Deck0 dk;
   ShopRegs sr; sr.valid = false;
   uint64_t mask = 0;
+  s_prod[local] = (live && d.prod_view) ? d.prod_view[env] : 0u;
   if (live) {
     bg_load_env(d, env, e);
     dk = bg_load_deck0(d, env);
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
         for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][l];
         Env be;
         bg_unpack(c, be);
+        bg_derive_ready(be, s_prod[l]);
         Deck0 bdk = bg_load_deck0(d, benv);
         ShopRegs bsr; bsr.valid = false;
         RngWin w;
@@ -246,6 +249,7 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
 #pragma unroll
         for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][local];
         bg_unpack(c, e);
+        bg_derive_ready(e, s_prod[local]);
         OutLds ol = s_out[local];
         o.reward = ol.reward; o.final_score = ol.final_score; o.flags = ol.flags;
         o.hand_type = (ol.misc & 0xff) - 1; o.terminated = (ol.misc & 0x100) != 0; o.error = ol.misc >> 16;
@@ -444,7 +448,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_
     uint32_t* g = bg_gblock(d, env, 0);
     bg_mt_seed(g, gs);
     bg_mt_twist(g, g); // first block = what the first 624 getrandbits(32) read
-    e.g_cur = 0; e.g_idx = 0; e.g_valid = 1;
+    e.g_cur = 0; e.g_idx = 0; e.g_cons = 0; e.g_valid = 1;
   }
   if (seed == 0) { // `master_seed or random.randint(0, 2**32 - 1)` (:88): _randbelow(2**32), k = 33 bits
     uint64_t r;
@@ -461,9 +465,16 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_
   bg_deckmt(d, env)[BG_MT_N] = BG_MT_N;
   bg_mt_seed(bg_shopgenmt(d, env), base + 2000u);
   bg_shopgenmt(d, env)[BG_MT_N] = BG_MT_N;
-  e.d_head = 0; e.d_ready = 0; // look-ahead rings are functions of the streams: invalidate
-  e.s_ready = 0;
+  // look-ahead rings are functions of the streams: invalidate (producer counters restart at the consumer counters)
+  e.d_head = 0; e.d_cons = 0; e.d_ready = 0;
+  e.s_cons = 0; e.s_ready = 0;
   d.smeta[env] = 0;
+  {
+    uint32_t gp = reseed_global ? 1u : (uint32_t)((e.g_cons + e.g_valid) & 0xff);
+    uint32_t pv = 0u | (0u << 8) | (gp << 16);
+    d.prod_out[env] = pv;
+    ((uint32_t*)d.prod_in)[env] = pv;
+  }
   bg_store_env(d, env, e);
 }
 
@@ -480,28 +491,23 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
   int env = blockIdx.x * BG_BLOCK + threadIdx.x;
   if (env >= d.N) return;
   size_t N = d.N;
+  // consumer counters (written by step / rollout kernels; each group sits in one 32-bit word, so a concurrent writer can
+  // only make this kernel see a NEWER consumer state, which just frees more slots)
   uint32_t w5 = ((const uint32_t*)&d.hot[(size_t)5 * N + env])[3];
   uint32_t w6 = ((const uint32_t*)&d.hot[(size_t)6 * N + env])[3];
   uint2 w7 = *((const uint2*)&d.hot[(size_t)7 * N + env]);
-  int d_ready = bg_b(w5, 3);
-  int g_cur = bg_b(w6, 2), g_valid = bg_b(w6, 3);
-  int g_idx = (int)(w7.x & 0xffffu);
-  int s_ready = bg_b(w7.y, 1);
+  uint32_t prod = d.prod_in[env];
+  int d_cons = bg_b(w5, 3), g_cons = bg_b(w6, 3), s_cur = bg_b(w7.y, 0), s_cons = bg_b(w7.y, 1);
+  int d_ready = (int)((prod - (uint32_t)d_cons) & 0xffu);
+  int s_ready = (int)(((prod >> 8) - (uint32_t)s_cons) & 0xffu);
+  int g_valid = (int)(((prod >> 16) - (uint32_t)g_cons) & 0xffu);
   bool seeded = bg_deckmt(d, env)[BG_MT_N] != 0; // index word is 0 only before the first bg_seed
-  if (!seeded) return;
-  if (g_valid > 0 && g_idx >= BG_MT_N) { // finish a pending block switch so the exhausted block can be reused
-    g_cur = (g_cur + 1 == d.KG) ? 0 : g_cur + 1; g_idx -= BG_MT_N; g_valid--;
-    ((uint32_t*)&d.hot[(size_t)6 * N + env])[3] = (w6 & 0x0000ffffu) | ((uint32_t)g_cur << 16) | ((uint32_t)g_valid << 24);
-    ((uint32_t*)&d.hot[(size_t)7 * N + env])[0] = (w7.x & 0xffff0000u) | (uint32_t)g_idx;
-    if (g_valid <= 0) atomicOr(d.err, BG_DEVERR_GSTREAM);
-  }
-  if (d_ready < d.KD) { uint32_t i = atomicAdd(&d.wl_count[0], 1u); d.wl[i] = (uint32_t)env; }
+  if (!seeded) { d.prod_out[env] = prod; return; }
   if (s_ready < d.KS - 1) {
     // one work item per missing slot (balanced: every lane of the dense kernel seeds exactly one stream); the shop
     // seeds were drawn ahead from stream 2 into a small per-env ring
     uint32_t sm = d.smeta[env];
     int head = (int)(sm & 0xffu), cnt = (int)((sm >> 8) & 0xffu);
-    int s_cur = bg_b(w7.y, 0);
     int emitted = 0;
     while (s_ready + emitted < d.KS - 1 && cnt > 0) {
       int slot = s_cur + 1 + s_ready + emitted; while (slot >= d.KS) slot -= d.KS;
@@ -512,10 +518,12 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
     }
     if (emitted) {
       d.smeta[env] = (uint32_t)head | ((uint32_t)cnt << 8);
-      ((uint32_t*)&d.hot[(size_t)7 * N + env])[1] = (w7.y & 0xffff00ffu) | ((uint32_t)(s_ready + emitted) << 8);
+      prod = (prod & 0xffff00ffu) | ((((prod >> 8) + (uint32_t)emitted) & 0xffu) << 8);
     }
     if (cnt < 16) { uint32_t i = atomicAdd(&d.wl_count[1], 1u); d.wl[N + i] = (uint32_t)env; }
   }
+  d.prod_out[env] = prod; // the deck / block kernels bump their byte of prod_out when their data is written
+  if (d_ready < d.KD) { uint32_t i = atomicAdd(&d.wl_count[0], 1u); d.wl[i] = (uint32_t)env; }
   if (g_valid > 0 && g_valid < d.KG) { uint32_t i = atomicAdd(&d.wl_count[2], 1u); d.wl[2 * N + i] = (uint32_t)env; }
 }
 
@@ -527,9 +535,11 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
   uint32_t count = d.wl_count[0];
   for (uint32_t item = blockIdx.x * BG_BLOCK + tid; item < count; item += gridDim.x * BG_BLOCK) {
     int env = (int)d.wl[item];
-    uint32_t* w5p = ((uint32_t*)&d.hot[(size_t)5 * N + env]) + 3;
-    uint32_t w5 = *w5p;
-    int d_head = bg_b(w5, 2), d_ready = bg_b(w5, 3);
+    uint32_t w5 = ((const uint32_t*)&d.hot[(size_t)5 * N + env])[3];
+    uint32_t prod = d.prod_out[env];
+    int d_head = bg_b(w5, 2), d_cons = bg_b(w5, 3);
+    int d_ready = (int)((prod - (uint32_t)d_cons) & 0xffu);
+    int made = 0;
     uint32_t* mt = bg_deckmt(d, env);
     uint32_t mti = mt[BG_MT_N];
     while (d_ready < d.KD) {
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
         uint8_t a = sdeck[i][tid], b = sdeck[j][tid];
         sdeck[i][tid] = b; sdeck[j][tid] = a;
       }
-      int slot = d_head + d_ready; if (slot >= d.KD) slot -= d.KD;
+      int slot = (d_head + d_ready) % d.KD;
 #pragma unroll
       for (int k = 0; k < BG_NDECK; k++) {
         uint32_t wv[4] = {0, 0, 0, 0};
@@ -560,10 +570,10 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
         for (int b = 0; b < 16; b++) { int i = k * 16 + b; if (i < 52) wv[b >> 2] |= (uint32_t)sdeck[i][tid] << (8 * (b & 3)); }
         d.ndeck[((size_t)slot * BG_NDECK + k) * N + env] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
       }
-      d_ready++;
+      d_ready++; made++;
     }
     mt[BG_MT_N] = mti;
-    *w5p = (w5 & 0x00ffffffu) | ((uint32_t)d_ready << 24);
+    d.prod_out[env] = (prod & 0xffffff00u) | ((prod + (uint32_t)made) & 0xffu); // kernels of one refill run back to back
   }
 }
 
@@ -602,16 +612,23 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_gblk_kernel(BgDev d) {
   uint32_t count = d.wl_count[2];
   for (uint32_t item = blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
     int env = (int)d.wl[2 * N + item];
-    uint32_t* w6p = ((uint32_t*)&d.hot[(size_t)6 * N + env]) + 3;
-    uint32_t w6 = *w6p;
-    int g_cur = bg_b(w6, 2), g_valid = bg_b(w6, 3);
+    uint32_t w6 = ((const uint32_t*)&d.hot[(size_t)6 * N + env])[3];
+    uint32_t prod = d.prod_out[env];
+    int g_cur = bg_b(w6, 2), g_cons = bg_b(w6, 3);
+    int g_valid = (int)(((prod >> 16) - (uint32_t)g_cons) & 0xffu);
+    int made = 0;
     while (g_valid > 0 && g_valid < d.KG) {
-      int last = g_cur + g_valid - 1; if (last >= d.KG) last -= d.KG;
+      int last = (g_cur + g_valid - 1) % d.KG;
       int nxt = last + 1 == d.KG ? 0 : last + 1;
       bg_mt_twist(bg_gblock(d, env, last), bg_gblock(d, env, nxt));
-      g_valid++;
+      g_valid++; made++;
     }
-    *w6p = (w6 & 0x00ffffffu) | ((uint32_t)g_valid << 24);
+    if (made) {
+      uint32_t g = ((prod >> 16) + (uint32_t)made) & 0xffu;
+      // only this lane touches byte 2 of this env's word during a refill; bytes 0/1 may be updated concurrently by the
+      // deck kernel of the SAME refill only if kernels overlapped -- they run back to back on one stream
+      d.prod_out[env] = (d.prod_out[env] & 0xff00ffffu) | (g << 16);
+    }
   }
 }
 
@@ -645,7 +662,14 @@ struct bg_handle {
   // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
   bool profiling;
   int rollout_version; // 1 = lane-per-env kernel, 2 = block-compacted kernel (BG_ROLLOUT_V)
-  std::vector<hipEvent_t> ev_rollout, ev_refill, ev_step; // start/stop pairs
+  // refill pipeline: double-buffered producer counters, a side stream and per-parity completion events
+  uint32_t* d_prod[2];
+  long refill_seq;       // refills launched so far; refill #i writes d_prod[i & 1]
+  bool async_refill;     // BG_ASYNC_REFILL (default on): bg_rollout overlaps refill #i with rollout chunk i+1
+  hipStream_t side;
+  hipEvent_t ev_refill[2];
+  hipEvent_t ev_rollout;
+  std::vector<hipEvent_t> ev_rollout_t, ev_refill_t, ev_step_t; // start/stop pairs
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
 };
 
@@ -714,13 +738,13 @@ int bg_set_profiling(bg_handle* h, int enable) {
 int bg_get_profile(bg_handle* h, double* out8) {
   if (!h || !out8) return BG_E_ARG;
   BG_HIP(hipDeviceSynchronize());
-  double nr = (double)(h->ev_rollout.size() / 2), nf = (double)(h->ev_refill.size() / 2), ns = (double)(h->ev_step.size() / 2);
+  double nr = (double)(h->ev_rollout_t.size() / 2), nf = (double)(h->ev_refill_t.size() / 2), ns = (double)(h->ev_step_t.size() / 2);
   double steps = 0;
   for (int t : h->rollout_steps) steps += t;
   h->rollout_steps.clear();
-  out8[0] = bg_ev_sum(h->ev_rollout); out8[1] = nr; out8[2] = steps;
-  out8[3] = bg_ev_sum(h->ev_refill); out8[4] = nf;
-  out8[5] = bg_ev_sum(h->ev_step); out8[6] = ns; out8[7] = 0;
+  out8[0] = bg_ev_sum(h->ev_rollout_t); out8[1] = nr; out8[2] = steps;
+  out8[3] = bg_ev_sum(h->ev_refill_t); out8[4] = nf;
+  out8[5] = bg_ev_sum(h->ev_step_t); out8[6] = ns; out8[7] = 0;
   return 0;
 }
 
@@ -735,12 +759,15 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   bg_handle* h = new bg_handle();
   h->device_id = device_id; h->seeded = false; h->bytes = 0; h->profiling = false;
   { const char* rv = getenv("BG_ROLLOUT_V"); h->rollout_version = rv ? atoi(rv) : 2; }
+  { const char* av = getenv("BG_ASYNC_REFILL"); h->async_refill = av ? atoi(av) != 0 : true; }
+  h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = nullptr;
+  h->ev_refill[0] = h->ev_refill[1] = nullptr; h->ev_rollout = nullptr;
   h->d_seeds = nullptr; h->d_mask = nullptr;
   memset(&h->dev, 0, sizeof(h->dev));
   BgDev& d = h->dev;
   d.N = n_envs; d.flags = flags; d.max_ante = max_ante;
   const char* kg = getenv("BG_KG"); const char* ks = getenv("BG_KS"); const char* kd = getenv("BG_KD");
-  d.KG = kg ? atoi(kg) : 6; d.KS = ks ? atoi(ks) : 12; d.KD = kd ? atoi(kd) : 11; // ~46 KB of look-ahead per env
+  d.KG = kg ? atoi(kg) : 8; d.KS = ks ? atoi(ks) : 13; d.KD = kd ? atoi(kd) : 12; // ~60 KB of look-ahead per env
   if (d.KG < 2 || d.KS < 2 || d.KD < 1 || d.KG > 250 || d.KS > 250 || d.KD > 250) { delete h; g_create_err = "bg_create: bad ring depths"; return BG_E_ARG; }
   size_t N = (size_t)n_envs;
   hipError_t e = hipSetDevice(device_id);
@@ -758,6 +785,12 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (e == hipSuccess) e = bg_alloc(h, &d.wl_shop, 2 * N * (size_t)(d.KS - 1));
   if (e == hipSuccess) e = bg_alloc(h, &d.sseed, 32 * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.smeta, N);
+  if (e == hipSuccess) e = bg_alloc(h, &h->d_prod[0], N);
+  if (e == hipSuccess) e = bg_alloc(h, &h->d_prod[1], N);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_refill[0], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_refill[1], hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_rollout, hipEventDisableTiming);
   if (e == hipSuccess) e = bg_alloc(h, &d.dbg, 16);
   if (e == hipSuccess) e = bg_alloc(h, &d.err, 4);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_seeds, N);
@@ -767,6 +800,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
     bg_destroy(h);
     return BG_E_HIP;
   }
+  d.prod_view = h->d_prod[0]; d.prod_in = h->d_prod[0]; d.prod_out = h->d_prod[1];
   h->h_tmpl.assign(BG_NTMPL * N, make_uint4(0, 0, 0, 0));
   *out = h;
   return 0;
@@ -775,6 +809,11 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
 int bg_destroy(bg_handle* h) {
   if (!h) return 0;
   BgDev& d = h->dev;
+  (void)hipDeviceSynchronize();
+  if (h->side) (void)hipStreamDestroy(h->side);
+  for (int i = 0; i < 2; i++) if (h->ev_refill[i]) (void)hipEventDestroy(h->ev_refill[i]);
+  if (h->ev_rollout) (void)hipEventDestroy(h->ev_rollout);
+  hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
   hipFree(d.hot); hipFree(d.deck); hipFree(d.cold); hipFree(d.tmpl); hipFree(d.ndeck); hipFree(d.gblk); hipFree(d.sblk);
   hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.wl_shop); hipFree(d.sseed); hipFree(d.smeta); hipFree(d.dbg);
   delete h;
@@ -785,20 +824,51 @@ const char* bg_last_error(const bg_handle* h) { return h ? h->err.c_str() : g_cr
 int bg_num_envs(const bg_handle* h) { return h ? h->dev.N : 0; }
 uint64_t bg_state_bytes(const bg_handle* h) { return h ? h->bytes : 0; }
 
+// ---- refill pipeline ----------------------------------------------------------------------------------------
+// refill #i reads the consumer counters (hot chunks) + d_prod[(i-1)&1] and writes rings + d_prod[i&1]
+static uint32_t* bg_prod_latest(bg_handle* h) { return h->d_prod[(h->refill_seq + 1) & 1]; } // output of refill seq-1
+
+static BgDev bg_dev_view(bg_handle* h, const uint32_t* view) {
+  BgDev d = h->dev;
+  d.prod_view = view;
+  return d;
+}
+
+// make `s` wait until refill #(seq-1-back) is complete (events are recorded per parity)
+static int bg_wait_refill(bg_handle* h, hipStream_t s, int back) {
+  long i = h->refill_seq - 1 - back;
+  if (i < 0) return 0;
+  BG_HIP(hipStreamWaitEvent(s, h->ev_refill[i & 1], 0));
+  return 0;
+}
+
+static int bg_refill_on(bg_handle* h, hipStream_t s) {
+  BgDev d = h->dev;
+  d.prod_in = bg_prod_latest(h);
+  d.prod_out = h->d_prod[h->refill_seq & 1];
+  d.prod_view = nullptr;
+  bg_ev_begin(h, h->ev_refill_t, s);
+  BG_HIP(hipMemsetAsync(d.wl_count, 0, 4 * sizeof(uint32_t), s));
+  hipLaunchKernelGGL(bg_refill_scan_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, d);
+  int dense = bg_grid(h) < 1024 ? bg_grid(h) : 1024; // grid-stride over the compacted work lists
+  hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, d);
+  hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, d);
+  hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, d);
+  hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, d);
+  bg_ev_end(h, h->ev_refill_t, s);
+  BG_HIP(hipGetLastError());
+  BG_HIP(hipEventRecord(h->ev_refill[h->refill_seq & 1], s));
+  h->refill_seq++;
+  return 0;
+}
+
+// synchronous flavour: ordered after everything on `stream`, and everything later on `stream` is ordered after it
 int bg_refill(bg_handle* h, void* stream) {
   if (!h) return BG_E_ARG;
   hipStream_t s = (hipStream_t)stream;
-  bg_ev_begin(h, h->ev_refill, s);
-  BG_HIP(hipMemsetAsync(h->dev.wl_count, 0, 4 * sizeof(uint32_t), s));
-  hipLaunchKernelGGL(bg_refill_scan_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, h->dev);
-  int dense = bg_grid(h) < 1024 ? bg_grid(h) : 1024; // grid-stride over the compacted work lists
-  hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, h->dev);
-  hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, h->dev);
-  hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, h->dev);
-  hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, h->dev);
-  bg_ev_end(h, h->ev_refill, s);
-  BG_HIP(hipGetLastError());
-  return 0;
+  int rc = bg_wait_refill(h, s, 0); // the previous refill may still be running on the side stream
+  if (rc) return rc;
+  return bg_refill_on(h, s);
 }
 
 int bg_check(bg_handle* h, void* stream) {
@@ -821,7 +891,10 @@ int bg_seed(bg_handle* h, const int64_t* seeds_host, const uint8_t* mask_host, i
   size_t N = h->dev.N;
   BG_HIP(hipMemcpyAsync(h->d_seeds, seeds_host, N * sizeof(int64_t), hipMemcpyHostToDevice, s));
   if (mask_host) BG_HIP(hipMemcpyAsync(h->d_mask, mask_host, N, hipMemcpyHostToDevice, s));
-  hipLaunchKernelGGL(bg_seed_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, h->dev, (const int64_t*)h->d_seeds,
+  { int rcw = bg_wait_refill(h, s, 0); if (rcw) return rcw; }
+  BgDev dseed = bg_dev_view(h, bg_prod_latest(h));
+  dseed.prod_in = h->d_prod[0]; dseed.prod_out = h->d_prod[1]; // the seed kernel resets BOTH producer-counter buffers
+  hipLaunchKernelGGL(bg_seed_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, dseed, (const int64_t*)h->d_seeds,
                      mask_host ? (const uint8_t*)h->d_mask : (const uint8_t*)nullptr, reseed_global);
   BG_HIP(hipGetLastError());
   // the copies above read pageable host memory: make sure they are done before the caller reuses the buffers
@@ -852,7 +925,9 @@ static InfoPtrs bg_info(const bg_info_ptrs* o) {
 int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void* stream) {
   int rc = bg_require_seeded(h);
   if (rc) return rc;
-  hipLaunchKernelGGL(bg_reset_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev, mask_dev, bg_obs(obs));
+  rc = bg_wait_refill(h, (hipStream_t)stream, 0);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bg_reset_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), mask_dev, bg_obs(obs));
   BG_HIP(hipGetLastError());
   return bg_refill(h, stream);
 }
@@ -862,17 +937,19 @@ int bg_step(bg_handle* h, const int32_t* actions_dev, const bg_obs_ptrs* obs, do
   int rc = bg_require_seeded(h);
   if (rc) return rc;
   if (!actions_dev) return BG_E_ARG;
-  bg_ev_begin(h, h->ev_step, (hipStream_t)stream);
-  hipLaunchKernelGGL(bg_step_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev, actions_dev,
+  rc = bg_wait_refill(h, (hipStream_t)stream, 0);
+  if (rc) return rc;
+  bg_ev_begin(h, h->ev_step_t, (hipStream_t)stream);
+  hipLaunchKernelGGL(bg_step_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), actions_dev,
                      bg_obs(obs), reward_dev, terminated_dev, truncated_dev, bg_info(info));
-  bg_ev_end(h, h->ev_step, (hipStream_t)stream);
+  bg_ev_end(h, h->ev_step_t, (hipStream_t)stream);
   BG_HIP(hipGetLastError());
   return bg_refill(h, stream);
 }
 
 int bg_observe(bg_handle* h, const bg_obs_ptrs* obs, void* stream) {
   if (!h) return BG_E_ARG;
-  hipLaunchKernelGGL(bg_observe_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, h->dev, bg_obs(obs));
+  hipLaunchKernelGGL(bg_observe_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), bg_obs(obs));
   BG_HIP(hipGetLastError());
   return 0;
 }
@@ -889,8 +966,13 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
   // (KG-1) full blocks of 624 words ahead; a step draws < 24 words without and < 110 with the scorer-level joker
   // chain (8 cards x 5 jokers x 2 + 5 x randint, accepted plays are >= 2 steps apart).
   int ring = h->dev.KD < h->dev.KS - 1 ? h->dev.KD : h->dev.KS - 1;
+  int gblocks = h->dev.KG - 1;
+  // With the refill overlapped on the side stream a chunk only sees what the refill BEFORE the previous chunk produced,
+  // so the rings must hold two chunks' worth.
+  const bool async = h->async_refill && ring >= 2 && gblocks >= 2;
+  if (async) { ring /= 2; gblocks /= 2; }
   int max_chunk = 3 * ring;
-  int gchunk = ((h->dev.KG - 1) * BG_MT_N) / ((h->dev.flags & BG_FLAG_SCORER_JOKERS) ? 110 : 24);
+  int gchunk = (gblocks * BG_MT_N) / ((h->dev.flags & BG_FLAG_SCORER_JOKERS) ? 110 : 24);
   if (gchunk < max_chunk) max_chunk = gchunk;
   if (max_chunk < 1) max_chunk = 1;
   int done = 0;
@@ -915,8 +997,14 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
       if (o.boss_blind_active) o.boss_blind_active += off; if (o.boss_blind_type) o.boss_blind_type += off;
       if (o.face_down_cards) o.face_down_cards += off * 8;
     }
-    bg_ev_begin(h, h->ev_rollout, (hipStream_t)stream);
+    bg_ev_begin(h, h->ev_rollout_t, (hipStream_t)stream);
     if (h->profiling) h->rollout_steps.push_back(chunk);
+    // async: this chunk may start as soon as the refill before the previous one is complete; sync: after the last one
+    rc = bg_wait_refill(h, (hipStream_t)stream, async ? 1 : 0);
+    if (rc) return rc;
+    const uint32_t* view = (async && h->refill_seq >= 2) ? h->d_prod[h->refill_seq & 1] : bg_prod_latest(h);
+    if (async && h->refill_seq < 2) { rc = bg_wait_refill(h, (hipStream_t)stream, 0); if (rc) return rc; }
+    BgDev dv = bg_dev_view(h, view);
     {
       const bool hash = (policy & BG_POLICY_HASH_OBS) != 0;
       const int pol = policy & 0xff;
@@ -926,17 +1014,23 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
       hipStream_t st = (hipStream_t)stream;
       uint64_t tt = t0 + (uint64_t)done;
       if (h->rollout_version == 1) {
-        if (hash) hipLaunchKernelGGL(bg_rollout_kernel<true>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, h->dev, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
-        else hipLaunchKernelGGL(bg_rollout_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, h->dev, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
+        if (hash) hipLaunchKernelGGL(bg_rollout_kernel<true>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
+        else hipLaunchKernelGGL(bg_rollout_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
       } else {
         dim3 g2((h->dev.N + BG_RB - 1) / BG_RB);
-        if (hash) hipLaunchKernelGGL(bg_rollout2_kernel<true>, g2, dim3(BG_RB), 0, st, h->dev, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
-        else hipLaunchKernelGGL(bg_rollout2_kernel<false>, g2, dim3(BG_RB), 0, st, h->dev, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
+        if (hash) hipLaunchKernelGGL(bg_rollout2_kernel<true>, g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
+        else hipLaunchKernelGGL(bg_rollout2_kernel<false>, g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
       }
     }
-    bg_ev_end(h, h->ev_rollout, (hipStream_t)stream);
+    bg_ev_end(h, h->ev_rollout_t, (hipStream_t)stream);
     BG_HIP(hipGetLastError());
-    rc = bg_refill(h, stream);
+    if (async) { // refill on the side stream, ordered after this chunk and after the previous refill
+      BG_HIP(hipEventRecord(h->ev_rollout, (hipStream_t)stream));
+      BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));
+      rc = bg_wait_refill(h, h->side, 0);
+      if (rc) return rc;
+      rc = bg_refill_on(h, h->side);
+    } else rc = bg_refill(h, stream);
     if (rc) return rc;
     done += chunk;
   }
@@ -977,7 +1071,7 @@ int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_h
   BG_HIP(hipMemcpyAsync(h->dev.tmpl, h->h_tmpl.data(), BG_NTMPL * N * sizeof(uint4), hipMemcpyHostToDevice, s));
   if (apply_now) {
     if (mask_host) BG_HIP(hipMemcpyAsync(h->d_mask, mask_host, N, hipMemcpyHostToDevice, s));
-    hipLaunchKernelGGL(bg_inject_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, h->dev,
+    hipLaunchKernelGGL(bg_inject_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, bg_dev_view(h, bg_prod_latest(h)),
                        mask_host ? (const uint8_t*)h->d_mask : (const uint8_t*)nullptr);
     BG_HIP(hipGetLastError());
   }
@@ -995,6 +1089,7 @@ static void bg_slices(bg_handle* h, std::vector<BgSlice>& v) {
   v.push_back({d.gblk, 1, (size_t)d.KG * BG_MTS * 4}); v.push_back({d.sblk, 1, (size_t)d.KS * BG_MTS * 4});
   v.push_back({d.deckmt, 1, (size_t)BG_MTS * 4}); v.push_back({d.shopgenmt, 1, (size_t)BG_MTS * 4});
   v.push_back({d.sseed, 1, 32 * 4}); v.push_back({d.smeta, 1, 4});
+  v.push_back({bg_prod_latest(h), 1, 4});
 }
 uint64_t bg_state_blob_bytes(const bg_handle* h) {
   if (!h) return 0;
@@ -1034,6 +1129,12 @@ int bg_set_state(bg_handle* h, int env_index, const void* blob_host, uint64_t bl
   for (auto& s : v) {
     BG_HIP(hipMemcpy2D((uint8_t*)s.base + (size_t)env_index * s.elem, N * s.elem, in, s.elem, s.elem, s.rows, hipMemcpyHostToDevice));
     in += s.rows * s.elem;
+  }
+  { // both producer-counter buffers must agree for this env (an overlapped rollout reads the older one)
+    uint32_t w = 0;
+    BG_HIP(hipMemcpy(&w, bg_prod_latest(h) + env_index, 4, hipMemcpyDeviceToHost));
+    BG_HIP(hipMemcpy(h->d_prod[0] + env_index, &w, 4, hipMemcpyHostToDevice));
+    BG_HIP(hipMemcpy(h->d_prod[1] + env_index, &w, 4, hipMemcpyHostToDevice));
   }
   h->seeded = true;
   return 0;

@@ -99,7 +99,7 @@ __device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, De
       if (k == 0) { dk.lo = ((uint64_t)c.y << 32) | c.x; dk.hi = ((uint64_t)c.w << 32) | c.z; }
     }
     e.d_head = (e.d_head + 1 == d.KD) ? 0 : e.d_head + 1;
-    e.d_ready--;
+    e.d_ready--; e.d_cons = (e.d_cons + 1) & 0xff;
   }
   // reset template (harness injection, applied after every reset)
   uint4 t0 = d.tmpl[env], t1 = d.tmpl[(size_t)d.N + env];
@@ -181,7 +181,7 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
 __device__ __forceinline__ void bg_generate_shop(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr) {
   if (e.s_ready <= 0) { atomicOr(d.err, BG_DEVERR_SHOPRING); return; }
   e.s_cur = (e.s_cur + 1 == d.KS) ? 0 : e.s_cur + 1;
-  e.s_ready--;
+  e.s_ready--; e.s_cons = (e.s_cons + 1) & 0xff;
   e.s_idx = 0;
   e.bflags |= BG_BF_SHOP_EXISTS;
   e.shop_ante = e.ante;
