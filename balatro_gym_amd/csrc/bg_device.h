@@ -251,16 +251,20 @@ struct JTables {
   double pow15[16];    // 1.5 ** k   (Baron)
   double pow08[16];    // 0.8 ** k   (boss_blinds.py:436)
 };
+// LDS pointers keep their address space in the type: a generic pointer stored in a struct compiles to FLAT loads (the
+// vector-memory path, ~1-2k cycles when nothing hides it) instead of ds_read (~100 cycles).
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) const JTables lds_JTables;
 struct RngWin {
-  const JTables* jt;
-  uint32_t* lds;   // &win[0][lane]
+  lds_JTables* jt;
+  lds_u32* lds;   // &win[0][lane]
   int g_blk, g_start, g_len; // window over the global stream: block, first index, words
   int s_start, s_len;        // window over the current shop stream
 };
 __device__ __forceinline__ void bg_win_init(RngWin& w, uint32_t* lds_lane, const JTables* jt = nullptr) {
-  w.jt = jt; w.lds = lds_lane; w.g_blk = -1; w.g_start = 0; w.g_len = 0; w.s_start = 0; w.s_len = 0;
+  w.jt = (lds_JTables*)jt; w.lds = (lds_u32*)lds_lane; w.g_blk = -1; w.g_start = 0; w.g_len = 0; w.s_start = 0; w.s_len = 0;
 }
-__device__ __noinline__ void bg_win_fill(uint32_t* lds, const uint32_t* src, int len) {
+__device__ __noinline__ void bg_win_fill(lds_u32* lds, const uint32_t* src, int len) {
 #pragma unroll 1
   for (int base = 0; base < len; base += 24) { // 24 independent loads in flight, then one wait
     uint32_t v[24];

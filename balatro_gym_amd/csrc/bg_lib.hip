@@ -546,7 +546,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
       // the ~51-70 words a shuffle consumes are consecutive words of the stream: fetch them with independent loads
       if (mti >= BG_MT_N) { bg_mt_twist(mt, mt); mti = 0; }
       int wl = BG_MT_N - (int)mti; if (wl > BG_RWIN) wl = BG_RWIN;
-      bg_win_fill(&rwin[0][tid], mt + mti, wl);
+      bg_win_fill((lds_u32*)&rwin[0][tid], mt + mti, wl);
       int wpos = 0;
       int p = 0;
       for (int s = 0; s < 4; s++) for (int r = 0; r < 13; r++) sdeck[p++][tid] = (uint8_t)(r * 4 + s); // :519-522

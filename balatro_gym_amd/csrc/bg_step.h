@@ -113,7 +113,7 @@ __device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, De
 // ---------------------------------------------------------------------------------------------------------
 // shop.py:104-139 + balatro_env_2.py:1383-1392
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double bg_shop_cost_mult(const Env& e, const JTables* jt) { // shop.py:104-108
+__device__ __forceinline__ double bg_shop_cost_mult(const Env& e, lds_JTables* jt) { // shop.py:104-108
   int k = e.shop_ante - 1;
   k = k < 0 ? 0 : (k > 100 ? 100 : k);
   double m = jt->pow115[k];
@@ -308,7 +308,7 @@ __device__ __forceinline__ void bg_tables_init(JTables* t) {
   }
   __syncthreads();
 }
-__device__ __forceinline__ uint32_t bg_joker_flags(const Env& e, const JTables* jt) {
+__device__ __forceinline__ uint32_t bg_joker_flags(const Env& e, lds_JTables* jt) {
   uint32_t f = 0;
 #pragma unroll 1
   for (int j = 0; j < e.njokers; j++) f |= jt->jf[bg_get8(e.jokers, j)];
@@ -452,14 +452,15 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     bg_gskip(d, e, consumed);
     chips += ic; mult += im;
     x_mult *= (double)(1ull << xexp);
-    BG_PROBE(8);
     // :216-244 main phase, joker order; one randint(0, 23) per joker
     uint32_t suits = ((scnt & 0xfu) ? 1u : 0u) | ((scnt & 0xf0u) ? 2u : 0u) | ((scnt & 0xf00u) ? 4u : 0u) | ((scnt & 0xf000u) ? 8u : 0u);
     uint32_t cond = 1u | (n <= 3 ? 2u : 0u) | (e.hands_left == 1 ? 4u : 0u) | (e.discards_left == 0 ? 8u : 0u) | (suits << 4) |
                     ((suits & ~9u) == 0 ? 1u << 8 : 0u) | (((suits & 1u) && __popc(suits) > 1) ? 1u << 9 : 0u) |
                     (__popc(suits) == 4 ? 1u << 10 : 0u) | (kings > 0 ? 1u << 11 : 0u) | (queens > 0 ? 1u << 12 : 0u) | (1u << (16 + ht));
     double baron = w.jt->pow15[kings];
+    BG_PROBE(8);
     bg_gprefetch(d, env, e, w, nj * 2 + 6);
+    BG_PROBE(13);
 #pragma unroll 1
     for (int j = 0; j < nj; j++) {
       uint32_t mis = bg_randbelow<false>(d, env, e, w, 24u);
@@ -472,6 +473,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
       double xf = vk == 2 ? (double)c : (vk == 6 ? baron : 1.0);
       if (ok) { chips += cadd; mult += madd; x_mult *= xf; }
     }
+    BG_PROBE(14);
   }
   int64_t final_score = (int64_t)((double)(chips * mult) * x_mult); // unified_scoring.py:286
   // :741-742 steel needs card states (not on this path): int(score * 1.0)

@@ -154,7 +154,7 @@ def main():
 
     if rank == 0:
         value = env_steps / elapsed
-        # roofline of the dominant kernel (bg_rollout_kernel): algorithmic bytes per launch / mean launch duration
+        # roofline of the dominant kernel (bg_rollout2_kernel): algorithmic bytes per launch / mean launch duration
         launches = max(1, prof["rollout_launches"])
         fused = prof["rollout_fused_steps"] / launches           # mean fused steps T per launch
         a_step = OBS_BYTES + IO_BYTES + 2 * STATE_BYTES / max(1.0, fused)
@@ -175,7 +175,7 @@ def main():
                        "parallelism": f"shard{world} (independent envs, no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
-                         "kernel": "bg_rollout_kernel", "algorithmic_bytes_per_env_step": a_step,
+                         "kernel": "bg_rollout2_kernel", "algorithmic_bytes_per_env_step": a_step,
                          "mean_launch_us": mean_launch_s * 1e6, "launches": launches,
                          "refill_mean_launch_us": prof["refill_ms"] / max(1, prof["refill_launches"]) * 1e3},
             "episodes": int(agg[1].item()), "accepted_plays": int(agg[2].item()),

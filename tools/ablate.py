@@ -54,8 +54,8 @@ def run(n, scorer, policy, chunk, steps, obs_mode, max_ante=4, label=""):
         blocks = (n + 255) // 256
         T = max(1, out[4] // blocks)
         print(f"    phase cycles per block-step: A {out[0]/blocks/T:9.0f}  B {out[1]/blocks/T:9.0f}  C {out[2]/blocks/T:9.0f}  items/block-step {out[3]/blocks/T:6.1f}")
-        names = {5: "gather", 6: "classify", 7: "boss-check+joker-individual", 8: "bloodstone+skip", 9: "joker-main", 10: "boss-ratio+state", 11: "reward", 12: "outcome"}
-        print("    play path cycles per block-step: " + " | ".join(f"{names[i]} {out[i]/blocks/T:.0f}" for i in range(5, 13)))
+        names = {5: "gather", 6: "classify", 7: "boss-check+joker-individual", 8: "bloodstone+skip", 9: "joker-main", 10: "boss-ratio+state", 11: "reward", 12: "outcome", 13: "main-prefetch", 14: "main-loop"}
+        print("    play path cycles per block-step: " + " | ".join(f"{names[i]} {out[i]/blocks/T:.0f}" for i in range(5, 15)))
     env.close()
 
 
