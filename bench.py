@@ -161,6 +161,14 @@ def main():
         bytes_per_launch = a_step * n * fused
         mean_launch_s = prof["rollout_ms"] / launches * 1e-3
         achieved = bytes_per_launch / mean_launch_s / 1e9 if mean_launch_s > 0 else 0.0
+        # HBM traffic of that kernel from the PMC counters (rocprofv3, separate FETCH_SIZE / WRITE_SIZE passes of this same
+        # command; the corrected per-env-step figure is committed under profiles/ and scaled to this run's launch shape)
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_v8_hbm_traffic.json")) as f:
+                traffic = json.load(f)["hbm_bytes_per_env_step"] * n * fused
+        except Exception:
+            pass
         out = {
             "metric": "env-steps/sec at 65536 envs, random policy; achieved HBM GB/s vs peak",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -174,7 +182,7 @@ def main():
                        "ring_depths": {k: os.environ.get(k, "default") for k in ("BG_KG", "BG_KS", "BG_KD")},
                        "parallelism": f"shard{world} (independent envs, no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "bg_rollout2_kernel", "algorithmic_bytes_per_env_step": a_step,
                          "mean_launch_us": mean_launch_s * 1e6, "launches": launches,
                          "refill_mean_launch_us": prof["refill_ms"] / max(1, prof["refill_launches"]) * 1e3},
