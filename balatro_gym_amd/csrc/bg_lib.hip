@@ -573,7 +573,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
       d_ready++; made++;
     }
     mt[BG_MT_N] = mti;
-    d.prod_out[env] = (prod & 0xffffff00u) | ((prod + (uint32_t)made) & 0xffu); // kernels of one refill run back to back
+    ((uint8_t*)&d.prod_out[env])[0] = (uint8_t)((prod + (uint32_t)made) & 0xffu); // byte store: the block kernel may run concurrently
   }
 }
 
@@ -627,7 +627,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_gblk_kernel(BgDev d) {
       uint32_t g = ((prod >> 16) + (uint32_t)made) & 0xffu;
       // only this lane touches byte 2 of this env's word during a refill; bytes 0/1 may be updated concurrently by the
       // deck kernel of the SAME refill only if kernels overlapped -- they run back to back on one stream
-      d.prod_out[env] = (d.prod_out[env] & 0xff00ffffu) | (g << 16);
+      ((uint8_t*)&d.prod_out[env])[2] = (uint8_t)g;
     }
   }
 }
@@ -666,7 +666,8 @@ struct bg_handle {
   uint32_t* d_prod[2];
   long refill_seq;       // refills launched so far; refill #i writes d_prod[i & 1]
   bool async_refill;     // BG_ASYNC_REFILL (default on): bg_rollout overlaps refill #i with rollout chunk i+1
-  hipStream_t side;
+  hipStream_t side, side2, side3; // side: overlapped refills; side2/3: the deck and block kernels of one refill run beside the shop kernel
+  hipEvent_t ev_scan, ev_deck, ev_gblk;
   hipEvent_t ev_refill[2];
   hipEvent_t ev_rollout;
   std::vector<hipEvent_t> ev_rollout_t, ev_refill_t, ev_step_t; // start/stop pairs
@@ -760,7 +761,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   h->device_id = device_id; h->seeded = false; h->bytes = 0; h->profiling = false;
   { const char* rv = getenv("BG_ROLLOUT_V"); h->rollout_version = rv ? atoi(rv) : 2; }
   { const char* av = getenv("BG_ASYNC_REFILL"); h->async_refill = av ? atoi(av) != 0 : true; }
-  h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = nullptr;
+  h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
   h->ev_refill[0] = h->ev_refill[1] = nullptr; h->ev_rollout = nullptr;
   h->d_seeds = nullptr; h->d_mask = nullptr;
   memset(&h->dev, 0, sizeof(h->dev));
@@ -788,6 +789,11 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (e == hipSuccess) e = bg_alloc(h, &h->d_prod[0], N);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_prod[1], N);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_scan, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_deck, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_gblk, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_refill[0], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_refill[1], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_rollout, hipEventDisableTiming);
@@ -811,6 +817,11 @@ int bg_destroy(bg_handle* h) {
   BgDev& d = h->dev;
   (void)hipDeviceSynchronize();
   if (h->side) (void)hipStreamDestroy(h->side);
+  if (h->side2) (void)hipStreamDestroy(h->side2);
+  if (h->side3) (void)hipStreamDestroy(h->side3);
+  if (h->ev_scan) (void)hipEventDestroy(h->ev_scan);
+  if (h->ev_deck) (void)hipEventDestroy(h->ev_deck);
+  if (h->ev_gblk) (void)hipEventDestroy(h->ev_gblk);
   for (int i = 0; i < 2; i++) if (h->ev_refill[i]) (void)hipEventDestroy(h->ev_refill[i]);
   if (h->ev_rollout) (void)hipEventDestroy(h->ev_rollout);
   hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
@@ -851,10 +862,19 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   BG_HIP(hipMemsetAsync(d.wl_count, 0, 4 * sizeof(uint32_t), s));
   hipLaunchKernelGGL(bg_refill_scan_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, d);
   int dense = bg_grid(h) < 1024 ? bg_grid(h) : 1024; // grid-stride over the compacted work lists
-  hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, d);
+  // the three kinds of work are independent once the lists exist: run them side by side (each is a few hundred
+  // latency-bound waves), join before the completion event
+  BG_HIP(hipEventRecord(h->ev_scan, s));
+  BG_HIP(hipStreamWaitEvent(h->side2, h->ev_scan, 0));
+  BG_HIP(hipStreamWaitEvent(h->side3, h->ev_scan, 0));
   hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, d);
-  hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, d);
-  hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, d);
+  hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side2, d);
+  hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
+  hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
+  BG_HIP(hipEventRecord(h->ev_deck, h->side2));
+  BG_HIP(hipEventRecord(h->ev_gblk, h->side3));
+  BG_HIP(hipStreamWaitEvent(s, h->ev_deck, 0));
+  BG_HIP(hipStreamWaitEvent(s, h->ev_gblk, 0));
   bg_ev_end(h, h->ev_refill_t, s);
   BG_HIP(hipGetLastError());
   BG_HIP(hipEventRecord(h->ev_refill[h->refill_seq & 1], s));
