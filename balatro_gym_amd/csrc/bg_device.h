@@ -245,6 +245,7 @@ __device__ __forceinline__ uint32_t bg_twist(uint32_t a, uint32_t b, uint32_t fa
 struct JTables {
   uint64_t jd[152];    // individual-phase descriptor per joker id (bg_jdesc)
   uint32_t jm[152];    // main-phase descriptor per joker id (bg_jmain_desc)
+  uint64_t jr[152];    // rank set of jd[] expanded to a 4-bit-per-rank mask (for the played-rank histogram)
   uint8_t jf[152];     // name-group flags used by reward shaping / discard hooks
   uint8_t cost[152];   // JokerInfo.base_cost (jokers.py)
   double pow115[101];  // 1.15 ** k  (shop.py:105)

@@ -150,10 +150,10 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
   __shared__ uint4 s_state[BG_NHOT][BG_RB];
   __shared__ uint4 s_shop[4][BG_RB];
   __shared__ OutLds s_out[BG_RB];
-  __shared__ uint32_t s_items[BG_RB];
-  __shared__ uint32_t s_nitems;
+  __shared__ uint32_t s_items[2][BG_RB]; // work lists: 0 = PLAY_HAND, 1 = every other deferred action
+  __shared__ uint32_t s_nitems[2];
   __shared__ uint32_t s_prod[BG_RB];
-  __shared__ uint32_t win[BG_WIN][BG_BLOCK];
+  __shared__ uint32_t win[2][BG_WIN][BG_BLOCK]; // one RNG window set per phase-B wave
   __shared__ JTables jt;
   bg_tables_init(&jt);
   const int local = threadIdx.x;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
 #define BG_TICK() __builtin_readcyclecounter()
 #endif
   for (int t = 0; t < T; t++) {
-    if (local == 0) s_nitems = 0;
+    if (local < 2) s_nitems[local] = 0;
     __syncthreads();
 #ifdef BG_TIMING
     unsigned long long c0 = BG_TICK();
@@ -194,8 +194,9 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
         else deferred = true;
       }
       if (deferred) {
-        uint32_t slot = atomicAdd(&s_nitems, 1u);
-        s_items[slot] = (uint32_t)local | ((uint32_t)action << 16);
+        const int cls = (e.phase == 0 && action == 0) ? 0 : 1;
+        uint32_t slot = atomicAdd(&s_nitems[cls], 1u);
+        s_items[cls][slot] = (uint32_t)local | ((uint32_t)action << 16);
         uint4 c[BG_NHOT];
         bg_pack(e, c);
 #pragma unroll
@@ -206,11 +207,13 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
 #ifdef BG_TIMING
     unsigned long long c1 = BG_TICK();
 #endif
-    // ---------------- phase B: dense over the work list (wave 0, 64 items per round)
+    // ---------------- phase B: dense over the work lists; wave 0 takes the plays, wave 1 everything else, side by side
+    // (one code path: a wave only walks the branches its own class takes)
     {
-      uint32_t nitems = s_nitems;
-      if (local < BG_BLOCK) for (uint32_t it = (uint32_t)local; it < nitems; it += BG_BLOCK) { // one wave owns the RNG window
-        uint32_t item = s_items[it];
+      const int cls = local >> 6;
+      uint32_t nitems = cls < 2 ? s_nitems[cls] : 0u;
+      if (cls < 2) for (uint32_t it = (uint32_t)(local & (BG_BLOCK - 1)); it < nitems; it += BG_BLOCK) {
+        uint32_t item = s_items[cls][it];
         int l = (int)(item & 0xffffu), a = (int)(item >> 16);
         int benv = blockIdx.x * BG_RB + l;
         uint4 c[BG_NHOT];
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
         Deck0 bdk = bg_load_deck0(d, benv);
         ShopRegs bsr; bsr.valid = false;
         RngWin w;
-        bg_win_init(w, &win[0][local & (BG_BLOCK - 1)], &jt);
+        bg_win_init(w, &win[cls][0][local & (BG_BLOCK - 1)], &jt);
         StepOut bo;
         bg_step_init(bo);
         bg_env_dispatch(d, benv, be, w, bsr, bdk, a, bo);
@@ -240,7 +243,7 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
     __syncthreads();
 #ifdef BG_TIMING
     unsigned long long c2 = BG_TICK();
-    tBitems += s_nitems;
+    tBitems += s_nitems[0] + s_nitems[1];
 #endif
     // ---------------- phase C
     if (live) {

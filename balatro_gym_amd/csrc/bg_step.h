@@ -301,6 +301,7 @@ __device__ __forceinline__ void bg_tables_init(JTables* t) {
   for (int id = threadIdx.x; id < 152; id += blockDim.x) {
     t->jd[id] = bg_jdesc(id);
     t->jm[id] = bg_jmain_desc(id);
+    { uint64_t rm = 0; uint32_t r = (uint32_t)bg_jdesc(id) & 0x7fffu; for (int k = 0; k < 15; k++) if ((r >> k) & 1u) rm |= 0xfull << (4 * k); t->jr[id] = rm; }
     t->jf[id] = (uint8_t)bg_jflags(id);
     t->cost[id] = id < 151 ? BG_JOKER_COST[id] : 0;
     if (id < 101) t->pow115[id] = BG_POW115[id];
@@ -409,19 +410,29 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     // and mult add up, and every x factor is exactly 2.0.
     const int nj = e.njokers;
     int ic = 0, im = 0, xexp = 0, j8 = -1, jb = -1;
-#pragma unroll 1
-    for (int j = 0; j < nj; j++) {
-      uint64_t dsc = w.jt->jd[bg_get8(e.jokers, j)];
+    // all table reads first (independent LDS reads), then straight-line arithmetic per joker slot
+    uint64_t jds[5], jrs[5];
+    uint32_t dms[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      int id = j < nj ? (int)((e.jokers >> (8 * j)) & 0xff) : 0;
+      jds[j] = w.jt->jd[id]; jrs[j] = w.jt->jr[id]; dms[j] = w.jt->jm[id];
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      uint64_t dsc = jds[j];
       uint32_t sp = (uint32_t)(dsc >> 20) & 3u;
       if (sp == 1u) j8 = j;
-      if (sp == 2u) { jb = j; continue; } // Bloodstone is settled card by card below
-      int cnt = 0;
+      if (sp == 2u) jb = j;
+      // matching cards = sum of the histogram nibbles selected by the rank mask, or the suit's count
+      uint64_t x = phist & jrs[j];
+      uint32_t y = (uint32_t)(x & 0x0f0f0f0f0f0f0f0full) + (uint32_t)((x >> 4) & 0x0f0f0f0f0f0f0f0full) +
+                   (uint32_t)((x & 0x0f0f0f0f0f0f0f0full) >> 32) + (uint32_t)(((x >> 4) & 0x0f0f0f0f0f0f0f0full) >> 32);
+      y += y >> 16;
+      int cnt = (int)((y + (y >> 8)) & 0xffu);
       uint32_t suit1 = (uint32_t)(dsc >> 16) & 7u;
       if (suit1) cnt = (int)((scnt >> (4 * (suit1 - 1))) & 0xfu);
-      else {
-#pragma unroll 1
-        for (uint32_t rm = (uint32_t)dsc & 0x7fffu; rm; rm &= rm - 1) cnt += (int)((phist >> (4 * (__ffs((int)rm) - 1))) & 0xf);
-      }
+      if (sp == 2u) cnt = 0; // Bloodstone is settled card by card below
       ic += cnt * (int)((dsc >> 24) & 0xffu); im += cnt * (int)((dsc >> 32) & 0xffu);
       if ((dsc >> 22) & 1u) xexp += cnt;
     }
@@ -431,23 +442,25 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     int consumed = 2 * n * nj + 2 * n8;
     if (jb >= 0 && ((scnt >> 8) & 0xfu)) {
       // Bloodstone on a Heart: x2 iff the pair's random() < 0.5.  Pair (c, jb) sits 2*(c*nj + jb) words ahead, plus 2
-      // for every extra 8-Ball draw that precedes it in card-major order.
-      bg_gprefetch(d, env, e, w, consumed);
+      // for every extra 8-Ball draw that precedes it in card-major order: up to 8 independent two-word reads.
+      int boff[8];
       int eights = 0;
-#pragma unroll 1
-      for (int c = 0; c < n; c++) {
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
         int code = (int)((pcodes >> (8 * c)) & 0xff);
         int rk = (code >> 2) + 2;
-        if ((code & 3) == 2) {
-          int off = 2 * (c * nj + jb) + 2 * (eights + ((j8 >= 0 && j8 < jb && rk == 8) ? 1 : 0));
-          uint32_t ra, rb;
-          if (off + 1 < w.g_len) { ra = bg_temper(w.lds[off * BG_BLOCK]); rb = bg_temper(w.lds[(off + 1) * BG_BLOCK]); }
-          else { ra = bg_gpeek(d, env, e, off); rb = bg_gpeek(d, env, e, off + 1); }
-          double b = ((double)(ra >> 5) * 67108864.0 + (double)(rb >> 6)) * (1.0 / 9007199254740992.0);
-          if (b < 0.5) xexp++;
-        }
-        if (j8 >= 0 && rk == 8) eights++;
+        boff[c] = (c < n && (code & 3) == 2) ? 2 * (c * nj + jb) + 2 * (eights + ((j8 >= 0 && j8 < jb && rk == 8) ? 1 : 0)) : -1;
+        if (c < n && j8 >= 0 && rk == 8) eights++;
       }
+      uint32_t ra[8], rb[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) { ra[c] = 0; rb[c] = 0; if (boff[c] >= 0) { ra[c] = bg_gpeek(d, env, e, boff[c]); rb[c] = bg_gpeek(d, env, e, boff[c] + 1); } }
+#pragma unroll
+      for (int c = 0; c < 8; c++)
+        if (boff[c] >= 0) {
+          double bl = ((double)(ra[c] >> 5) * 67108864.0 + (double)(rb[c] >> 6)) * (1.0 / 9007199254740992.0);
+          if (bl < 0.5) xexp++;
+        }
     }
     bg_gskip(d, e, consumed);
     chips += ic; mult += im;
@@ -459,19 +472,54 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
                     (__popc(suits) == 4 ? 1u << 10 : 0u) | (kings > 0 ? 1u << 11 : 0u) | (queens > 0 ? 1u << 12 : 0u) | (1u << (16 + ht));
     double baron = w.jt->pow15[kings];
     BG_PROBE(8);
-    bg_gprefetch(d, env, e, w, nj * 2 + 6);
+    bg_gprefetch(d, env, e, w, 16);
     BG_PROBE(13);
+    // The nj draws are `_randbelow(24)`: 5-bit words, rejected when >= 24.  Instead of a rejection loop per joker (a wave
+    // iterates until its unluckiest lane is done), look at the next 16 words at once: the j-th ACCEPTED word is joker
+    // j's draw.  Only Misprint uses the value.
+    uint32_t mis_of[5] = {0, 0, 0, 0, 0};
+    {
+      bg_gnorm(d, e);
+      uint32_t off0 = (uint32_t)(e.g_idx - w.g_start);
+      bool fast = w.g_blk == e.g_cur && off0 + 16u <= (uint32_t)w.g_len;
+      uint32_t acc = 0;
+      if (fast) {
+#pragma unroll
+        for (int i = 0; i < 16; i++) { uint32_t r5 = bg_temper(w.lds[(off0 + i) * BG_BLOCK]) >> 27; acc |= (r5 < 24u ? 1u : 0u) << i; }
+        fast = __popc(acc) >= nj;
+      }
+      if (fast) {
+        uint32_t m = acc;
+        int last = 0;
+#pragma unroll
+        for (int j = 0; j < 5; j++)
+          if (j < nj) {
+            last = __ffs((int)m) - 1;
+            m &= m - 1;
+            if (((dms[j] >> 5) & 7u) == 3u) mis_of[j] = bg_temper(w.lds[(off0 + last) * BG_BLOCK]) >> 27;
+          }
+        e.g_idx += last + 1;
+      } else {
 #pragma unroll 1
-    for (int j = 0; j < nj; j++) {
-      uint32_t mis = bg_randbelow<false>(d, env, e, w, 24u);
-      uint32_t dm = w.jt->jm[bg_get8(e.jokers, j)];
-      bool ok = (cond >> (dm & 31u)) & 1u;
-      uint32_t vk = (dm >> 5) & 7u;
-      int c = (int)(dm >> 8);
-      int madd = vk == 0 ? c : (vk == 3 ? (int)mis : (vk == 4 ? 3 * nj : (vk == 7 ? 13 * queens : 0)));
-      int cadd = vk == 1 ? c : (vk == 5 ? 30 * e.discards_left : 0);
-      double xf = vk == 2 ? (double)c : (vk == 6 ? baron : 1.0);
-      if (ok) { chips += cadd; mult += madd; x_mult *= xf; }
+        for (int j = 0; j < nj; j++) {
+          uint32_t v = bg_randbelow<false>(d, env, e, w, 24u);
+#pragma unroll
+          for (int q = 0; q < 5; q++) if (q == j) mis_of[q] = v;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+      if (j < nj) {
+        uint32_t dm = dms[j];
+        bool ok = (cond >> (dm & 31u)) & 1u;
+        uint32_t vk = (dm >> 5) & 7u;
+        int c = (int)(dm >> 8);
+        int madd = vk == 0 ? c : (vk == 3 ? (int)mis_of[j] : (vk == 4 ? 3 * nj : (vk == 7 ? 13 * queens : 0)));
+        int cadd = vk == 1 ? c : (vk == 5 ? 30 * e.discards_left : 0);
+        double xf = vk == 2 ? (double)c : (vk == 6 ? baron : 1.0);
+        if (ok) { chips += cadd; mult += madd; x_mult *= xf; }
+      }
     }
     BG_PROBE(14);
   }
