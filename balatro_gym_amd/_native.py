@@ -65,7 +65,9 @@ _lib = None
 
 
 def lib_path() -> str:
-    return _build.LIB
+    # BALATRO_MI355X_LIB points at an installed / experimental build of the same C ABI (still the HIP library: there is
+    # no other implementation to fall back to)
+    return os.environ.get("BALATRO_MI355X_LIB") or _build.LIB
 
 
 def load(build_if_missing: bool = True):
@@ -74,7 +76,7 @@ def load(build_if_missing: bool = True):
     if _lib is not None:
         return _lib
     path = lib_path()
-    if build_if_missing and _build.needs_build():
+    if build_if_missing and path == _build.LIB and _build.needs_build():
         try:
             _build.build()
         except Exception as exc:  # no hipcc on the box and no prebuilt .so

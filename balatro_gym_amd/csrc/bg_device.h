@@ -194,15 +194,22 @@ __device__ __forceinline__ uint32_t* bg_sblock(const BgDev& d, int env, int slot
 __device__ __forceinline__ uint32_t* bg_deckmt(const BgDev& d, int env) { return d.deckmt + (size_t)env * BG_MTS; }
 __device__ __forceinline__ uint32_t* bg_shopgenmt(const BgDev& d, int env) { return d.shopgenmt + (size_t)env * BG_MTS; }
 
-// development cycle probes (-DBG_TIMING): the first active lane of the wave adds the cycles since the previous probe
+// development cycle probes (-DBG_TIMING): the first active lane of the wave adds the cycles since the previous probe to
+// a per-workgroup LDS accumulator; kernels flush it to d.dbg once at their end (a global atomic per probe would serialise
+// ~1000 waves on one L2 word and distort what is being measured)
 #ifdef BG_TIMING
+__shared__ unsigned long long bg_probe_lds[32];
 #define BG_PROBE_BEGIN() unsigned long long _pt = __builtin_readcyclecounter()
 #define BG_PROBE(k) do { unsigned long long _n = __builtin_readcyclecounter(); \
-    if (d.dbg && (int)threadIdx.x == __ffsll((long long)__ballot(1)) - 1 + (int)(threadIdx.x & ~63u)) atomicAdd(&d.dbg[k], _n - _pt); \
+    if ((int)threadIdx.x == __ffsll((long long)__ballot(1)) - 1 + (int)(threadIdx.x & ~63u)) atomicAdd(&bg_probe_lds[k], _n - _pt); \
     _pt = __builtin_readcyclecounter(); } while (0)
+#define BG_PROBE_INIT() do { if (threadIdx.x < 32) bg_probe_lds[threadIdx.x] = 0; __syncthreads(); } while (0)
+#define BG_PROBE_FLUSH(d) do { __syncthreads(); if (threadIdx.x < 32 && (d).dbg && bg_probe_lds[threadIdx.x]) atomicAdd(&(d).dbg[threadIdx.x], bg_probe_lds[threadIdx.x]); } while (0)
 #else
 #define BG_PROBE_BEGIN() do {} while (0)
 #define BG_PROBE(k) do {} while (0)
+#define BG_PROBE_INIT() do {} while (0)
+#define BG_PROBE_FLUSH(d) do {} while (0)
 #endif
 
 struct Deck0 { uint64_t lo, hi; };
@@ -315,22 +322,63 @@ __device__ __forceinline__ void bg_gprefetch(const BgDev& d, int env, Env& e, Rn
   w.g_blk = e.g_cur; w.g_start = e.g_idx; w.g_len = len;
   w.s_len = 0; // the window storage is shared with the shop stream
 }
-// next raw word of the current shop's random.Random(shop_seed) (shop.py:96)
+// The current shop's random.Random(shop_seed) (shop.py:96).  The ring slot holds the SEEDED MT19937 state S (the refill
+// kernel never twists it); word k of the first output block is B(k) = far ^ twist(S[k], nxt) with
+//   far = k < 227 ? S[k + 397] : B(k - 227),   nxt = k < 623 ? S[k + 1] : B(0)
+// i.e. at most three levels deep.  A shop visit reads ~13 words per inventory, so the window below (k + len <= 227: every
+// operand is a seeded word) covers everything but many-reroll visits, which take the slow exact path.
+__device__ __noinline__ uint32_t bg_sword_slow(const uint32_t* S, int k) {
+  uint32_t far;
+  if (k < BG_MT_N - BG_MT_M) far = S[k + BG_MT_M];
+  else {
+    const int k1 = k - (BG_MT_N - BG_MT_M); // 0..396
+    uint32_t far1;
+    if (k1 < BG_MT_N - BG_MT_M) far1 = S[k1 + BG_MT_M];
+    else { const int k2 = k1 - (BG_MT_N - BG_MT_M); far1 = bg_twist(S[k2], S[k2 + 1], S[k2 + BG_MT_M]); } // k2 < 170
+    far = bg_twist(S[k1], S[k1 + 1], far1);
+  }
+  const uint32_t nxt = k < BG_MT_N - 1 ? S[k + 1] : bg_twist(S[0], S[1], S[BG_MT_M]);
+  return bg_twist(S[k], nxt, far);
+}
 __device__ __forceinline__ uint32_t bg_sdraw(const BgDev& d, int env, Env& e, RngWin& w) {
   if (e.s_idx >= BG_MT_N) { atomicOr(d.err, BG_DEVERR_SHOPBLK); return 0u; }
   uint32_t off = (uint32_t)(e.s_idx - w.s_start);
   uint32_t y;
   if (off < (uint32_t)w.s_len) y = w.lds[off * BG_BLOCK];
-  else y = bg_sblock(d, env, e.s_cur)[e.s_idx];
+  else y = bg_sword_slow(bg_sblock(d, env, e.s_cur), e.s_idx);
   e.s_idx++;
   return bg_temper(y);
 }
+// regenerate the next `count` (<= 24) words of the shop stream into the window: 14 independent 16-byte loads for a
+// fresh stream (s_idx == 0, every generate_shop), scalar loads at other positions (rerolls)
+__device__ __noinline__ void bg_swin_fill0(lds_u32* lds, const uint32_t* S) {
+  const uint4* S4 = (const uint4*)S;
+  uint32_t A[28], F[28];
+#pragma unroll
+  for (int g = 0; g < 7; g++) { uint4 v = S4[g]; A[4 * g] = v.x; A[4 * g + 1] = v.y; A[4 * g + 2] = v.z; A[4 * g + 3] = v.w; }
+#pragma unroll
+  for (int g = 0; g < 7; g++) { uint4 v = S4[99 + g]; F[4 * g] = v.x; F[4 * g + 1] = v.y; F[4 * g + 2] = v.z; F[4 * g + 3] = v.w; } // words 396..423
+#pragma unroll
+  for (int i = 0; i < 24; i++) lds[i * BG_BLOCK] = bg_twist(A[i], A[i + 1], F[i + 1]);
+}
+__device__ __noinline__ void bg_swin_fill(lds_u32* lds, const uint32_t* S, int k0, int len) {
+  uint32_t A[25], F[24];
+#pragma unroll
+  for (int j = 0; j < 25; j++) A[j] = (j <= len) ? S[k0 + j] : 0u;
+#pragma unroll
+  for (int j = 0; j < 24; j++) F[j] = (j < len) ? S[k0 + j + BG_MT_M] : 0u;
+#pragma unroll
+  for (int j = 0; j < 24; j++) if (j < len) lds[j * BG_BLOCK] = bg_twist(A[j], A[j + 1], F[j]);
+}
 __device__ __forceinline__ void bg_sprefetch(const BgDev& d, int env, Env& e, RngWin& w, int count) {
-  int len = BG_MT_N - e.s_idx;
+  int len = (BG_MT_N - BG_MT_M) - e.s_idx; // stay where every operand is a seeded word
   if (len > count) len = count;
+  if (len > 24) len = 24;
   if (len > BG_WIN) len = BG_WIN;
   if (len < 0) len = 0;
-  bg_win_fill(w.lds, bg_sblock(d, env, e.s_cur) + e.s_idx, len);
+  const uint32_t* S = bg_sblock(d, env, e.s_cur);
+  if (e.s_idx == 0 && len == 24) bg_swin_fill0(w.lds, S);
+  else if (len > 0) bg_swin_fill(w.lds, S, e.s_idx, len);
   w.s_start = e.s_idx; w.s_len = len;
   w.g_len = 0; w.g_blk = -1;
 }

@@ -139,22 +139,27 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, in
 //   C  lane = env: merge, curriculum cap, SAME_STEP auto-reset, observation / reward / terminated stores, statistics
 // State stays in registers (lane = env) across the T fused steps; LDS is only the exchange between the two lane maps.
 // ---------------------------------------------------------------------------------------------------------
+#ifndef BG_RB
 #define BG_RB 256 // envs per workgroup
+#endif
 struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags; }; // misc: hand_type+1 | terminated<<8 | has_shop<<9
 
 template <bool HASH>
 __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
                                                               uint64_t env_index0, uint64_t t0, ObsPtrs obs,
                                                               int obs_stride_steps, double* reward, uint8_t* term,
-                                                              int32_t* actions_out, bg_rollout_stats* stats) {
+                                                              int32_t* actions_out, bg_rollout_stats* stats,
+                                                              uint32_t th_play, uint32_t th_other, uint32_t th_ready) {
   __shared__ uint4 s_state[BG_NHOT][BG_RB];
   __shared__ uint4 s_shop[4][BG_RB];
   __shared__ OutLds s_out[BG_RB];
-  __shared__ uint32_t s_items[2][BG_RB]; // work lists: 0 = PLAY_HAND, 1 = every other deferred action
+  __shared__ uint32_t s_items[2][BG_RB]; // work queues: 0 = PLAY_HAND, 1 = every other deferred action
   __shared__ uint32_t s_nitems[2];
+  __shared__ uint32_t s_nready;
   __shared__ uint32_t s_prod[BG_RB];
   __shared__ uint32_t win[2][BG_WIN][BG_BLOCK]; // one RNG window set per phase-B wave
   __shared__ JTables jt;
+  BG_PROBE_INIT();
   bg_tables_init(&jt);
   const int local = threadIdx.x;
   const int env = blockIdx.x * BG_RB + local;
@@ -166,28 +171,39 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
   ShopRegs sr; sr.valid = false;
   uint64_t mask = 0;
   s_prod[local] = (live && d.prod_view) ? d.prod_view[env] : 0u;
+  if (local < 2) s_nitems[local] = 0;
+  if (local == 0) s_nready = 0;
   if (live) {
     bg_load_env(d, env, e);
     dk = bg_load_deck0(d, env);
     mask = bg_action_mask(d, env, e, sr);
   }
 #ifdef BG_TIMING
-  unsigned long long tA = 0, tB = 0, tC = 0, tBitems = 0;
+  unsigned long long tA = 0, tB = 0, tC = 0, tBitems = 0, tIter = 0, tRounds = 0;
 #define BG_TICK() __builtin_readcyclecounter()
 #endif
-  for (int t = 0; t < T; t++) {
-    if (local < 2) s_nitems[local] = 0;
-    __syncthreads();
+  // Envs are independent, so the lanes of a workgroup need not sit on the same step: every lane carries its own step
+  // counter t.  An iteration lets every runnable lane take ONE step; lanes whose action needs the heavy code park their
+  // state in LDS and wait.  Phase B only runs once a queue holds enough items to fill its wave (or too few lanes are
+  // still runnable), so the ~40k-cycle latency of the play path is paid per ~60 plays instead of per ~20.
+  int t = 0;
+  bool blocked = false;
+  int action = 0;
+  StepOut o;
+  bg_step_init(o);
+  __syncthreads();
+  for (;;) {
 #ifdef BG_TIMING
     unsigned long long c0 = BG_TICK();
 #endif
-    // ---------------- phase A
-    StepOut o;
-    bg_step_init(o);
-    int action = 0;
-    bool deferred = false;
-    if (live) {
+    // ---------------- phase A: policy, guards, cheap actions inline, everything else queued
+    bool fin = false;
+    if (live && !blocked && t < T) {
+      BG_PROBE_BEGIN();
+      bg_step_init(o);
       action = bg_policy_action(e, mask, policy, policy_seed, env_index0 + (uint64_t)env, t0 + (uint64_t)t);
+      BG_PROBE(20);
+      bool deferred = false;
       if (bg_step_guards(e, mask, action, o)) {
         if (e.phase == 0 && action >= 2 && action < 10) bg_toggle_select(e, action - 2);
         else if (e.phase == 1 && action == 31) { e.phase = 0; bg_draw_cards(e); }              // shop end :1247-1251
@@ -201,19 +217,33 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
         bg_pack(e, c);
 #pragma unroll
         for (int k = 0; k < BG_NHOT; k++) s_state[k][local] = c[k];
-      }
+        s_out[local].misc = 0; // not processed yet
+        blocked = true;
+      } else fin = true;
+      BG_PROBE(21);
+    }
+    {
+      const bool runnable_next = live && !blocked && (t + (fin ? 1 : 0)) < T;
+      const unsigned long long bal = __ballot(runnable_next);
+      if ((local & 63) == 0 && bal) atomicAdd(&s_nready, (uint32_t)__popcll(bal));
     }
     __syncthreads();
 #ifdef BG_TIMING
     unsigned long long c1 = BG_TICK();
 #endif
-    // ---------------- phase B: dense over the work lists; wave 0 takes the plays, wave 1 everything else, side by side
-    // (one code path: a wave only walks the branches its own class takes)
-    {
+    const uint32_t nq0 = s_nitems[0], nq1 = s_nitems[1], nready = s_nready;
+    const bool run_b = (nq0 + nq1) > 0 && (nq0 >= th_play || nq1 >= th_other || nready < th_ready);
+    const uint32_t rem0 = run_b ? (nq0 > BG_BLOCK ? nq0 - BG_BLOCK : 0u) : nq0;
+    const uint32_t rem1 = run_b ? (nq1 > BG_BLOCK ? nq1 - BG_BLOCK : 0u) : nq1;
+    // ---------------- phase B: one batch of up to 64 items per queue; wave 0 takes the plays, wave 1 everything else,
+    // side by side (one code path: a wave only walks the branches its own class takes)
+    if (run_b) {
       const int cls = local >> 6;
-      uint32_t nitems = cls < 2 ? s_nitems[cls] : 0u;
-      if (cls < 2) for (uint32_t it = (uint32_t)(local & (BG_BLOCK - 1)); it < nitems; it += BG_BLOCK) {
-        uint32_t item = s_items[cls][it];
+      const int lane = local & (BG_BLOCK - 1);
+      const uint32_t nitems = cls == 0 ? nq0 : (cls == 1 ? nq1 : 0u);
+      const uint32_t nb = nitems > BG_BLOCK ? BG_BLOCK : nitems;
+      if (cls < 2 && (uint32_t)lane < nb) {
+        uint32_t item = s_items[cls][lane];
         int l = (int)(item & 0xffffu), a = (int)(item >> 16);
         int benv = blockIdx.x * BG_RB + l;
         uint4 c[BG_NHOT];
@@ -225,7 +255,7 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
         Deck0 bdk = bg_load_deck0(d, benv);
         ShopRegs bsr; bsr.valid = false;
         RngWin w;
-        bg_win_init(w, &win[cls][0][local & (BG_BLOCK - 1)], &jt);
+        bg_win_init(w, &win[cls][0][lane], &jt);
         StepOut bo;
         bg_step_init(bo);
         bg_env_dispatch(d, benv, be, w, bsr, bdk, a, bo);
@@ -235,34 +265,50 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
         if (bsr.valid) { s_shop[0][l] = bsr.c3; s_shop[1][l] = bsr.c4; s_shop[2][l] = bsr.c5; s_shop[3][l] = bsr.c6; }
         OutLds ol;
         ol.reward = bo.reward; ol.final_score = bo.final_score;
-        ol.misc = (bo.hand_type + 1) | (bo.terminated ? 0x100 : 0) | (bsr.valid ? 0x200 : 0) | (bo.error << 16);
+        ol.misc = (bo.hand_type + 1) | (bo.terminated ? 0x100 : 0) | (bsr.valid ? 0x200 : 0) | 0x400 | (bo.error << 16);
         ol.flags = bo.flags;
         s_out[l] = ol;
+      }
+      // items beyond the batch move to the front of their queue (only this wave touches the queue during phase B)
+      if (cls < 2 && nitems > nb) {
+        for (uint32_t i = (uint32_t)lane; i < nitems - nb; i += BG_BLOCK) {
+          uint32_t v = s_items[cls][i + nb];
+          s_items[cls][i] = v;
+        }
       }
     }
     __syncthreads();
 #ifdef BG_TIMING
     unsigned long long c2 = BG_TICK();
-    tBitems += s_nitems[0] + s_nitems[1];
+    if (run_b) { tBitems += (nq0 - rem0) + (nq1 - rem1); tRounds++; }
+    tIter++;
 #endif
-    // ---------------- phase C
-    if (live) {
-      if (deferred) {
-        uint4 c[BG_NHOT];
+    if (local == 0) { s_nready = 0; s_nitems[0] = rem0; s_nitems[1] = rem1; }
+    // ---------------- phase C: finish the step of every lane that took one (inline in A, or just served by phase B)
+    BG_PROBE_BEGIN();
+    if (blocked && (s_out[local].misc & 0x400)) {
+      uint4 c[BG_NHOT];
 #pragma unroll
-        for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][local];
-        bg_unpack(c, e);
-        bg_derive_ready(e, s_prod[local]);
-        OutLds ol = s_out[local];
-        o.reward = ol.reward; o.final_score = ol.final_score; o.flags = ol.flags;
-        o.hand_type = (ol.misc & 0xff) - 1; o.terminated = (ol.misc & 0x100) != 0; o.error = ol.misc >> 16;
-        if (ol.misc & 0x200) { sr.c3 = s_shop[0][local]; sr.c4 = s_shop[1][local]; sr.c5 = s_shop[2][local]; sr.c6 = s_shop[3][local]; sr.valid = true; }
-      }
+      for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][local];
+      bg_unpack(c, e);
+      bg_derive_ready(e, s_prod[local]);
+      OutLds ol = s_out[local];
+      o.reward = ol.reward; o.final_score = ol.final_score; o.flags = ol.flags;
+      o.hand_type = (ol.misc & 0xff) - 1; o.terminated = (ol.misc & 0x100) != 0; o.error = ol.misc >> 16;
+      if (ol.misc & 0x200) { sr.c3 = s_shop[0][local]; sr.c4 = s_shop[1][local]; sr.c5 = s_shop[2][local]; sr.c6 = s_shop[3][local]; sr.valid = true; }
+      blocked = false;
+      fin = true;
+    }
+    BG_PROBE(16);
+    if (fin) {
       if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
       if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; } // SAME_STEP auto-reset
+      BG_PROBE(17);
       mask = bg_action_mask(d, env, e, sr);
+      BG_PROBE(18);
       size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
       uint64_t h = bg_write_obs<HASH>(d, env, row, e, dk, obs, mask, sr);
+      BG_PROBE(19);
       if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
       if (reward) reward[row] = o.reward;
       if (term) term[row] = o.terminated ? 1 : 0;
@@ -270,15 +316,18 @@ __global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, i
       n_steps++;
       rbits ^= (uint64_t)__double_as_longlong(o.reward) * (2 * (uint64_t)(t0 + t) + 1);
       if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
+      t++;
     }
+    const int more = __syncthreads_or((live && (blocked || t < T)) ? 1 : 0);
 #ifdef BG_TIMING
-    __syncthreads();
     unsigned long long c3 = BG_TICK();
     tA += c1 - c0; tB += c2 - c1; tC += c3 - c2;
 #endif
+    if (!more) break; // every lane has done its T steps
   }
 #ifdef BG_TIMING
-  if (local == 0 && d.dbg) { atomicAdd(&d.dbg[0], tA); atomicAdd(&d.dbg[1], tB); atomicAdd(&d.dbg[2], tC); atomicAdd(&d.dbg[3], tBitems); atomicAdd(&d.dbg[4], (unsigned long long)T); }
+  if (local == 0) { bg_probe_lds[0] = tA; bg_probe_lds[1] = tB; bg_probe_lds[2] = tC; bg_probe_lds[3] = tBitems; bg_probe_lds[4] = (unsigned long long)T; bg_probe_lds[15] = tIter | (tRounds << 32); }
+  BG_PROBE_FLUSH(d);
 #endif
   if (live) bg_store_env(d, env, e);
   if (stats) {
@@ -325,67 +374,99 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_observe_kernel(BgDev d, ObsPtrs o
 // MT19937 on a lane-private contiguous state block (word i at p[i]; see bg_device.h for why this is not SoA)
 // ---------------------------------------------------------------------------------------------------------
 // CPython random_seed()/init_by_array() for a ONE-word key (every stream / shop / global seed is < 2**32).
-// The key-dependent passes are 1247 DEPENDENT steps per stream; the only way to make them cheap is to keep memory out
-// of the dependency chain: pass 1 regenerates init_genrand(19650218) in a second register chain (no loads at all),
-// pass 2 and the block twist fetch their operands in batches of BG_MTB independent loads before running the chain.
-#define BG_MTB 16
-#define BG_RWIN 96 // words of the deck stream prefetched per shuffle (refill kernel)
-// All stores/loads of the state are 16-byte vectors on 16-byte aligned groups: a lane walks its own block, so a
-// wave-level access touches 64 different lines whatever the width -- 4x fewer instructions = 4x less TA time.
+// The key-dependent passes are 1247 DEPENDENT steps per stream.  Memory stays out of the chains completely: pass 1
+// (i = 1..623 plus the wrapped step at i = 1) runs in registers and keeps only its last value; pass 2 needs pass 1's
+// mt[i] again, and gets it from a SECOND run of the pass-1 recurrence in lockstep (two independent chains = ILP) --
+// recomputing 623 steps is far cheaper than writing 2.5 KB per stream and reading it back.  The only memory traffic
+// is the final state: 156 16-byte stores.
 __device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) {
   uint4* p4 = (uint4*)p;
-  uint32_t g = 19650218u; // init_genrand seed; g tracks init_genrand's mt[i]
-  uint32_t prev = g;      // mt[0]
-  uint32_t mt1 = 0;
-  // first pass, i = 1..623 (key index j is always 0); group q = words 4q..4q+3
+  uint32_t g = 19650218u, a = g, a1 = 0; // g: init_genrand(19650218) recurrence; a: pass-1 recurrence
+#pragma unroll 4
+  for (int i = 1; i < BG_MT_N; i++) {
+    g = 1812433253u * (g ^ (g >> 30)) + (uint32_t)i;
+    a = (g ^ ((a ^ (a >> 30)) * 1664525u)) + key;
+    if (i == 1) a1 = a;
+  }
+  // wrap: mt[0] = mt[623]; 624th iteration of pass 1 at i = 1
+  const uint32_t a1w = (a1 ^ ((a ^ (a >> 30)) * 1664525u)) + key;
+  // pass 2: i = 2..623 (then the wrapped step at i = 1), beside a rerun of pass 1 that supplies mt[i]
+  g = 19650218u; a = g;
+  g = 1812433253u * (g ^ (g >> 30)) + 1u;
+  a = (g ^ ((a ^ (a >> 30)) * 1664525u)) + key; // pass-1 mt[1] (before the wrap)
+  uint32_t bprev = a1w, w2 = 0, w3 = 0;
+#pragma unroll 2
   for (int q = 0; q < BG_MT_N / 4; q++) {
-    uint32_t v[4];
+    uint32_t v[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      int i = 4 * q + c;
-      if (i == 0) { v[c] = 0u; continue; }
-      g = 1812433253u * (g ^ (g >> 30)) + (uint32_t)i;
-      uint32_t x = (g ^ ((prev ^ (prev >> 30)) * 1664525u)) + key;
-      v[c] = x;
-      if (i == 1) mt1 = x;
-      prev = x;
-    }
-    p4[q] = make_uint4(v[0], v[1], v[2], v[3]);
-  }
-  { // wrap: mt[0] = mt[623]; 624th iteration at i = 1
-    uint32_t mt0 = prev;
-    uint32_t x = (mt1 ^ ((mt0 ^ (mt0 >> 30)) * 1664525u)) + key;
-    mt1 = x;
-    prev = x;
-  }
-  // second pass: 622 iterations i = 2..623, then the wrapped one at i = 1; words 0 and 1 are finalised at the end
-  uint32_t w2 = 0, w3 = 0;
-  for (int base = 0; base < BG_MT_N / 4; base += BG_MTB / 4) {
-    uint4 buf[BG_MTB / 4];
-#pragma unroll
-    for (int j = 0; j < BG_MTB / 4; j++) buf[j] = p4[base + j];
-#pragma unroll
-    for (int j = 0; j < BG_MTB / 4; j++) {
-      int q = base + j;
-      uint32_t v[4] = {buf[j].x, buf[j].y, buf[j].z, buf[j].w};
-#pragma unroll
-      for (int c = 0; c < 4; c++) {
-        int i = 4 * q + c;
-        if (i >= 2) {
-          uint32_t x = (v[c] ^ ((prev ^ (prev >> 30)) * 1566083941u)) - (uint32_t)i;
-          v[c] = x;
-          prev = x;
-        }
+      const int i = 4 * q + c;
+      if (i >= 2) {
+        g = 1812433253u * (g ^ (g >> 30)) + (uint32_t)i;
+        a = (g ^ ((a ^ (a >> 30)) * 1664525u)) + key;
+        bprev = (a ^ ((bprev ^ (bprev >> 30)) * 1566083941u)) - (uint32_t)i;
+        v[c] = bprev;
       }
-      if (q == 0) { w2 = v[2]; w3 = v[3]; }
-      else p4[q] = make_uint4(v[0], v[1], v[2], v[3]);
     }
+    if (q == 0) { w2 = v[2]; w3 = v[3]; }
+    else p4[q] = make_uint4(v[0], v[1], v[2], v[3]);
   }
-  uint32_t mt0 = prev; // mt[0] = mt[623]
-  uint32_t w1 = (mt1 ^ ((mt0 ^ (mt0 >> 30)) * 1566083941u)) - 1u;
+  const uint32_t w1 = (a1w ^ ((bprev ^ (bprev >> 30)) * 1566083941u)) - 1u; // mt[0] = mt[623], wrapped step at i = 1
   p4[0] = make_uint4(0x80000000u, w1, w2, w3);
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Lazy MT19937 for the streams only the refill kernels read (deck shuffles, shop seeds).  genrand_uint32() regenerates
+// all 624 words when the block is exhausted; computing word k of the next block just before it is read gives the same
+// sequence (new[k] = old[k+397 mod 624 (already new for k >= 227)] ^ twist(old[k], old[k+1]); k = 623 pairs with the
+// new word 0) and never needs the 624-word pass.  State: [new words 0..c) | old words c..624), cursor c in word 624.
+// A window = the next 4*G aligned words from the cursor's 16-byte group on: 2*(G+1) independent 16-byte loads, one
+// wait, the new (untempered) words go to LDS [word][lane]; commit writes back exactly the words that were consumed.
+// 4*G < 227, so no operand of a window is produced inside the same window.
+template <int G>
+__device__ __forceinline__ void bg_lazy_window(const uint32_t* S, uint32_t c, lds_u32* win, uint4 (&oldv)[G]) {
+  const uint4* S4 = (const uint4*)S;
+  const uint32_t q0 = c >> 2;
+  uint32_t f0 = q0 + 99u; if (f0 >= 156u) f0 -= 156u; // group of word (4*q0 + 396) mod 624
+  uint32_t A[4 * G + 4], F[4 * G + 4];
+#pragma unroll
+  for (int g = 0; g <= G; g++) {
+    uint32_t q = q0 + (uint32_t)g; if (q >= 156u) q -= 156u;
+    uint4 v = S4[q];
+    A[4 * g] = v.x; A[4 * g + 1] = v.y; A[4 * g + 2] = v.z; A[4 * g + 3] = v.w;
+  }
+#pragma unroll
+  for (int g = 0; g <= G; g++) {
+    uint32_t q = f0 + (uint32_t)g; if (q >= 156u) q -= 156u;
+    uint4 v = S4[q];
+    F[4 * g] = v.x; F[4 * g + 1] = v.y; F[4 * g + 2] = v.z; F[4 * g + 3] = v.w;
+  }
+#pragma unroll
+  for (int i = 0; i < 4 * G; i++) win[i * BG_BLOCK] = bg_twist(A[i], A[i + 1], F[i + 1]);
+#pragma unroll
+  for (int g = 0; g < G; g++) oldv[g] = make_uint4(A[4 * g], A[4 * g + 1], A[4 * g + 2], A[4 * g + 3]);
+}
+// write back the `used` words consumed from the cursor on (aligned coordinates [c & 3, (c & 3) + used)); returns the new cursor
+template <int G>
+__device__ __forceinline__ uint32_t bg_lazy_commit(uint32_t* S, uint32_t c, uint32_t used, lds_u32* win, const uint4 (&oldv)[G]) {
+  uint4* S4 = (uint4*)S;
+  const uint32_t q0 = c >> 2, off = c & 3u, end = off + used;
+#pragma unroll
+  for (int g = 0; g < G; g++) {
+    if ((uint32_t)(4 * g) < end) {
+      uint32_t o[4] = {oldv[g].x, oldv[g].y, oldv[g].z, oldv[g].w};
+#pragma unroll
+      for (int k = 0; k < 4; k++) { const uint32_t i = (uint32_t)(4 * g + k); if (i >= off && i < end) o[k] = win[i * BG_BLOCK]; }
+      uint32_t q = q0 + (uint32_t)g; if (q >= 156u) q -= 156u;
+      S4[q] = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  uint32_t nc = c + used; if (nc >= (uint32_t)BG_MT_N) nc -= (uint32_t)BG_MT_N;
+  return nc;
+}
+
+#define BG_MTB 16 // words per batch of the block twist
+#define BG_LAZY_SEEDED 0x80000000u // flag in the cursor word of a lazy stream (set by bg_seed)
 // genrand_uint32()'s block regeneration: dst[kk] = twist(src[kk], src[kk+1], kk < 227 ? src[kk+397] : dst[kk-227]),
 // last element uses the NEW dst[0].  dst == src gives CPython's in-place update (operands are loaded per batch before
 // any element of the batch is stored; BG_MTB < 227 keeps the kk-227 operands already written).
@@ -420,20 +501,6 @@ __device__ void bg_mt_twist(const uint32_t* src, uint32_t* dst) {
   }
 }
 
-// genrand_uint32() on an authoritative stream state (624 words + index word at [624])
-__device__ __forceinline__ uint32_t bg_mt_next(uint32_t* p, uint32_t& mti) {
-  if (mti >= BG_MT_N) { bg_mt_twist(p, p); mti = 0; }
-  uint32_t y = p[mti];
-  mti++;
-  return bg_temper(y);
-}
-__device__ __forceinline__ uint32_t bg_mt_randbelow(uint32_t* p, uint32_t& mti, uint32_t n) {
-  int k = 32 - __clz(n);
-  uint32_t r;
-  do { r = bg_mt_next(p, mti) >> (32 - k); } while (r >= n);
-  return r;
-}
-
 // DeterministicRNG(seed) (balatro_env_2.py:84-106) for streams 0 ('deck_shuffle') and 2 ('shop_generation'), plus the
 // per-env global stream seeded G(seed).  Streams are seeded `(master + 1000 * i) % 2**32` (:105).
 __global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_t* __restrict__ seeds,
@@ -465,9 +532,9 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_
   }
   uint32_t base = (uint32_t)(uint64_t)seed;
   bg_mt_seed(bg_deckmt(d, env), base);
-  bg_deckmt(d, env)[BG_MT_N] = BG_MT_N;
+  bg_deckmt(d, env)[BG_MT_N] = BG_LAZY_SEEDED; // lazy streams: cursor 0 (bit 31 marks "seeded" for the refill scan)
   bg_mt_seed(bg_shopgenmt(d, env), base + 2000u);
-  bg_shopgenmt(d, env)[BG_MT_N] = BG_MT_N;
+  bg_shopgenmt(d, env)[BG_MT_N] = BG_LAZY_SEEDED;
   // look-ahead rings are functions of the streams: invalidate (producer counters restart at the consumer counters)
   e.d_head = 0; e.d_cons = 0; e.d_ready = 0;
   e.s_cons = 0; e.s_ready = 0;
@@ -530,9 +597,10 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
   if (g_valid > 0 && g_valid < d.KG) { uint32_t i = atomicAdd(&d.wl_count[2], 1u); d.wl[2 * N + i] = (uint32_t)env; }
 }
 
+#define BG_DECK_G 25 // 16-byte groups per lazy window of the deck stream (>= 97 words; a shuffle reads ~70)
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
   __shared__ uint8_t sdeck[52][BG_BLOCK];
-  __shared__ uint32_t rwin[BG_RWIN][BG_BLOCK];
+  __shared__ uint32_t rwin[4 * BG_DECK_G][BG_BLOCK];
   size_t N = d.N;
   int tid = threadIdx.x;
   uint32_t count = d.wl_count[0];
@@ -544,69 +612,83 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
     int d_ready = (int)((prod - (uint32_t)d_cons) & 0xffu);
     int made = 0;
     uint32_t* mt = bg_deckmt(d, env);
-    uint32_t mti = mt[BG_MT_N];
+    uint32_t cur = mt[BG_MT_N] & 0x3ffu;
+    lds_u32* win = (lds_u32*)&rwin[0][tid];
     while (d_ready < d.KD) {
-      // the ~51-70 words a shuffle consumes are consecutive words of the stream: fetch them with independent loads
-      if (mti >= BG_MT_N) { bg_mt_twist(mt, mt); mti = 0; }
-      int wl = BG_MT_N - (int)mti; if (wl > BG_RWIN) wl = BG_RWIN;
-      bg_win_fill((lds_u32*)&rwin[0][tid], mt + mti, wl);
-      int wpos = 0;
       int p = 0;
       for (int s = 0; s < 4; s++) for (int r = 0; r < 13; r++) sdeck[p++][tid] = (uint8_t)(r * 4 + s); // :519-522
-      for (int i = 51; i >= 1; i--) { // random.shuffle: j = _randbelow(i + 1)
-        int k = 32 - __clz((uint32_t)(i + 1));
-        uint32_t j;
-        do {
-          uint32_t y;
-          if (wpos < wl) { y = bg_temper(rwin[wpos][tid]); wpos++; mti++; }
-          else y = bg_mt_next(mt, mti);
-          j = y >> (32 - k);
-        } while (j >= (uint32_t)(i + 1));
-        uint8_t a = sdeck[i][tid], b = sdeck[j][tid];
-        sdeck[i][tid] = b; sdeck[j][tid] = a;
+      int i = 51; // random.shuffle: for i = 51..1: j = _randbelow(i + 1), swap
+#pragma unroll 1
+      while (i >= 1) {
+        uint4 oldv[BG_DECK_G];
+        bg_lazy_window<BG_DECK_G>(mt, cur, win, oldv);
+        const uint32_t off = cur & 3u, cap = 4u * BG_DECK_G - off;
+        uint32_t used = 0;
+        while (i >= 1 && used < cap) {
+          const int k = 32 - __clz((uint32_t)(i + 1));
+          const uint32_t j = bg_temper(win[(off + used) * BG_BLOCK]) >> (32 - k);
+          used++;
+          if (j <= (uint32_t)i) {
+            uint8_t a = sdeck[i][tid], b = sdeck[j][tid];
+            sdeck[i][tid] = b; sdeck[j][tid] = a;
+            i--;
+          }
+        }
+        cur = bg_lazy_commit<BG_DECK_G>(mt, cur, used, win, oldv);
       }
       int slot = (d_head + d_ready) % d.KD;
 #pragma unroll
       for (int k = 0; k < BG_NDECK; k++) {
         uint32_t wv[4] = {0, 0, 0, 0};
 #pragma unroll
-        for (int b = 0; b < 16; b++) { int i = k * 16 + b; if (i < 52) wv[b >> 2] |= (uint32_t)sdeck[i][tid] << (8 * (b & 3)); }
+        for (int b = 0; b < 16; b++) { int i2 = k * 16 + b; if (i2 < 52) wv[b >> 2] |= (uint32_t)sdeck[i2][tid] << (8 * (b & 3)); }
         d.ndeck[((size_t)slot * BG_NDECK + k) * N + env] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
       }
       d_ready++; made++;
     }
-    mt[BG_MT_N] = mti;
+    mt[BG_MT_N] = cur | BG_LAZY_SEEDED;
     ((uint8_t*)&d.prod_out[env])[0] = (uint8_t)((prod + (uint32_t)made) & 0xffu); // byte store: the block kernel may run concurrently
   }
 }
 
 // top up the per-env ring of pre-drawn shop seeds: `rng.get_int('shop_generation', 0, 2**31 - 1)` (:1389) in stream order
+#define BG_SEED_G 16 // one lazy window of the shop_generation stream per refill: >= 61 words, ~30 accepted seeds
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_seedring_kernel(BgDev d) {
+  __shared__ uint32_t rwin[4 * BG_SEED_G][BG_BLOCK];
   size_t N = d.N;
   uint32_t count = d.wl_count[1];
+  lds_u32* win = (lds_u32*)&rwin[0][threadIdx.x];
   for (uint32_t item = blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
     int env = (int)d.wl[N + item];
     uint32_t sm = d.smeta[env];
     int head = (int)(sm & 0xffu), cnt = (int)((sm >> 8) & 0xffu);
     uint32_t* mt = bg_shopgenmt(d, env);
-    uint32_t mti = mt[BG_MT_N];
-    while (cnt < 32) {
-      d.sseed[(size_t)env * 32 + ((head + cnt) & 31)] = bg_mt_randbelow(mt, mti, 2147483648u);
-      cnt++;
+    uint32_t cur = mt[BG_MT_N] & 0x3ffu;
+#pragma unroll 1
+    while (cnt < 32) { // almost always one window
+      uint4 oldv[BG_SEED_G];
+      bg_lazy_window<BG_SEED_G>(mt, cur, win, oldv);
+      const uint32_t off = cur & 3u, cap = 4u * BG_SEED_G - off;
+      uint32_t used = 0;
+      while (cnt < 32 && used < cap) { // _randbelow(2**31): k = 32 bits, accept r < 2**31
+        const uint32_t r = bg_temper(win[(off + used) * BG_BLOCK]);
+        used++;
+        if (r < 2147483648u) { d.sseed[(size_t)env * 32 + ((head + cnt) & 31)] = r; cnt++; }
+      }
+      cur = bg_lazy_commit<BG_SEED_G>(mt, cur, used, win, oldv);
     }
-    mt[BG_MT_N] = mti;
+    mt[BG_MT_N] = cur | BG_LAZY_SEEDED;
     d.smeta[env] = (uint32_t)head | ((uint32_t)cnt << 8);
   }
 }
 
-// `random.Random(shop_seed)` (shop.py:96): seed + first block, one stream per lane
+// `random.Random(shop_seed)` (shop.py:96): one stream per lane, pure ALU + 156 stores.  The slot holds the SEEDED state;
+// the consumer regenerates the few words a shop visit reads (bg_sprefetch), so no block twist is ever run for a shop.
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop_kernel(BgDev d) {
   uint32_t count = d.wl_count[3];
   for (uint32_t item = blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
     uint32_t es = d.wl_shop[2 * (size_t)item], seed = d.wl_shop[2 * (size_t)item + 1];
-    uint32_t* blk = bg_sblock(d, (int)(es & 0xffffffu), (int)(es >> 24));
-    bg_mt_seed(blk, seed);
-    bg_mt_twist(blk, blk);
+    bg_mt_seed(bg_sblock(d, (int)(es & 0xffffffu), (int)(es >> 24)), seed);
   }
 }
 
@@ -668,6 +750,7 @@ struct bg_handle {
   // refill pipeline: double-buffered producer counters, a side stream and per-parity completion events
   uint32_t* d_prod[2];
   long refill_seq;       // refills launched so far; refill #i writes d_prod[i & 1]
+  uint32_t th_play, th_other, th_ready; // phase-B batching thresholds of bg_rollout2_kernel (BG_TH_PLAY / _OTHER / _READY)
   bool async_refill;     // BG_ASYNC_REFILL (default on): bg_rollout overlaps refill #i with rollout chunk i+1
   hipStream_t side, side2, side3; // side: overlapped refills; side2/3: the deck and block kernels of one refill run beside the shop kernel
   hipEvent_t ev_scan, ev_deck, ev_gblk;
@@ -727,8 +810,16 @@ extern "C" {
 int bg_debug_counters(bg_handle* h, unsigned long long* out16) {
   if (!h || !out16) return BG_E_ARG;
   BG_HIP(hipDeviceSynchronize());
-  BG_HIP(hipMemcpy(out16, h->dev.dbg, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-  BG_HIP(hipMemset(h->dev.dbg, 0, 16 * sizeof(unsigned long long)));
+  BG_HIP(hipMemcpy(out16, h->dev.dbg, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+  BG_HIP(hipMemset(h->dev.dbg, 0, 32 * sizeof(unsigned long long)));
+  return 0;
+}
+
+// development aid: the four work-list lengths of the most recent refill (decks, seed rings, global blocks, shop streams)
+int bg_debug_worklists(bg_handle* h, unsigned int* out4) {
+  if (!h || !out4) return BG_E_ARG;
+  BG_HIP(hipDeviceSynchronize());
+  BG_HIP(hipMemcpy(out4, h->dev.wl_count, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost));
   return 0;
 }
 
@@ -764,6 +855,11 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   h->device_id = device_id; h->seeded = false; h->bytes = 0; h->profiling = false;
   { const char* rv = getenv("BG_ROLLOUT_V"); h->rollout_version = rv ? atoi(rv) : 2; }
   { const char* av = getenv("BG_ASYNC_REFILL"); h->async_refill = av ? atoi(av) != 0 : true; }
+  { // phase B runs when a queue reaches its threshold or fewer than th_ready lanes can still step (1/1/anything = lockstep)
+    const char* a = getenv("BG_TH_PLAY"); const char* b = getenv("BG_TH_OTHER"); const char* c = getenv("BG_TH_READY");
+    h->th_play = a ? (uint32_t)atoi(a) : 44u; h->th_other = b ? (uint32_t)atoi(b) : 56u; h->th_ready = c ? (uint32_t)atoi(c) : (uint32_t)(BG_RB / 2);
+    if (h->th_play < 1) h->th_play = 1; if (h->th_other < 1) h->th_other = 1; if (h->th_ready < 1) h->th_ready = 1;
+  }
   h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
   h->ev_refill[0] = h->ev_refill[1] = nullptr; h->ev_rollout = nullptr;
   h->d_seeds = nullptr; h->d_mask = nullptr;
@@ -800,7 +896,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_refill[0], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_refill[1], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_rollout, hipEventDisableTiming);
-  if (e == hipSuccess) e = bg_alloc(h, &d.dbg, 16);
+  if (e == hipSuccess) e = bg_alloc(h, &d.dbg, 32);
   if (e == hipSuccess) e = bg_alloc(h, &d.err, 4);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_seeds, N);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_mask, N);
@@ -1041,8 +1137,8 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
         else hipLaunchKernelGGL(bg_rollout_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
       } else {
         dim3 g2((h->dev.N + BG_RB - 1) / BG_RB);
-        if (hash) hipLaunchKernelGGL(bg_rollout2_kernel<true>, g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
-        else hipLaunchKernelGGL(bg_rollout2_kernel<false>, g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
+        if (hash) hipLaunchKernelGGL(bg_rollout2_kernel<true>, g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, h->th_play, h->th_other, h->th_ready);
+        else hipLaunchKernelGGL(bg_rollout2_kernel<false>, g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, h->th_play, h->th_other, h->th_ready);
       }
     }
     bg_ev_end(h, h->ev_rollout_t, (hipStream_t)stream);

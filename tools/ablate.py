@@ -47,13 +47,18 @@ def run(n, scorer, policy, chunk, steps, obs_mode, max_ante=4, label=""):
           flush=True)
     if os.environ.get("BG_TIMING"):
         import ctypes as C2
-        out = (C2.c_ulonglong * 16)()
+        out = (C2.c_ulonglong * 32)()
         L = nat.load()
         L.bg_debug_counters.argtypes = [C2.c_void_p, C2.POINTER(C2.c_ulonglong)]
         L.bg_debug_counters(env._h, out)
         blocks = (n + 255) // 256
         T = max(1, out[4] // blocks)
         print(f"    phase cycles per block-step: A {out[0]/blocks/T:9.0f}  B {out[1]/blocks/T:9.0f}  C {out[2]/blocks/T:9.0f}  items/block-step {out[3]/blocks/T:6.1f}")
+        iters, rounds = out[15] & 0xffffffff, out[15] >> 32
+        print(f"    per block-step: iterations {iters/blocks/T:5.2f}  phase-B rounds {rounds/blocks/T:5.2f}  items per round {out[3]/max(1,rounds):5.1f}"
+              f"  | cycles per iteration A {out[0]/max(1,iters):7.0f} C {out[2]/max(1,iters):7.0f}  per round B {out[1]/max(1,rounds):7.0f}")
+        print("    A/C sections, cycles per wave-iteration: " + " | ".join(f"{nm} {out[i]/max(1,iters)/4:.0f}" for i, nm in
+              [(20, "policy"), (21, "guards+cheap+enqueue"), (16, "merge"), (17, "cap+reset"), (18, "mask"), (19, "obs")]))
         names = {5: "gather", 6: "classify", 7: "boss-check+joker-individual", 8: "bloodstone+skip", 9: "joker-main", 10: "boss-ratio+state", 11: "reward", 12: "outcome", 13: "main-prefetch", 14: "main-loop"}
         print("    play path cycles per block-step: " + " | ".join(f"{names[i]} {out[i]/blocks/T:.0f}" for i in range(5, 15)))
     env.close()
