@@ -351,7 +351,7 @@ __device__ __forceinline__ uint32_t bg_sdraw(const BgDev& d, int env, Env& e, Rn
 }
 // regenerate the next `count` (<= 24) words of the shop stream into the window: 14 independent 16-byte loads for a
 // fresh stream (s_idx == 0, every generate_shop), scalar loads at other positions (rerolls)
-__device__ __noinline__ void bg_swin_fill0(lds_u32* lds, const uint32_t* S) {
+__device__ __forceinline__ void bg_swin_fill0(lds_u32* lds, const uint32_t* S) {
   const uint4* S4 = (const uint4*)S;
   uint32_t A[28], F[28];
 #pragma unroll
@@ -361,7 +361,7 @@ __device__ __noinline__ void bg_swin_fill0(lds_u32* lds, const uint32_t* S) {
 #pragma unroll
   for (int i = 0; i < 24; i++) lds[i * BG_BLOCK] = bg_twist(A[i], A[i + 1], F[i + 1]);
 }
-__device__ __noinline__ void bg_swin_fill(lds_u32* lds, const uint32_t* S, int k0, int len) {
+__device__ __forceinline__ void bg_swin_fill(lds_u32* lds, const uint32_t* S, int k0, int len) {
   uint32_t A[25], F[24];
 #pragma unroll
   for (int j = 0; j < 25; j++) A[j] = (j <= len) ? S[k0 + j] : 0u;

@@ -144,8 +144,11 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, in
 #endif
 struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags; }; // misc: hand_type+1 | terminated<<8 | has_shop<<9
 
+#ifndef BG_RB_WAVES
+#define BG_RB_WAVES 1
+#endif
 template <bool HASH>
-__global__ __launch_bounds__(BG_RB, 1) void bg_rollout2_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
+__global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
                                                               uint64_t env_index0, uint64_t t0, ObsPtrs obs,
                                                               int obs_stride_steps, double* reward, uint8_t* term,
                                                               int32_t* actions_out, bg_rollout_stats* stats,
@@ -421,10 +424,11 @@ __device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) {
 // sequence (new[k] = old[k+397 mod 624 (already new for k >= 227)] ^ twist(old[k], old[k+1]); k = 623 pairs with the
 // new word 0) and never needs the 624-word pass.  State: [new words 0..c) | old words c..624), cursor c in word 624.
 // A window = the next 4*G aligned words from the cursor's 16-byte group on: 2*(G+1) independent 16-byte loads, one
-// wait, the new (untempered) words go to LDS [word][lane]; commit writes back exactly the words that were consumed.
+// wait, the new (untempered) words and the old ones go to LDS [word][lane]; commit writes back exactly the words that
+// were consumed (whole 16-byte groups, untouched words keep their old value).
 // 4*G < 227, so no operand of a window is produced inside the same window.
 template <int G>
-__device__ __forceinline__ void bg_lazy_window(const uint32_t* S, uint32_t c, lds_u32* win, uint4 (&oldv)[G]) {
+__device__ __forceinline__ void bg_lazy_window(const uint32_t* S, uint32_t c, lds_u32* win, lds_u32* old) {
   const uint4* S4 = (const uint4*)S;
   const uint32_t q0 = c >> 2;
   uint32_t f0 = q0 + 99u; if (f0 >= 156u) f0 -= 156u; // group of word (4*q0 + 396) mod 624
@@ -442,21 +446,19 @@ __device__ __forceinline__ void bg_lazy_window(const uint32_t* S, uint32_t c, ld
     F[4 * g] = v.x; F[4 * g + 1] = v.y; F[4 * g + 2] = v.z; F[4 * g + 3] = v.w;
   }
 #pragma unroll
-  for (int i = 0; i < 4 * G; i++) win[i * BG_BLOCK] = bg_twist(A[i], A[i + 1], F[i + 1]);
-#pragma unroll
-  for (int g = 0; g < G; g++) oldv[g] = make_uint4(A[4 * g], A[4 * g + 1], A[4 * g + 2], A[4 * g + 3]);
+  for (int i = 0; i < 4 * G; i++) { win[i * BG_BLOCK] = bg_twist(A[i], A[i + 1], F[i + 1]); old[i * BG_BLOCK] = A[i]; }
 }
 // write back the `used` words consumed from the cursor on (aligned coordinates [c & 3, (c & 3) + used)); returns the new cursor
 template <int G>
-__device__ __forceinline__ uint32_t bg_lazy_commit(uint32_t* S, uint32_t c, uint32_t used, lds_u32* win, const uint4 (&oldv)[G]) {
+__device__ __forceinline__ uint32_t bg_lazy_commit(uint32_t* S, uint32_t c, uint32_t used, lds_u32* win, lds_u32* old) {
   uint4* S4 = (uint4*)S;
   const uint32_t q0 = c >> 2, off = c & 3u, end = off + used;
-#pragma unroll
+#pragma unroll 4
   for (int g = 0; g < G; g++) {
     if ((uint32_t)(4 * g) < end) {
-      uint32_t o[4] = {oldv[g].x, oldv[g].y, oldv[g].z, oldv[g].w};
+      uint32_t o[4];
 #pragma unroll
-      for (int k = 0; k < 4; k++) { const uint32_t i = (uint32_t)(4 * g + k); if (i >= off && i < end) o[k] = win[i * BG_BLOCK]; }
+      for (int k = 0; k < 4; k++) { const uint32_t i = (uint32_t)(4 * g + k); o[k] = (i >= off && i < end) ? win[i * BG_BLOCK] : old[i * BG_BLOCK]; }
       uint32_t q = q0 + (uint32_t)g; if (q >= 156u) q -= 156u;
       S4[q] = make_uint4(o[0], o[1], o[2], o[3]);
     }
@@ -597,10 +599,13 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
   if (g_valid > 0 && g_valid < d.KG) { uint32_t i = atomicAdd(&d.wl_count[2], 1u); d.wl[2 * N + i] = (uint32_t)env; }
 }
 
-#define BG_DECK_G 25 // 16-byte groups per lazy window of the deck stream (>= 97 words; a shuffle reads ~70)
+// 16-byte groups per lazy window of the deck stream: >= 37 words, a shuffle reads ~70 (two or three windows).  Sized so
+// that the kernel needs <= 168 VGPRs: its waves must fit on SIMDs that already hold a rollout wave (~336 of the 512
+// registers) -- with a 256-register build the kernel only ran in the gaps between rollout launches (7x longer).
+#define BG_DECK_G 10
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
   __shared__ uint8_t sdeck[52][BG_BLOCK];
-  __shared__ uint32_t rwin[4 * BG_DECK_G][BG_BLOCK];
+  __shared__ uint32_t rwin[4 * BG_DECK_G][BG_BLOCK], rold[4 * BG_DECK_G][BG_BLOCK];
   size_t N = d.N;
   int tid = threadIdx.x;
   uint32_t count = d.wl_count[0];
@@ -614,14 +619,14 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
     uint32_t* mt = bg_deckmt(d, env);
     uint32_t cur = mt[BG_MT_N] & 0x3ffu;
     lds_u32* win = (lds_u32*)&rwin[0][tid];
+    lds_u32* old = (lds_u32*)&rold[0][tid];
     while (d_ready < d.KD) {
       int p = 0;
       for (int s = 0; s < 4; s++) for (int r = 0; r < 13; r++) sdeck[p++][tid] = (uint8_t)(r * 4 + s); // :519-522
       int i = 51; // random.shuffle: for i = 51..1: j = _randbelow(i + 1), swap
 #pragma unroll 1
       while (i >= 1) {
-        uint4 oldv[BG_DECK_G];
-        bg_lazy_window<BG_DECK_G>(mt, cur, win, oldv);
+        bg_lazy_window<BG_DECK_G>(mt, cur, win, old);
         const uint32_t off = cur & 3u, cap = 4u * BG_DECK_G - off;
         uint32_t used = 0;
         while (i >= 1 && used < cap) {
@@ -634,7 +639,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
             i--;
           }
         }
-        cur = bg_lazy_commit<BG_DECK_G>(mt, cur, used, win, oldv);
+        cur = bg_lazy_commit<BG_DECK_G>(mt, cur, used, win, old);
       }
       int slot = (d_head + d_ready) % d.KD;
 #pragma unroll
@@ -654,10 +659,11 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
 // top up the per-env ring of pre-drawn shop seeds: `rng.get_int('shop_generation', 0, 2**31 - 1)` (:1389) in stream order
 #define BG_SEED_G 16 // one lazy window of the shop_generation stream per refill: >= 61 words, ~30 accepted seeds
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_seedring_kernel(BgDev d) {
-  __shared__ uint32_t rwin[4 * BG_SEED_G][BG_BLOCK];
+  __shared__ uint32_t rwin[4 * BG_SEED_G][BG_BLOCK], rold[4 * BG_SEED_G][BG_BLOCK];
   size_t N = d.N;
   uint32_t count = d.wl_count[1];
   lds_u32* win = (lds_u32*)&rwin[0][threadIdx.x];
+  lds_u32* old = (lds_u32*)&rold[0][threadIdx.x];
   for (uint32_t item = blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
     int env = (int)d.wl[N + item];
     uint32_t sm = d.smeta[env];
@@ -666,8 +672,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_seedring_kernel(BgDev d) {
     uint32_t cur = mt[BG_MT_N] & 0x3ffu;
 #pragma unroll 1
     while (cnt < 32) { // almost always one window
-      uint4 oldv[BG_SEED_G];
-      bg_lazy_window<BG_SEED_G>(mt, cur, win, oldv);
+      bg_lazy_window<BG_SEED_G>(mt, cur, win, old);
       const uint32_t off = cur & 3u, cap = 4u * BG_SEED_G - off;
       uint32_t used = 0;
       while (cnt < 32 && used < cap) { // _randbelow(2**31): k = 32 bits, accept r < 2**31
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_seedring_kernel(BgDev d) {
         used++;
         if (r < 2147483648u) { d.sseed[(size_t)env * 32 + ((head + cnt) & 31)] = r; cnt++; }
       }
-      cur = bg_lazy_commit<BG_SEED_G>(mt, cur, used, win, oldv);
+      cur = bg_lazy_commit<BG_SEED_G>(mt, cur, used, win, old);
     }
     mt[BG_MT_N] = cur | BG_LAZY_SEEDED;
     d.smeta[env] = (uint32_t)head | ((uint32_t)cnt << 8);
