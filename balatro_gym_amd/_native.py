@@ -39,7 +39,7 @@ FLAG_SCORER_JOKERS = 1
 FLAG_AUTORESET = 2
 POLICY_UNIFORM, POLICY_SMALL_ONLY, POLICY_CYCLE3 = 0, 1, 2
 
-EXPORTS = ["bg_create", "bg_destroy", "bg_last_error", "bg_num_envs", "bg_state_bytes", "bg_seed", "bg_reset",
+EXPORTS = ["bg_create", "bg_destroy", "bg_last_error", "bg_num_envs", "bg_max_fused_steps", "bg_state_bytes", "bg_seed", "bg_reset",
            "bg_step", "bg_observe", "bg_rollout", "bg_inject", "bg_state_blob_bytes", "bg_get_state", "bg_set_state",
            "bg_refill", "bg_check", "bg_set_profiling", "bg_get_profile"]
 
@@ -97,6 +97,7 @@ def load(build_if_missing: bool = True):
     L.bg_last_error.restype = C.c_char_p
     L.bg_last_error.argtypes = [vp]
     L.bg_num_envs.argtypes = [vp]
+    L.bg_max_fused_steps.argtypes = [vp]
     L.bg_state_bytes.restype = u64
     L.bg_state_bytes.argtypes = [vp]
     L.bg_seed.argtypes = [vp, vp, vp, i32, vp]

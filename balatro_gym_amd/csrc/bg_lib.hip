@@ -592,7 +592,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
       d.smeta[env] = (uint32_t)head | ((uint32_t)cnt << 8);
       prod = (prod & 0xffff00ffu) | ((((prod >> 8) + (uint32_t)emitted) & 0xffu) << 8);
     }
-    if (cnt < 16) { uint32_t i = atomicAdd(&d.wl_count[1], 1u); d.wl[N + i] = (uint32_t)env; }
+    if (cnt < 24) { uint32_t i = atomicAdd(&d.wl_count[1], 1u); d.wl[N + i] = (uint32_t)env; }
   }
   d.prod_out[env] = prod; // the deck / block kernels bump their byte of prod_out when their data is written
   if (d_ready < d.KD) { uint32_t i = atomicAdd(&d.wl_count[0], 1u); d.wl[i] = (uint32_t)env; }
@@ -872,7 +872,12 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   BgDev& d = h->dev;
   d.N = n_envs; d.flags = flags; d.max_ante = max_ante;
   const char* kg = getenv("BG_KG"); const char* ks = getenv("BG_KS"); const char* kd = getenv("BG_KD");
-  d.KG = kg ? atoi(kg) : 8; d.KS = ks ? atoi(ks) : 13; d.KD = kd ? atoi(kd) : 12; // ~60 KB of look-ahead per env
+  // Look-ahead depth = how many steps one bg_rollout launch may fuse (bg_max_fused_steps).  Deeper rings amortise the
+  // refill over more steps; per env they cost 2.5 KB per global / shop slot and 64 B per deck: ~198 KB (64 fused steps),
+  // ~105 KB (32) or ~60 KB (16) -- picked so that the state stays a modest share of the 288 GB.
+  const int dg = n_envs <= 262144 ? 25 : (n_envs <= 1048576 ? 13 : 8);
+  const int dsd = n_envs <= 262144 ? 48 : (n_envs <= 1048576 ? 24 : 12);
+  d.KG = kg ? atoi(kg) : dg; d.KS = ks ? atoi(ks) : dsd + 1; d.KD = kd ? atoi(kd) : dsd;
   if (d.KG < 2 || d.KS < 2 || d.KD < 1 || d.KG > 250 || d.KS > 250 || d.KD > 250) { delete h; g_create_err = "bg_create: bad ring depths"; return BG_E_ARG; }
   size_t N = (size_t)n_envs;
   hipError_t e = hipSetDevice(device_id);
@@ -937,6 +942,27 @@ int bg_destroy(bg_handle* h) {
 
 const char* bg_last_error(const bg_handle* h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 int bg_num_envs(const bg_handle* h) { return h ? h->dev.N : 0; }
+
+// The look-ahead rings bound how many steps may be fused between two refills.  An env consumes at most one
+// pre-shuffled deck and one pre-seeded shop stream per 3 steps (reset -> 45/47 -> select -> failing play;
+// shop generated -> 31 -> select -> winning play), so R ready entries cover 3*R steps.  The global stream has
+// (KG-1) full blocks of 624 words ahead; a step draws < 24 words without and < 110 with the scorer-level joker
+// chain (8 cards x 5 jokers x 2 + 5 x randint, accepted plays are >= 2 steps apart).
+// With the refill overlapped on the side stream a chunk only sees what the refill BEFORE the previous chunk produced,
+// so the rings must hold two chunks' worth.
+static int bg_chunk_limit(const bg_handle* h, bool* async_out) {
+  int ring = h->dev.KD < h->dev.KS - 1 ? h->dev.KD : h->dev.KS - 1;
+  int gblocks = h->dev.KG - 1;
+  const bool async = h->async_refill && ring >= 2 && gblocks >= 2;
+  if (async) { ring /= 2; gblocks /= 2; }
+  int max_chunk = 3 * ring;
+  int gchunk = (gblocks * BG_MT_N) / ((h->dev.flags & BG_FLAG_SCORER_JOKERS) ? 110 : 24);
+  if (gchunk < max_chunk) max_chunk = gchunk;
+  if (max_chunk < 1) max_chunk = 1;
+  if (async_out) *async_out = async;
+  return max_chunk;
+}
+int bg_max_fused_steps(const bg_handle* h) { return h ? bg_chunk_limit(h, nullptr) : 0; }
 uint64_t bg_state_bytes(const bg_handle* h) { return h ? h->bytes : 0; }
 
 // ---- refill pipeline ----------------------------------------------------------------------------------------
@@ -1084,21 +1110,8 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
   int rc = bg_require_seeded(h);
   if (rc) return rc;
   if (T <= 0) return BG_E_ARG;
-  // The look-ahead rings bound how many steps may be fused between two refills.  An env consumes at most one
-  // pre-shuffled deck and one pre-seeded shop stream per 3 steps (reset -> 45/47 -> select -> failing play;
-  // shop generated -> 31 -> select -> winning play), so R ready entries cover 3*R steps.  The global stream has
-  // (KG-1) full blocks of 624 words ahead; a step draws < 24 words without and < 110 with the scorer-level joker
-  // chain (8 cards x 5 jokers x 2 + 5 x randint, accepted plays are >= 2 steps apart).
-  int ring = h->dev.KD < h->dev.KS - 1 ? h->dev.KD : h->dev.KS - 1;
-  int gblocks = h->dev.KG - 1;
-  // With the refill overlapped on the side stream a chunk only sees what the refill BEFORE the previous chunk produced,
-  // so the rings must hold two chunks' worth.
-  const bool async = h->async_refill && ring >= 2 && gblocks >= 2;
-  if (async) { ring /= 2; gblocks /= 2; }
-  int max_chunk = 3 * ring;
-  int gchunk = (gblocks * BG_MT_N) / ((h->dev.flags & BG_FLAG_SCORER_JOKERS) ? 110 : 24);
-  if (gchunk < max_chunk) max_chunk = gchunk;
-  if (max_chunk < 1) max_chunk = 1;
+  bool async = false;
+  const int max_chunk = bg_chunk_limit(h, &async);
   int done = 0;
   while (done < T) {
     int chunk = T - done < max_chunk ? T - done : max_chunk;

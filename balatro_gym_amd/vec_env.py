@@ -107,6 +107,11 @@ class BalatroVecEnv:
     def state_bytes(self) -> int:
         return int(self._L.bg_state_bytes(self._h))
 
+    @property
+    def max_fused_steps(self) -> int:
+        """Steps `rollout` runs as one kernel launch (bg_max_fused_steps): the natural length of [T, N] obs buffers."""
+        return int(self._L.bg_max_fused_steps(self._h))
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             torch.cuda.synchronize(self.device)

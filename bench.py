@@ -109,8 +109,8 @@ def main():
     env = BalatroVecEnv(n, [1000 + g for g in range(lo, hi)], device=local_rank, scorer_jokers=True, autoreset=True,
                         max_ante=MAX_ANTE)
     env.inject(jokers=[jokers_for(g) for g in range(lo, hi)], apply_now=True)
-    # ring depths come from BG_KG / BG_KS / BG_KD (bg_create); chunk = what the library fuses per launch
-    chunk = args.chunk or int(os.environ.get("BG_BENCH_CHUNK", "0")) or 16
+    # chunk = steps per bg_rollout call = what the library fuses into one launch (ring depths: bg_create / BG_KG,KS,KD)
+    chunk = args.chunk or int(os.environ.get("BG_BENCH_CHUNK", "0")) or min(64, env.max_fused_steps)
     ob = ObsBuffers(n, dev, steps=chunk) if args.keep_obs and chunk > 1 else None
 
     def run(nsteps, t0):

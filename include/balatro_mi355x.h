@@ -131,6 +131,9 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
 int bg_destroy(bg_handle* h);
 const char* bg_last_error(const bg_handle* h); /* also valid with h == NULL after a failed bg_create */
 int bg_num_envs(const bg_handle* h);
+/* Largest T that bg_rollout runs as ONE kernel launch (longer rollouts are split into launches of this many steps, with
+ * an RNG look-ahead refill between them).  Size [T, N] observation buffers to a multiple of it. */
+int bg_max_fused_steps(const bg_handle* h);
 uint64_t bg_state_bytes(const bg_handle* h); /* HBM held by the library for this handle */
 
 /* Replaces: `DeterministicRNG(seed)` (balatro_env_2.py:84-106) for the masked envs; seeds_host[i] is env i's master seed,

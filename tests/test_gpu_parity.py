@@ -1,3 +1,4 @@
+
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI (ctypes ->
 libbalatro_mi355x.so), against (1) the committed golden traces generated from the Python reference and (2) the CPU
 oracle on fresh seeds.  Integer / byte / index results and float64 rewards must be BIT-exact (tolerance 0).
@@ -187,6 +188,16 @@ def test_fused_rollout_vs_oracle(policy, scorer):
     for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
         assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
     env.close()
+
+
+@pytest.mark.parametrize("rings,async_refill", [("8,13,12", "1"), ("4,5,4", "1"), ("8,13,12", "0")])
+def test_fused_rollout_shallow_rings(monkeypatch, rings, async_refill):
+    """Same comparison with shallow look-ahead rings: one bg_rollout call becomes many launches with a refill between
+    them (overlapped on the side streams, or synchronous), which must not change a single bit."""
+    kg, ks, kd = rings.split(",")
+    monkeypatch.setenv("BG_KG", kg); monkeypatch.setenv("BG_KS", ks); monkeypatch.setenv("BG_KD", kd)
+    monkeypatch.setenv("BG_ASYNC_REFILL", async_refill)
+    test_fused_rollout_vs_oracle(2, True)
 
 
 def test_rollout_properties_full_size():
