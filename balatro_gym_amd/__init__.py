@@ -10,7 +10,7 @@ __all__ = ["Action", "Phase", "BalatroEnv", "BalatroVecEnv", "ShardedBalatroVecE
 
 
 def __getattr__(name):  # lazy: importing the package must not need torch / the GPU
-    if name in ("BalatroVecEnv", "ObsBuffers"):
+    if name in ("BalatroVecEnv", "ObsBuffers", "RowBuffers"):
         from . import vec_env
         return getattr(vec_env, name)
     if name in ("BalatroEnv", "make_balatro_env"):

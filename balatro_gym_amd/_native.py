@@ -31,6 +31,17 @@ OBS_SPEC = {
     "face_down_cards": ("int64", (8,)),
 }
 OBS_BYTES = 330
+# packed record of bg_rollout_rows (include/balatro_mi355x.h BG_ROW_*): key -> byte offset; reward / action / terminated ride along
+ROW_BYTES = 352
+ROW_OFFSETS = {
+    "selected_cards": 0, "face_down_cards": 64, "chips_scored": 128, "round_chips_scored": 144, "progress_ratio": 148,
+    "mult": 152, "chips_needed": 156, "money": 160, "hands_played": 164, "best_hand_this_ante": 168, "action_mask": 176,
+    "joker_ids": 236, "shop_items": 256, "shop_costs": 276, "consumables": 296, "ante": 306, "shop_rerolls": 308,
+    "hand": 310, "hand_levels": 318, "hand_size": 330, "deck_size": 331, "round": 332, "hands_left": 333,
+    "discards_left": 334, "joker_count": 335, "joker_slots": 336, "consumable_count": 337, "consumable_slots": 338,
+    "phase": 339, "boss_blind_active": 340, "boss_blind_type": 341,
+}
+ROW_EXTRA = {"reward": (136, "float64"), "action": (172, "int32"), "terminated": (342, "uint8")}
 INFO_KEYS = ["final_score", "error", "flags", "aux", "hand_type", "cards_played", "reward_terms"]
 INFO_SPEC = {"final_score": ("int64", ()), "error": ("int32", ()), "flags": ("int32", ()), "aux": ("int32", ()),
              "hand_type": ("int8", ()), "cards_played": ("int8", ()), "reward_terms": ("float64", (8,))}
@@ -40,7 +51,7 @@ FLAG_AUTORESET = 2
 POLICY_UNIFORM, POLICY_SMALL_ONLY, POLICY_CYCLE3 = 0, 1, 2
 
 EXPORTS = ["bg_create", "bg_destroy", "bg_last_error", "bg_num_envs", "bg_max_fused_steps", "bg_state_bytes", "bg_seed", "bg_reset",
-           "bg_step", "bg_observe", "bg_rollout", "bg_inject", "bg_state_blob_bytes", "bg_get_state", "bg_set_state",
+           "bg_step", "bg_observe", "bg_rollout", "bg_rollout_rows", "bg_inject", "bg_state_blob_bytes", "bg_get_state", "bg_set_state",
            "bg_refill", "bg_check", "bg_set_profiling", "bg_get_profile"]
 
 
@@ -105,6 +116,7 @@ def load(build_if_missing: bool = True):
     L.bg_step.argtypes = [vp, vp, C.POINTER(ObsPtrs), vp, vp, vp, C.POINTER(InfoPtrs), vp]
     L.bg_observe.argtypes = [vp, C.POINTER(ObsPtrs), vp]
     L.bg_rollout.argtypes = [vp, i32, i32, u64, u64, u64, C.POINTER(ObsPtrs), i32, vp, vp, vp, vp, vp]
+    L.bg_rollout_rows.argtypes = [vp, i32, i32, u64, u64, u64, vp, u64, i32, vp, vp]
     L.bg_inject.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp]
     L.bg_state_blob_bytes.restype = u64
     L.bg_state_blob_bytes.argtypes = [vp]

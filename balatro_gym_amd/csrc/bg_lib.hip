@@ -23,7 +23,7 @@ struct InfoPtrs {
   double* reward_terms;
 };
 
-static_assert(sizeof(ObsPtrs) == sizeof(bg_obs_ptrs), "ObsPtrs must mirror bg_obs_ptrs");
+static_assert(offsetof(ObsPtrs, rows) == sizeof(bg_obs_ptrs), "the first 31 members of ObsPtrs must mirror bg_obs_ptrs");
 static_assert(sizeof(InfoPtrs) == sizeof(bg_info_ptrs), "InfoPtrs must mirror bg_info_ptrs");
 
 // ---------------------------------------------------------------------------------------------------------
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_step_kernel(BgDev d, const int32_
   if (o.terminated && (d.flags & BG_FLAG_AUTORESET)) { bg_env_reset(d, env, e, dk); o.flags |= BG_INFO_AUTORESET; }
   bg_store_env(d, env, e);
   mask = bg_action_mask(d, env, e, sr);
-  bg_write_obs<false>(d, env, (size_t)env, e, dk, obs, mask, sr);
+  bg_write_obs<false>(d, env, (size_t)env, e, dk, obs, mask, sr, RowExtra{0.0, 0, 0u});
   bg_emit(d, env, (size_t)env, o, reward, term, trunc, info);
 }
 
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, in
       if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; } // SAME_STEP auto-reset
       mask = bg_action_mask(d, env, e, sr);
       size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
-      uint64_t h = bg_write_obs<HASH>(d, env, row, e, dk, obs, mask, sr);
+      uint64_t h = bg_write_obs<HASH>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u});
       if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
       if (reward) reward[row] = o.reward;
       if (term) term[row] = o.terminated ? 1 : 0;
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
       mask = bg_action_mask(d, env, e, sr);
       BG_PROBE(18);
       size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
-      uint64_t h = bg_write_obs<HASH>(d, env, row, e, dk, obs, mask, sr);
+      uint64_t h = bg_write_obs<HASH>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u});
       BG_PROBE(19);
       if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
       if (reward) reward[row] = o.reward;
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_reset_kernel(BgDev d, const uint8
   if (!mask_in || mask_in[env]) { bg_env_reset(d, env, e, dk); bg_store_env(d, env, e); }
   ShopRegs sr; sr.valid = false;
   uint64_t mask = bg_action_mask(d, env, e, sr);
-  bg_write_obs<false>(d, env, (size_t)env, e, dk, obs, mask, sr);
+  bg_write_obs<false>(d, env, (size_t)env, e, dk, obs, mask, sr, RowExtra{0.0, 0, 0u});
 }
 
 __global__ __launch_bounds__(BG_BLOCK) void bg_observe_kernel(BgDev d, ObsPtrs obs) {
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_observe_kernel(BgDev d, ObsPtrs o
   Deck0 dk = bg_load_deck0(d, env);
   ShopRegs sr; sr.valid = false;
   uint64_t mask = bg_action_mask(d, env, e, sr);
-  bg_write_obs<false>(d, env, (size_t)env, e, dk, obs, mask, sr);
+  bg_write_obs<false>(d, env, (size_t)env, e, dk, obs, mask, sr, RowExtra{0.0, 0, 0u});
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1063,7 +1063,8 @@ static int bg_require_seeded(bg_handle* h) {
 
 static ObsPtrs bg_obs(const bg_obs_ptrs* o) {
   ObsPtrs p;
-  if (o) memcpy(&p, o, sizeof(p)); else memset(&p, 0, sizeof(p));
+  memset(&p, 0, sizeof(p));
+  if (o) memcpy(&p, o, sizeof(*o)); // the 31 per-key pointers; rows / row_stride stay 0
   return p;
 }
 static InfoPtrs bg_info(const bg_info_ptrs* o) {
@@ -1104,9 +1105,10 @@ int bg_observe(bg_handle* h, const bg_obs_ptrs* obs, void* stream) {
   return 0;
 }
 
-int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t env_index0, uint64_t t0,
-               const bg_obs_ptrs* obs, int obs_stride_steps, double* reward_dev, uint8_t* terminated_dev,
-               int32_t* actions_out_dev, bg_rollout_stats* stats_dev, void* stream) {
+static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t env_index0, uint64_t t0,
+                           const bg_obs_ptrs* obs, uint8_t* rows_dev, size_t row_stride, int obs_stride_steps,
+                           double* reward_dev, uint8_t* terminated_dev, int32_t* actions_out_dev,
+                           bg_rollout_stats* stats_dev, void* stream) {
   int rc = bg_require_seeded(h);
   if (rc) return rc;
   if (T <= 0) return BG_E_ARG;
@@ -1117,6 +1119,7 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
     int chunk = T - done < max_chunk ? T - done : max_chunk;
     ObsPtrs o = bg_obs(obs);
     size_t off = obs_stride_steps ? (size_t)done * (size_t)h->dev.N : 0;
+    if (rows_dev) { o.rows = rows_dev + off * row_stride; o.row_stride = (uint32_t)row_stride; }
     if (off) {
       // advance every non-null pointer by `off` rows
       if (o.hand) o.hand += off * 8; if (o.hand_size) o.hand_size += off; if (o.deck_size) o.deck_size += off;
@@ -1172,6 +1175,26 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
     done += chunk;
   }
   return 0;
+}
+
+int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t env_index0, uint64_t t0,
+               const bg_obs_ptrs* obs, int obs_stride_steps, double* reward_dev, uint8_t* terminated_dev,
+               int32_t* actions_out_dev, bg_rollout_stats* stats_dev, void* stream) {
+  return bg_rollout_impl(h, T, policy, policy_seed, env_index0, t0, obs, nullptr, 0, obs_stride_steps, reward_dev,
+                         terminated_dev, actions_out_dev, stats_dev, stream);
+}
+
+int bg_rollout_rows(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t env_index0, uint64_t t0,
+                    uint8_t* rows_dev, uint64_t row_stride_bytes, int rows_stride_steps, bg_rollout_stats* stats_dev,
+                    void* stream) {
+  if (!h) return BG_E_ARG;
+  if (!rows_dev || row_stride_bytes < BG_ROW_BYTES || (row_stride_bytes & 15) || ((uintptr_t)rows_dev & 15) || row_stride_bytes > 0xffffffffull) {
+    h->err = "bg_rollout_rows: rows_dev must be 16-byte aligned and row_stride_bytes a multiple of 16, >= BG_ROW_BYTES";
+    return BG_E_ARG;
+  }
+  if (h->rollout_version == 1) { h->err = "bg_rollout_rows needs the block-compacted rollout kernel (BG_ROLLOUT_V=2)"; return BG_E_ARG; }
+  return bg_rollout_impl(h, T, policy, policy_seed, env_index0, t0, nullptr, rows_dev, (size_t)row_stride_bytes,
+                         rows_stride_steps, nullptr, nullptr, nullptr, stats_dev, stream);
 }
 
 int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_host, const int64_t* money_host,

@@ -47,6 +47,30 @@ class ObsBuffers:
         self.ptrs = nat.ObsPtrs(**{k: self.tensors[k].data_ptr() for k in nat.OBS_KEYS})
 
 
+class RowBuffers:
+    """[steps, N] packed records for `BalatroVecEnv.rollout` (bg_rollout_rows): one 352-byte record per (step, env),
+    every observation key -- plus the step's reward / action / terminated -- a strided, correctly typed VIEW of the
+    same byte tensor (`tensors[key]`, `reward`, `action`, `terminated`); `.contiguous()` gives the dense per-key array.
+    """
+
+    def __init__(self, n: int, device: torch.device, steps: int = 1):
+        self.n, self.steps = n, steps
+        self.rows = torch.zeros((steps, n, nat.ROW_BYTES), dtype=torch.uint8, device=device)
+        self.tensors: Dict[str, torch.Tensor] = {}
+        for k in nat.OBS_KEYS:
+            dt, shape = nat.OBS_SPEC[k]
+            self.tensors[k] = self._view(nat.ROW_OFFSETS[k], dt, shape)
+        self.reward = self._view(nat.ROW_EXTRA["reward"][0], "float64", ())
+        self.action = self._view(nat.ROW_EXTRA["action"][0], "int32", ())
+        self.terminated = self._view(nat.ROW_EXTRA["terminated"][0], "uint8", ())
+
+    def _view(self, off: int, dt: str, shape) -> torch.Tensor:
+        item = np.dtype(dt).itemsize
+        count = int(np.prod(shape, dtype=np.int64))
+        v = self.rows[:, :, off:off + count * item].view(_TORCH_DT[dt])  # [steps, n, count], last dim contiguous
+        return v if shape else v[:, :, 0]
+
+
 class BalatroVecEnv:
     """N independent Balatro games stepped in lockstep on one GPU.
 
@@ -175,7 +199,21 @@ class BalatroVecEnv:
                 terminated: Optional[torch.Tensor] = None, actions: Optional[torch.Tensor] = None,
                 zero_stats: bool = True):
         """Fused random-policy rollout (bg_rollout).  With obs_buffers of `steps` rows every step's observation is
-        kept ([T, N, ...]); otherwise the live observation tensors are overwritten each step."""
+        kept ([T, N, ...]); otherwise the live observation tensors are overwritten each step.  A `RowBuffers` selects
+        the packed-record output (bg_rollout_rows): same values, one record per (step, env)."""
+        if isinstance(obs_buffers, RowBuffers):
+            if obs_buffers.steps < steps and obs_buffers.steps > 1:
+                raise ValueError("obs_buffers has fewer rows than steps")
+            if reward is not None or terminated is not None or actions is not None:
+                raise ValueError("packed records already carry reward / action / terminated")
+            if zero_stats:
+                self._stats.zero_()
+            with torch.cuda.device(self.device):
+                self._check(self._L.bg_rollout_rows(
+                    self._h, int(steps), int(policy), C.c_uint64(policy_seed), C.c_uint64(env_index0), C.c_uint64(t0),
+                    C.c_void_p(obs_buffers.rows.data_ptr()), C.c_uint64(nat.ROW_BYTES), 1 if obs_buffers.steps > 1 else 0,
+                    C.c_void_p(self._stats.data_ptr()), self._stream()), "bg_rollout_rows")
+            return self._stats
         ob = obs_buffers or self._obs
         stride = 1 if (obs_buffers is not None and obs_buffers.steps > 1) else 0
         if stride and obs_buffers.steps < steps:

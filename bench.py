@@ -28,12 +28,15 @@ if ROOT not in sys.path:
 
 ENVS_PER_GPU = 65536
 OBS_BYTES, IO_BYTES, STATE_BYTES = 330, 10, 192  # A_step(T) = 340 + 384 / T bytes per env-step
+# (the packed-record layout writes 352 bytes per env-step, 12 of them padding / the action and terminated flag; the
+#  roofline keeps SURVEY's 340 algorithmic bytes)
 HBM_PEAK_GBPS = 8000.0                           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec peak)
 
 IMPLEMENTED = [1, 136, 27, 38, 61, 16, 34, 108, 23, 22, 53, 97, 50, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
                131, 132, 133, 134, 135, 48, 128, 122, 72, 140, 31, 39, 40, 41, 101, 124, 26, 33, 104, 147, 118, 119,
                116, 117]
 POLICY_CYCLE3 = 2
+TRAFFIC_FILE = {"rows": "r01_v11_hbm_traffic.json", "keys": "r01_v10_hbm_traffic.json"}  # PMC results per output layout
 POLICY_SEED = 20251001
 MAX_ANTE = 4
 
@@ -81,6 +84,8 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--chunk", type=int, default=0, help="fused steps per rollout call (0 = as many as the rings allow)")
     ap.add_argument("--keep-obs", type=int, default=1, help="write every step's observation to a [chunk, N] buffer")
+    ap.add_argument("--obs-layout", choices=["rows", "keys"], default="rows",
+                    help="rows: one packed 352-byte record per (step, env) (bg_rollout_rows); keys: one array per key")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-obs", action="store_true", help="also RCCL all_gather the last observation per chunk")
     args = ap.parse_args()
@@ -89,7 +94,7 @@ def main():
     import torch.distributed as dist
     from balatro_gym_amd import BalatroVecEnv
     from balatro_gym_amd.sharded import shard_range
-    from balatro_gym_amd.vec_env import ObsBuffers
+    from balatro_gym_amd.vec_env import ObsBuffers, RowBuffers
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -111,7 +116,9 @@ def main():
     env.inject(jokers=[jokers_for(g) for g in range(lo, hi)], apply_now=True)
     # chunk = steps per bg_rollout call = what the library fuses into one launch (ring depths: bg_create / BG_KG,KS,KD)
     chunk = args.chunk or int(os.environ.get("BG_BENCH_CHUNK", "0")) or min(64, env.max_fused_steps)
-    ob = ObsBuffers(n, dev, steps=chunk) if args.keep_obs and chunk > 1 else None
+    ob = None
+    if args.keep_obs and chunk > 1:
+        ob = (RowBuffers if args.obs_layout == "rows" else ObsBuffers)(n, dev, steps=chunk)
 
     def run(nsteps, t0):
         done = 0
@@ -165,7 +172,7 @@ def main():
         # command; the corrected per-env-step figure is committed under profiles/ and scaled to this run's launch shape)
         traffic = None
         try:
-            with open(os.path.join(ROOT, "profiles", "r01_v8_hbm_traffic.json")) as f:
+            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE[args.obs_layout])) as f:
                 traffic = json.load(f)["hbm_bytes_per_env_step"] * n * fused
         except Exception:
             pass
@@ -177,7 +184,10 @@ def main():
             "config": {"workload": "BASELINE configs[2]: 65536 envs per GPU, 5 random implemented jokers per env "
                                    "(scorer-level joker chain), Antes 1-4 cap, counter-hash random policy (blind "
                                    "45/46/47 by env index, shop->31, else uniform over valid), SAME_STEP auto-reset, "
-                                   "every step's 330-byte observation written to HBM",
+                                   "every step's 330-byte observation written to HBM"
+                                   + (" as one packed 352-byte record per (step, env) incl. reward/action/terminated"
+                                      if args.obs_layout == "rows" else " as one [T, N] array per key"),
+                       "obs_layout": args.obs_layout,
                        "envs_per_gpu": n, "total_envs": total, "fused_steps_per_launch": fused,
                        "ring_depths": {k: os.environ.get(k, "default") for k in ("BG_KG", "BG_KS", "BG_KD")},
                        "parallelism": f"shard{world} (independent envs, no data-path collective)"},

@@ -161,6 +161,52 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
                const bg_obs_ptrs* obs, int obs_stride_steps, double* reward_dev, uint8_t* terminated_dev,
                int32_t* actions_out_dev, bg_rollout_stats* stats_dev, void* stream);
 
+/* bg_rollout with ONE packed record per (step, env) instead of one array per key: record (t, i) starts at
+ * rows_dev + ((t * rows_stride_steps ? t : 0) * N + i) * row_stride_bytes, i.e. a [T, N, row_stride_bytes] byte tensor
+ * when rows_stride_steps != 0 (a [N, row_stride_bytes] tensor overwritten every step when 0).  Every field keeps the
+ * reference's dtype at a naturally aligned offset (BG_ROW_*), so each key is a strided view of the same buffer; the
+ * step's reward, action and terminated flag ride in the record.  A record is written by one lane with whole 16-byte
+ * stores, which keeps HBM write traffic at the record size however far the envs of a workgroup drift apart in time.
+ * rows_dev must be 16-byte aligned, row_stride_bytes a multiple of 16 and >= BG_ROW_BYTES. */
+#define BG_ROW_BYTES 352
+#define BG_ROW_SELECTED_CARDS 0       /* int64[8] */
+#define BG_ROW_FACE_DOWN_CARDS 64     /* int64[8] */
+#define BG_ROW_CHIPS_SCORED 128       /* int64 */
+#define BG_ROW_REWARD 136             /* float64: reward of this step */
+#define BG_ROW_ROUND_CHIPS_SCORED 144 /* int32 */
+#define BG_ROW_PROGRESS_RATIO 148     /* float32 */
+#define BG_ROW_MULT 152               /* int32 */
+#define BG_ROW_CHIPS_NEEDED 156       /* int32 */
+#define BG_ROW_MONEY 160              /* int32 */
+#define BG_ROW_HANDS_PLAYED 164       /* int32 */
+#define BG_ROW_BEST_HAND_THIS_ANTE 168 /* int32 */
+#define BG_ROW_ACTION 172             /* int32: action taken at this step */
+#define BG_ROW_ACTION_MASK 176        /* int8[60] */
+#define BG_ROW_JOKER_IDS 236          /* int16[10] */
+#define BG_ROW_SHOP_ITEMS 256         /* int16[10] */
+#define BG_ROW_SHOP_COSTS 276         /* int16[10] */
+#define BG_ROW_CONSUMABLES 296        /* int16[5] */
+#define BG_ROW_ANTE 306               /* int16 */
+#define BG_ROW_SHOP_REROLLS 308       /* int16 */
+#define BG_ROW_HAND 310               /* int8[8] */
+#define BG_ROW_HAND_LEVELS 318        /* int8[12] */
+#define BG_ROW_HAND_SIZE 330          /* int8; the following scalars are int8 each */
+#define BG_ROW_DECK_SIZE 331
+#define BG_ROW_ROUND 332
+#define BG_ROW_HANDS_LEFT 333
+#define BG_ROW_DISCARDS_LEFT 334
+#define BG_ROW_JOKER_COUNT 335
+#define BG_ROW_JOKER_SLOTS 336
+#define BG_ROW_CONSUMABLE_COUNT 337
+#define BG_ROW_CONSUMABLE_SLOTS 338
+#define BG_ROW_PHASE 339
+#define BG_ROW_BOSS_BLIND_ACTIVE 340
+#define BG_ROW_BOSS_BLIND_TYPE 341
+#define BG_ROW_TERMINATED 342         /* uint8: the step ended the episode (SAME_STEP auto-reset: the record already shows the new episode) */
+int bg_rollout_rows(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t env_index0, uint64_t t0,
+                    uint8_t* rows_dev, uint64_t row_stride_bytes, int rows_stride_steps, bg_rollout_stats* stats_dev,
+                    void* stream);
+
 /* Harness injection (configs 3-4): per-env "reset template" applied by every reset of that env -- owned jokers (ids
  * from jokers.py), money, ante and hand levels; -1 / NULL leaves a field at its reset default.  apply_now != 0 also
  * writes them into the live state.  Replaces direct writes to env.state.* (e.g. train_balatro_agent.py:150). */

@@ -200,6 +200,57 @@ def test_fused_rollout_shallow_rings(monkeypatch, rings, async_refill):
     test_fused_rollout_vs_oracle(2, True)
 
 
+@pytest.mark.parametrize("policy,scorer", [(0, False), (2, True)])
+def test_packed_record_rollout_vs_oracle(policy, scorer):
+    """bg_rollout_rows: one 352-byte record per (step, env); every key, the reward, the action and the terminated flag
+    read back through the strided views must equal the oracle's, bit for bit."""
+    from balatro_gym_amd.vec_env import RowBuffers
+    from oracle.gen_golden import IMPLEMENTED
+    n, T = 256, 96
+    seeds = [77_000 + 5 * i for i in range(n)]
+    jokers = [random.Random(2000 + i).sample(IMPLEMENTED, 5) for i in range(n)] if scorer else None
+    max_ante = 4 if scorer else 0
+    env = _vec(n, seeds, scorer_jokers=scorer, autoreset=True, max_ante=max_ante)
+    if jokers:
+        env.inject(jokers=jokers, apply_now=True)
+    rb = RowBuffers(n, env.device, steps=T)
+    env.rollout(T, policy=policy, policy_seed=99, env_index0=3, t0=11, obs_buffers=rb)
+    env.check()
+    got_stats = env.stats()
+    wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, T, policy, 99, scorer, max_ante, jokers, env_index0=3, t0=11)
+    assert np.array_equal(rb.action.cpu().numpy(), wa)
+    assert np.array_equal(rb.terminated.cpu().numpy(), wt)
+    assert np.array_equal(rb.reward.contiguous().cpu().numpy().view(np.uint64), wr.view(np.uint64))
+    for k in OBS_KEYS:
+        g = rb.tensors[k].contiguous().cpu().numpy()
+        assert g.dtype == wobs[k].dtype and np.array_equal(g, wobs[k]), f"record key {k} differs"
+    pad = rb.rows[:, :, 343:].cpu().numpy()
+    assert not pad.any()
+    for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
+        assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
+    env.close()
+
+
+def test_packed_records_same_content_full_size():
+    """At N = 65 536 the observation checksum (hash of every row, BG_POLICY_HASH_OBS) must not depend on the output
+    layout, and the packed records must agree with the per-key arrays of the same rollout on every key."""
+    import torch
+    from balatro_gym_amd.vec_env import ObsBuffers, RowBuffers
+    n, T = 65536, 24
+    seeds = [1000 + i for i in range(n)]
+    out = []
+    for packed in (False, True):
+        env = _vec(n, seeds, autoreset=True)
+        ob = (RowBuffers if packed else ObsBuffers)(n, env.device, steps=T)
+        env.rollout(T, policy=2 | 0x100, policy_seed=7, obs_buffers=ob)
+        env.check()
+        out.append((env.stats(), ob))
+        env.close()
+    assert out[0][0] == out[1][0]
+    for k in OBS_KEYS:
+        assert torch.equal(out[0][1].tensors[k], out[1][1].tensors[k].contiguous()), k
+
+
 def test_rollout_properties_full_size():
     """Size-independent properties at BASELINE.json's N = 65 536: determinism, chunking invariance (one T=48 call ==
     48 T=1 calls), sharding invariance (two half-size handles with env_index0 offsets == one full handle)."""

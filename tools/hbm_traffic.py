@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; separate runs, as MI355X_MICROARCH.md prescribes) of
+`bench.py` into profiles/<tag>_hbm_traffic.json: HBM bytes per launch / per env-step of the rollout kernel.
+
+usage: hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <envs> <fused_steps> <out.json> [note]
+"""
+import csv, json, sys
+
+
+def mean_counter(path, counter, kernel="bg_rollout2_kernel"):
+    vals = []
+    for r in csv.DictReader(open(path)):
+        if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            vals.append(float(r["Counter_Value"]))
+    vals = vals[len(vals) // 4:]  # steady state: drop the first quarter (first launches start from cold rings)
+    return sum(vals) / len(vals), len(vals)
+
+
+def main():
+    fcsv, wcsv, envs, fused, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]
+    note = sys.argv[6] if len(sys.argv) > 6 else ""
+    f, nf = mean_counter(fcsv, "FETCH_SIZE")
+    w, nw = mean_counter(wcsv, "WRITE_SIZE")
+    hbm = 2 * f * 1024 + w * 1024
+    alg = 330 + 10 + 2 * 192 / fused
+    json.dump({
+        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
+                  "--no-cpu-baseline, bg_rollout2_kernel<false>, mean over steady-state launches. " + note,
+        "kernel": "bg_rollout2_kernel", "envs": envs, "fused_steps_per_launch": fused, "launches_averaged": [nf, nw],
+        "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
+        "correction": "gfx950 FETCH_SIZE counts 1/2 of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md HBM): fetch "
+                      "bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE taken as reported (* 1024)",
+        "hbm_bytes_per_launch": hbm, "hbm_bytes_per_env_step": hbm / (envs * fused),
+        "algorithmic_bytes_per_env_step": alg,
+    }, open(out, "w"), indent=1)
+    print(open(out).read())
+
+
+if __name__ == "__main__":
+    main()
