@@ -212,15 +212,30 @@ __shared__ unsigned long long bg_probe_lds[32];
 #define BG_PROBE_FLUSH(d) do {} while (0)
 #endif
 
-struct Deck0 { uint64_t lo, hi; };
+// The 52 card codes of an env's deck, as seen by the step code.  lane-per-env kernels keep the first 16 in registers
+// and read the rest from HBM; the block-compacted rollout kernel keeps every deck of its workgroup in LDS
+// ([dword 0..15][lane of the workgroup], bank = lane) so that no card lookup of a step -- phase B's gather, the boss
+// checks, the observation's hand -- is an HBM round trip.
+#ifndef BG_RB
+#define BG_RB 256 // envs per workgroup of bg_rollout2_kernel
+#endif
+typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+struct Deck0 { uint64_t lo, hi; lds_u32* lds; };
 __device__ __forceinline__ Deck0 bg_load_deck0(const BgDev& d, int env) {
   uint4 c = d.deck[env];
   Deck0 r;
   r.lo = ((uint64_t)c.y << 32) | c.x;
   r.hi = ((uint64_t)c.w << 32) | c.z;
+  r.lds = nullptr;
   return r;
 }
+// whole deck HBM -> LDS column `col` (= &s_deck[0][lane])
+__device__ __forceinline__ void bg_deck_to_lds(lds_u32* col, int k, uint4 c) {
+  col[(4 * k) * BG_RB] = c.x; col[(4 * k + 1) * BG_RB] = c.y; col[(4 * k + 2) * BG_RB] = c.z; col[(4 * k + 3) * BG_RB] = c.w;
+}
 __device__ __forceinline__ int bg_card(const BgDev& d, int env, const Deck0& k, int idx) {
+  if (k.lds) return (int)((const lds_u8*)k.lds)[(idx >> 2) * (BG_RB * 4) + (idx & 3)];
   if (idx < 16) return (int)(((idx < 8 ? k.lo : k.hi) >> (8 * (idx & 7))) & 0xffull);
   const uint8_t* p = (const uint8_t*)&d.deck[(size_t)(idx >> 4) * d.N + env];
   return p[idx & 15];
@@ -261,7 +276,6 @@ struct JTables {
 };
 // LDS pointers keep their address space in the type: a generic pointer stored in a struct compiles to FLAT loads (the
 // vector-memory path, ~1-2k cycles when nothing hides it) instead of ds_read (~100 cycles).
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
 typedef __attribute__((address_space(3))) const JTables lds_JTables;
 struct RngWin {
   lds_JTables* jt;

@@ -139,9 +139,6 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, in
 //   C  lane = env: merge, curriculum cap, SAME_STEP auto-reset, observation / reward / terminated stores, statistics
 // State stays in registers (lane = env) across the T fused steps; LDS is only the exchange between the two lane maps.
 // ---------------------------------------------------------------------------------------------------------
-#ifndef BG_RB
-#define BG_RB 256 // envs per workgroup
-#endif
 struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags; }; // misc: hand_type+1 | terminated<<8 | has_shop<<9
 
 #ifndef BG_RB_WAVES
@@ -160,6 +157,7 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
   __shared__ uint32_t s_nitems[2];
   __shared__ uint32_t s_nready;
   __shared__ uint32_t s_prod[BG_RB];
+  __shared__ uint32_t s_deck[16][BG_RB];        // every env's 52 card codes (Deck0::lds)
   __shared__ uint32_t win[2][BG_WIN][BG_BLOCK]; // one RNG window set per phase-B wave
   __shared__ JTables jt;
   BG_PROBE_INIT();
@@ -176,9 +174,11 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
   s_prod[local] = (live && d.prod_view) ? d.prod_view[env] : 0u;
   if (local < 2) s_nitems[local] = 0;
   if (local == 0) s_nready = 0;
+  dk.lo = 0; dk.hi = 0; dk.lds = (lds_u32*)&s_deck[0][local];
   if (live) {
     bg_load_env(d, env, e);
-    dk = bg_load_deck0(d, env);
+#pragma unroll
+    for (int k = 0; k < BG_NDECK; k++) bg_deck_to_lds(dk.lds, k, d.deck[(size_t)k * d.N + env]);
     mask = bg_action_mask(d, env, e, sr);
   }
 #ifdef BG_TIMING
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
         Env be;
         bg_unpack(c, be);
         bg_derive_ready(be, s_prod[l]);
-        Deck0 bdk = bg_load_deck0(d, benv);
+        Deck0 bdk; bdk.lo = 0; bdk.hi = 0; bdk.lds = (lds_u32*)&s_deck[0][l];
         ShopRegs bsr; bsr.valid = false;
         RngWin w;
         bg_win_init(w, &win[cls][0][lane], &jt);

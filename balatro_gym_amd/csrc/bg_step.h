@@ -96,7 +96,8 @@ __device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, De
     for (int k = 0; k < BG_NDECK; k++) {
       uint4 c = d.ndeck[((size_t)e.d_head * BG_NDECK + k) * d.N + env];
       d.deck[(size_t)k * d.N + env] = c;
-      if (k == 0) { dk.lo = ((uint64_t)c.y << 32) | c.x; dk.hi = ((uint64_t)c.w << 32) | c.z; }
+      if (dk.lds) bg_deck_to_lds(dk.lds, k, c);
+      else if (k == 0) { dk.lo = ((uint64_t)c.y << 32) | c.x; dk.hi = ((uint64_t)c.w << 32) | c.z; }
     }
     e.d_head = (e.d_head + 1 == d.KD) ? 0 : e.d_head + 1;
     e.d_ready--; e.d_cons = (e.d_cons + 1) & 0xff;
