@@ -221,24 +221,29 @@ __shared__ unsigned long long bg_probe_lds[32];
 #endif
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-struct Deck0 { uint64_t lo, hi; lds_u32* lds; };
+struct Deck0 { uint64_t lo, hi; };   // first 16 cards in registers, the rest read from HBM
+struct DeckLds { lds_u32* col; };     // &s_deck[0][lane of the workgroup]
 __device__ __forceinline__ Deck0 bg_load_deck0(const BgDev& d, int env) {
   uint4 c = d.deck[env];
   Deck0 r;
   r.lo = ((uint64_t)c.y << 32) | c.x;
   r.hi = ((uint64_t)c.w << 32) | c.z;
-  r.lds = nullptr;
   return r;
 }
-// whole deck HBM -> LDS column `col` (= &s_deck[0][lane])
-__device__ __forceinline__ void bg_deck_to_lds(lds_u32* col, int k, uint4 c) {
-  col[(4 * k) * BG_RB] = c.x; col[(4 * k + 1) * BG_RB] = c.y; col[(4 * k + 2) * BG_RB] = c.z; col[(4 * k + 3) * BG_RB] = c.w;
+// chunk k (16 cards) of a freshly consumed deck
+__device__ __forceinline__ void bg_deck_set(Deck0& dk, int k, uint4 c) {
+  if (k == 0) { dk.lo = ((uint64_t)c.y << 32) | c.x; dk.hi = ((uint64_t)c.w << 32) | c.z; }
+}
+__device__ __forceinline__ void bg_deck_set(DeckLds& dk, int k, uint4 c) {
+  dk.col[(4 * k) * BG_RB] = c.x; dk.col[(4 * k + 1) * BG_RB] = c.y; dk.col[(4 * k + 2) * BG_RB] = c.z; dk.col[(4 * k + 3) * BG_RB] = c.w;
 }
 __device__ __forceinline__ int bg_card(const BgDev& d, int env, const Deck0& k, int idx) {
-  if (k.lds) return (int)((const lds_u8*)k.lds)[(idx >> 2) * (BG_RB * 4) + (idx & 3)];
   if (idx < 16) return (int)(((idx < 8 ? k.lo : k.hi) >> (8 * (idx & 7))) & 0xffull);
   const uint8_t* p = (const uint8_t*)&d.deck[(size_t)(idx >> 4) * d.N + env];
   return p[idx & 15];
+}
+__device__ __forceinline__ int bg_card(const BgDev& d, int env, const DeckLds& k, int idx) {
+  return (int)((const lds_u8*)k.col)[(idx >> 2) * (BG_RB * 4) + (idx & 3)];
 }
 
 // ---------------------------------------------------------------------------------------------------------

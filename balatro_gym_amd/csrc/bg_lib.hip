@@ -168,17 +168,17 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
   uint64_t n_steps = 0, n_eps = 0, n_plays = 0, rbits = 0, ohash = 0;
   int64_t ssum = 0;
   Env e;
-  Deck0 dk;
+  DeckLds dk;
   ShopRegs sr; sr.valid = false;
   uint64_t mask = 0;
   s_prod[local] = (live && d.prod_view) ? d.prod_view[env] : 0u;
   if (local < 2) s_nitems[local] = 0;
   if (local == 0) s_nready = 0;
-  dk.lo = 0; dk.hi = 0; dk.lds = (lds_u32*)&s_deck[0][local];
+  dk.col = (lds_u32*)&s_deck[0][local];
   if (live) {
     bg_load_env(d, env, e);
 #pragma unroll
-    for (int k = 0; k < BG_NDECK; k++) bg_deck_to_lds(dk.lds, k, d.deck[(size_t)k * d.N + env]);
+    for (int k = 0; k < BG_NDECK; k++) bg_deck_set(dk, k, d.deck[(size_t)k * d.N + env]);
     mask = bg_action_mask(d, env, e, sr);
   }
 #ifdef BG_TIMING
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
         Env be;
         bg_unpack(c, be);
         bg_derive_ready(be, s_prod[l]);
-        Deck0 bdk; bdk.lo = 0; bdk.hi = 0; bdk.lds = (lds_u32*)&s_deck[0][l];
+        DeckLds bdk; bdk.col = (lds_u32*)&s_deck[0][l];
         ShopRegs bsr; bsr.valid = false;
         RngWin w;
         bg_win_init(w, &win[cls][0][lane], &jt);

@@ -76,7 +76,8 @@ __device__ __forceinline__ uint64_t bg_action_mask(const BgDev& d, int env, cons
 // reset (balatro_env_2.py:505-558).  The shuffled deck comes from the look-ahead ring filled by the refill kernel
 // (`rng.shuffle('deck_shuffle', deck)` :525 depends on nothing but stream 0).
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, Deck0& dk) {
+template <class DK>
+__device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, DK& dk) {
   e.ante = 1; e.round = 1; e.phase = 2; e.chips_needed = 300; e.chips_scored = 0; e.round_chips = 0; e.money = 4;
   e.hand = 0; e.nhand = 0; e.sel = 0; e.nsel = 0; e.hands_left = 4; e.discards_left = 3; e.hand_size = 8;
   e.njokers = 0; e.jokers = 0; e.ncons = 0; e.cons0 = 0; e.cons1 = 0; e.n_magic = 0; e.n_minim = 0;
@@ -96,8 +97,7 @@ __device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, De
     for (int k = 0; k < BG_NDECK; k++) {
       uint4 c = d.ndeck[((size_t)e.d_head * BG_NDECK + k) * d.N + env];
       d.deck[(size_t)k * d.N + env] = c;
-      if (dk.lds) bg_deck_to_lds(dk.lds, k, c);
-      else if (k == 0) { dk.lo = ((uint64_t)c.y << 32) | c.x; dk.hi = ((uint64_t)c.w << 32) | c.z; }
+      bg_deck_set(dk, k, c);
     }
     e.d_head = (e.d_head + 1 == d.KD) ? 0 : e.d_head + 1;
     e.d_ready--; e.d_cons = (e.d_cons + 1) & 0xff;
@@ -146,30 +146,72 @@ __device__ __forceinline__ int bg_candidate(uint64_t sorted, int j) {
 __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr) {
   bg_sprefetch(d, env, e, w, 24); // shop.py:111-139
   double mult = bg_shop_cost_mult(e, w.jt);
-  int third = PK_TAROT + (int)bg_randbelow<true>(d, env, e, w, 3u); // rng.choice([...]) is evaluated before the loop
+  int owned145 = 0;
+#pragma unroll 1
+  for (int q = 0; q < e.njokers; q++) owned145 += bg_get8(e.jokers, q) <= 145 ? 1 : 0;
+  const uint32_t nc = (uint32_t)(145 - owned145); // 140..145: _randbelow(nc) looks at 8 bits
+  // The seven draws -- choice of the third pack (_randbelow(3)), random.sample(candid, 3) by the selection-set method
+  // (Lib/random.py sample(), n > 21: _randbelow(nc) until new), the voucher (_randbelow(2)), two randint(0, 51) -- are
+  // rejection loops over consecutive words.  A loop per draw makes the wave iterate until its unluckiest lane accepts;
+  // instead classify all 24 window words at once (one acceptance mask per kind of draw) and walk the masks with ffs.
+  int third_r = 0, p0 = 0, p1 = 0, p2 = 0, v = 0, ca = 0, cb = 0;
+  bool fast = w.s_len >= 24 && w.s_start == e.s_idx;
+  if (fast) {
+    uint32_t m3 = 0, m2 = 0, m8 = 0, m52 = 0;
+    uint32_t r8[6] = {0, 0, 0, 0, 0, 0}; // the 8-bit candidates, packed (kept for the "until new" tests)
+#pragma unroll
+    for (int i = 0; i < 24; i++) {
+      const uint32_t y = bg_temper(w.lds[i * BG_BLOCK]);
+      m3 |= ((y >> 30) < 3u ? 1u : 0u) << i; m2 |= ((y >> 30) < 2u ? 1u : 0u) << i;
+      m8 |= ((y >> 24) < nc ? 1u : 0u) << i; m52 |= ((y >> 26) < 52u ? 1u : 0u) << i;
+      r8[i >> 2] |= (y >> 24) << (8 * (i & 3));
+      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0); // four words in flight are enough; 24 would cost ~30 registers
+    }
+    // word of accepted position i (dynamic): re-read from the window
+#define BG_SW(i) bg_temper(w.lds[(i) * BG_BLOCK])
+    uint32_t rem = 0xffffffu; // words not consumed yet
+    int i0 = __ffs((int)(m3 & rem)) - 1; fast = fast && i0 >= 0; rem &= ~((2u << (i0 & 31)) - 1u);
+    int i1 = __ffs((int)(m8 & rem)) - 1; fast = fast && i1 >= 0; rem &= ~((2u << (i1 & 31)) - 1u);
+    p0 = (int)(BG_SW(i1 & 31) >> 24);
+    uint32_t ne = 0;
+#pragma unroll
+    for (int i = 0; i < 24; i++) ne |= (((r8[i >> 2] >> (8 * (i & 3))) & 0xffu) != (uint32_t)p0 ? 1u : 0u) << i;
+    int i2 = __ffs((int)(m8 & ne & rem)) - 1; fast = fast && i2 >= 0; rem &= ~((2u << (i2 & 31)) - 1u);
+    p1 = (int)(BG_SW(i2 & 31) >> 24);
+#pragma unroll
+    for (int i = 0; i < 24; i++) ne &= ~((((r8[i >> 2] >> (8 * (i & 3))) & 0xffu) == (uint32_t)p1 ? 1u : 0u) << i);
+    int i3 = __ffs((int)(m8 & ne & rem)) - 1; fast = fast && i3 >= 0; rem &= ~((2u << (i3 & 31)) - 1u);
+    p2 = (int)(BG_SW(i3 & 31) >> 24);
+    int i4 = __ffs((int)(m2 & rem)) - 1; fast = fast && i4 >= 0; rem &= ~((2u << (i4 & 31)) - 1u);
+    int i5 = __ffs((int)(m52 & rem)) - 1; fast = fast && i5 >= 0; rem &= ~((2u << (i5 & 31)) - 1u);
+    int i6 = __ffs((int)(m52 & rem)) - 1; fast = fast && i6 >= 0;
+    third_r = (int)(BG_SW(i0 & 31) >> 30); v = (int)(BG_SW(i4 & 31) >> 30);
+    ca = (int)(BG_SW(i5 & 31) >> 26); cb = (int)(BG_SW(i6 & 31) >> 26);
+#undef BG_SW
+    if (fast) e.s_idx += i6 + 1;
+  }
+  if (!fast) { // window too short for this lane's rejections (or no window): the plain loops
+    third_r = (int)bg_randbelow<true>(d, env, e, w, 3u); // rng.choice([...]) is evaluated before the loop
+    int guard = 0;
+    p0 = (int)bg_randbelow<true>(d, env, e, w, nc);
+    do { p1 = (int)bg_randbelow<true>(d, env, e, w, nc); } while (p1 == p0 && ++guard < 4096);
+    do { p2 = (int)bg_randbelow<true>(d, env, e, w, nc); } while ((p2 == p0 || p2 == p1) && ++guard < 4096);
+    v = (int)bg_randbelow<true>(d, env, e, w, 2u); // 0 'Voucher: Magic Trick' 600, 1 'Voucher: Minimalist' 750
+    ca = (int)bg_randbelow<true>(d, env, e, w, 52u); cb = (int)bg_randbelow<true>(d, env, e, w, 52u); // randint(0, 51)
+  }
+  int third = PK_TAROT + third_r;
   int c_pack2 = third == PK_TAROT ? 600 : (third == PK_PLANET ? 900 : 1300);
   int32_t cost[9];
   uint32_t tp[9];
   cost[0] = (int32_t)(250.0 * mult); tp[0] = IT_PACK | (PK_STANDARD << 8);
   cost[1] = (int32_t)(500.0 * mult); tp[1] = IT_PACK | (PK_JOKER << 8);
   cost[2] = (int32_t)((double)c_pack2 * mult); tp[2] = IT_PACK | ((uint32_t)third << 8);
-  int owned145 = 0;
-#pragma unroll 1
-  for (int q = 0; q < e.njokers; q++) owned145 += bg_get8(e.jokers, q) <= 145 ? 1 : 0;
-  uint32_t nc = (uint32_t)(145 - owned145);
-  // random.sample(candid, 3): n > 21 -> selection-set method (Lib/random.py sample())
-  int p0, p1, p2, guard = 0;
-  p0 = (int)bg_randbelow<true>(d, env, e, w, nc);
-  do { p1 = (int)bg_randbelow<true>(d, env, e, w, nc); } while (p1 == p0 && ++guard < 4096);
-  do { p2 = (int)bg_randbelow<true>(d, env, e, w, nc); } while ((p2 == p0 || p2 == p1) && ++guard < 4096);
   uint64_t sj = bg_sorted_jokers(e);
   int j0 = bg_candidate(sj, p0), j1 = bg_candidate(sj, p1), j2 = bg_candidate(sj, p2);
   cost[3] = (int32_t)((double)w.jt->cost[j0] * mult); tp[3] = IT_JOKER | ((uint32_t)j0 << 8);
   cost[4] = (int32_t)((double)w.jt->cost[j1] * mult); tp[4] = IT_JOKER | ((uint32_t)j1 << 8);
   cost[5] = (int32_t)((double)w.jt->cost[j2] * mult); tp[5] = IT_JOKER | ((uint32_t)j2 << 8);
-  int v = (int)bg_randbelow<true>(d, env, e, w, 2u); // 0 'Voucher: Magic Trick' 600, 1 'Voucher: Minimalist' 750
   cost[6] = (int32_t)((v ? 750.0 : 600.0) * mult); tp[6] = IT_VOUCHER | ((uint32_t)v << 8);
-  int ca = (int)bg_randbelow<true>(d, env, e, w, 52u), cb = (int)bg_randbelow<true>(d, env, e, w, 52u); // randint(0, 51)
   cost[7] = 40; tp[7] = IT_CARD | ((uint32_t)ca << 8);
   cost[8] = 40; tp[8] = IT_CARD | ((uint32_t)cb << 8);
   bg_shop_pack(sr, cost, tp);
@@ -318,7 +360,8 @@ __device__ __forceinline__ uint32_t bg_joker_flags(const Env& e, lds_JTables* jt
 }
 
 // boss_blinds.py:343-378 on_hand_drawn as applied by balatro_env_2.py:936-948
-__device__ __forceinline__ void bg_boss_on_hand_drawn(const BgDev& d, int env, Env& e, RngWin& w, const Deck0& dk) {
+template <class DK>
+__device__ __forceinline__ void bg_boss_on_hand_drawn(const BgDev& d, int env, Env& e, RngWin& w, const DK& dk) {
   uint32_t fd = 0;
   int n = e.nhand;
   int h0 = -1, h1 = -1;
@@ -355,7 +398,8 @@ __device__ __forceinline__ void bg_boss_on_hand_drawn(const BgDev& d, int env, E
 // ---------------------------------------------------------------------------------------------------------
 // PLAY_HAND  balatro_env_2.py:645-960
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, const Deck0& dk, StepOut& o) {
+template <class DK>
+__device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, const DK& dk, StepOut& o) {
   BG_PROBE_BEGIN();
   // :650-660 selected cards in selection order.  Everything the scorer needs is kept as small histograms:
   //   phist  15 x 4-bit counts per rank (2..14), scnt 4 x 4-bit counts per suit, pcodes the card codes by play index,
@@ -635,7 +679,8 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
 }
 
 // DISCARD  balatro_env_2.py:962-1050
-__device__ __forceinline__ void bg_step_discard(const BgDev& d, int env, Env& e, const RngWin& w, const Deck0& dk, StepOut& o) {
+template <class DK>
+__device__ __forceinline__ void bg_step_discard(const BgDev& d, int env, Env& e, const RngWin& w, const DK& dk, StepOut& o) {
   int n = 0, nfaces = 0;
 #pragma unroll 1
   for (int i = 0; i < e.nsel; i++) {
@@ -792,7 +837,8 @@ __device__ __forceinline__ void bg_toggle_select(Env& e, int pos) {
 }
 
 // dispatch of a VALID action (balatro_env_2.py:629-637)
-__device__ __forceinline__ void bg_env_dispatch(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, const Deck0& dk,
+template <class DK>
+__device__ __forceinline__ void bg_env_dispatch(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, const DK& dk,
                                                 int action, StepOut& o) {
   if (e.phase == 0) {
     if (action == 0) bg_step_play_hand(d, env, e, w, sr, dk, o);
@@ -826,7 +872,8 @@ __device__ __forceinline__ bool bg_step_guards(const Env& e, uint64_t mask, int 
 }
 
 // balatro_env_2.py:616-637 step()
-__device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, const Deck0& dk, uint64_t mask,
+template <class DK>
+__device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, const DK& dk, uint64_t mask,
                                             int action, StepOut& o) {
   bg_step_init(o);
   if (bg_step_guards(e, mask, action, o)) bg_env_dispatch(d, env, e, w, sr, dk, action, o);
@@ -856,8 +903,8 @@ struct RowExtra { double reward; int32_t action; uint32_t terminated; }; // rewa
 // Packed records (p.rows): the lanes of a workgroup sit on different steps, so with one array per key every 32-byte
 // sector of the narrow keys is completed by several partial writes issued iterations apart -- measured 2.2x the
 // algorithmic write traffic.  A record is 22 whole 16-byte stores owned by ONE lane: nothing is shared between lanes.
-template <bool HASH>
-__device__ __forceinline__ uint64_t bg_write_obs(const BgDev& d, int env, size_t row, const Env& e, const Deck0& dk,
+template <bool HASH, class DK>
+__device__ __forceinline__ uint64_t bg_write_obs(const BgDev& d, int env, size_t row, const Env& e, const DK& dk,
                                                 const ObsPtrs& p, uint64_t mask, ShopRegs& sr, const RowExtra& rx) {
   uint64_t hsh = 0x9E3779B97F4A7C15ull;
 #define BG_MIX(v) do { if (HASH) { hsh ^= (uint64_t)(v); hsh *= 0xBF58476D1CE4E5B9ull; hsh ^= hsh >> 29; } } while (0)
