@@ -159,6 +159,8 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
   __shared__ uint32_t s_prod[BG_RB];
   __shared__ uint32_t s_deck[16][BG_RB];        // every env's 52 card codes (Deck0::lds)
   __shared__ uint32_t win[2][BG_WIN][BG_BLOCK]; // one RNG window set per phase-B wave
+  __shared__ bg_u32x4 s_stage[BG_RB / BG_BLOCK][BG_BLOCK * 6];              // packed records leave through LDS (bg_write_obs_impl)
+  __shared__ unsigned long long s_rowaddr[BG_RB / BG_BLOCK][BG_BLOCK];
   __shared__ JTables jt;
   BG_PROBE_INIT();
   bg_tables_init(&jt);
@@ -310,7 +312,8 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
       mask = bg_action_mask(d, env, e, sr);
       BG_PROBE(18);
       size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
-      uint64_t h = bg_write_obs<HASH>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u});
+      uint64_t h = bg_write_obs_impl<HASH, true>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u},
+                                                RowStage{(lds_u4*)&s_stage[local >> 6][0], (lds_u64*)&s_rowaddr[local >> 6][0]});
       BG_PROBE(19);
       if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
       if (reward) reward[row] = o.reward;

@@ -11,7 +11,7 @@ sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 from balatro_gym_amd import BalatroVecEnv  # noqa: E402
 from balatro_gym_amd import _native as nat  # noqa: E402
-from balatro_gym_amd.vec_env import ObsBuffers  # noqa: E402
+from balatro_gym_amd.vec_env import ObsBuffers, RowBuffers  # noqa: E402
 from bench import IMPLEMENTED, jokers_for  # noqa: E402
 
 
@@ -22,6 +22,8 @@ def run(n, scorer, policy, chunk, steps, obs_mode, max_ante=4, label=""):
     ob = None
     if obs_mode == "keep":
         ob = ObsBuffers(n, env.device, steps=chunk)
+    elif obs_mode == "rows":
+        ob = RowBuffers(n, env.device, steps=chunk)
     elif obs_mode == "none":
         ob = ObsBuffers(1, env.device)
         ob.ptrs = nat.ObsPtrs()  # all NULL
@@ -59,6 +61,7 @@ def run(n, scorer, policy, chunk, steps, obs_mode, max_ante=4, label=""):
               f"  | cycles per iteration A {out[0]/max(1,iters):7.0f} C {out[2]/max(1,iters):7.0f}  per round B {out[1]/max(1,rounds):7.0f}")
         print("    A/C sections, cycles per wave-iteration: " + " | ".join(f"{nm} {out[i]/max(1,iters)/4:.0f}" for i, nm in
               [(20, "policy"), (21, "guards+cheap+enqueue"), (16, "merge"), (17, "cap+reset"), (18, "mask"), (19, "obs")]))
+        print(f"    phase-B wave time per round: plays {out[22]/max(1,rounds):.0f}  others {out[23]/max(1,rounds):.0f}")
         names = {5: "gather", 6: "classify", 7: "boss-check+joker-individual", 8: "bloodstone+skip", 9: "joker-main", 10: "boss-ratio+state", 11: "reward", 12: "outcome", 13: "main-prefetch", 14: "main-loop"}
         print("    play path cycles per block-step: " + " | ".join(f"{names[i]} {out[i]/blocks/T:.0f}" for i in range(5, 15)))
     env.close()
@@ -67,7 +70,8 @@ def run(n, scorer, policy, chunk, steps, obs_mode, max_ante=4, label=""):
 if __name__ == "__main__":
     chunk = int(os.environ.get("CHUNK", "16"))
     steps = chunk * 8
-    run(65536, True, 2, chunk, steps, "keep", label="C3 baseline")
+    run(65536, True, 2, chunk, steps, "rows", label="C3 packed records (bench)")
+    run(65536, True, 2, chunk, steps, "keep", label="C3 one array per key")
     if os.environ.get("BG_TIMING"):
         run(65536, False, 2, chunk, steps, "keep", max_ante=0, label="C2 no jokers")
         sys.exit(0)
