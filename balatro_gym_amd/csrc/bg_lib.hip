@@ -139,6 +139,12 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, in
 //   C  lane = env: merge, curriculum cap, SAME_STEP auto-reset, observation / reward / terminated stores, statistics
 // State stays in registers (lane = env) across the T fused steps; LDS is only the exchange between the two lane maps.
 // ---------------------------------------------------------------------------------------------------------
+// Workgroup barrier that orders LDS only.  __syncthreads() also drains the wave's outstanding global stores
+// (s_waitcnt vmcnt(0)): right after phase C that exposes the whole record write-out (~90 KB per CU per iteration through
+// a ~16 B/clk store path).  No lane reads another wave's global stores inside the kernel except an env's own state, which
+// only ever passes through this CU's one vector-memory pipeline, in order; everything exchanged between waves is LDS.
+__device__ __forceinline__ void bg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags; }; // misc: hand_type+1 | terminated<<8 | has_shop<<9
 
 #ifndef BG_RB_WAVES
@@ -156,6 +162,7 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
   __shared__ uint32_t s_items[2][BG_RB]; // work queues: 0 = PLAY_HAND, 1 = every other deferred action
   __shared__ uint32_t s_nitems[2];
   __shared__ uint32_t s_nready;
+  __shared__ uint32_t s_more[2];
   __shared__ uint32_t s_prod[BG_RB];
   __shared__ uint32_t s_deck[16][BG_RB];        // every env's 52 card codes (Deck0::lds)
   __shared__ uint32_t win[2][BG_WIN][BG_BLOCK]; // one RNG window set per phase-B wave
@@ -176,6 +183,8 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
   s_prod[local] = (live && d.prod_view) ? d.prod_view[env] : 0u;
   if (local < 2) s_nitems[local] = 0;
   if (local == 0) s_nready = 0;
+  if (local < 2) s_more[local] = 0;
+  uint32_t iter_no = 0;
   dk.col = (lds_u32*)&s_deck[0][local];
   if (live) {
     bg_load_env(d, env, e);
@@ -232,7 +241,7 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
       const unsigned long long bal = __ballot(runnable_next);
       if ((local & 63) == 0 && bal) atomicAdd(&s_nready, (uint32_t)__popcll(bal));
     }
-    __syncthreads();
+    bg_barrier_lds();
 #ifdef BG_TIMING
     unsigned long long c1 = BG_TICK();
 #endif
@@ -282,13 +291,14 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
         }
       }
     }
-    __syncthreads();
+    if (run_b) __syncthreads(); else bg_barrier_lds();
 #ifdef BG_TIMING
     unsigned long long c2 = BG_TICK();
     if (run_b) { tBitems += (nq0 - rem0) + (nq1 - rem1); tRounds++; }
     tIter++;
 #endif
     if (local == 0) { s_nready = 0; s_nitems[0] = rem0; s_nitems[1] = rem1; }
+    const uint32_t par = iter_no & 1u;
     // ---------------- phase C: finish the step of every lane that took one (inline in A, or just served by phase B)
     BG_PROBE_BEGIN();
     if (blocked && (s_out[local].misc & 0x400)) {
@@ -324,7 +334,12 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
       if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
       t++;
     }
-    const int more = __syncthreads_or((live && (blocked || t < T)) ? 1 : 0);
+    // any lane with steps left?  (flag per iteration parity: written here, read after the barrier, cleared one iteration later)
+    if (__ballot(live && (blocked || t < T)) != 0ull && (local & 63) == 0) s_more[par] = 1u;
+    bg_barrier_lds();
+    const uint32_t more = s_more[par];
+    if (local == 0) s_more[par ^ 1u] = 0u;
+    iter_no++;
 #ifdef BG_TIMING
     unsigned long long c3 = BG_TICK();
     tA += c1 - c0; tB += c2 - c1; tC += c3 - c2;
