@@ -165,11 +165,18 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
   __shared__ uint32_t s_more[2];
   __shared__ uint32_t s_prod[BG_RB];
   __shared__ uint32_t s_deck[16][BG_RB];        // every env's 52 card codes (Deck0::lds)
-  __shared__ uint32_t win[2][BG_WIN][BG_BLOCK]; // one RNG window set per phase-B wave
-  __shared__ bg_u32x4 s_stage[BG_RB / BG_BLOCK][BG_BLOCK * 6];              // packed records leave through LDS (bg_write_obs_impl)
+  // one storage, two uses that never overlap in time (a workgroup barrier separates them): phase B's two RNG windows
+  // ([2][BG_WIN][64] words) and phase C's record staging (per wave 64 x 6 pieces of 16 bytes, bg_write_obs_impl)
+  constexpr int kWinBytes = 2 * BG_WIN * BG_BLOCK * 4, kStageBytes = (BG_RB / BG_BLOCK) * BG_BLOCK * 6 * 16;
+  __shared__ bg_u32x4 s_scratch[(kWinBytes > kStageBytes ? kWinBytes : kStageBytes) / 16];
+  uint32_t (*win)[BG_WIN][BG_BLOCK] = (uint32_t (*)[BG_WIN][BG_BLOCK])s_scratch;
+  bg_u32x4 (*s_stage)[BG_BLOCK * 6] = (bg_u32x4 (*)[BG_BLOCK * 6])s_scratch;
   __shared__ unsigned long long s_rowaddr[BG_RB / BG_BLOCK][BG_BLOCK];
   __shared__ JTables jt;
   BG_PROBE_INIT();
+  // the refill kernels of the previous launch run beside this kernel and their (ALU-bound) waves land on the same SIMDs as
+  // the latency-critical one-wave phases here: let this kernel's waves issue first
+  __builtin_amdgcn_s_setprio(3);
   bg_tables_init(&jt);
   const int local = threadIdx.x;
   const int env = blockIdx.x * BG_RB + local;
@@ -880,7 +887,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   { const char* av = getenv("BG_ASYNC_REFILL"); h->async_refill = av ? atoi(av) != 0 : true; }
   { // phase B runs when a queue reaches its threshold or fewer than th_ready lanes can still step (1/1/anything = lockstep)
     const char* a = getenv("BG_TH_PLAY"); const char* b = getenv("BG_TH_OTHER"); const char* c = getenv("BG_TH_READY");
-    h->th_play = a ? (uint32_t)atoi(a) : 44u; h->th_other = b ? (uint32_t)atoi(b) : 56u; h->th_ready = c ? (uint32_t)atoi(c) : (uint32_t)(BG_RB / 2);
+    h->th_play = a ? (uint32_t)atoi(a) : (uint32_t)(BG_RB / 4); h->th_other = b ? (uint32_t)atoi(b) : (uint32_t)(BG_RB * 5 / 16); h->th_ready = c ? (uint32_t)atoi(c) : (uint32_t)(BG_RB / 4);
     if (h->th_play < 1) h->th_play = 1; if (h->th_other < 1) h->th_other = 1; if (h->th_ready < 1) h->th_ready = 1;
   }
   h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;

@@ -1033,7 +1033,7 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
           const uint32_t r = np == 6 ? (q * 10923u) >> 16 : q >> 2;         // q / np
           const uint32_t c = q - r * (uint32_t)np;
           const unsigned long long a = rs.addr[r];
-          *(bg_u32x4*)(a + 16ull * (uint32_t)(6 * sl) + 16ull * c) = rs.stage[q];
+          *(__attribute__((address_space(1))) bg_u32x4*)(a + 16ull * (uint32_t)(6 * sl) + 16ull * c) = rs.stage[q]; // global_store, not flat
         }
       }
     } else {

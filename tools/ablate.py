@@ -53,7 +53,7 @@ def run(n, scorer, policy, chunk, steps, obs_mode, max_ante=4, label=""):
         L = nat.load()
         L.bg_debug_counters.argtypes = [C2.c_void_p, C2.POINTER(C2.c_ulonglong)]
         L.bg_debug_counters(env._h, out)
-        blocks = (n + 255) // 256
+        blocks = (n + 127) // 128  # BG_RB
         T = max(1, out[4] // blocks)
         print(f"    phase cycles per block-step: A {out[0]/blocks/T:9.0f}  B {out[1]/blocks/T:9.0f}  C {out[2]/blocks/T:9.0f}  items/block-step {out[3]/blocks/T:6.1f}")
         iters, rounds = out[15] & 0xffffffff, out[15] >> 32
