@@ -407,21 +407,31 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_observe_kernel(BgDev d, ObsPtrs o
 // mt[i] again, and gets it from a SECOND run of the pass-1 recurrence in lockstep (two independent chains = ILP) --
 // recomputing 623 steps is far cheaper than writing 2.5 KB per stream and reading it back.  The only memory traffic
 // is the final state: 156 16-byte stores.
+// init_genrand(19650218), the key-independent state init_by_array starts from: a compile-time table read with scalar
+// loads (the index is the loop counter, uniform over the wave) instead of a third multiply chain per step
+struct BgGenrandTab {
+  uint32_t g[BG_MT_N];
+  constexpr BgGenrandTab() : g{} {
+    uint32_t x = 19650218u;
+    g[0] = x;
+    for (int i = 1; i < BG_MT_N; i++) { x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i; g[i] = x; }
+  }
+};
+static constexpr BgGenrandTab BG_GENRAND{};
+
 __device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) {
   uint4* p4 = (uint4*)p;
-  uint32_t g = 19650218u, a = g, a1 = 0; // g: init_genrand(19650218) recurrence; a: pass-1 recurrence
+  uint32_t a = BG_GENRAND.g[0], a1 = 0; // a: pass-1 recurrence
 #pragma unroll 4
   for (int i = 1; i < BG_MT_N; i++) {
-    g = 1812433253u * (g ^ (g >> 30)) + (uint32_t)i;
-    a = (g ^ ((a ^ (a >> 30)) * 1664525u)) + key;
+    a = (BG_GENRAND.g[i] ^ ((a ^ (a >> 30)) * 1664525u)) + key;
     if (i == 1) a1 = a;
   }
   // wrap: mt[0] = mt[623]; 624th iteration of pass 1 at i = 1
   const uint32_t a1w = (a1 ^ ((a ^ (a >> 30)) * 1664525u)) + key;
   // pass 2: i = 2..623 (then the wrapped step at i = 1), beside a rerun of pass 1 that supplies mt[i]
-  g = 19650218u; a = g;
-  g = 1812433253u * (g ^ (g >> 30)) + 1u;
-  a = (g ^ ((a ^ (a >> 30)) * 1664525u)) + key; // pass-1 mt[1] (before the wrap)
+  a = BG_GENRAND.g[0];
+  a = (BG_GENRAND.g[1] ^ ((a ^ (a >> 30)) * 1664525u)) + key; // pass-1 mt[1] (before the wrap)
   uint32_t bprev = a1w, w2 = 0, w3 = 0;
 #pragma unroll 2
   for (int q = 0; q < BG_MT_N / 4; q++) {
@@ -430,8 +440,7 @@ __device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) {
     for (int c = 0; c < 4; c++) {
       const int i = 4 * q + c;
       if (i >= 2) {
-        g = 1812433253u * (g ^ (g >> 30)) + (uint32_t)i;
-        a = (g ^ ((a ^ (a >> 30)) * 1664525u)) + key;
+        a = (BG_GENRAND.g[i] ^ ((a ^ (a >> 30)) * 1664525u)) + key;
         bprev = (a ^ ((bprev ^ (bprev >> 30)) * 1566083941u)) - (uint32_t)i;
         v[c] = bprev;
       }
@@ -568,7 +577,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_
   d.smeta[env] = 0;
   {
     uint32_t gp = reseed_global ? 1u : (uint32_t)((e.g_cons + e.g_valid) & 0xff);
-    uint32_t pv = 0u | (0u << 8) | (gp << 16);
+    uint32_t pv = 0u | (0u << 8) | (gp << 16) | 0x80000000u; // bit 31: this env's streams are seeded (refill scan)
     d.prod_out[env] = pv;
     ((uint32_t*)d.prod_in)[env] = pv;
   }
@@ -598,7 +607,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
   int d_ready = (int)((prod - (uint32_t)d_cons) & 0xffu);
   int s_ready = (int)(((prod >> 8) - (uint32_t)s_cons) & 0xffu);
   int g_valid = (int)(((prod >> 16) - (uint32_t)g_cons) & 0xffu);
-  bool seeded = bg_deckmt(d, env)[BG_MT_N] != 0; // index word is 0 only before the first bg_seed
+  const bool seeded = (prod >> 31) != 0; // set by bg_seed (a dense word: no trip to the env's 2.5 KB stream block)
   if (!seeded) { d.prod_out[env] = prod; return; }
   if (s_ready < d.KS - 1) {
     // one work item per missing slot (balanced: every lane of the dense kernel seeds exactly one stream); the shop
@@ -1022,10 +1031,11 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   BG_HIP(hipEventRecord(h->ev_scan, s));
   BG_HIP(hipStreamWaitEvent(h->side2, h->ev_scan, 0));
   BG_HIP(hipStreamWaitEvent(h->side3, h->ev_scan, 0));
-  hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, d);
-  hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side2, d);
-  hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
-  hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
+  static const int skip = getenv("BG_DEV_SKIP_REFILL") ? atoi(getenv("BG_DEV_SKIP_REFILL")) : 0; // development: contention experiments only (breaks the rings)
+  if (!(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, d);
+  if (!(skip & 2)) hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side2, d);
+  if (!(skip & 4)) hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
+  if (!(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
   BG_HIP(hipEventRecord(h->ev_deck, h->side2));
   BG_HIP(hipEventRecord(h->ev_gblk, h->side3));
   BG_HIP(hipStreamWaitEvent(s, h->ev_deck, 0));
