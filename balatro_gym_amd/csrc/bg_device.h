@@ -330,6 +330,28 @@ __device__ __forceinline__ uint32_t bg_gpeek(const BgDev& d, int env, const Env&
   if (e.g_valid < need) { atomicOr(d.err, BG_DEVERR_GSTREAM); return 0u; }
   return bg_temper(bg_gblock(d, env, blk)[idx]);
 }
+// the 12 tempered words `skip` positions ahead of the cursor, in three (unaligned) 16-byte loads: the spare words behind a
+// ring block mirror the head of the next one (bg_refill_gblk_kernel).  avail = which of them the ring already holds.
+struct __attribute__((packed, aligned(4))) BgU4 { uint32_t x, y, z, w; };
+__device__ __forceinline__ void bg_gpeek12(const BgDev& d, int env, const Env& e, int skip, uint32_t (&out)[12], uint32_t& avail) {
+  int idx = e.g_idx + skip, blk = e.g_cur, need = 1;
+  if (idx >= BG_MT_N) { idx -= BG_MT_N; blk = (blk + 1 == d.KG) ? 0 : blk + 1; need = 2; }
+  if (idx >= BG_MT_N) { idx -= BG_MT_N; blk = (blk + 1 == d.KG) ? 0 : blk + 1; need = 3; }
+  avail = 0;
+  if (e.g_valid >= need) {
+    const int in_blk = BG_MT_N - idx; // words before the mirror
+    avail = (e.g_valid > need || in_blk >= 12) ? 0xfffu : ((1u << in_blk) - 1u);
+    const BgU4* p = (const BgU4*)(bg_gblock(d, env, blk) + idx);
+#pragma unroll
+    for (int g = 0; g < 3; g++) {
+      BgU4 v = p[g];
+      out[4 * g] = bg_temper(v.x); out[4 * g + 1] = bg_temper(v.y); out[4 * g + 2] = bg_temper(v.z); out[4 * g + 3] = bg_temper(v.w);
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 12; i++) out[i] = 0u;
+  }
+}
 // fetch the next `count` words of the global stream into the window (stops at the block end)
 __device__ __forceinline__ void bg_gprefetch(const BgDev& d, int env, Env& e, RngWin& w, int count) {
   bg_gnorm(d, e);

@@ -185,7 +185,6 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
   int64_t ssum = 0;
   Env e;
   DeckLds dk;
-  ShopRegs sr; sr.valid = false;
   uint64_t mask = 0;
   s_prod[local] = (live && d.prod_view) ? d.prod_view[env] : 0u;
   if (local < 2) s_nitems[local] = 0;
@@ -197,7 +196,11 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
     bg_load_env(d, env, e);
 #pragma unroll
     for (int k = 0; k < BG_NDECK; k++) bg_deck_set(dk, k, d.deck[(size_t)k * d.N + env]);
+    // s_shop[.][lane] always holds the shop of a lane that is in the shop phase (phase B keeps it current), so no lane
+    // carries the 16 shop registers through the kernel
+    ShopRegs sr; sr.valid = false;
     mask = bg_action_mask(d, env, e, sr);
+    if (sr.valid) { s_shop[0][local] = sr.c3; s_shop[1][local] = sr.c4; s_shop[2][local] = sr.c5; s_shop[3][local] = sr.c6; }
   }
 #ifdef BG_TIMING
   unsigned long long tA = 0, tB = 0, tC = 0, tBitems = 0, tIter = 0, tRounds = 0;
@@ -317,7 +320,6 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
       OutLds ol = s_out[local];
       o.reward = ol.reward; o.final_score = ol.final_score; o.flags = ol.flags;
       o.hand_type = (ol.misc & 0xff) - 1; o.terminated = (ol.misc & 0x100) != 0; o.error = ol.misc >> 16;
-      if (ol.misc & 0x200) { sr.c3 = s_shop[0][local]; sr.c4 = s_shop[1][local]; sr.c5 = s_shop[2][local]; sr.c6 = s_shop[3][local]; sr.valid = true; }
       blocked = false;
       fin = true;
     }
@@ -326,6 +328,10 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
       if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
       if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; } // SAME_STEP auto-reset
       BG_PROBE(17);
+      ShopRegs sr; sr.valid = false;
+      if (e.phase == 1 && (e.bflags & BG_BF_SHOP_EXISTS)) {
+        sr.c3 = s_shop[0][local]; sr.c4 = s_shop[1][local]; sr.c5 = s_shop[2][local]; sr.c6 = s_shop[3][local]; sr.valid = true;
+      }
       mask = bg_action_mask(d, env, e, sr);
       BG_PROBE(18);
       size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
@@ -745,6 +751,12 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_gblk_kernel(BgDev d) {
       int last = (g_cur + g_valid - 1) % d.KG;
       int nxt = last + 1 == d.KG ? 0 : last + 1;
       bg_mt_twist(bg_gblock(d, env, last), bg_gblock(d, env, nxt));
+      { // the 16 spare words behind a block mirror the head of its successor: a 16-word read never has to change blocks
+        const uint4* h4 = (const uint4*)bg_gblock(d, env, nxt);
+        uint4* t4 = (uint4*)(bg_gblock(d, env, last) + BG_MT_N);
+        uint4 v0 = h4[0], v1 = h4[1], v2 = h4[2], v3 = h4[3];
+        t4[0] = v0; t4[1] = v1; t4[2] = v2; t4[3] = v3;
+      }
       g_valid++; made++;
     }
     if (made) {
@@ -1025,7 +1037,8 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   bg_ev_begin(h, h->ev_refill_t, s);
   BG_HIP(hipMemsetAsync(d.wl_count, 0, 4 * sizeof(uint32_t), s));
   hipLaunchKernelGGL(bg_refill_scan_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, d);
-  int dense = bg_grid(h) < 1024 ? bg_grid(h) : 1024; // grid-stride over the compacted work lists
+  static const int dense_cap = getenv("BG_REFILL_BLOCKS") ? atoi(getenv("BG_REFILL_BLOCKS")) : 1024;
+  int dense = bg_grid(h) < dense_cap ? bg_grid(h) : dense_cap; // grid-stride over the compacted work lists
   // the three kinds of work are independent once the lists exist: run them side by side (each is a few hundred
   // latency-bound waves), join before the completion event
   BG_HIP(hipEventRecord(h->ev_scan, s));

@@ -485,28 +485,32 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     bg_gnorm(d, e);
     int n8 = j8 >= 0 ? (int)((phist >> 32) & 0xf) : 0; // 8 Ball: one extra random() per played 8 (:167)
     int consumed = 2 * n * nj + 2 * n8;
-    if (jb >= 0 && ((scnt >> 8) & 0xfu)) {
+    // Every RNG word the chain looks at is requested in ONE batch of independent loads: Bloodstone's two words per played
+    // Heart, and the 12 words that follow the individual phase's `consumed` (eagerly drawn, never looked at) words, where
+    // the main phase's randint draws will fall (5 accepted among 12 words fails once in ~3000 plays: then the loop).
+    const bool blood = jb >= 0 && ((scnt >> 8) & 0xfu);
+    int boff[8];
+    {
       // Bloodstone on a Heart: x2 iff the pair's random() < 0.5.  Pair (c, jb) sits 2*(c*nj + jb) words ahead, plus 2
-      // for every extra 8-Ball draw that precedes it in card-major order: up to 8 independent two-word reads.
-      int boff[8];
+      // for every extra 8-Ball draw that precedes it in card-major order.
       int eights = 0;
 #pragma unroll
       for (int c = 0; c < 8; c++) {
         int code = (int)((pcodes >> (8 * c)) & 0xff);
         int rk = (code >> 2) + 2;
-        boff[c] = (c < n && (code & 3) == 2) ? 2 * (c * nj + jb) + 2 * (eights + ((j8 >= 0 && j8 < jb && rk == 8) ? 1 : 0)) : -1;
+        boff[c] = (blood && c < n && (code & 3) == 2) ? 2 * (c * nj + jb) + 2 * (eights + ((j8 >= 0 && j8 < jb && rk == 8) ? 1 : 0)) : -1;
         if (c < n && j8 >= 0 && rk == 8) eights++;
       }
-      uint32_t ra[8], rb[8];
-#pragma unroll
-      for (int c = 0; c < 8; c++) { ra[c] = 0; rb[c] = 0; if (boff[c] >= 0) { ra[c] = bg_gpeek(d, env, e, boff[c]); rb[c] = bg_gpeek(d, env, e, boff[c] + 1); } }
-#pragma unroll
-      for (int c = 0; c < 8; c++)
-        if (boff[c] >= 0) {
-          double bl = ((double)(ra[c] >> 5) * 67108864.0 + (double)(rb[c] >> 6)) * (1.0 / 9007199254740992.0);
-          if (bl < 0.5) xexp++;
-        }
     }
+    // random() < 0.5 for random() = ((a >> 5) * 2**26 + (b >> 6)) / 2**53 is decided by the top bit of the FIRST word
+    // alone ((a >> 5) < 2**26), so one word per Heart is read and no float arithmetic is needed.
+    uint32_t ra[8], mw[12];
+    uint32_t avail = 0; // main-phase words the ring already holds
+#pragma unroll
+    for (int c = 0; c < 8; c++) { ra[c] = 0x80000000u; if (boff[c] >= 0) ra[c] = bg_gpeek(d, env, e, boff[c]); }
+    bg_gpeek12(d, env, e, consumed, mw, avail);
+#pragma unroll
+    for (int c = 0; c < 8; c++) xexp += (int)((ra[c] >> 31) ^ 1u);
     bg_gskip(d, e, consumed);
     chips += ic; mult += im;
     x_mult *= (double)(1ull << xexp);
@@ -517,31 +521,38 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
                     (__popc(suits) == 4 ? 1u << 10 : 0u) | (kings > 0 ? 1u << 11 : 0u) | (queens > 0 ? 1u << 12 : 0u) | (1u << (16 + ht));
     double baron = w.jt->pow15[kings];
     BG_PROBE(8);
-    bg_gprefetch(d, env, e, w, 16);
     BG_PROBE(13);
     // The nj draws are `_randbelow(24)`: 5-bit words, rejected when >= 24.  Instead of a rejection loop per joker (a wave
-    // iterates until its unluckiest lane is done), look at the next 16 words at once: the j-th ACCEPTED word is joker
+    // iterates until its unluckiest lane is done), look at the next 12 words at once: the j-th ACCEPTED word is joker
     // j's draw.  Only Misprint uses the value.
     uint32_t mis_of[5] = {0, 0, 0, 0, 0};
     {
       bg_gnorm(d, e);
-      uint32_t off0 = (uint32_t)(e.g_idx - w.g_start);
-      bool fast = w.g_blk == e.g_cur && off0 + 16u <= (uint32_t)w.g_len;
       uint32_t acc = 0;
-      if (fast) {
+      uint64_t r5lo = 0, r5hi = 0; // the twelve 5-bit candidates, one per byte
 #pragma unroll
-        for (int i = 0; i < 16; i++) { uint32_t r5 = bg_temper(w.lds[(off0 + i) * BG_BLOCK]) >> 27; acc |= (r5 < 24u ? 1u : 0u) << i; }
-        fast = __popc(acc) >= nj;
+      for (int i = 0; i < 12; i++) {
+        const uint32_t r5 = mw[i] >> 27;
+        acc |= (r5 < 24u ? 1u : 0u) << i;
+        if (i < 8) r5lo |= (uint64_t)r5 << (8 * i); else r5hi |= (uint64_t)r5 << (8 * (i - 8));
+      }
+      // usable only up to the last word the ring holds, and only if the nj-th accepted word lies inside
+      uint32_t usable = acc & avail;
+      bool fast = avail == 0xfffu ? __popc(acc) >= nj : false;
+      if (!fast && avail) { // ring ends inside the 12 words: accepted words must all come before the first missing one
+        const int first_missing = __ffs((int)(~avail & 0xfffu)) - 1;
+        usable = acc & ((1u << first_missing) - 1u);
+        fast = __popc(usable) >= nj;
       }
       if (fast) {
-        uint32_t m = acc;
+        uint32_t m = usable;
         int last = 0;
 #pragma unroll
         for (int j = 0; j < 5; j++)
           if (j < nj) {
             last = __ffs((int)m) - 1;
             m &= m - 1;
-            if (((dms[j] >> 5) & 7u) == 3u) mis_of[j] = bg_temper(w.lds[(off0 + last) * BG_BLOCK]) >> 27;
+            if (((dms[j] >> 5) & 7u) == 3u) mis_of[j] = (uint32_t)(((last < 8 ? r5lo : r5hi) >> (8 * (last & 7))) & 0x1fu);
           }
         e.g_idx += last + 1;
       } else {
