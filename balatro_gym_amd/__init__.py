@@ -6,7 +6,8 @@ steps tens of thousands of games in lockstep on one GPU; `ShardedBalatroVecEnv` 
 """
 from .constants import Action, Phase  # noqa: F401
 
-__all__ = ["Action", "Phase", "BalatroEnv", "BalatroVecEnv", "ShardedBalatroVecEnv", "make_balatro_env", "shard_range"]
+__all__ = ["Action", "Phase", "BalatroEnv", "BalatroVecEnv", "BalatroSB3VecEnv", "ShardedBalatroVecEnv", "make_balatro_env",
+           "shard_range"]
 
 
 def __getattr__(name):  # lazy: importing the package must not need torch / the GPU
@@ -16,6 +17,9 @@ def __getattr__(name):  # lazy: importing the package must not need torch / the 
     if name in ("BalatroEnv", "make_balatro_env"):
         from . import env
         return getattr(env, name)
+    if name in ("BalatroSB3VecEnv", "FIXED_SPEC", "fix_observation"):
+        from . import sb3_adapter
+        return getattr(sb3_adapter, name)
     if name in ("ShardedBalatroVecEnv", "shard_range"):
         from . import sharded
         return getattr(sharded, name)

@@ -78,3 +78,33 @@ def test_shard_range_partitions_everything():
                 lo, hi = shard_range(total, world, r)
                 cover.extend(range(lo, hi))
             assert cover == list(range(total))
+
+
+def test_sb3_fixed_observation_space_and_transform():
+    """BalatroEnvFixed's observation fixes (train_balatro_fixed.py:29-207), batched: 51 keys, scalars -> (1,), MultiBinary
+    -> int8, int16 array keys of the upgrade list -> int32, never-produced keys -> zeros of the declared shape."""
+    import torch
+    from balatro_gym_amd import _native as nat
+    from balatro_gym_amd.sb3_adapter import FIXED_SPEC, fix_observation
+    assert len(FIXED_SPEC) == 51 and list(FIXED_SPEC)[:31] == nat.OBS_KEYS
+    assert FIXED_SPEC["ante"] == ("int16", (1,), True)              # scalar first: dtype kept
+    assert FIXED_SPEC["chips_scored"] == ("int64", (1,), True)
+    assert FIXED_SPEC["joker_ids"] == ("int32", (10,), True)        # int upgrade
+    assert FIXED_SPEC["shop_costs"][0] == "int32" and FIXED_SPEC["shop_items"][0] == "int32"
+    assert FIXED_SPEC["consumables"] == ("int16", (5,), True)       # not in the upgrade list
+    assert FIXED_SPEC["selected_cards"] == ("int8", (8,), True) and FIXED_SPEC["action_mask"] == ("int8", (60,), True)
+    assert FIXED_SPEC["hand_one_hot"] == ("float32", (8, 52), False) and FIXED_SPEC["win_probability"] == ("float32", (1,), False)
+    n = 5
+    tdt = {"int8": torch.int8, "int16": torch.int16, "int32": torch.int32, "int64": torch.int64, "float32": torch.float32}
+    obs = {}
+    for k in nat.OBS_KEYS:
+        dt, shape = nat.OBS_SPEC[k]
+        obs[k] = (torch.arange(n * int(np.prod(shape, dtype=np.int64))).reshape((n,) + tuple(shape)) % 3).to(tdt[dt])
+    fixed = fix_observation(obs)
+    assert set(fixed) == set(FIXED_SPEC)
+    for k, (dt, shape, produced) in FIXED_SPEC.items():
+        assert tuple(fixed[k].shape) == (n,) + shape and fixed[k].dtype == tdt[dt], k
+        if produced:
+            assert torch.equal(fixed[k].reshape(n, -1).to(torch.int64), obs[k].reshape(n, -1).to(torch.int64)), k
+        else:
+            assert not fixed[k].any()

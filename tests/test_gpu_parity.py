@@ -351,3 +351,39 @@ def test_invalid_actions_and_no_raise():
         for k in OBS_KEYS:
             assert torch.equal(env.obs[k], before[k]), (bad, k)
     env.close()
+
+
+def test_sb3_adapter_conventions():
+    """BalatroSB3VecEnv: VecEnv calling convention, BalatroEnvFixed's 51-key observation, SafeBalatroEnv's endings
+    (N consecutive invalid actions -> terminated with -50, step limit -> truncated + terminal_observation)."""
+    import torch
+    from balatro_gym_amd.sb3_adapter import FIXED_SPEC, BalatroSB3VecEnv
+    n = 64
+    venv = BalatroSB3VecEnv(n, seed=300, max_invalid_actions=5, max_episode_steps=40)
+    obs = venv.reset()
+    assert set(obs) == set(FIXED_SPEC)
+    for k, (dt, shape, _) in FIXED_SPEC.items():
+        assert obs[k].shape == (n,) + shape and obs[k].dtype == np.dtype(dt), k
+    # the fixed observation is the raw one, reshaped / retyped
+    raw = {k: v.cpu().numpy() for k, v in venv.env.obs.items()}
+    for k in OBS_KEYS:
+        assert np.array_equal(obs[k].reshape(n, -1).astype(np.int64), raw[k].reshape(n, -1).astype(np.int64)), k
+    # env 0 only sends an invalid action (59); the others toggle card 0 for ever (first valid action elsewhere)
+    kills = truncs = 0
+    for t in range(45):
+        mask = obs["action_mask"]
+        act = np.array([2 if mask[i, 2] else int(np.flatnonzero(mask[i])[0]) for i in range(n)], dtype=np.int64)
+        act[0] = 59
+        obs, rew, done, infos = venv.step(act)
+        assert rew.dtype == np.float32 and done.dtype == np.bool_ and len(infos) == n
+        if infos[0].get("invalid_action_termination"):
+            kills += 1
+            assert rew[0] == -50.0 and done[0] and "terminal_observation" in infos[0] and not infos[0]["TimeLimit.truncated"]
+            assert (t + 1) % 5 == 0
+        for i in range(1, n):
+            if infos[i].get("max_steps_reached"):
+                truncs += 1
+                assert done[i] and infos[i]["TimeLimit.truncated"] and set(infos[i]["terminal_observation"]) == set(FIXED_SPEC)
+                assert obs["phase"][i, 0] == 2  # a fresh episode: blind select
+    assert kills == 9 and truncs > 0
+    venv.close()
