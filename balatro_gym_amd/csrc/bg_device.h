@@ -64,6 +64,11 @@ struct BgDev {
   const uint32_t* prod_in;
   uint32_t* prod_out;
   unsigned long long* dbg; // [16] phase cycle counters (development builds, -DBG_TIMING)
+  // card states (BG_FLAG_CARD_STATES; null otherwise): per deck INDEX enhancement | edition << 4 | seal << 8 as u16,
+  // eight cards per 16-byte chunk, plus the copy every reset re-applies and the 'card_enhancement' stream (index 11)
+  uint4* cstate;     // uint4[7][N]
+  uint4* ctmpl;      // uint4[7][N]
+  uint32_t* cardmt;  // u32[N][640], lazy MT19937 (cursor in word 624)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -221,8 +226,15 @@ __shared__ unsigned long long bg_probe_lds[32];
 #endif
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
-struct Deck0 { uint64_t lo, hi; };   // first 16 cards in registers, the rest read from HBM
-struct DeckLds { lds_u32* col; };     // &s_deck[0][lane of the workgroup]
+struct Deck0 { uint64_t lo, hi; static constexpr bool kCards = false; };   // first 16 cards in registers, the rest read from HBM
+struct DeckLds { lds_u32* col; static constexpr bool kCards = false; };     // &s_deck[0][lane of the workgroup]
+// the same decks in kernels built for card states (cards.py CardState: enhancement / edition / seal per deck index)
+struct Deck0C : Deck0 { static constexpr bool kCards = true; };
+struct DeckLdsC : DeckLds { static constexpr bool kCards = true; };
+#define BG_NCST 7 // 16-byte chunks of card state per env
+__device__ __forceinline__ uint32_t bg_cstate(const BgDev& d, int env, int ci) { // enh | edition << 4 | seal << 8
+  return (uint32_t)((const uint16_t*)&d.cstate[(size_t)(ci >> 3) * d.N + env])[ci & 7];
+}
 __device__ __forceinline__ Deck0 bg_load_deck0(const BgDev& d, int env) {
   uint4 c = d.deck[env];
   Deck0 r;
@@ -259,6 +271,21 @@ __device__ __forceinline__ uint32_t bg_temper(uint32_t y) {
 __device__ __forceinline__ uint32_t bg_twist(uint32_t a, uint32_t b, uint32_t far) {
   uint32_t y = (a & 0x80000000u) | (b & 0x7fffffffu);
   return far ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+}
+
+// One word / one random() of a lazy MT19937 stream (see bg_lib.hip: word c of the next block is made when it is read).
+// Serial loads and a store per word: only for rare draws (GLASS / LUCKY cards on the 'card_enhancement' stream).
+__device__ __forceinline__ uint32_t bg_lazy_next(uint32_t* S) {
+  uint32_t c = S[BG_MT_N] & 0x3ffu;
+  const uint32_t c1 = c + 1 == BG_MT_N ? 0u : c + 1, cf = c + BG_MT_M >= BG_MT_N ? c + BG_MT_M - BG_MT_N : c + BG_MT_M;
+  const uint32_t y = bg_twist(S[c], S[c1], S[cf]);
+  S[c] = y;
+  S[BG_MT_N] = c1 | 0x80000000u;
+  return bg_temper(y);
+}
+__device__ __forceinline__ double bg_lazy_random(uint32_t* S) {
+  const uint32_t a = bg_lazy_next(S) >> 5, b = bg_lazy_next(S) >> 6;
+  return ((double)a * 67108864.0 + (double)b) * (1.0 / 9007199254740992.0);
 }
 
 // Per-lane LDS window over the next raw words of an RNG block.  The draws of a play (joker chain: ~2 words per

@@ -14,6 +14,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 #include <string>
 #include <vector>
 
@@ -47,8 +48,10 @@ __device__ __forceinline__ void bg_emit(const BgDev& d, int env, size_t row, con
   }
 }
 
+template <bool CARDS>
 __global__ __launch_bounds__(BG_BLOCK) void bg_step_kernel(BgDev d, const int32_t* __restrict__ actions, ObsPtrs obs,
                                                           double* reward, uint8_t* term, uint8_t* trunc, InfoPtrs info) {
+  using DeckT = typename std::conditional<CARDS, Deck0C, Deck0>::type;
   __shared__ uint32_t win[BG_WIN][BG_BLOCK];
   __shared__ JTables jt;
   bg_tables_init(&jt);
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_step_kernel(BgDev d, const int32_
   bg_win_init(w, &win[0][threadIdx.x], &jt);
   Env e;
   bg_load_env(d, env, e);
-  Deck0 dk = bg_load_deck0(d, env);
+  DeckT dk; static_cast<Deck0&>(dk) = bg_load_deck0(d, env);
   ShopRegs sr; sr.valid = false;
   StepOut o;
   uint64_t mask = bg_action_mask(d, env, e, sr);
@@ -150,7 +153,7 @@ struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags;
 #ifndef BG_RB_WAVES
 #define BG_RB_WAVES 1
 #endif
-template <bool HASH>
+template <bool HASH, bool CARDS>
 __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
                                                               uint64_t env_index0, uint64_t t0, ObsPtrs obs,
                                                               int obs_stride_steps, double* reward, uint8_t* term,
@@ -183,8 +186,9 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
   const bool live = env < d.N;
   uint64_t n_steps = 0, n_eps = 0, n_plays = 0, rbits = 0, ohash = 0;
   int64_t ssum = 0;
+  using DeckT = typename std::conditional<CARDS, DeckLdsC, DeckLds>::type;
   Env e;
-  DeckLds dk;
+  DeckT dk;
   uint64_t mask = 0;
   s_prod[local] = (live && d.prod_view) ? d.prod_view[env] : 0u;
   if (local < 2) s_nitems[local] = 0;
@@ -276,7 +280,7 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
         Env be;
         bg_unpack(c, be);
         bg_derive_ready(be, s_prod[l]);
-        DeckLds bdk; bdk.col = (lds_u32*)&s_deck[0][l];
+        DeckT bdk; bdk.col = (lds_u32*)&s_deck[0][l];
         ShopRegs bsr; bsr.valid = false;
         RngWin w;
         bg_win_init(w, &win[cls][0][lane], &jt);
@@ -381,12 +385,14 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
   }
 }
 
+template <bool CARDS>
 __global__ __launch_bounds__(BG_BLOCK) void bg_reset_kernel(BgDev d, const uint8_t* __restrict__ mask_in, ObsPtrs obs) {
+  using DeckT = typename std::conditional<CARDS, Deck0C, Deck0>::type;
   int env = blockIdx.x * BG_BLOCK + threadIdx.x;
   if (env >= d.N) return;
   Env e;
   bg_load_env(d, env, e);
-  Deck0 dk = bg_load_deck0(d, env);
+  DeckT dk; static_cast<Deck0&>(dk) = bg_load_deck0(d, env);
   if (!mask_in || mask_in[env]) { bg_env_reset(d, env, e, dk); bg_store_env(d, env, e); }
   ShopRegs sr; sr.valid = false;
   uint64_t mask = bg_action_mask(d, env, e, sr);
@@ -577,6 +583,10 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_
   bg_deckmt(d, env)[BG_MT_N] = BG_LAZY_SEEDED; // lazy streams: cursor 0 (bit 31 marks "seeded" for the refill scan)
   bg_mt_seed(bg_shopgenmt(d, env), base + 2000u);
   bg_shopgenmt(d, env)[BG_MT_N] = BG_LAZY_SEEDED;
+  if (d.cardmt) { // 'card_enhancement' is stream 11 of DeterministicRNG (:96-105)
+    bg_mt_seed(d.cardmt + (size_t)env * BG_MTS, base + 11000u);
+    d.cardmt[(size_t)env * BG_MTS + BG_MT_N] = BG_LAZY_SEEDED;
+  }
   // look-ahead rings are functions of the streams: invalidate (producer counters restart at the consumer counters)
   e.d_head = 0; e.d_cons = 0; e.d_ready = 0;
   e.s_cons = 0; e.s_ready = 0;
@@ -934,6 +944,11 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (e == hipSuccess) e = bg_alloc(h, &d.ndeck, (size_t)d.KD * BG_NDECK * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.gblk, (size_t)d.KG * BG_MTS * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.sblk, (size_t)d.KS * BG_MTS * N);
+  if (e == hipSuccess && (flags & BG_FLAG_CARD_STATES)) {
+    e = bg_alloc(h, &d.cstate, (size_t)BG_NCST * N);
+    if (e == hipSuccess) e = bg_alloc(h, &d.ctmpl, (size_t)BG_NCST * N);
+    if (e == hipSuccess) e = bg_alloc(h, &d.cardmt, (size_t)BG_MTS * N);
+  }
   if (e == hipSuccess) e = bg_alloc(h, &d.deckmt, (size_t)BG_MTS * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.shopgenmt, (size_t)BG_MTS * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.wl_count, 4);
@@ -981,7 +996,7 @@ int bg_destroy(bg_handle* h) {
   if (h->ev_rollout) (void)hipEventDestroy(h->ev_rollout);
   hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
   hipFree(d.hot); hipFree(d.deck); hipFree(d.cold); hipFree(d.tmpl); hipFree(d.ndeck); hipFree(d.gblk); hipFree(d.sblk);
-  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.wl_shop); hipFree(d.sseed); hipFree(d.smeta); hipFree(d.dbg);
+  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.wl_shop); hipFree(d.sseed); hipFree(d.smeta); hipFree(d.dbg); hipFree(d.cstate); hipFree(d.ctmpl); hipFree(d.cardmt);
   delete h;
   return 0;
 }
@@ -1126,7 +1141,8 @@ int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void
   if (rc) return rc;
   rc = bg_wait_refill(h, (hipStream_t)stream, 0);
   if (rc) return rc;
-  hipLaunchKernelGGL(bg_reset_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), mask_dev, bg_obs(obs));
+  if (h->dev.cstate) hipLaunchKernelGGL(bg_reset_kernel<true>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), mask_dev, bg_obs(obs));
+  else hipLaunchKernelGGL(bg_reset_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), mask_dev, bg_obs(obs));
   BG_HIP(hipGetLastError());
   return bg_refill(h, stream);
 }
@@ -1139,8 +1155,10 @@ int bg_step(bg_handle* h, const int32_t* actions_dev, const bg_obs_ptrs* obs, do
   rc = bg_wait_refill(h, (hipStream_t)stream, 0);
   if (rc) return rc;
   bg_ev_begin(h, h->ev_step_t, (hipStream_t)stream);
-  hipLaunchKernelGGL(bg_step_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), actions_dev,
-                     bg_obs(obs), reward_dev, terminated_dev, truncated_dev, bg_info(info));
+  if (h->dev.cstate) hipLaunchKernelGGL(bg_step_kernel<true>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), actions_dev,
+                                        bg_obs(obs), reward_dev, terminated_dev, truncated_dev, bg_info(info));
+  else hipLaunchKernelGGL(bg_step_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), actions_dev,
+                          bg_obs(obs), reward_dev, terminated_dev, truncated_dev, bg_info(info));
   bg_ev_end(h, h->ev_step_t, (hipStream_t)stream);
   BG_HIP(hipGetLastError());
   return bg_refill(h, stream);
@@ -1202,12 +1220,17 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       hipStream_t st = (hipStream_t)stream;
       uint64_t tt = t0 + (uint64_t)done;
       if (h->rollout_version == 1) {
+        if (h->dev.cstate) { h->err = "card states need the block-compacted rollout kernel (BG_ROLLOUT_V=2)"; return BG_E_ARG; }
         if (hash) hipLaunchKernelGGL(bg_rollout_kernel<true>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
         else hipLaunchKernelGGL(bg_rollout_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
       } else {
         dim3 g2((h->dev.N + BG_RB - 1) / BG_RB);
-        if (hash) hipLaunchKernelGGL(bg_rollout2_kernel<true>, g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, h->th_play, h->th_other, h->th_ready);
-        else hipLaunchKernelGGL(bg_rollout2_kernel<false>, g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, h->th_play, h->th_other, h->th_ready);
+#define BG_LAUNCH_R2(HASHV, CARDSV) hipLaunchKernelGGL((bg_rollout2_kernel<HASHV, CARDSV>), g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, \
+                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, h->th_play, h->th_other, h->th_ready)
+        const bool cards = h->dev.cstate != nullptr;
+        if (hash && cards) BG_LAUNCH_R2(true, true); else if (hash) BG_LAUNCH_R2(true, false);
+        else if (cards) BG_LAUNCH_R2(false, true); else BG_LAUNCH_R2(false, false);
+#undef BG_LAUNCH_R2
       }
     }
     bg_ev_end(h, h->ev_rollout_t, (hipStream_t)stream);
@@ -1243,6 +1266,44 @@ int bg_rollout_rows(bg_handle* h, int T, int policy, uint64_t policy_seed, uint6
   if (h->rollout_version == 1) { h->err = "bg_rollout_rows needs the block-compacted rollout kernel (BG_ROLLOUT_V=2)"; return BG_E_ARG; }
   return bg_rollout_impl(h, T, policy, policy_seed, env_index0, t0, nullptr, rows_dev, (size_t)row_stride_bytes,
                          rows_stride_steps, nullptr, nullptr, nullptr, stats_dev, stream);
+}
+
+__global__ __launch_bounds__(BG_BLOCK) void bg_inject_cards_kernel(BgDev d, const uint16_t* __restrict__ cs, const uint8_t* __restrict__ mask_in, int apply_now) {
+  int env = blockIdx.x * BG_BLOCK + threadIdx.x;
+  if (env >= d.N) return;
+  if (mask_in && !mask_in[env]) return;
+  const uint4* src = (const uint4*)(cs + (size_t)env * 56); // 52 states padded to 56 u16 = 7 x 16 bytes
+#pragma unroll
+  for (int k = 0; k < BG_NCST; k++) {
+    uint4 v = src[k];
+    d.ctmpl[(size_t)k * d.N + env] = v;
+    if (apply_now) d.cstate[(size_t)k * d.N + env] = v;
+  }
+}
+
+int bg_inject_cards(bg_handle* h, const uint8_t* enh_host, const uint8_t* edition_host, const uint8_t* seal_host,
+                    const uint8_t* mask_host, int apply_now, void* stream) {
+  if (!h) return BG_E_ARG;
+  if (!h->dev.cstate) { h->err = "bg_inject_cards: the handle was created without BG_FLAG_CARD_STATES"; return BG_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  const size_t N = h->dev.N;
+  std::vector<uint16_t> packed(N * 56, 0);
+  for (size_t i = 0; i < N; i++)
+    for (int c = 0; c < 52; c++) {
+      const uint32_t e = enh_host ? enh_host[i * 52 + c] : 0, d = edition_host ? edition_host[i * 52 + c] : 0, sl = seal_host ? seal_host[i * 52 + c] : 0;
+      if (e > 15 || d > 15 || sl > 15) { h->err = "bg_inject_cards: state codes are 0..15"; return BG_E_ARG; }
+      packed[i * 56 + c] = (uint16_t)(e | (d << 4) | (sl << 8));
+    }
+  uint16_t* dcs = nullptr;
+  BG_HIP(hipMalloc(&dcs, packed.size() * sizeof(uint16_t)));
+  BG_HIP(hipMemcpyAsync(dcs, packed.data(), packed.size() * sizeof(uint16_t), hipMemcpyHostToDevice, s));
+  if (mask_host) BG_HIP(hipMemcpyAsync(h->d_mask, mask_host, N, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(bg_inject_cards_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, h->dev, (const uint16_t*)dcs,
+                     mask_host ? (const uint8_t*)h->d_mask : (const uint8_t*)nullptr, apply_now);
+  BG_HIP(hipGetLastError());
+  BG_HIP(hipStreamSynchronize(s));
+  BG_HIP(hipFree(dcs));
+  return 0;
 }
 
 int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_host, const int64_t* money_host,
@@ -1298,6 +1359,7 @@ static void bg_slices(bg_handle* h, std::vector<BgSlice>& v) {
   v.push_back({d.deckmt, 1, (size_t)BG_MTS * 4}); v.push_back({d.shopgenmt, 1, (size_t)BG_MTS * 4});
   v.push_back({d.sseed, 1, 32 * 4}); v.push_back({d.smeta, 1, 4});
   v.push_back({bg_prod_latest(h), 1, 4});
+  if (d.cstate) { v.push_back({d.cstate, BG_NCST, 16}); v.push_back({d.ctmpl, BG_NCST, 16}); v.push_back({d.cardmt, 1, (size_t)BG_MTS * 4}); }
 }
 uint64_t bg_state_blob_bytes(const bg_handle* h) {
   if (!h) return 0;

@@ -109,6 +109,10 @@ __device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, DK
   if (t0.y & 0x40000000u) e.money = (int32_t)t0.z;
   if (t0.y & 0x20000000u) e.ante = (int)bg_b(t0.y, 2);
   if (t0.y & 0x10000000u) e.levels = (uint64_t)t1.x | ((uint64_t)(t1.y & 0xffffu) << 32);
+  if constexpr (DK::kCards) { // card_states = {} (:511), then the harness re-applies its injected states
+#pragma unroll
+    for (int k = 0; k < BG_NCST; k++) d.cstate[(size_t)k * d.N + env] = d.ctmpl[(size_t)k * d.N + env];
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -234,7 +238,14 @@ __device__ __forceinline__ void bg_generate_shop(const BgDev& d, int env, Env& e
 }
 
 // balatro_env_2.py:1326-1381 (card-state gold money needs card states: not on this path)
+template <bool CARDS = false>
 __device__ __forceinline__ void bg_advance_round(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr) {
+  if constexpr (CARDS) { // :1334-1343 every GOLD card held in hand pays $3
+    int gold = 0;
+#pragma unroll 1
+    for (int i = 0; i < e.nhand; i++) if ((bg_cstate(d, env, bg_get8(e.hand, i)) & 0xfu) == 7u) gold += 3;
+    e.money += gold;
+  }
   if (e.boss_type) { e.money += 5; e.boss_type = 0; e.boss_types = 0; e.boss_cards = 0; e.face_down = 0; }
   e.round_chips = 0; e.best_hand = 0; e.hp_ante = 0;
   if (e.round == 3) {
@@ -407,23 +418,42 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   uint64_t phist = 0, pcodes = 0, pmask = 0;
   uint32_t scnt = 0;
   int n = 0, chip_sum = 0;
+  // card states (CardAdapter.to_scoring_format :287-325): BONUS +30, STONE +50 and no rank / suit, FOIL +50; the seals
+  // and the GLASS / LUCKY rolls are settled after the scorer (:703-734)
+  uint32_t stone = 0;                      // bit per play index
+  uint64_t dhist = 0;                      // rank histogram of the DECK cards played (boss Plant, face synergy)
+  uint64_t cst = 0;                        // enh | seal << 4 per play index, one byte each
 #pragma unroll 1
   for (int i = 0; i < e.nsel; i++) {
     int pos = bg_get8(e.sel, i);
     if (pos < e.nhand) {
       int ci = bg_get8(e.hand, pos);
       int code = bg_card(d, env, dk, ci);
-      phist += 1ull << (4 * ((code >> 2) + 2));
-      scnt += 1u << (4 * (code & 3));
+      int bonus = 0;
+      bool is_stone = false;
+      if constexpr (DK::kCards) {
+        const uint32_t cs = bg_cstate(d, env, ci);
+        const uint32_t enh = cs & 0xfu;
+        bonus = enh == 1u ? 30 : (enh == 6u ? 50 : 0);
+        if (((cs >> 4) & 0xfu) == 1u) bonus += 50;
+        is_stone = enh == 6u;
+        cst |= (uint64_t)(enh | (((cs >> 8) & 0xfu) << 4)) << (8 * n);
+        dhist += 1ull << (4 * ((code >> 2) + 2));
+      }
+      if (is_stone) { phist += 1ull; scnt += 1u << 16; stone |= 1u << n; } // rank 0, suit 'Stone'
+      else { phist += 1ull << (4 * ((code >> 2) + 2)); scnt += 1u << (4 * (code & 3)); }
       pcodes |= (uint64_t)code << (8 * n);
       pmask |= 1ull << ci;
-      chip_sum += bg_card_chips(code);
+      chip_sum += bg_card_chips(code) + bonus;
       n++;
       e.highlighted |= 1u << pos; // :663-666 highlights are never cleared by a play
     }
   }
+  if constexpr (!DK::kCards) dhist = phist;
   int jacks = (int)((phist >> 44) & 0xf), queens = (int)((phist >> 48) & 0xf), kings = (int)((phist >> 52) & 0xf);
-  int faces = jacks + queens + kings + (int)((phist >> 56) & 0xf); // rank >= 11 counts the ace (:862)
+  // the reward's face synergy (:862) and The Plant (boss_blinds.py:425) look at the deck card, stone or not
+  const int djqk = (int)(((dhist >> 44) & 0xf) + ((dhist >> 48) & 0xf) + ((dhist >> 52) & 0xf));
+  int faces = djqk + (int)((dhist >> 56) & 0xf); // rank >= 11 counts the ace (:862)
   BG_PROBE(5);
   // :669-671 classify deck[p] for highlighted POSITIONS p
   uint64_t hc = 0; int nh = 0;
@@ -498,8 +528,9 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
       for (int c = 0; c < 8; c++) {
         int code = (int)((pcodes >> (8 * c)) & 0xff);
         int rk = (code >> 2) + 2;
-        boff[c] = (blood && c < n && (code & 3) == 2) ? 2 * (c * nj + jb) + 2 * (eights + ((j8 >= 0 && j8 < jb && rk == 8) ? 1 : 0)) : -1;
-        if (c < n && j8 >= 0 && rk == 8) eights++;
+        const bool st = (stone >> c) & 1u; // a STONE card has no rank and no suit for the jokers
+        boff[c] = (blood && c < n && !st && (code & 3) == 2) ? 2 * (c * nj + jb) + 2 * (eights + ((j8 >= 0 && j8 < jb && !st && rk == 8) ? 1 : 0)) : -1;
+        if (c < n && j8 >= 0 && !st && rk == 8) eights++;
       }
     }
     // random() < 0.5 for random() = ((a >> 5) * 2**26 + (b >> 6)) / 2**53 is decided by the top bit of the FIRST word
@@ -515,8 +546,11 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     chips += ic; mult += im;
     x_mult *= (double)(1ull << xexp);
     // :216-244 main phase, joker order; one randint(0, 23) per joker
-    uint32_t suits = ((scnt & 0xfu) ? 1u : 0u) | ((scnt & 0xf0u) ? 2u : 0u) | ((scnt & 0xf00u) ? 4u : 0u) | ((scnt & 0xf000u) ? 8u : 0u);
-    uint32_t cond = 1u | (n <= 3 ? 2u : 0u) | (e.hands_left == 1 ? 4u : 0u) | (e.discards_left == 0 ? 8u : 0u) | (suits << 4) |
+    // bit 4 = 'Stone': complete_joker_effects.py:98-114 compare suit STRINGS, so a STONE card is a fifth kind of suit for
+    // Blackboard / Seeing Double / Flower Pot (and no suit at all for the four suit jokers)
+    uint32_t suits = ((scnt & 0xfu) ? 1u : 0u) | ((scnt & 0xf0u) ? 2u : 0u) | ((scnt & 0xf00u) ? 4u : 0u) | ((scnt & 0xf000u) ? 8u : 0u) |
+                     ((scnt & 0xf0000u) ? 16u : 0u);
+    uint32_t cond = 1u | (n <= 3 ? 2u : 0u) | (e.hands_left == 1 ? 4u : 0u) | (e.discards_left == 0 ? 8u : 0u) | ((suits & 15u) << 4) |
                     ((suits & ~9u) == 0 ? 1u << 8 : 0u) | (((suits & 1u) && __popc(suits) > 1) ? 1u << 9 : 0u) |
                     (__popc(suits) == 4 ? 1u << 10 : 0u) | (kings > 0 ? 1u << 11 : 0u) | (queens > 0 ? 1u << 12 : 0u) | (1u << (16 + ht));
     double baron = w.jt->pow15[kings];
@@ -580,7 +614,38 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     BG_PROBE(14);
   }
   int64_t final_score = (int64_t)((double)(chips * mult) * x_mult); // unified_scoring.py:286
-  // :741-742 steel needs card states (not on this path): int(score * 1.0)
+  int retriggers = 0;
+  if constexpr (DK::kCards) {
+    // :703-734 per played card: GLASS rolls once, LUCKY twice on the 'card_enhancement' stream (the second roll < 0.0667
+    // pays $20); GOLD seal $3, RED seal a retrigger, BLUE seal a planet of the played hand type
+    int extra_money = 0, blue = 0;
+#pragma unroll 1
+    for (int c = 0; c < n; c++) {
+      const uint32_t b = (uint32_t)(cst >> (8 * c)) & 0xffu, enh = b & 0xfu, seal = b >> 4;
+      if (enh == 4u) (void)bg_lazy_random(d.cardmt + (size_t)env * BG_MTS);
+      else if (enh == 8u) {
+        (void)bg_lazy_random(d.cardmt + (size_t)env * BG_MTS);
+        if (bg_lazy_random(d.cardmt + (size_t)env * BG_MTS) < 0.0667) extra_money += 20;
+      }
+      if (seal == 1u) extra_money += 3; else if (seal == 2u) retriggers++; else if (seal == 3u) blue++;
+    }
+    if (blue && e.ncons < 2) { // :732-734 guard against the un-grown list, :765-767 append under the same guard
+      const int PLANET_ID[12] = {38, 30, 31, 32, 33, 34, 35, 36, 37, 39, 40, 41};
+#pragma unroll 1
+      for (int q = 0; q < blue; q++)
+        if (e.ncons < 2) { if (e.ncons == 0) e.cons0 = PLANET_ID[ht]; else e.cons1 = PLANET_ID[ht]; e.ncons++; }
+    }
+    // :741-742 STEEL cards held in hand and not selected: x1.5 each
+    double steel = 1.0;
+    uint32_t selpos = 0;
+#pragma unroll 1
+    for (int q = 0; q < e.nsel; q++) { int sp = bg_get8(e.sel, q); if (sp < e.nhand) selpos |= 1u << sp; }
+#pragma unroll 1
+    for (int i = 0; i < e.nhand; i++)
+      if (!((selpos >> i) & 1u) && (bg_cstate(d, env, bg_get8(e.hand, i)) & 0xfu) == 5u) steel *= 1.5;
+    final_score = (int64_t)((double)final_score * steel);
+    e.money += extra_money;
+  }
   // :745-755 boss scoring ratio (boss_blinds.py:409-445)
   if (e.boss_type) {
     int64_t mc = bchips, mm = bmult;
@@ -588,7 +653,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     else if (e.boss_type == 22) mc = 0;
     else if (e.boss_type == 23) { mc = (int64_t)((double)mc * 0.75); mm = (int64_t)((double)mm * 0.75); }
     int deb = 0;
-    if (e.boss_type == 14) deb = jacks + queens + kings;                        // The Plant: face cards
+    if (e.boss_type == 14) deb = djqk;                                          // The Plant: face cards (deck rank)
     else if (e.boss_type == 24) deb = n;                                        // The Violet: every card
     else if (e.boss_type == 16) deb = __popcll(e.boss_cards & pmask);           // The Pillar: played before
     if (deb > 0) {
@@ -599,7 +664,8 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     double cr = (double)mc / (double)bchips, mr = (double)mm / (double)bmult;
     final_score = (int64_t)((double)final_score * cr * mr);
   }
-  // :758-759 int(final * (1 + 0.5 * red seals)) with no card states is the identity
+  // :758-759 int(final * (1 + 0.5 * red seals))
+  if constexpr (DK::kCards) final_score = (int64_t)((double)final_score * (1.0 + (double)retriggers * 0.5));
   // :775-786
   int64_t need1 = e.chips_needed > 1 ? e.chips_needed : 1;
   double old_progress = (double)e.round_chips / (double)need1;
@@ -674,7 +740,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   if (e.round_chips >= (int64_t)e.chips_needed) {
     double bonus = 25.0 + 10.0 * (double)e.ante;
     r += bonus < 50.0 ? bonus : 50.0;
-    bg_advance_round(d, env, e, w, sr);
+    bg_advance_round<DK::kCards>(d, env, e, w, sr);
     o.flags |= 1; // beat_blind
   } else if (e.hands_left <= 1) {
     r += -50.0 * (1.0 - new_progress);
@@ -796,6 +862,7 @@ __device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, Rn
 }
 
 // BLIND_SELECT  balatro_env_2.py:1255-1318
+template <bool CARDS = false>
 __device__ __forceinline__ void bg_step_blind(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, int action, StepOut& o) {
   if (action < 48) {
     int b = action - 45;
@@ -826,7 +893,7 @@ __device__ __forceinline__ void bg_step_blind(const BgDev& d, int env, Env& e, R
     bg_draw_cards(e);
   } else { // 48 SKIP_BLIND :1305-1316
     o.reward = -5.0;
-    bg_advance_round(d, env, e, w, sr);
+    bg_advance_round<CARDS>(d, env, e, w, sr);
     o.flags |= 4;
   }
 }
@@ -871,7 +938,7 @@ __device__ __forceinline__ void bg_env_dispatch(const BgDev& d, int env, Env& e,
       e.nsel = 0; e.sel = 0;
     }
   } else if (e.phase == 1) bg_step_shop(d, env, e, w, sr, action, o);
-  else if (e.phase == 2) bg_step_blind(d, env, e, w, sr, action, o);
+  else if (e.phase == 2) bg_step_blind<DK::kCards>(d, env, e, w, sr, action, o);
 }
 
 // the guards in front of the dispatch (balatro_env_2.py:619-627); returns true when the action must be dispatched

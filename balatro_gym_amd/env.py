@@ -88,13 +88,13 @@ class BalatroEnv(_EnvBase):
     metadata = {"render_modes": ["human", "rgb_array"], "render_fps": 4}
 
     def __init__(self, *, render_mode: str | None = None, seed: int | None = None, device: int = 0,
-                 scorer_jokers: bool = False, max_ante: int = 0):
+                 scorer_jokers: bool = False, max_ante: int = 0, card_states: bool = False):
         self.render_mode = render_mode
         self._seed = seed
         self.action_space = _spaces.Discrete(ACTION_SPACE_SIZE)
         self.observation_space = make_observation_space()
         self._vec = BalatroVecEnv(1, None if seed is None else [seed], device=device, scorer_jokers=scorer_jokers,
-                                  autoreset=False, max_ante=max_ante)
+                                  autoreset=False, max_ante=max_ante, card_states=card_states)
         self._action = torch.zeros(1, dtype=torch.int32, device=self._vec.device)
 
     # -- helpers
@@ -192,6 +192,10 @@ class BalatroEnv(_EnvBase):
     # harness helper used by the parity tests
     def inject(self, **kw):
         self._vec.inject(**kw)
+
+    def inject_cards(self, cards, apply_now: bool = True):
+        """cards = iterable of (deck_index, enhancement, edition, seal): env.card_states[idx] = CardState(...) (card_states=True)."""
+        self._vec.inject_cards([list(cards)], apply_now=apply_now)
 
 
 def make_balatro_env(**kwargs):

@@ -82,7 +82,8 @@ class BalatroVecEnv:
     num_actions = 60
 
     def __init__(self, num_envs: int, seeds: Optional[Sequence[int]] = None, *, device: int | str | torch.device = 0,
-                 scorer_jokers: bool = False, autoreset: bool = True, max_ante: int = 0, info_terms: bool = True):
+                 scorer_jokers: bool = False, autoreset: bool = True, max_ante: int = 0, info_terms: bool = True,
+                 card_states: bool = False):
         if not torch.cuda.is_available():
             raise nat.NativeError("BalatroVecEnv needs a HIP device (torch.cuda.is_available() is False); "
                                   "there is no CPU fallback")
@@ -92,7 +93,9 @@ class BalatroVecEnv:
         self.autoreset = bool(autoreset)
         self.scorer_jokers = bool(scorer_jokers)
         self.max_ante = int(max_ante)
-        flags = (nat.FLAG_SCORER_JOKERS if scorer_jokers else 0) | (nat.FLAG_AUTORESET if autoreset else 0)
+        self.card_states = bool(card_states)
+        flags = ((nat.FLAG_SCORER_JOKERS if scorer_jokers else 0) | (nat.FLAG_AUTORESET if autoreset else 0) |
+                 (nat.FLAG_CARD_STATES if card_states else 0))
         self._h = C.c_void_p()
         rc = self._L.bg_create(self.num_envs, self.device.index or 0, flags, self.max_ante, C.byref(self._h))
         if rc != 0:
@@ -260,6 +263,22 @@ class BalatroVecEnv:
         with torch.cuda.device(self.device):
             self._check(self._L.bg_inject(self._h, jptr, nptr, mptr, aptr, lptr, kptr, 1 if apply_now else 0,
                                           self._stream()), "bg_inject")
+
+    def inject_cards(self, cards, mask=None, apply_now: bool = True):
+        """Card states (cards.py CardState) per env: cards[i] = iterable of (deck_index, enhancement, edition, seal) codes.
+        Re-applied after every reset, like `inject` (needs card_states=True)."""
+        n = self.num_envs
+        enh = np.zeros((n, 52), np.uint8); edi = np.zeros((n, 52), np.uint8); seal = np.zeros((n, 52), np.uint8)
+        for i, cs in enumerate(cards):
+            for (idx, e, d, s) in cs:
+                enh[i, idx], edi[i, idx], seal[i, idx] = e, d, s
+        mk = None if mask is None else np.ascontiguousarray(np.asarray(mask, np.uint8))
+        with torch.cuda.device(self.device):
+            self._check(self._L.bg_inject_cards(
+                self._h, enh.ctypes.data_as(C.c_void_p), edi.ctypes.data_as(C.c_void_p), seal.ctypes.data_as(C.c_void_p),
+                None if mk is None else mk.ctypes.data_as(C.c_void_p), 1 if apply_now else 0, self._stream()), "bg_inject_cards")
+        if apply_now:
+            self.observe()
 
     def get_state(self, env_index: int) -> bytes:
         """save_state() (balatro_env_2.py:1575-1593) as a versioned binary blob."""

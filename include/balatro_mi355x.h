@@ -28,6 +28,7 @@ extern "C" {
 /* bg_create flags */
 #define BG_FLAG_SCORER_JOKERS 1u /* hand the scorer joker NAMES (unified_scoring.py:313-351) so the joker chain is live */
 #define BG_FLAG_AUTORESET 2u     /* SAME_STEP auto-reset: a terminated env is reset() inside the same bg_step call */
+#define BG_FLAG_CARD_STATES 4u  /* keep cards.py CardState (enhancement / edition / seal) per deck index: bg_inject_cards */
 
 /* error codes */
 #define BG_E_ARG (-1)
@@ -213,6 +214,16 @@ int bg_rollout_rows(bg_handle* h, int T, int policy, uint64_t policy_seed, uint6
 int bg_inject(bg_handle* h, const int32_t* jokers_host /*[N,5] or NULL*/, const int32_t* njokers_host /*[N]*/,
               const int64_t* money_host /*[N] or NULL*/, const int32_t* ante_host /*[N] or NULL*/,
               const uint8_t* levels_host /*[N,12] or NULL*/, const uint8_t* mask_host, int apply_now, void* stream);
+
+/* Card states (cards.py:62-139 CardState; the reference sets them through tarot cards -- not on this path -- the harness
+ * injects them directly, like env.card_states[idx] = CardState(...)): per env and deck INDEX (position in the shuffled
+ * deck, 0..51) the enhancement (0 none, 1 BONUS, 2 MULT, 3 WILD, 4 GLASS, 5 STEEL, 6 STONE, 7 GOLD, 8 LUCKY), edition
+ * (0 none, 1 FOIL, 2 HOLOGRAPHIC, 3 POLYCHROME) and seal (0 none, 1 GOLD, 2 RED, 3 BLUE, 4 PURPLE) codes, [N, 52] u8 each
+ * (NULL = all 0).  Effects on the path: balatro_env_2.py:287-325 (chips, stone), :703-767 (glass / lucky rolls on stream
+ * 'card_enhancement', seals, steel, retriggers), :1334-1343 (gold).  reset() clears the states (:511); the injected set
+ * is re-applied after every reset, like bg_inject's template.  Needs BG_FLAG_CARD_STATES at bg_create. */
+int bg_inject_cards(bg_handle* h, const uint8_t* enh_host, const uint8_t* edition_host, const uint8_t* seal_host,
+                    const uint8_t* mask_host, int apply_now, void* stream);
 
 /* Replaces: save_state()/load_state() (balatro_env_2.py:1575-1615).  Blob = versioned raw copy of one env's state
  * (game + all RNG streams + look-ahead rings).  bg_state_blob_bytes gives the size. */

@@ -12,7 +12,7 @@ from tests.helpers import OBS_KEYS, load_trace, trace_injection
 
 pytestmark = pytest.mark.gpu
 
-GPU_TRACES = ["c1_small_only", "c2_cycle3", "c3_jokers", "c5_uniform", "c5_uniform_rich"]
+GPU_TRACES = ["c1_small_only", "c2_cycle3", "c3_jokers", "c5_uniform", "c5_uniform_rich", "cards_levels"]
 TERMS = 8
 
 
@@ -40,9 +40,12 @@ def test_golden_trace(name):
     tr = load_trace(name)
     S, T = tr["actions"].shape
     seeds = [int(s) for s in tr["seeds"]]
-    env = _vec(S, seeds, scorer_jokers=bool(tr["scorer_jokers"]), autoreset=False, max_ante=int(tr["max_ante"]))
     inj = [trace_injection(tr, si) for si in range(S)]
-    assert not any(i["cards"] for i in inj)
+    has_cards = any(i["cards"] for i in inj)
+    env = _vec(S, seeds, scorer_jokers=bool(tr["scorer_jokers"]), autoreset=False, max_ante=int(tr["max_ante"]),
+               card_states=has_cards)
+    if has_cards:  # cards.py CardState per deck index, re-applied after every reset like the other injections
+        env.inject_cards([i["cards"] for i in inj], apply_now=True)
     if any(i["jokers"] or i["money"] is not None or i["ante"] is not None or i["levels"] for i in inj):
         levels = np.zeros((S, 12), np.uint8)
         for si, i in enumerate(inj):
@@ -128,9 +131,13 @@ def test_step_vs_oracle_fresh_seeds(policy, scorer):
     env.close()
 
 
-def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_index0=0, t0=0):
+def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_index0=0, t0=0, cards=None):
     """SAME_STEP auto-reset rollout on the oracle; returns per-step obs/rewards/terminated and the stats dict."""
     orc = _oracle_envs(n, seeds, scorer, max_ante, jokers)
+    if cards:
+        for o, cs in zip(orc, cards):
+            for (idx, e_, d_, s_) in cs:
+                o.set_card_state(idx, e_, d_, s_)
     obs = {k: [] for k in OBS_KEYS}
     rewards = np.zeros((T, n)); terms = np.zeros((T, n), np.uint8); acts = np.zeros((T, n), np.int32)
     stats = {"steps": 0, "episodes": 0, "plays": 0, "score_sum": 0, "reward_bits": 0}
@@ -144,6 +151,9 @@ def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_in
                 if jokers:
                     o.set_jokers(jokers[i])
                     ob = o.obs()
+                if cards:
+                    for (idx, e_, d_, s_) in cards[i]:
+                        o.set_card_state(idx, e_, d_, s_)
                 stats["episodes"] += 1
             rewards[t, i] = r; terms[t, i] = term; acts[t, i] = a
             stats["steps"] += 1
@@ -250,6 +260,37 @@ def test_packed_records_same_content_full_size():
     assert out[0][0] == out[1][0]
     for k in OBS_KEYS:
         assert torch.equal(out[0][1].tensors[k], out[1][1].tensors[k].contiguous()), k
+
+
+def test_card_states_rollout_vs_oracle():
+    """Card states (BONUS / GLASS / STEEL / STONE / GOLD / LUCKY, FOIL, GOLD / RED / BLUE seals) on random deck indexes of
+    every env, through the fused rollout with packed records: bit-exact against the oracle, resets included."""
+    from balatro_gym_amd.vec_env import RowBuffers
+    from oracle.gen_golden import IMPLEMENTED
+    n, T = 200, 128
+    seeds = [91_000 + 7 * i for i in range(n)]
+    jokers = [random.Random(3000 + i).sample(IMPLEMENTED, 5) for i in range(n)]
+    cards = []
+    for i in range(n):
+        rr = random.Random(4000 + i)
+        cards.append([(d, rr.choice([0, 1, 4, 5, 6, 7, 8]), rr.choice([0, 0, 1]), rr.choice([0, 0, 1, 2, 3]))
+                      for d in rr.sample(range(52), 20)])
+    env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4, card_states=True)
+    env.inject(jokers=jokers, apply_now=True)
+    env.inject_cards(cards, apply_now=True)
+    rb = RowBuffers(n, env.device, steps=T)
+    env.rollout(T, policy=0, policy_seed=31, obs_buffers=rb)
+    env.check()
+    got_stats = env.stats()
+    wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, T, 0, 31, True, 4, jokers, cards=cards)
+    assert np.array_equal(rb.action.cpu().numpy(), wa)
+    assert np.array_equal(rb.terminated.cpu().numpy(), wt)
+    assert np.array_equal(rb.reward.contiguous().cpu().numpy().view(np.uint64), wr.view(np.uint64))
+    for k in OBS_KEYS:
+        assert np.array_equal(rb.tensors[k].contiguous().cpu().numpy(), wobs[k]), f"record key {k} differs"
+    for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
+        assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
+    env.close()
 
 
 def test_rollout_properties_full_size():
