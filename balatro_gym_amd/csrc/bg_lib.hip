@@ -918,7 +918,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   { const char* av = getenv("BG_ASYNC_REFILL"); h->async_refill = av ? atoi(av) != 0 : true; }
   { // phase B runs when a queue reaches its threshold or fewer than th_ready lanes can still step (1/1/anything = lockstep)
     const char* a = getenv("BG_TH_PLAY"); const char* b = getenv("BG_TH_OTHER"); const char* c = getenv("BG_TH_READY");
-    h->th_play = a ? (uint32_t)atoi(a) : (uint32_t)(BG_RB / 4); h->th_other = b ? (uint32_t)atoi(b) : (uint32_t)(BG_RB * 5 / 16); h->th_ready = c ? (uint32_t)atoi(c) : (uint32_t)(BG_RB / 4);
+    h->th_play = a ? (uint32_t)atoi(a) : (uint32_t)(BG_RB * 5 / 16); h->th_other = b ? (uint32_t)atoi(b) : (uint32_t)(BG_RB * 5 / 16); h->th_ready = c ? (uint32_t)atoi(c) : (uint32_t)(BG_RB * 3 / 16);
     if (h->th_play < 1) h->th_play = 1; if (h->th_other < 1) h->th_other = 1; if (h->th_ready < 1) h->th_ready = 1;
   }
   h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
@@ -1052,7 +1052,7 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   bg_ev_begin(h, h->ev_refill_t, s);
   BG_HIP(hipMemsetAsync(d.wl_count, 0, 4 * sizeof(uint32_t), s));
   hipLaunchKernelGGL(bg_refill_scan_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, d);
-  static const int dense_cap = getenv("BG_REFILL_BLOCKS") ? atoi(getenv("BG_REFILL_BLOCKS")) : 1024;
+  static const int dense_cap = getenv("BG_REFILL_BLOCKS") ? atoi(getenv("BG_REFILL_BLOCKS")) : 512; // two refill waves per CU per kernel
   int dense = bg_grid(h) < dense_cap ? bg_grid(h) : dense_cap; // grid-stride over the compacted work lists
   // the three kinds of work are independent once the lists exist: run them side by side (each is a few hundred
   // latency-bound waves), join before the completion event
