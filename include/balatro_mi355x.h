@@ -154,7 +154,7 @@ int bg_step(bg_handle* h, const int32_t* actions_dev, const bg_obs_ptrs* obs, do
 /* Replaces: `_get_observation()` / `_get_action_mask()` (balatro_env_2.py:1426-1541) without stepping. */
 int bg_observe(bg_handle* h, const bg_obs_ptrs* obs, void* stream);
 
-/* Fused random-policy rollout: T lockstep steps with the counter-hash policy computed on device and SAME_STEP
+/* Fused random-policy rollout: T steps of every env with the counter-hash policy computed on device and SAME_STEP
  * auto-reset, observations of step t written to row t of [T, N, ...] buffers when obs_stride_steps != 0 (or
  * overwritten in place when 0).  env_index0 = global index of this handle's env 0 (sharding); t0 = first step number.
  * Replaces the driver loop of balatro_env_2.py:1835-1859 / SB3 rollout collection. */
