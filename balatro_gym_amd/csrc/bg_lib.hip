@@ -514,6 +514,7 @@ __device__ __forceinline__ uint32_t bg_lazy_commit(uint32_t* S, uint32_t c, uint
 }
 
 #define BG_MTB 16 // words per batch of the block twist
+#define BG_SSEED 128 // pre-drawn shop seeds per env (power of two, < 256: the count lives in a byte); >= 2 x the shops a launch can use
 #define BG_LAZY_SEEDED 0x80000000u // flag in the cursor word of a lazy stream (set by bg_seed)
 // genrand_uint32()'s block regeneration: dst[kk] = twist(src[kk], src[kk+1], kk < 227 ? src[kk+397] : dst[kk-227]),
 // last element uses the NEW dst[0].  dst == src gives CPython's in-place update (operands are loaded per batch before
@@ -635,14 +636,14 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
       int slot = s_cur + 1 + s_ready + emitted; while (slot >= d.KS) slot -= d.KS;
       uint32_t i = atomicAdd(&d.wl_count[3], 1u);
       d.wl_shop[2 * (size_t)i] = (uint32_t)env | ((uint32_t)slot << 24);
-      d.wl_shop[2 * (size_t)i + 1] = d.sseed[(size_t)env * 32 + head];
-      head = (head + 1) & 31; cnt--; emitted++;
+      d.wl_shop[2 * (size_t)i + 1] = d.sseed[(size_t)env * BG_SSEED + head];
+      head = (head + 1) & (BG_SSEED - 1); cnt--; emitted++;
     }
     if (emitted) {
       d.smeta[env] = (uint32_t)head | ((uint32_t)cnt << 8);
       prod = (prod & 0xffff00ffu) | ((((prod >> 8) + (uint32_t)emitted) & 0xffu) << 8);
     }
-    if (cnt < 24) { uint32_t i = atomicAdd(&d.wl_count[1], 1u); d.wl[N + i] = (uint32_t)env; }
+    if (cnt < BG_SSEED - 8) { uint32_t i = atomicAdd(&d.wl_count[1], 1u); d.wl[N + i] = (uint32_t)env; }
   }
   d.prod_out[env] = prod; // the deck / block kernels bump their byte of prod_out when their data is written
   if (d_ready < d.KD) { uint32_t i = atomicAdd(&d.wl_count[0], 1u); d.wl[i] = (uint32_t)env; }
@@ -721,14 +722,14 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_seedring_kernel(BgDev d) {
     uint32_t* mt = bg_shopgenmt(d, env);
     uint32_t cur = mt[BG_MT_N] & 0x3ffu;
 #pragma unroll 1
-    while (cnt < 32) { // almost always one window
+    while (cnt < BG_SSEED) { // one or two windows in steady state
       bg_lazy_window<BG_SEED_G>(mt, cur, win, old);
       const uint32_t off = cur & 3u, cap = 4u * BG_SEED_G - off;
       uint32_t used = 0;
-      while (cnt < 32 && used < cap) { // _randbelow(2**31): k = 32 bits, accept r < 2**31
+      while (cnt < BG_SSEED && used < cap) { // _randbelow(2**31): k = 32 bits, accept r < 2**31
         const uint32_t r = bg_temper(win[(off + used) * BG_BLOCK]);
         used++;
-        if (r < 2147483648u) { d.sseed[(size_t)env * 32 + ((head + cnt) & 31)] = r; cnt++; }
+        if (r < 2147483648u) { d.sseed[(size_t)env * BG_SSEED + ((head + cnt) & (BG_SSEED - 1))] = r; cnt++; }
       }
       cur = bg_lazy_commit<BG_SEED_G>(mt, cur, used, win, old);
     }
@@ -929,10 +930,11 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   d.N = n_envs; d.flags = flags; d.max_ante = max_ante;
   const char* kg = getenv("BG_KG"); const char* ks = getenv("BG_KS"); const char* kd = getenv("BG_KD");
   // Look-ahead depth = how many steps one bg_rollout launch may fuse (bg_max_fused_steps).  Deeper rings amortise the
-  // refill over more steps; per env they cost 2.5 KB per global / shop slot and 64 B per deck: ~198 KB (64 fused steps),
-  // ~105 KB (32) or ~60 KB (16) -- picked so that the state stays a modest share of the 288 GB.
-  const int dg = n_envs <= 262144 ? 25 : (n_envs <= 1048576 ? 13 : 8);
-  const int dsd = n_envs <= 262144 ? 48 : (n_envs <= 1048576 ? 24 : 12);
+  // refill over more steps and the end-of-launch tail (lanes that finished early wait for the slowest env of their
+  // workgroup) over more work; per env they cost 2.5 KB per global / shop slot and 64 B per deck: ~386 KB (128 fused steps),
+  // ~198 KB (64), ~105 KB (32) or ~60 KB (16) -- picked so that the state stays a modest share of the 288 GB.
+  const int dg = n_envs <= 65536 ? 49 : (n_envs <= 262144 ? 25 : (n_envs <= 1048576 ? 13 : 8));
+  const int dsd = n_envs <= 65536 ? 96 : (n_envs <= 262144 ? 48 : (n_envs <= 1048576 ? 24 : 12));
   d.KG = kg ? atoi(kg) : dg; d.KS = ks ? atoi(ks) : dsd + 1; d.KD = kd ? atoi(kd) : dsd;
   if (d.KG < 2 || d.KS < 2 || d.KD < 1 || d.KG > 250 || d.KS > 250 || d.KD > 250) { delete h; g_create_err = "bg_create: bad ring depths"; return BG_E_ARG; }
   size_t N = (size_t)n_envs;
@@ -954,7 +956,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (e == hipSuccess) e = bg_alloc(h, &d.wl_count, 4);
   if (e == hipSuccess) e = bg_alloc(h, &d.wl, 3 * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.wl_shop, 2 * N * (size_t)(d.KS - 1));
-  if (e == hipSuccess) e = bg_alloc(h, &d.sseed, 32 * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.sseed, (size_t)BG_SSEED * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.smeta, N);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_prod[0], N);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_prod[1], N);
@@ -1357,7 +1359,7 @@ static void bg_slices(bg_handle* h, std::vector<BgSlice>& v) {
   // per-env contiguous MT blocks: one "row" of KG*2560 / KS*2560 / 2560 bytes at base + env * elem
   v.push_back({d.gblk, 1, (size_t)d.KG * BG_MTS * 4}); v.push_back({d.sblk, 1, (size_t)d.KS * BG_MTS * 4});
   v.push_back({d.deckmt, 1, (size_t)BG_MTS * 4}); v.push_back({d.shopgenmt, 1, (size_t)BG_MTS * 4});
-  v.push_back({d.sseed, 1, 32 * 4}); v.push_back({d.smeta, 1, 4});
+  v.push_back({d.sseed, 1, BG_SSEED * 4}); v.push_back({d.smeta, 1, 4});
   v.push_back({bg_prod_latest(h), 1, 4});
   if (d.cstate) { v.push_back({d.cstate, BG_NCST, 16}); v.push_back({d.ctmpl, BG_NCST, 16}); v.push_back({d.cardmt, 1, (size_t)BG_MTS * 4}); }
 }

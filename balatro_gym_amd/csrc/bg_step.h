@@ -1056,8 +1056,9 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
   uint32_t mq[15];
 #pragma unroll
   for (int w = 0; w < 15; w++) {
-    uint32_t bits = (uint32_t)(mask >> (4 * w)) & 0xfu;
-    mq[w] = (bits & 1u) | ((bits & 2u) << 7) | ((bits & 4u) << 14) | ((bits & 8u) << 21);
+    // four mask bits -> four 0/1 bytes: x * (1 + 2^7 + 2^14 + 2^21) puts bit i at position 8 i (no two terms overlap)
+    const uint32_t bits = (uint32_t)(mask >> (4 * w)) & 0xfu;
+    mq[w] = __umul24(bits, 0x204081u) & 0x01010101u;
   }
   BG_MIX(((uint64_t)(uint32_t)e.hp_total << 32) | (uint32_t)e.best_hand);
   BG_MIX(e.boss_type);

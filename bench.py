@@ -115,7 +115,7 @@ def main():
                         max_ante=MAX_ANTE)
     env.inject(jokers=[jokers_for(g) for g in range(lo, hi)], apply_now=True)
     # chunk = steps per bg_rollout call = what the library fuses into one launch (ring depths: bg_create / BG_KG,KS,KD)
-    chunk = args.chunk or int(os.environ.get("BG_BENCH_CHUNK", "0")) or min(64, env.max_fused_steps)
+    chunk = args.chunk or int(os.environ.get("BG_BENCH_CHUNK", "0")) or min(128, env.max_fused_steps)
     ob = None
     if args.keep_obs and chunk > 1:
         ob = (RowBuffers if args.obs_layout == "rows" else ObsBuffers)(n, dev, steps=chunk)
