@@ -366,6 +366,7 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
 #ifdef BG_TIMING
   if (local == 0) { bg_probe_lds[0] = tA; bg_probe_lds[1] = tB; bg_probe_lds[2] = tC; bg_probe_lds[3] = tBitems; bg_probe_lds[4] = (unsigned long long)T; bg_probe_lds[15] = tIter | (tRounds << 32); }
   BG_PROBE_FLUSH(d);
+  if (local == 0 && d.dbg) { atomicMax(&d.dbg[24], tIter); atomicMin(&d.dbg[25], ~tIter); atomicAdd(&d.dbg[26], 1ull); } // iterations per workgroup: max, ~min, count
 #endif
   if (live) bg_store_env(d, env, e);
   if (stats) {

@@ -61,6 +61,8 @@ def run(n, scorer, policy, chunk, steps, obs_mode, max_ante=4, label=""):
               f"  | cycles per iteration A {out[0]/max(1,iters):7.0f} C {out[2]/max(1,iters):7.0f}  per round B {out[1]/max(1,rounds):7.0f}")
         print("    A/C sections, cycles per wave-iteration: " + " | ".join(f"{nm} {out[i]/max(1,iters)/4:.0f}" for i, nm in
               [(20, "policy"), (21, "guards+cheap+enqueue"), (16, "merge"), (17, "cap+reset"), (18, "mask"), (19, "obs")]))
+        if out[26]:
+            print(f"    iterations per workgroup-launch: mean {iters/max(1,out[26]):.1f}  max {out[24]}  min {(~out[25]) & 0xffffffffffffffff} (max/min are over all launches)")
         print(f"    phase-B wave time per round: plays {out[22]/max(1,rounds):.0f}  others {out[23]/max(1,rounds):.0f}")
         names = {5: "gather", 6: "classify", 7: "boss-check+joker-individual", 8: "bloodstone+skip", 9: "joker-main", 10: "boss-ratio+state", 11: "reward", 12: "outcome", 13: "main-prefetch", 14: "main-loop"}
         print("    play path cycles per block-step: " + " | ".join(f"{names[i]} {out[i]/blocks/T:.0f}" for i in range(5, 15)))
