@@ -125,7 +125,7 @@ def main():
         while done < nsteps:
             c = min(chunk, nsteps - done)
             env.rollout(c, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, env_index0=lo, t0=t0 + done,
-                        obs_buffers=ob if (ob is not None and c == chunk) else None, zero_stats=False)
+                        obs_buffers=ob, zero_stats=False)  # a shorter last call fills the first c rows
             if args.gather_obs and world > 1:
                 gathered = torch.empty(world * env.obs_flat.numel(), dtype=torch.uint8, device=dev)
                 dist.all_gather_into_tensor(gathered, env.obs_flat)
