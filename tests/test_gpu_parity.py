@@ -364,10 +364,14 @@ def test_single_env_gym_surface():
     env.close(); env2.close()
 
 
-def test_save_load_state_roundtrip():
+@pytest.mark.parametrize("cards", [False, True])
+def test_save_load_state_roundtrip(cards):
     import torch
     n = 64
-    env = _vec(n, [300 + i for i in range(n)], autoreset=True)
+    env = _vec(n, [300 + i for i in range(n)], autoreset=True, scorer_jokers=cards, card_states=cards)
+    if cards:  # the blob then also carries the card states, their reset copy and the 'card_enhancement' stream
+        env.inject(jokers=[[1, 61, 27][: 1 + i % 3] for i in range(n)], apply_now=True)
+        env.inject_cards([[(d, [4, 8, 5, 1][d % 4], d % 2, d % 4) for d in range(0, 52, 3)] for _ in range(n)])
     env.rollout(40, policy=0, policy_seed=3)
     blob = env.get_state(5)
     env.rollout(25, policy=0, policy_seed=3, t0=40)
