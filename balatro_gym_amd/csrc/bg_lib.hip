@@ -169,11 +169,11 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
   __shared__ uint32_t s_prod[BG_RB];
   __shared__ uint32_t s_deck[16][BG_RB];        // every env's 52 card codes (Deck0::lds)
   // one storage, two uses that never overlap in time (a workgroup barrier separates them): phase B's two RNG windows
-  // ([2][BG_WIN][64] words) and phase C's record staging (per wave 64 x 6 pieces of 16 bytes, bg_write_obs_impl)
-  constexpr int kWinBytes = 2 * BG_WIN * BG_BLOCK * 4, kStageBytes = (BG_RB / BG_BLOCK) * BG_BLOCK * 6 * 16;
+  // ([2][BG_WIN][64] words) and phase C's record staging (per wave 64 x BG_STAGE_NP pieces of 16 bytes, bg_write_obs_impl)
+  constexpr int kWinBytes = 2 * BG_WIN * BG_BLOCK * 4, kStageBytes = (BG_RB / BG_BLOCK) * BG_BLOCK * BG_STAGE_NP * 16;
   __shared__ bg_u32x4 s_scratch[(kWinBytes > kStageBytes ? kWinBytes : kStageBytes) / 16];
   uint32_t (*win)[BG_WIN][BG_BLOCK] = (uint32_t (*)[BG_WIN][BG_BLOCK])s_scratch;
-  bg_u32x4 (*s_stage)[BG_BLOCK * 6] = (bg_u32x4 (*)[BG_BLOCK * 6])s_scratch;
+  bg_u32x4 (*s_stage)[BG_BLOCK * BG_STAGE_NP] = (bg_u32x4 (*)[BG_BLOCK * BG_STAGE_NP])s_scratch;
   __shared__ unsigned long long s_rowaddr[BG_RB / BG_BLOCK][BG_BLOCK];
   __shared__ JTables jt;
   BG_PROBE_INIT();

@@ -978,7 +978,17 @@ struct RowExtra { double reward; int32_t action; uint32_t terminated; };
 typedef uint32_t bg_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bg_u32x4 lds_u4;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-struct RowStage { lds_u4* stage; lds_u64* addr; }; // reward / action / terminated ride in the record
+#ifndef BG_STAGE_NP
+#define BG_STAGE_NP 11 // 16-byte pieces of a record staged at a time: runs of 176 bytes per row and store instruction
+#endif
+struct RowStage { lds_u4* stage; lds_u64* addr; };
+// lanes of one wave exchanging data through LDS: the hardware queue is in order per wave, the compiler must not move
+// LDS accesses across the hand-over point
+#ifdef BG_WAVE_SYNC_FENCE
+#define BG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#else
+#define BG_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
+#endif // reward / action / terminated ride in the record
 
 // `row` = env + t * N for [T, N, ...] rollout buffers.  Returns a 64-bit hash of the row (rollout checksum; the same
 // value for both output layouts).
@@ -1095,25 +1105,29 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
     if (STAGE) {
       // The lanes that finished a step this iteration write their records out TOGETHER: 16 bytes per lane straight to
       // 64 different rows keeps the store path busy ~4x longer than the same bytes in row-contiguous runs (measured:
-      // 22 such stores were a quarter of the kernel).  Six 16-byte pieces of every record go to LDS, then lane `rank`
-      // stores pieces rank, rank + A, ... of the A x 6 staged ones: consecutive lanes = consecutive pieces of a row.
+      // 22 such stores were a quarter of the kernel).  BG_STAGE_NP 16-byte pieces of every record go to LDS, then lane `rank`
+      // stores pieces rank, rank + A, ... of the A x BG_STAGE_NP staged ones: consecutive lanes = consecutive pieces of a row.
       const unsigned long long act = __ballot(1);
       const uint32_t A = (uint32_t)__popcll(act);
       const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
       rs.addr[rank] = (unsigned long long)rowp;
 #pragma unroll
-      for (int sl = 0; sl < 4; sl++) {
-        const int np = sl < 3 ? 6 : 4; // pieces of this slice
+      for (int sl = 0; sl < 22 / BG_STAGE_NP; sl++) {
+        constexpr int np = BG_STAGE_NP; // pieces per slice (divides 22)
 #pragma unroll
-        for (int c = 0; c < np; c++) { const int k = 6 * sl + c; rs.stage[rank * np + c] = bg_u32x4{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]}; }
+        for (int c = 0; c < np; c++) { const int k = np * sl + c; rs.stage[rank * np + c] = bg_u32x4{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]}; }
+        // other lanes of this wave read what this lane just wrote: make the writes of the whole wave land first (the
+        // LDS queue is in order per wave; the fence keeps the compiler from moving the reads across)
+        BG_WAVE_SYNC();
 #pragma unroll
         for (int k = 0; k < np; k++) {
           const uint32_t q = (uint32_t)k * A + rank;                        // < np * A
-          const uint32_t r = np == 6 ? (q * 10923u) >> 16 : q >> 2;         // q / np
+          const uint32_t r = (q * (uint32_t)((65536 + np - 1) / np)) >> 16; // q / np (exact for q < 64 * np, np in {2, 11, 22})
           const uint32_t c = q - r * (uint32_t)np;
           const unsigned long long a = rs.addr[r];
-          *(__attribute__((address_space(1))) bg_u32x4*)(a + 16ull * (uint32_t)(6 * sl) + 16ull * c) = rs.stage[q]; // global_store, not flat
+          *(__attribute__((address_space(1))) bg_u32x4*)(a + 16ull * (uint32_t)(np * sl) + 16ull * c) = rs.stage[q]; // global_store, not flat
         }
+        BG_WAVE_SYNC(); // ... and the reads before the next slice overwrites the staging
       }
     } else {
       uint4* q = (uint4*)rowp;
