@@ -293,6 +293,12 @@ def test_card_states_rollout_vs_oracle():
     env.close()
 
 
+def test_lane_per_env_rollout_kernel(monkeypatch):
+    """The first fused kernel (BG_ROLLOUT_V=1, lane = env, lockstep) is kept for A/B comparisons: same bits."""
+    monkeypatch.setenv("BG_ROLLOUT_V", "1")
+    test_fused_rollout_vs_oracle(2, True)
+
+
 def test_rollout_properties_full_size():
     """Size-independent properties at BASELINE.json's N = 65 536: determinism, chunking invariance (one T=48 call ==
     48 T=1 calls), sharding invariance (two half-size handles with env_index0 offsets == one full handle)."""
