@@ -219,6 +219,7 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
   int action = 0;
   StepOut o;
   bg_step_init(o);
+  const PolicyLane pl = bg_policy_lane(policy, policy_seed, env_index0 + (uint64_t)env);
   __syncthreads();
   for (;;) {
 #ifdef BG_TIMING
@@ -229,7 +230,7 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d
     if (live && !blocked && t < T) {
       BG_PROBE_BEGIN();
       bg_step_init(o);
-      action = bg_policy_action(e, mask, policy, policy_seed, env_index0 + (uint64_t)env, t0 + (uint64_t)t);
+      action = bg_policy_action(e, mask, policy, pl, t0 + (uint64_t)t);
       BG_PROBE(20);
       bool deferred = false;
       if (bg_step_guards(e, mask, action, o)) {

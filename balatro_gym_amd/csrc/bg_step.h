@@ -1200,6 +1200,44 @@ __device__ __forceinline__ uint64_t bg_write_obs(const BgDev& d, int env, size_t
   return bg_write_obs_impl<HASH, false>(d, env, row, e, dk, p, mask, sr, rx, RowStage{nullptr, nullptr});
 }
 
+// The same policy with everything that depends only on the env hoisted out of the step loop (the 64-bit `% 3` and one of
+// the three 64-bit multiplies), and the k-th valid action found by a branch-free popcount descent instead of a loop whose
+// trip count differs per lane.
+struct PolicyLane { uint64_t seed_env; int blind; };
+__device__ __forceinline__ PolicyLane bg_policy_lane(int policy, uint64_t policy_seed, uint64_t env_index) {
+  PolicyLane p;
+  p.seed_env = policy_seed + 0x9E3779B97F4A7C15ull * (env_index + 1);
+  p.blind = policy == 2 ? 45 + (int)(env_index % 3) : 45;
+  return p;
+}
+__device__ __forceinline__ int bg_policy_action(const Env& e, uint64_t mask, int policy, const PolicyLane& pl, uint64_t t) {
+  if (policy != 0) {
+    if (e.phase == 2) return pl.blind;
+    if (e.phase == 1) return 31;
+  }
+  const int nv = __popcll(mask);
+  if (!nv) return 0;
+  uint64_t x = pl.seed_env + 0xD1B54A32D192ED03ull * (t + 1);
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  uint32_t k = (uint32_t)(x >> 32) % (uint32_t)nv;
+  const uint32_t lo = (uint32_t)mask, hi = (uint32_t)(mask >> 32);
+  uint32_t c = (uint32_t)__popc(lo);
+  uint32_t w = k < c ? lo : hi;
+  int base = k < c ? 0 : 32;
+  k = k < c ? k : k - c;
+#pragma unroll
+  for (int sh = 16; sh >= 1; sh >>= 1) { // k-th set bit of w
+    c = (uint32_t)__popc(w & ((1u << sh) - 1u));
+    const bool up = k >= c;
+    w = up ? w >> sh : w;
+    base += up ? sh : 0;
+    k = up ? k - c : k;
+  }
+  return base;
+}
+
 // counter-hash policy on a 60-bit action mask; phase overrides for the scripted policies
 __device__ __forceinline__ int bg_policy_action(const Env& e, uint64_t mask, int policy, uint64_t policy_seed,
                                                 uint64_t env_index, uint64_t t) {
