@@ -108,3 +108,27 @@ def test_sb3_fixed_observation_space_and_transform():
             assert torch.equal(fixed[k].reshape(n, -1).to(torch.int64), obs[k].reshape(n, -1).to(torch.int64)), k
         else:
             assert not fixed[k].any()
+
+
+def test_packed_record_layout_matches_header():
+    """The record offsets the Python views use are the BG_ROW_* constants of include/balatro_mi355x.h, every key is
+    naturally aligned and no two fields overlap."""
+    import re
+    from balatro_gym_amd import _native as nat
+    text = open(os.path.join(ROOT, "include", "balatro_mi355x.h")).read()
+    hdr = {m.group(1).lower(): int(m.group(2)) for m in re.finditer(r"#define BG_ROW_([A-Z_0-9]+)\s+(\d+)", text)}
+    assert hdr.pop("bytes") == nat.ROW_BYTES == 352
+    offs = dict(nat.ROW_OFFSETS)
+    offs.update({k: v[0] for k, v in nat.ROW_EXTRA.items()})
+    assert offs == hdr
+    spans = []
+    for k, off in offs.items():
+        dt, shape = nat.OBS_SPEC[k] if k in nat.OBS_SPEC else (nat.ROW_EXTRA[k][1], ())
+        item = np.dtype(dt).itemsize
+        size = item * int(np.prod(shape, dtype=np.int64))
+        assert off % item == 0, k
+        spans.append((off, off + size, k))
+    spans.sort()
+    for (a0, a1, ka), (b0, b1, kb) in zip(spans, spans[1:]):
+        assert a1 <= b0, (ka, kb)
+    assert spans[-1][1] <= nat.ROW_BYTES
