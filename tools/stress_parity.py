@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Development aid: a longer randomized parity run than the test suite (fused rollout, packed records, vs the C oracle)."""
+import os, random, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from balatro_gym_amd import BalatroVecEnv
+from balatro_gym_amd.vec_env import RowBuffers
+from tests.helpers import OBS_KEYS
+from tests.test_gpu_parity import _oracle_rollout
+from bench import IMPLEMENTED
+
+def run(n, T, policy, scorer, cards_on, seed0, max_ante):
+    seeds = [seed0 + 11 * i for i in range(n)]
+    jokers = [random.Random(seed0 + i).sample(IMPLEMENTED if i % 2 else list(range(1, 151)), i % 6) for i in range(n)] if scorer else None
+    cards = None
+    if cards_on:
+        cards = []
+        for i in range(n):
+            rr = random.Random(seed0 * 7 + i)
+            cards.append([(d, rr.choice([0, 1, 4, 5, 6, 7, 8]), rr.choice([0, 0, 1, 2]), rr.choice([0, 0, 1, 2, 3])) for d in rr.sample(range(52), 26)])
+    env = BalatroVecEnv(n, seeds, scorer_jokers=scorer, autoreset=True, max_ante=max_ante, card_states=cards_on)
+    if jokers:
+        env.inject(jokers=jokers, apply_now=True)
+    if cards:
+        env.inject_cards(cards, apply_now=True)
+    rb = RowBuffers(n, env.device, steps=T)
+    t = time.time()
+    env.rollout(T, policy=policy, policy_seed=seed0, obs_buffers=rb)
+    env.check()
+    st = env.stats()
+    wobs, wr, wt, wa, wst = _oracle_rollout(n, seeds, T, policy, seed0, scorer, max_ante, jokers, cards=cards)
+    assert np.array_equal(rb.action.cpu().numpy(), wa)
+    assert np.array_equal(rb.terminated.cpu().numpy(), wt)
+    assert np.array_equal(rb.reward.contiguous().cpu().numpy().view(np.uint64), wr.view(np.uint64))
+    for k in OBS_KEYS:
+        assert np.array_equal(rb.tensors[k].contiguous().cpu().numpy(), wobs[k]), k
+    for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
+        assert st[k] == wst[k], k
+    env.close()
+    print(f"ok n={n} T={T} policy={policy} scorer={scorer} cards={cards_on} episodes={st['episodes']} plays={st['plays']} ({time.time()-t:.0f} s)", flush=True)
+
+if __name__ == "__main__":
+    run(1000, 300, 0, True, False, 123457, 6)
+    run(1000, 300, 2, True, False, 223457, 4)
+    run(777, 260, 0, True, True, 323457, 8)
+    run(1500, 200, 0, False, False, 423457, 0)
+    run(1000, 300, 1, False, False, 523457, 0)
+    print("STRESS OK")
