@@ -41,6 +41,11 @@ def run(n, T, policy, scorer, cards_on, seed0, max_ante):
     print(f"ok n={n} T={T} policy={policy} scorer={scorer} cards={cards_on} episodes={st['episodes']} plays={st['plays']} ({time.time()-t:.0f} s)", flush=True)
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "big":
+        run(8192, 384, 0, True, True, 987001, 8)
+        run(8192, 384, 2, True, False, 987002, 4)
+        print("BIG STRESS OK")
+        sys.exit(0)
     run(1000, 300, 0, True, False, 123457, 6)
     run(1000, 300, 2, True, False, 223457, 4)
     run(777, 260, 0, True, True, 323457, 8)
