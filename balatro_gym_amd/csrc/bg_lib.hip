@@ -815,6 +815,7 @@ struct bg_handle {
   uint32_t* d_prod[2];
   long refill_seq;       // refills launched so far; refill #i writes d_prod[i & 1]
   uint32_t th_play, th_other, th_ready; // phase-B batching thresholds of bg_rollout2_kernel (BG_TH_PLAY / _OTHER / _READY)
+  uint32_t thk_play, thk_other, thk_ready; // the same when the output is one array per key (lighter batching: less step drift)
   bool async_refill;     // BG_ASYNC_REFILL (default on): bg_rollout overlaps refill #i with rollout chunk i+1
   hipStream_t side, side2, side3; // side: overlapped refills; side2/3: the deck and block kernels of one refill run beside the shop kernel
   hipEvent_t ev_scan, ev_deck, ev_gblk;
@@ -922,6 +923,10 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   { // phase B runs when a queue reaches its threshold or fewer than th_ready lanes can still step (1/1/anything = lockstep)
     const char* a = getenv("BG_TH_PLAY"); const char* b = getenv("BG_TH_OTHER"); const char* c = getenv("BG_TH_READY");
     h->th_play = a ? (uint32_t)atoi(a) : (uint32_t)(BG_RB * 5 / 16); h->th_other = b ? (uint32_t)atoi(b) : (uint32_t)(BG_RB * 5 / 16); h->th_ready = c ? (uint32_t)atoi(c) : (uint32_t)(BG_RB * 3 / 16);
+    // per-key [T, N] arrays: envs that drift apart in time complete the 32-byte sectors of the narrow keys with several
+    // partial writes, so the drift is kept short there (2.15 G -> 2.98 G env-steps/s; packed records are immune)
+    h->thk_play = a ? h->th_play : (uint32_t)(BG_RB / 8); h->thk_other = b ? h->th_other : (uint32_t)(BG_RB / 8);
+    h->thk_ready = c ? h->th_ready : (uint32_t)(BG_RB * 25 / 32);
     if (h->th_play < 1) h->th_play = 1; if (h->th_other < 1) h->th_other = 1; if (h->th_ready < 1) h->th_ready = 1;
   }
   h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
@@ -1230,7 +1235,9 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       } else {
         dim3 g2((h->dev.N + BG_RB - 1) / BG_RB);
 #define BG_LAUNCH_R2(HASHV, CARDSV) hipLaunchKernelGGL((bg_rollout2_kernel<HASHV, CARDSV>), g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, \
-                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, h->th_play, h->th_other, h->th_ready)
+                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr)
+        const bool per_key = !rows_dev && obs && obs_stride_steps != 0; // [T, N] arrays per key
+        const uint32_t thp = per_key ? h->thk_play : h->th_play, tho = per_key ? h->thk_other : h->th_other, thr = per_key ? h->thk_ready : h->th_ready;
         const bool cards = h->dev.cstate != nullptr;
         if (hash && cards) BG_LAUNCH_R2(true, true); else if (hash) BG_LAUNCH_R2(true, false);
         else if (cards) BG_LAUNCH_R2(false, true); else BG_LAUNCH_R2(false, false);
