@@ -445,6 +445,13 @@ void bo_set_template_jokers(bo_env* e, const int32_t* ids, int n) {
   for (int i = 0; i < e->tmpl_njokers; i++) e->tmpl_jokers[i] = ids[i];
   bo_set_jokers(e, ids, e->tmpl_njokers);
 }
+/* harness injection: state.consumables = [names of ids]; kept as the template bo_rollout re-applies after every reset */
+void bo_set_consumables(bo_env* e, const int32_t* ids, int n) {
+  e->tmpl_ncons = n > 2 ? 2 : (n < 0 ? 0 : n);
+  for (int i = 0; i < e->tmpl_ncons; i++) e->tmpl_cons[i] = ids[i];
+  e->nconsumables = e->tmpl_ncons;
+  for (int i = 0; i < e->tmpl_ncons; i++) e->consumables[i] = ids[i];
+}
 void bo_set_money(bo_env* e, int64_t money) { e->money = money; }
 void bo_set_ante(bo_env* e, int ante) { e->ante = ante; }
 void bo_set_hand_level(bo_env* e, int ht, int level) { e->hand_levels[ht] = (uint8_t)(level < 1 ? 1 : level > 15 ? 15 : level); e->obs_levels[ht] = e->hand_levels[ht]; }
@@ -492,7 +499,7 @@ void bo_get_obs(const bo_env* e, bo_obs* o) { /* balatro_env_2.py:1473-1541 */
   for (int i = 0; i < e->njokers && i < 10; i++) o->joker_ids[i] = (int16_t)e->jokers[i];
   o->joker_slots = (int8_t)e->joker_slots;
   o->consumable_count = (int8_t)e->nconsumables;
-  for (int i = 0; i < e->nconsumables && i < 5; i++) o->consumables[i] = (int16_t)e->consumables[i];
+  for (int i = 0; i < e->nconsumables && i < 5; i++) o->consumables[i] = (int16_t)((e->consumables[i] & 0x80) ? 0 : e->consumables[i]); /* enum-form names map to 0 (:1570) */
   o->consumable_slots = (int8_t)e->consumable_slots;
   o->shop_rerolls = (int16_t)e->shop_reroll_cost_state;
   for (int i = 0; i < 12; i++) o->hand_levels[i] = (int8_t)e->obs_levels[i];
@@ -999,6 +1006,189 @@ static void step_blind_select(bo_env* e, int action, double* reward, bo_info* in
   }
 }
 
+
+/* ---------------------------------------------------------------------------------------------------------
+ * _use_consumable (balatro_env_2.py:1066-1172) over ConsumableManager.use_consumable (consumables.py:622-652),
+ * TarotEffects.apply_tarot (:111-327) and SpectralEffects.apply_spectral (:354-613).
+ *
+ * A consumable is held as its _get_consumable_ids id (:1545-1567: tarots 1-22, planets 30-41, spectrals 50-67);
+ * bit 7 marks a name in enum form ('THE_FOOL', what The Emperor creates, consumables.py:168): it is used like the
+ * natural name (TarotCard[name.upper().replace(' ', '_')], :631) but the observation shows id 0.
+ *
+ * Facts of the reference this follows (all reproduced by the golden trace `consumables`):
+ *  - target cards are CLASSES made by CardAdapter.to_consumable_format (:328-343), so rank / suit edits (Strength, Death,
+ *    Star, Moon, Sun, World) never reach the deck; only enhancement / edition / seal are copied back (:1122-1138), as the
+ *    INTEGER values of consumables.py's enums (its Seal enum is RED 1, BLUE 2, GOLD 3, PURPLE 4 while cards.py, which
+ *    the env compares against, has GOLD 1, RED 2, BLUE 3: Talisman's "gold" seal acts as a blue one, and so on);
+ *  - to_dict()['consumables'] is the live list (:220): created items are appended by the effect AND again by :1157-1160;
+ *    to_dict()['jokers'] is a fresh list, so joker edits (Ankh, Hex, Wraith's append) are lost and only :1147-1155 counts;
+ *  - list.remove(target) raises ValueError (Hanged Man, Familiar, Grim, Incantation with a target) and cards.Card is a
+ *    frozen dataclass (Sigil, Ouija raise after their random.choice): BO_ERR_CONSUMABLE_RAISES, reward -1.0 by harness
+ *    convention, the state stays as the exception leaves it (nothing popped, selection kept);
+ *  - Immolate and Cryptid change the deck length: not restated (BO_ERR_CONSUMABLE_DECK, state untouched).
+ * --------------------------------------------------------------------------------------------------------- */
+static const int WRAITH_JOKER[14] = {137, 138, 139, 140, 0, 142, 143, 144, 145, 146, 147, 148, 149, 150}; /* consumables.py:474-476 by JOKER_LIBRARY name; 'Drivers License' is not a library name */
+static const int SOUL_JOKER[5] = {146, 147, 148, 149, 150};                                               /* :590 */
+
+static void use_consumable(bo_env* e, int ci, double* reward, bo_info* info) {
+  if (ci >= e->nconsumables) { *reward = -1.0; info->error = BO_ERR_CONSUMABLE; return; } /* :1068-1069 (masked out before) */
+  const int code = e->consumables[ci], id = code & 0x7f;
+  /* :1074-1083 target cards in selection order */
+  int tgt[8], nt = 0;
+  for (int i = 0; i < e->nsel; i++) {
+    int pos = e->sel[i];
+    if (pos < e->nhand && e->hand[pos] < 52) tgt[nt++] = e->hand[pos];
+  }
+  bo_mt* g = &e->grand;
+  int success = 0, raises = 0, unsupported = 0;
+  int64_t money_gained = 0;
+  int planet = -1;
+  int aff[8], naff = 0, set_enh = -1, set_edi = -1, set_seal = -1; /* cards_affected + the attribute the effect changed */
+  int items[4], nitems = 0, jcreated[2], njc = 0, hs_change = 0;
+  const int slots = e->consumable_slots;
+#define AFFECT_FIRST(n) do { for (int i_ = 0; i_ < nt && i_ < (n); i_++) aff[naff++] = tgt[i_]; } while (0)
+  switch (id) {
+    case 1: /* The Fool :127-134 */
+      if (e->nconsumables > 0) {
+        int c = e->consumables[bo_mt_randbelow(g, (uint32_t)e->nconsumables)];
+        if (e->nconsumables < 5) e->consumables[e->nconsumables++] = c; /* live list, no slot check */
+        items[nitems++] = c; success = 1;
+      }
+      break;
+    case 2: case 4: case 6: /* Magician LUCKY :136-143, Empress MULT :157-164, Hierophant BONUS :177-184 */
+      if (nt > 0) { AFFECT_FIRST(2); set_enh = id == 2 ? 8 : id == 4 ? 2 : 1; success = 1; }
+      break;
+    case 3: /* The High Priestess :145-155: choice first, slot check second */
+      for (int k = 0; k < 2; k++) {
+        int p = 30 + (int)bo_mt_randbelow(g, 9);
+        if (e->nconsumables < slots) { e->consumables[e->nconsumables++] = p; items[nitems++] = p; }
+      }
+      success = 1;
+      break;
+    case 5: /* The Emperor :166-175: slot check first; names in enum form */
+      for (int k = 0; k < 2; k++)
+        if (e->nconsumables < slots) {
+          int t = (1 + (int)bo_mt_randbelow(g, 22)) | 0x80;
+          e->consumables[e->nconsumables++] = t; items[nitems++] = t;
+        }
+      success = 1;
+      break;
+    case 7: case 8: case 12: case 16: case 17: /* Lovers WILD, Chariot STEEL, Justice GLASS, Devil GOLD, Tower STONE */
+      if (nt >= 1) { AFFECT_FIRST(1); set_enh = id == 7 ? 3 : id == 8 ? 5 : id == 12 ? 4 : id == 16 ? 7 : 6; success = 1; }
+      break;
+    case 9: /* Strength :202-210: only cards below the ace are listed; the rank edit is lost */
+      if (nt > 0) { for (int i = 0; i < nt && i < 2; i++) if ((e->deck[tgt[i]] >> 2) + 2 < 14) aff[naff++] = tgt[i]; success = 1; }
+      break;
+    case 10: /* The Hermit :212-219 */
+      money_gained = e->money < 20 ? e->money : 20; success = 1;
+      break;
+    case 11: /* Wheel of Fortune :221-231: `target_cards and random.random() < 0.25` */
+      if (nt > 0 && bo_mt_random(g) < 0.25) { set_edi = 1 + (int)bo_mt_randbelow(g, 3); aff[naff++] = tgt[0]; success = 1; }
+      break;
+    case 13: /* The Hanged Man :241-251 */
+      if (nt > 0) raises = 1;
+      break;
+    case 14: /* Death :253-261 */
+      if (nt >= 2) { AFFECT_FIRST(2); success = 1; }
+      break;
+    case 15: /* Temperance :263-273 */
+      money_gained = 5 * e->njokers < 50 ? 5 * e->njokers : 50; success = 1;
+      break;
+    case 18: case 19: case 20: case 22: /* Star / Moon / Sun / World :291-316,329-336: suit edits are lost */
+      if (nt > 0) { AFFECT_FIRST(3); success = 1; }
+      break;
+    case 21: { /* Judgement :318-327 */
+      int p = 30 + (int)bo_mt_randbelow(g, 9);
+      if (e->nconsumables < slots) { e->consumables[e->nconsumables++] = p; items[nitems++] = p; }
+      success = 1;
+      break;
+    }
+    case 50: case 51: case 52: /* Familiar / Grim / Incantation :373-457: deck.remove(target class) */
+      if (nt >= 1) raises = 1;
+      break;
+    case 53: case 61: case 63: case 64: /* Talisman GOLD=3, Deja Vu RED=1, Trance BLUE=2, Medium PURPLE=4 (consumables.Seal values) */
+      if (nt >= 1) { AFFECT_FIRST(1); set_seal = id == 53 ? 3 : id == 61 ? 1 : id == 63 ? 2 : 4; success = 1; }
+      break;
+    case 54: /* Aura :467-474 */
+      if (nt >= 1) { set_edi = 1 + (int)bo_mt_randbelow(g, 3); aff[naff++] = tgt[0]; success = 1; }
+      break;
+    case 55: /* Wraith :476-488 */
+      if (e->njokers < e->joker_slots) { jcreated[njc++] = WRAITH_JOKER[bo_mt_randbelow(g, 14)]; hs_change = -1; success = 1; }
+      break;
+    case 56: case 57: { /* Sigil :490-498, Ouija :500-509: random.choice, then assignment to a frozen dataclass */
+      int n = 0;
+      for (int i = 0; i < e->nhand; i++) n += e->hand[i] < 52;
+      if (n > 0) { bo_mt_randbelow(g, id == 56 ? 4 : 13); raises = 1; }
+      break;
+    }
+    case 58: /* Ectoplasm :511-517 */
+      if (e->njokers > 0) { hs_change = -1; success = 1; }
+      break;
+    case 59: /* Immolate :519-531 */
+      unsupported = 1;
+      break;
+    case 60: /* Ankh :533-543: the "name" is a {'name','id'} dict unless the scorer-level harness hands out names */
+      if (e->njokers > 0) {
+        int k = (int)bo_mt_randbelow(g, (uint32_t)e->njokers);
+        jcreated[njc++] = (e->flags & BO_FLAG_SCORER_JOKERS) ? e->jokers[k] : 0;
+        success = 1;
+      }
+      break;
+    case 62: /* Hex :553-563 */
+      if (e->njokers > 0) { bo_mt_randbelow(g, (uint32_t)e->njokers); success = 1; }
+      break;
+    case 65: /* Cryptid :581-591 */
+      if (nt >= 1) unsupported = 1;
+      break;
+    case 66: /* The Soul :593-601 */
+      if (e->njokers < e->joker_slots) { jcreated[njc++] = SOUL_JOKER[bo_mt_randbelow(g, 5)]; success = 1; }
+      break;
+    case 67: /* Black Hole :603-610 */
+      success = 1;
+      break;
+    default:
+      if (id >= 30 && id <= 41) { planet = id - 30; success = 1; } /* :644-652 */
+      break; /* unknown name :654 */
+  }
+#undef AFFECT_FIRST
+  if (raises) { *reward = -1.0; info->error = BO_ERR_CONSUMABLE_RAISES; return; }
+  if (unsupported) { *reward = -1.0; info->error = BO_ERR_CONSUMABLE_DECK; return; }
+  if (success) { /* :1093-1164 */
+    double r = 0.0;
+    for (int i = ci; i + 1 < e->nconsumables; i++) e->consumables[i] = e->consumables[i + 1]; /* pop(consumable_idx) */
+    e->nconsumables--;
+    if (money_gained > 0) { e->money += money_gained; r += (double)money_gained / 10.0; }
+    if (planet >= 0) {
+      static const int PLANET_HT[12] = {1, 2, 3, 4, 5, 6, 7, 8, 0, 9, 10, 11}; /* Mercury..Eris :1103-1116 */
+      int ht = PLANET_HT[planet];
+      if (e->hand_levels[ht] < 15) e->hand_levels[ht]++;  /* engine.apply_planet scoring_engine.py:82-85 */
+      e->obs_levels[ht]++;                                 /* state.hand_levels[...] += 1 (uncapped) :1119 */
+      r += 10.0;
+    }
+    if (naff) {
+      for (int i = 0; i < naff; i++) {
+        if (set_enh >= 0) e->enh[aff[i]] = (uint8_t)set_enh;
+        if (set_edi >= 0) e->edi[aff[i]] = (uint8_t)set_edi;
+        if (set_seal >= 0) e->seal[aff[i]] = (uint8_t)set_seal;
+      }
+      r += (double)naff * 2.0;
+    }
+    if (njc) {
+      for (int i = 0; i < njc; i++)
+        if (e->njokers < e->joker_slots && jcreated[i] > 0 && e->njokers < BO_MAX_JOKERS) e->jokers[e->njokers++] = jcreated[i];
+      r += (double)njc * 15.0;
+    }
+    if (nitems) {
+      for (int i = 0; i < nitems; i++)
+        if (e->nconsumables < slots && e->nconsumables < 5) e->consumables[e->nconsumables++] = items[i];
+      r += (double)nitems * 5.0;
+    }
+    if (hs_change) e->hand_size += hs_change;
+    *reward = r;
+  } else { *reward = -1.0; info->error = BO_ERR_CONSUMABLE; } /* :1166-1168 */
+  e->nsel = 0; /* :1171 */
+}
+
 void bo_step(bo_env* e, int action, double* reward, uint8_t* terminated, bo_info* info) {
   bo_info local;
   if (!info) info = &local;
@@ -1021,23 +1211,7 @@ void bo_step(bo_env* e, int action, double* reward, uint8_t* terminated, bo_info
         if (at >= 0) { for (int i = at; i + 1 < e->nsel; i++) e->sel[i] = e->sel[i + 1]; e->nsel--; }
         else e->sel[e->nsel++] = pos;
       }
-    } else { /* 10..14 _use_consumable :1066-1172 -- planets only (consumables.py:644-652); tarots/spectrals are
-              * outside the restated path and report BO_ERR_CONSUMABLE */
-      int ci = action - 10;
-      int id = e->consumables[ci];
-      if (id >= 30 && id <= 41) {
-        static const int PLANET_HT[12] = {1, 2, 3, 4, 5, 6, 7, 8, 0, 9, 10, 11}; /* Mercury..Eris :1103-1116 */
-        int ht = PLANET_HT[id - 30];
-        for (int i = ci; i + 1 < e->nconsumables; i++) e->consumables[i] = e->consumables[i + 1];
-        e->nconsumables--;
-        if (e->hand_levels[ht] < 15) e->hand_levels[ht]++;  /* engine.apply_planet scoring_engine.py:82-85 */
-        e->obs_levels[ht]++;                                 /* state.hand_levels[...] += 1 (uncapped) :1119 */
-        *reward = 10.0;
-      } else {
-        *reward = -1.0; info->error = BO_ERR_CONSUMABLE;
-      }
-      e->nsel = 0; /* :1171 */
-    }
+    } else use_consumable(e, action - 10, reward, info); /* 10..14 :1066-1172 */
   } else if (e->phase == BO_PHASE_SHOP) step_shop(e, action, reward, info);
   else if (e->phase == BO_PHASE_BLIND_SELECT) step_blind_select(e, action, reward, info);
   /* CurriculumBalatroEnv.step (train_balatro_agent.py:146-152) wraps EVERY step, also the guarded ones */
@@ -1072,6 +1246,7 @@ int64_t bo_rollout(bo_env** envs, int n, int64_t env_index0, int T, int policy, 
       if (term) {
         bo_reset(e, 0, 0);
         if (e->tmpl_njokers > 0) bo_set_jokers(e, e->tmpl_jokers, e->tmpl_njokers);
+        if (e->tmpl_ncons > 0) bo_set_consumables(e, e->tmpl_cons, e->tmpl_ncons);
         eps++;
       }
       bo_get_obs(e, &obs); /* the reference builds the observation on every step (:1064) */

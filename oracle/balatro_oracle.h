@@ -46,9 +46,11 @@ enum {
   BO_ERR_VERDANT = 5,            /* boss_blinds.py:405 */
   BO_ERR_REROLL_FUNDS = 6,       /* shop.py:173 */
   BO_ERR_JOKER_SLOTS = 7,        /* shop.py:196 */
-  BO_ERR_CONSUMABLE = 8,         /* consumables are outside the restated path */
+  BO_ERR_CONSUMABLE = 8,         /* balatro_env_2.py:1166-1168 result['success'] is False */
   BO_ERR_MAX_ANTE = 9,           /* balatro_env_2.py:620 (terminated, reward 0) */
-  BO_ERR_MAX_SCORE = 10          /* balatro_env_2.py:623 */
+  BO_ERR_MAX_SCORE = 10,         /* balatro_env_2.py:623 */
+  BO_ERR_CONSUMABLE_RAISES = 11, /* the reference raises here (consumables.py:246,381,496,506): reward -1.0 by harness convention */
+  BO_ERR_CONSUMABLE_DECK = 12    /* Immolate / Cryptid change the deck length: not restated */
 };
 
 /* info.flags */
@@ -156,6 +158,8 @@ typedef struct bo_env {
   /* harness: reset template used by bo_rollout */
   int32_t tmpl_jokers[5];
   int32_t tmpl_njokers;
+  int32_t tmpl_cons[2];
+  int32_t tmpl_ncons;
 } bo_env;
 
 /* ---- CPython random.Random restated (Appendix B of SURVEY.md) ---- */
@@ -194,6 +198,7 @@ void bo_set_jokers(bo_env* e, const int32_t* ids, int n);          /* harness in
 void bo_set_card_state(bo_env* e, int deck_idx, int enh, int edi, int seal);
 void bo_set_hand_level(bo_env* e, int hand_type, int level);
 void bo_set_template_jokers(bo_env* e, const int32_t* ids, int n); /* jokers now + after every reset in bo_rollout */
+void bo_set_consumables(bo_env* e, const int32_t* ids, int n);     /* harness injection: state.consumables by id (config 4) */
 void bo_set_money(bo_env* e, int64_t money);   /* harness injection: state.money */
 void bo_set_ante(bo_env* e, int ante);         /* harness injection: state.ante */
 int bo_policy_action(const bo_env* e, int policy, uint64_t policy_seed, uint64_t env_index, uint64_t t);

@@ -155,7 +155,7 @@ def gen_score_hand():
 
 
 def trace(cfg_name, seeds, T, policy, scorer=False, jokers_fn=None, max_ante=0, money_fn=None, ante_fn=None,
-          cards_fn=None, levels_fn=None, pseed=7):
+          cards_fn=None, levels_fn=None, pseed=7, cons_fn=None):
     S = len(seeds)
     rec = {
         "seeds": np.array(seeds, dtype=np.int64), "policy": np.int32(policy), "policy_seed": np.uint64(pseed),
@@ -166,6 +166,7 @@ def trace(cfg_name, seeds, T, policy, scorer=False, jokers_fn=None, max_ante=0, 
         "inj_jokers": np.zeros((S, 5), np.int32), "inj_njokers": np.zeros(S, np.int32),
         "inj_money": np.full(S, -1, np.int64), "inj_ante": np.full(S, -1, np.int32),
         "inj_cards": np.zeros((S, 52, 3), np.uint8), "inj_levels": np.zeros((S, 12), np.uint8),
+        "inj_cons": np.zeros((S, 2), np.int32), "inj_ncons": np.zeros(S, np.int32),
     }
     obs_rec = None
     for si, seed in enumerate(seeds):
@@ -175,6 +176,9 @@ def trace(cfg_name, seeds, T, policy, scorer=False, jokers_fn=None, max_ante=0, 
         ante = ante_fn(si) if ante_fn else None
         cs = cards_fn(si) if cards_fn else []
         lv = levels_fn(si) if levels_fn else []
+        co = cons_fn(si) if cons_fn else []
+        rec["inj_ncons"][si] = len(co)
+        rec["inj_cons"][si, :len(co)] = co
         rec["inj_njokers"][si] = len(js)
         rec["inj_jokers"][si, :len(js)] = js
         if money is not None:
@@ -197,6 +201,8 @@ def trace(cfg_name, seeds, T, policy, scorer=False, jokers_fn=None, max_ante=0, 
                 env.set_card_state(i, e, d, s)
             for (ht, l) in lv:
                 env.set_hand_level(ht, l)
+            if co:
+                env.set_consumables(co)
 
         inject()
         obs = env.obs()
@@ -214,7 +220,7 @@ def trace(cfg_name, seeds, T, policy, scorer=False, jokers_fn=None, max_ante=0, 
             if "final_score" in info:
                 rec["final_score"][si, t] = info["final_score"]
                 rec["hand_type"][si, t] = int(info["hand_type"])
-            rec["error"][si, t] = 1 if "error" in info else 0
+            rec["error"][si, t] = 2 if info.get("raised") else (1 if "error" in info else 0)  # 2: the reference raised
             for k in OBS_KEYS:
                 obs_rec[k][si, t] = obs[k]
             if term:
@@ -256,6 +262,26 @@ def gen_traces():
           ante_fn=lambda i: [1, 3, 4, 6][i % 4])
 
 
+def gen_trace_consumables():
+    """Tarot / spectral / planet consumables: two injected per episode, all 52 ids but Immolate and Cryptid
+    (they change the deck length: not on the accelerated path); purple seals create more tarots on discards."""
+    pool = [i for i in list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68)) if i not in (59, 65)]
+
+    def cons_fn(i):
+        rr = random.Random(1300 + i)
+        return [pool[i % len(pool)], rr.choice(pool)] if i % 7 else [pool[i % len(pool)]]
+
+    def cards_fn(i):
+        rr = random.Random(1500 + i)
+        return [(d, rr.choice([0, 0, 0, 4, 8]), 0, rr.choice([0, 0, 4, 4])) for d in range(16)] if i % 3 == 0 else []
+
+    for scorer in (False, True):
+        trace("consumables_scorer" if scorer else "consumables", [(7000 if scorer else 6000) + i for i in range(50)], 320,
+              rh.POLICY_UNIFORM, scorer=scorer, max_ante=20, cons_fn=cons_fn, cards_fn=cards_fn,
+              jokers_fn=lambda i: random.Random(1700 + i).sample(list(range(1, 151)), i % 6),
+              money_fn=lambda i: [None, 3, 15, 200][i % 4])
+
+
 def gen_kat():
     """The reference's own known answers, as data."""
     kat = {"chips_test": [
@@ -286,7 +312,7 @@ def gen_kat():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["mt", "classify", "score", "traces", "kat"]
+    which = sys.argv[1:] or ["mt", "classify", "score", "traces", "consumables", "kat"]
     if "mt" in which:
         gen_mt()
     if "classify" in which:
@@ -295,6 +321,8 @@ def main():
         gen_score_hand()
     if "traces" in which:
         gen_traces()
+    if "consumables" in which:
+        gen_trace_consumables()
     if "kat" in which:
         gen_kat()
 

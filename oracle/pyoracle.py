@@ -108,6 +108,7 @@ def lib():
         L.bo_set_hand_level.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.bo_set_template_jokers.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.bo_set_money.argtypes = [C.c_void_p, C.c_int64]
+        L.bo_set_consumables.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.bo_set_ante.argtypes = [C.c_void_p, C.c_int]
         L.bo_policy_action.restype = C.c_int
         L.bo_policy_action.argtypes = [C.c_void_p, C.c_int, C.c_uint64, C.c_uint64, C.c_uint64]
@@ -198,6 +199,10 @@ class OracleEnv:
     def set_template_jokers(self, ids):
         arr = (C.c_int32 * len(ids))(*ids)
         self._L.bo_set_template_jokers(self._h, arr, len(ids))
+
+    def set_consumables(self, ids):
+        arr = (C.c_int32 * max(1, len(ids)))(*ids)
+        self._L.bo_set_consumables(self._h, arr, len(ids))
 
     def set_money(self, money):
         self._L.bo_set_money(self._h, money)

@@ -12,6 +12,9 @@ Harness conventions the reference leaves open (also restated in DESIGN.md):
   * scorer-level joker semantics (flag `scorer_jokers`): `UnifiedGameState.to_dict()` hands the scorer joker
     NAMES (as unified_scoring.py:313-351 does) instead of dicts, which makes the joker chain live.
   * counter-hash policy: action = k-th valid action, k = hash(policy_seed, env_index, t) mod n_valid.
+  * consumables that make the reference RAISE (The Hanged Man / Familiar / Grim / Incantation with a target card:
+    `list.remove` of a class that is not in the deck; Sigil / Ouija: assignment to a frozen dataclass): a batch of envs
+    cannot raise, so the step reports reward -1.0 with an error and the state stays exactly as the exception left it.
 """
 from __future__ import annotations
 
@@ -161,6 +164,11 @@ class RefEnv:
         self._enter()
         try:
             obs, reward, terminated, truncated, info = self.env.step(int(action))
+        except (ValueError, AttributeError) as ex:  # dataclasses.FrozenInstanceError is an AttributeError
+            if not (10 <= int(action) <= 14 and self.env.state.phase == 0):
+                raise
+            obs, reward, terminated, truncated = self.env._get_observation(), -1.0, False, False
+            info = {"error": f"raised {type(ex).__name__}", "raised": True}
         finally:
             self._leave()
         if self.max_ante and self.env.state.ante > self.max_ante:
@@ -180,6 +188,21 @@ class RefEnv:
         ht = self.ref["se"].HandType(hand_type)
         self.env.engine.set_hand_level(ht, level)
         self.env.state.hand_levels[ht] = self.env.engine.get_hand_level(ht)
+
+    CONSUMABLE_NAMES = {
+        1: 'The Fool', 2: 'The Magician', 3: 'The High Priestess', 4: 'The Empress', 5: 'The Emperor',
+        6: 'The Hierophant', 7: 'The Lovers', 8: 'The Chariot', 9: 'Strength', 10: 'The Hermit', 11: 'Wheel of Fortune',
+        12: 'Justice', 13: 'The Hanged Man', 14: 'Death', 15: 'Temperance', 16: 'The Devil', 17: 'The Tower',
+        18: 'The Star', 19: 'The Moon', 20: 'The Sun', 21: 'Judgement', 22: 'The World',
+        30: 'Mercury', 31: 'Venus', 32: 'Earth', 33: 'Mars', 34: 'Jupiter', 35: 'Saturn', 36: 'Uranus', 37: 'Neptune',
+        38: 'Pluto', 39: 'Planet X', 40: 'Ceres', 41: 'Eris',
+        50: 'Familiar', 51: 'Grim', 52: 'Incantation', 53: 'Talisman', 54: 'Aura', 55: 'Wraith', 56: 'Sigil', 57: 'Ouija',
+        58: 'Ectoplasm', 59: 'Immolate', 60: 'Ankh', 61: 'Deja Vu', 62: 'Hex', 63: 'Trance', 64: 'Medium', 65: 'Cryptid',
+        66: 'The Soul', 67: 'Black Hole'}
+
+    def set_consumables(self, ids):
+        """state.consumables by the ids of _get_consumable_ids (balatro_env_2.py:1545-1567)."""
+        self.env.state.consumables = [self.CONSUMABLE_NAMES[i] for i in ids]
 
     def set_money(self, money):
         self.env.state.money = money

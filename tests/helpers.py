@@ -16,7 +16,8 @@ OBS_KEYS = [
     "boss_blind_active", "boss_blind_type", "face_down_cards",
 ]
 
-TRACES = ["c1_small_only", "c2_cycle3", "c3_jokers", "c5_uniform", "c5_uniform_rich", "cards_levels"]
+TRACES = ["c1_small_only", "c2_cycle3", "c3_jokers", "c5_uniform", "c5_uniform_rich", "cards_levels", "consumables",
+          "consumables_scorer"]
 
 
 _trace_cache = {}
@@ -39,6 +40,7 @@ def trace_injection(tr, si):
         "ante": None if tr["inj_ante"][si] < 0 else int(tr["inj_ante"][si]),
         "cards": [(d, int(e), int(ed), int(s)) for d, (e, ed, s) in enumerate(tr["inj_cards"][si]) if e or ed or s],
         "levels": [(ht, int(l)) for ht, l in enumerate(tr["inj_levels"][si]) if l],
+        "consumables": [int(x) for x in tr["inj_cons"][si, :int(tr["inj_ncons"][si])]] if "inj_cons" in tr else [],
     }
     return inj
 

@@ -127,6 +127,8 @@ def replay_trace(name, make_env):
                 env.set_card_state(d, e, ed, s)
             for (ht, l) in inj["levels"]:
                 env.set_hand_level(ht, l)
+            if inj["consumables"]:
+                env.set_consumables(inj["consumables"])
 
         inject()
         assert_obs_equal(env.obs(), {k: tr["obs0_" + k][si] for k in OBS_KEYS}, f"{name} seed {seed} initial")
@@ -139,7 +141,8 @@ def replay_trace(name, make_env):
             assert term == bool(tr["terminated"][si, t]), ctx
             assert info.final_score == tr["final_score"][si, t], ctx
             assert info.hand_type == tr["hand_type"][si, t], ctx
-            assert (info.error != 0) == bool(tr["error"][si, t]) or info.error >= 9, ctx
+            assert (info.error != 0) == bool(tr["error"][si, t]) or info.error in (9, 10), ctx
+            assert (info.error == 11) == (tr["error"][si, t] == 2), ctx  # the reference raised (consumables.py:246,381,496,506)
             assert_obs_equal(obs, {k: tr["obs_" + k][si, t] for k in OBS_KEYS}, ctx)
             if term:
                 env.reset()

@@ -18,7 +18,7 @@ TERMS = ["progress", "milestone", "score", "hand_quality", "efficiency", "synerg
 
 
 def lockstep(seed, steps, policy, scorer=False, jokers=None, max_ante=0, env_index=0, money=None, ante=None,
-             cards=None, levels=None, pseed=11):
+             cards=None, levels=None, pseed=11, consumables=None):
     r = rh.RefEnv(seed, scorer_jokers=scorer, max_ante=max_ante)
     o = po.OracleEnv(seed, scorer_jokers=scorer, max_ante=max_ante)
 
@@ -34,6 +34,8 @@ def lockstep(seed, steps, policy, scorer=False, jokers=None, max_ante=0, env_ind
                 e.set_card_state(d, en, ed, s)
             for (ht, l) in (levels or []):
                 e.set_hand_level(ht, l)
+            if consumables:
+                e.set_consumables(consumables)
 
     inject()
     obs_r = r.obs()
@@ -87,6 +89,18 @@ def test_env_lockstep_card_states_and_levels():
         levels = [(ht, rr.randint(1, 15)) for ht in range(9)]
         lockstep(9500 + s, 400, rh.POLICY_UNIFORM, scorer=bool(s & 1), env_index=s, max_ante=20, cards=cards,
                  levels=levels, jokers=rr.sample(range(1, 151), s % 6))
+
+
+def test_env_lockstep_consumables():
+    """Tarot / spectral / planet use (balatro_env_2.py:1066-1172, consumables.py) incl. the cases where the reference
+    raises (harness convention: reward -1.0, state as the exception left it).  Immolate / Cryptid are not restated."""
+    pool = [i for i in list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68)) if i not in (59, 65)]
+    for s in range(25):
+        rr = random.Random(70 + s)
+        cards = [(d, rr.choice([0, 0, 4, 8]), 0, rr.choice([0, 4])) for d in range(16)] if s % 2 else None
+        lockstep(9700 + s, 400, rh.POLICY_UNIFORM, scorer=bool(s & 1), env_index=s, max_ante=20, cards=cards,
+                 consumables=[pool[(2 * s) % len(pool)], pool[(2 * s + 1) % len(pool)]], money=[None, 30][s % 2],
+                 jokers=rr.sample(range(1, 151), s % 6))
 
 
 def test_reseed_reproduces_first_shuffle():
