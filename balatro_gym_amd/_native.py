@@ -52,7 +52,7 @@ FLAG_CARD_STATES = 4
 POLICY_UNIFORM, POLICY_SMALL_ONLY, POLICY_CYCLE3 = 0, 1, 2
 
 EXPORTS = ["bg_create", "bg_destroy", "bg_last_error", "bg_num_envs", "bg_max_fused_steps", "bg_state_bytes", "bg_seed", "bg_reset",
-           "bg_step", "bg_observe", "bg_rollout", "bg_rollout_rows", "bg_inject", "bg_inject_cards", "bg_state_blob_bytes", "bg_get_state", "bg_set_state",
+           "bg_step", "bg_observe", "bg_rollout", "bg_rollout_rows", "bg_inject", "bg_inject_cards", "bg_inject_consumables", "bg_state_blob_bytes", "bg_get_state", "bg_set_state",
            "bg_refill", "bg_check", "bg_set_profiling", "bg_get_profile"]
 
 
@@ -120,6 +120,7 @@ def load(build_if_missing: bool = True):
     L.bg_rollout_rows.argtypes = [vp, i32, i32, u64, u64, u64, vp, u64, i32, vp, vp]
     L.bg_inject.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp]
     L.bg_inject_cards.argtypes = [vp, vp, vp, vp, vp, i32, vp]
+    L.bg_inject_consumables.argtypes = [vp, vp, vp, vp, i32, vp]
     L.bg_state_blob_bytes.restype = u64
     L.bg_state_blob_bytes.argtypes = [vp]
     L.bg_get_state.argtypes = [vp, i32, vp, u64]

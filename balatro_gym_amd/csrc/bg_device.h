@@ -69,6 +69,7 @@ struct BgDev {
   uint4* cstate;     // uint4[7][N]
   uint4* ctmpl;      // uint4[7][N]
   uint32_t* cardmt;  // u32[N][640], lazy MT19937 (cursor in word 624)
+  uint32_t* sealmt;  // u32[N][640], lazy MT19937 of stream 13 'seal_applications' (purple seals)
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -117,7 +118,7 @@ __device__ __forceinline__ void bg_unpack(const uint4 c[BG_NHOT], Env& e) {
   e.shop_reroll_state = (int32_t)c[2].z;
   e.shop_reroll_base = (int32_t)c[2].w;
   e.ante = bg_b(c[3].x, 0); e.round = bg_b(c[3].x, 1); e.phase = bg_b(c[3].x, 2); e.hands_left = bg_b(c[3].x, 3);
-  e.discards_left = bg_b(c[3].y, 0); e.hand_size = bg_b(c[3].y, 1); e.nhand = bg_b(c[3].y, 2); e.nsel = bg_b(c[3].y, 3);
+  e.discards_left = bg_b(c[3].y, 0); e.hand_size = (int)(int8_t)bg_b(c[3].y, 1); /* signed: Manacle / Wraith / Ectoplasm only ever lower it */ e.nhand = bg_b(c[3].y, 2); e.nsel = bg_b(c[3].y, 3);
   e.njokers = bg_b(c[3].z, 0); e.ncons = bg_b(c[3].z, 1); e.n_magic = bg_b(c[3].z, 2); e.n_minim = bg_b(c[3].z, 3);
   e.boss_type = bg_b(c[3].w, 0); e.boss_req = bg_b(c[3].w, 1); e.bflags = bg_b(c[3].w, 2); e.shop_n = bg_b(c[3].w, 3);
   e.hand = ((uint64_t)c[4].y << 32) | c[4].x;

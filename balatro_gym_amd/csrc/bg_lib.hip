@@ -589,6 +589,8 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_
   if (d.cardmt) { // 'card_enhancement' is stream 11 of DeterministicRNG (:96-105)
     bg_mt_seed(d.cardmt + (size_t)env * BG_MTS, base + 11000u);
     d.cardmt[(size_t)env * BG_MTS + BG_MT_N] = BG_LAZY_SEEDED;
+    bg_mt_seed(d.sealmt + (size_t)env * BG_MTS, base + 13000u); // 'seal_applications' is stream 13
+    d.sealmt[(size_t)env * BG_MTS + BG_MT_N] = BG_LAZY_SEEDED;
   }
   // look-ahead rings are functions of the streams: invalidate (producer counters restart at the consumer counters)
   e.d_head = 0; e.d_cons = 0; e.d_ready = 0;
@@ -793,6 +795,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_inject_kernel(BgDev d, const uint
   if (t0.y & 0x40000000u) e.money = (int32_t)t0.z;
   if (t0.y & 0x20000000u) e.ante = (int)bg_b(t0.y, 2);
   if (t0.y & 0x10000000u) { e.levels = (uint64_t)t1.x | ((uint64_t)(t1.y & 0xffffu) << 32); e.excess = 0; }
+  if (t1.z & 0x80000000u) { e.ncons = (int)bg_b(t1.z, 0); e.cons0 = bg_b(t1.z, 1); e.cons1 = bg_b(t1.z, 2); }
   bg_store_env(d, env, e);
 }
 
@@ -957,6 +960,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
     e = bg_alloc(h, &d.cstate, (size_t)BG_NCST * N);
     if (e == hipSuccess) e = bg_alloc(h, &d.ctmpl, (size_t)BG_NCST * N);
     if (e == hipSuccess) e = bg_alloc(h, &d.cardmt, (size_t)BG_MTS * N);
+    if (e == hipSuccess) e = bg_alloc(h, &d.sealmt, (size_t)BG_MTS * N);
   }
   if (e == hipSuccess) e = bg_alloc(h, &d.deckmt, (size_t)BG_MTS * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.shopgenmt, (size_t)BG_MTS * N);
@@ -1005,7 +1009,7 @@ int bg_destroy(bg_handle* h) {
   if (h->ev_rollout) (void)hipEventDestroy(h->ev_rollout);
   hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
   hipFree(d.hot); hipFree(d.deck); hipFree(d.cold); hipFree(d.tmpl); hipFree(d.ndeck); hipFree(d.gblk); hipFree(d.sblk);
-  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.wl_shop); hipFree(d.sseed); hipFree(d.smeta); hipFree(d.dbg); hipFree(d.cstate); hipFree(d.ctmpl); hipFree(d.cardmt);
+  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.wl_shop); hipFree(d.sseed); hipFree(d.smeta); hipFree(d.dbg); hipFree(d.cstate); hipFree(d.ctmpl); hipFree(d.cardmt); hipFree(d.sealmt);
   delete h;
   return 0;
 }
@@ -1359,6 +1363,37 @@ int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_h
   return 0;
 }
 
+int bg_inject_consumables(bg_handle* h, const int32_t* ids_host, const int32_t* n_host, const uint8_t* mask_host, int apply_now,
+                          void* stream) {
+  if (!h || !ids_host || !n_host) return BG_E_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  size_t N = h->dev.N;
+  for (size_t i = 0; i < N; i++) {
+    if (mask_host && !mask_host[i]) continue;
+    int n = n_host[i];
+    if (n < 0) { h->h_tmpl[N + i].z = 0; continue; } // back to the reset default (no consumables)
+    if (n > 2) { h->err = "bg_inject_consumables: an env holds at most consumable_slots = 2"; return BG_E_ARG; }
+    uint32_t v = 0x80000000u | (uint32_t)n;
+    for (int k = 0; k < n; k++) {
+      int id = ids_host[i * 2 + k];
+      bool planet = id >= 30 && id <= 41, other = (id >= 1 && id <= 22) || (id >= 50 && id <= 67);
+      if (!planet && !other) { h->err = "bg_inject_consumables: ids are 1-22 (tarots), 30-41 (planets), 50-67 (spectrals)"; return BG_E_ARG; }
+      if (other && !h->dev.cstate) { h->err = "bg_inject_consumables: tarot / spectral cards need BG_FLAG_CARD_STATES"; return BG_E_ARG; }
+      v |= (uint32_t)id << (8 * (k + 1));
+    }
+    h->h_tmpl[N + i].z = v;
+  }
+  BG_HIP(hipMemcpyAsync(h->dev.tmpl, h->h_tmpl.data(), BG_NTMPL * N * sizeof(uint4), hipMemcpyHostToDevice, s));
+  if (apply_now) {
+    if (mask_host) BG_HIP(hipMemcpyAsync(h->d_mask, mask_host, N, hipMemcpyHostToDevice, s));
+    hipLaunchKernelGGL(bg_inject_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, bg_dev_view(h, bg_prod_latest(h)),
+                       mask_host ? (const uint8_t*)h->d_mask : (const uint8_t*)nullptr);
+    BG_HIP(hipGetLastError());
+  }
+  BG_HIP(hipStreamSynchronize(s));
+  return 0;
+}
+
 // ---- save_state / load_state: raw per-env slices of every array, in a fixed order ----
 struct BgSlice { void* base; size_t rows; size_t elem; };
 static void bg_slices(bg_handle* h, std::vector<BgSlice>& v) {
@@ -1370,7 +1405,7 @@ static void bg_slices(bg_handle* h, std::vector<BgSlice>& v) {
   v.push_back({d.deckmt, 1, (size_t)BG_MTS * 4}); v.push_back({d.shopgenmt, 1, (size_t)BG_MTS * 4});
   v.push_back({d.sseed, 1, BG_SSEED * 4}); v.push_back({d.smeta, 1, 4});
   v.push_back({bg_prod_latest(h), 1, 4});
-  if (d.cstate) { v.push_back({d.cstate, BG_NCST, 16}); v.push_back({d.ctmpl, BG_NCST, 16}); v.push_back({d.cardmt, 1, (size_t)BG_MTS * 4}); }
+  if (d.cstate) { v.push_back({d.cstate, BG_NCST, 16}); v.push_back({d.ctmpl, BG_NCST, 16}); v.push_back({d.cardmt, 1, (size_t)BG_MTS * 4}); v.push_back({d.sealmt, 1, (size_t)BG_MTS * 4}); }
 }
 uint64_t bg_state_blob_bytes(const bg_handle* h) {
   if (!h) return 0;

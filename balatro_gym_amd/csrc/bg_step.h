@@ -109,6 +109,7 @@ __device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, DK
   if (t0.y & 0x40000000u) e.money = (int32_t)t0.z;
   if (t0.y & 0x20000000u) e.ante = (int)bg_b(t0.y, 2);
   if (t0.y & 0x10000000u) e.levels = (uint64_t)t1.x | ((uint64_t)(t1.y & 0xffffu) << 32);
+  if (t1.z & 0x80000000u) { e.ncons = (int)bg_b(t1.z, 0); e.cons0 = bg_b(t1.z, 1); e.cons1 = bg_b(t1.z, 2); }
   if constexpr (DK::kCards) { // card_states = {} (:511), then the harness re-applies its injected states
 #pragma unroll
     for (int k = 0; k < BG_NCST; k++) d.cstate[(size_t)k * d.N + env] = d.ctmpl[(size_t)k * d.N + env];
@@ -138,6 +139,11 @@ __device__ __forceinline__ uint64_t bg_sorted_jokers(const Env& e) {
       if (a > b2) v = (v & ~(0xffffull << (8 * i))) | ((uint64_t)b2 << (8 * i)) | ((uint64_t)a << (8 * (i + 1)));
     }
   }
+  // `j.id not in self.player.jokers` is a membership test: an id owned twice (Ankh's copy under scorer-level joker
+  // names) is stepped over once
+#pragma unroll
+  for (int i = 4; i >= 1; i--)
+    if (((v >> (8 * i)) & 0xffull) == ((v >> (8 * (i - 1))) & 0xffull)) v |= 0xffull << (8 * i);
   return v;
 }
 __device__ __forceinline__ int bg_candidate(uint64_t sorted, int j) {
@@ -150,9 +156,10 @@ __device__ __forceinline__ int bg_candidate(uint64_t sorted, int j) {
 __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr) {
   bg_sprefetch(d, env, e, w, 24); // shop.py:111-139
   double mult = bg_shop_cost_mult(e, w.jt);
+  const uint64_t sj = bg_sorted_jokers(e);
   int owned145 = 0;
-#pragma unroll 1
-  for (int q = 0; q < e.njokers; q++) owned145 += bg_get8(e.jokers, q) <= 145 ? 1 : 0;
+#pragma unroll
+  for (int q = 0; q < 5; q++) owned145 += bg_get8(sj, q) <= 145 ? 1 : 0;
   const uint32_t nc = (uint32_t)(145 - owned145); // 140..145: _randbelow(nc) looks at 8 bits
   // The seven draws -- choice of the third pack (_randbelow(3)), random.sample(candid, 3) by the selection-set method
   // (Lib/random.py sample(), n > 21: _randbelow(nc) until new), the voucher (_randbelow(2)), two randint(0, 51) -- are
@@ -210,7 +217,6 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
   cost[0] = (int32_t)(250.0 * mult); tp[0] = IT_PACK | (PK_STANDARD << 8);
   cost[1] = (int32_t)(500.0 * mult); tp[1] = IT_PACK | (PK_JOKER << 8);
   cost[2] = (int32_t)((double)c_pack2 * mult); tp[2] = IT_PACK | ((uint32_t)third << 8);
-  uint64_t sj = bg_sorted_jokers(e);
   int j0 = bg_candidate(sj, p0), j1 = bg_candidate(sj, p1), j2 = bg_candidate(sj, p2);
   cost[3] = (int32_t)((double)w.jt->cost[j0] * mult); tp[3] = IT_JOKER | ((uint32_t)j0 << 8);
   cost[4] = (int32_t)((double)w.jt->cost[j1] * mult); tp[4] = IT_JOKER | ((uint32_t)j1 << 8);
@@ -758,11 +764,12 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
 // DISCARD  balatro_env_2.py:962-1050
 template <class DK>
 __device__ __forceinline__ void bg_step_discard(const BgDev& d, int env, Env& e, const RngWin& w, const DK& dk, StepOut& o) {
-  int n = 0, nfaces = 0;
+  int n = 0, nfaces = 0, purple = 0;
 #pragma unroll 1
   for (int i = 0; i < e.nsel; i++) {
     int pos = bg_get8(e.sel, i);
     if (pos < e.nhand) {
+      if constexpr (DK::kCards) purple += ((bg_cstate(d, env, bg_get8(e.hand, pos)) >> 8) & 0xfu) == 4u; // :975-979
       int rk = (bg_card(d, env, dk, bg_get8(e.hand, pos)) >> 2) + 2;
       nfaces += (rk >= 11 && rk <= 13);
       n++;
@@ -789,6 +796,18 @@ __device__ __forceinline__ void bg_step_discard(const BgDev& d, int env, Env& e,
   e.discards_left -= 1;
   bg_draw_cards(e);
   e.nsel = 0; e.sel = 0;
+  if constexpr (DK::kCards) { // :1021-1032 purple seals -> rng.choice('seal_applications', tarots), stream 13
+#pragma unroll 1
+    for (int q = 0; q < purple; q++)
+      if (e.ncons < 2) {
+        uint32_t* S = d.sealmt + (size_t)env * BG_MTS;
+        uint32_t t;
+        int guard = 0;
+        do { t = bg_lazy_next(S) >> 27; } while (t >= 22u && ++guard < 4096); // _randbelow(22): getrandbits(5)
+        if (e.ncons == 0) e.cons0 = 1u + t; else e.cons1 = 1u + t;
+        e.ncons++;
+      }
+  }
   double r = 0.2;
   if (ndj) r += 0.5 * (double)ndj;
   if (money > 0) r += (double)money / 5.0;
@@ -914,6 +933,195 @@ __device__ __forceinline__ void bg_toggle_select(Env& e, int pos) {
   else { e.sel = bg_set8(e.sel, e.nsel, pos); e.nsel++; }
 }
 
+
+// _use_consumable (balatro_env_2.py:1066-1172) over ConsumableManager.use_consumable (consumables.py:622-652),
+// TarotEffects.apply_tarot (:111-327) and SpectralEffects.apply_spectral (:354-613).  A consumable is held as its
+// _get_consumable_ids id (:1545-1567: tarots 1-22, planets 30-41, spectrals 50-67); bit 7 marks a name in enum form
+// ('THE_FOOL', what The Emperor creates): used like the natural name, shown as id 0.  What the reference really does:
+//  - target cards are classes made by CardAdapter.to_consumable_format (:328-343): rank / suit edits never reach the deck,
+//    only enhancement / edition / seal are copied back (:1122-1138), as the INTEGER values of consumables.py's enums (its
+//    Seal enum is RED 1, BLUE 2, GOLD 3 while cards.py has GOLD 1, RED 2, BLUE 3: Talisman's seal acts as a blue one);
+//  - to_dict()['consumables'] is the live list: created items are appended by the effect and again by :1157-1160;
+//    to_dict()['jokers'] is a fresh list: only :1147-1155 adds jokers (by JOKER_LIBRARY name);
+//  - The Hanged Man / Familiar / Grim / Incantation with a target and Sigil / Ouija raise: error 11, reward -1.0 (harness
+//    convention), state as the exception leaves it; Immolate / Cryptid change the deck length: error 12, state untouched.
+// Kernels built without card states keep planets only (bg_inject_consumables refuses anything else for them).
+template <class DK>
+__device__ __forceinline__ void bg_use_consumable(const BgDev& d, int env, Env& e, RngWin& w, const DK& dk, int ci, StepOut& o) {
+  const int code = ci == 0 ? (int)e.cons0 : (int)e.cons1, id = code & 0x7f;
+  uint32_t L = (e.cons0 & 0xffu) | ((e.cons1 & 0xffu) << 8); // the live list, one byte per entry (3 at most, transiently)
+  int n = e.ncons;
+  bool success = false;
+  int money_gained = 0, planet = -1, naff = 0, set_enh = -1, set_edi = -1, set_seal = -1, nitems = 0, njc = 0, jc = 0, hs = 0;
+  uint64_t aff = 0;
+  uint32_t items = 0;
+  if (id >= 30 && id <= 41) { planet = id - 30; success = true; } // :644-652
+  else if constexpr (DK::kCards) {
+    uint64_t tg = 0; int nt = 0; // :1074-1083 target cards (deck indexes) in selection order
+#pragma unroll 1
+    for (int i = 0; i < e.nsel; i++) {
+      int pos = bg_get8(e.sel, i);
+      if (pos < e.nhand) { tg |= (uint64_t)bg_get8(e.hand, pos) << (8 * nt); nt++; }
+    }
+    bool raises = false, unsupported = false;
+    const int slots = 2;
+    switch (id) {
+      case 1: // The Fool :127-134 (the list holds at least the Fool itself)
+        if (n > 0) {
+          uint32_t c = (L >> (8 * bg_randbelow<false>(d, env, e, w, (uint32_t)n))) & 0xffu;
+          L |= c << (8 * n); n++; // live list, no slot check
+          items = c; nitems = 1; success = true;
+        }
+        break;
+      case 2: case 4: case 6: // Magician LUCKY :136-143, Empress MULT :157-164, Hierophant BONUS :177-184
+        if (nt > 0) { naff = nt < 2 ? nt : 2; aff = tg; set_enh = id == 2 ? 8 : (id == 4 ? 2 : 1); success = true; }
+        break;
+      case 3: // The High Priestess :145-155: choice first, slot check second
+#pragma unroll 1
+        for (int k = 0; k < 2; k++) {
+          uint32_t p = 30u + bg_randbelow<false>(d, env, e, w, 9u);
+          if (n < slots) { L |= p << (8 * n); n++; items |= p << (8 * nitems); nitems++; }
+        }
+        success = true;
+        break;
+      case 5: // The Emperor :166-175: slot check first; names in enum form
+#pragma unroll 1
+        for (int k = 0; k < 2; k++)
+          if (n < slots) {
+            uint32_t t = (1u + bg_randbelow<false>(d, env, e, w, 22u)) | 0x80u;
+            L |= t << (8 * n); n++; items |= t << (8 * nitems); nitems++;
+          }
+        success = true;
+        break;
+      case 7: case 8: case 12: case 16: case 17: // Lovers WILD, Chariot STEEL, Justice GLASS, Devil GOLD, Tower STONE
+        if (nt >= 1) { naff = 1; aff = tg; set_enh = id == 7 ? 3 : (id == 8 ? 5 : (id == 12 ? 4 : (id == 16 ? 7 : 6))); success = true; }
+        break;
+      case 9: // Strength :202-210: only cards below the ace are listed; the rank edit is lost
+        if (nt > 0) {
+#pragma unroll 1
+          for (int i = 0; i < nt && i < 2; i++) {
+            int ti = bg_get8(tg, i);
+            if ((bg_card(d, env, dk, ti) >> 2) + 2 < 14) { aff |= (uint64_t)ti << (8 * naff); naff++; }
+          }
+          success = true;
+        }
+        break;
+      case 10: // The Hermit :212-219
+        money_gained = e.money < 20 ? e.money : 20; success = true;
+        break;
+      case 11: // Wheel of Fortune :221-231: `target_cards and random.random() < 0.25`
+        if (nt > 0 && bg_grandom(d, env, e, w) < 0.25) {
+          set_edi = 1 + (int)bg_randbelow<false>(d, env, e, w, 3u); naff = 1; aff = tg; success = true;
+        }
+        break;
+      case 13: // The Hanged Man :241-251
+        raises = nt > 0;
+        break;
+      case 14: // Death :253-261
+        if (nt >= 2) { naff = 2; aff = tg; success = true; }
+        break;
+      case 15: // Temperance :263-273
+        money_gained = 5 * e.njokers < 50 ? 5 * e.njokers : 50; success = true;
+        break;
+      case 18: case 19: case 20: case 22: // Star / Moon / Sun / World: suit edits are lost
+        if (nt > 0) { naff = nt < 3 ? nt : 3; aff = tg; success = true; }
+        break;
+      case 21: { // Judgement :318-327
+        uint32_t p = 30u + bg_randbelow<false>(d, env, e, w, 9u);
+        if (n < slots) { L |= p << (8 * n); n++; items = p; nitems = 1; }
+        success = true;
+        break;
+      }
+      case 50: case 51: case 52: // Familiar / Grim / Incantation :373-457: deck.remove(target class)
+        raises = nt >= 1;
+        break;
+      case 53: case 61: case 63: case 64: // Talisman 3, Deja Vu 1, Trance 2, Medium 4 (consumables.Seal values)
+        if (nt >= 1) { naff = 1; aff = tg; set_seal = id == 53 ? 3 : (id == 61 ? 1 : (id == 63 ? 2 : 4)); success = true; }
+        break;
+      case 54: // Aura :467-474
+        if (nt >= 1) { set_edi = 1 + (int)bg_randbelow<false>(d, env, e, w, 3u); naff = 1; aff = tg; success = true; }
+        break;
+      case 55: // Wraith :476-488 (rare_jokers by JOKER_LIBRARY name; 'Drivers License' is not a library name)
+        if (e.njokers < 5) {
+          uint32_t k = bg_randbelow<false>(d, env, e, w, 14u);
+          jc = k == 4u ? 0 : 137 + (int)k; njc = 1; hs = -1; success = true;
+        }
+        break;
+      case 56: case 57: // Sigil :490-498, Ouija :500-509: random.choice, then assignment to a frozen dataclass
+        if (e.nhand > 0) { (void)bg_randbelow<false>(d, env, e, w, id == 56 ? 4u : 13u); raises = true; }
+        break;
+      case 58: // Ectoplasm :511-517
+        if (e.njokers > 0) { hs = -1; success = true; }
+        break;
+      case 59: // Immolate :519-531
+        unsupported = true;
+        break;
+      case 60: // Ankh :533-543: the "name" is a {'name','id'} dict unless the scorer-level harness hands out names
+        if (e.njokers > 0) {
+          uint32_t k = bg_randbelow<false>(d, env, e, w, (uint32_t)e.njokers);
+          jc = (d.flags & 1u) ? bg_get8(e.jokers, (int)k) : 0; njc = 1; success = true;
+        }
+        break;
+      case 62: // Hex :553-563
+        if (e.njokers > 0) { (void)bg_randbelow<false>(d, env, e, w, (uint32_t)e.njokers); success = true; }
+        break;
+      case 65: // Cryptid :581-591
+        unsupported = nt >= 1;
+        break;
+      case 66: // The Soul :593-601
+        if (e.njokers < 5) { jc = 146 + (int)bg_randbelow<false>(d, env, e, w, 5u); njc = 1; success = true; }
+        break;
+      case 67: // Black Hole :603-610
+        success = true;
+        break;
+      default: break; // unknown name :654
+    }
+    if (raises) { o.reward = -1.0; o.error = 11; return; }
+    if (unsupported) { o.reward = -1.0; o.error = 12; return; }
+  }
+  if (success) { // :1093-1164
+    double r = 0.0;
+    L = (L & ((1u << (8 * ci)) - 1u)) | ((L >> (8 * (ci + 1))) << (8 * ci)); n--; // pop(consumable_idx)
+    if (money_gained > 0) { e.money += money_gained; r += (double)money_gained / 10.0; }
+    if (planet >= 0) {
+      const int ht = (int)((0xba9087654321ull >> (4 * planet)) & 0xfull); // Mercury..Eris -> hand type :1103-1116
+      int lv = bg_level(e, ht);
+      if (lv < 15) e.levels += 1ull << (4 * ht);          // engine.apply_planet (scoring_engine.py:82-85)
+      else e.excess += 1ull << (4 * ht);                  // state.hand_levels[...] += 1 is uncapped (:1119)
+      r += 10.0;
+    }
+    if constexpr (DK::kCards) {
+      if (naff) {
+#pragma unroll 1
+        for (int i = 0; i < naff; i++) {
+          const int ti = bg_get8(aff, i);
+          uint16_t* q = &((uint16_t*)&d.cstate[(size_t)(ti >> 3) * d.N + env])[ti & 7];
+          uint32_t v = *q;
+          if (set_enh >= 0) v = (v & ~0xfu) | (uint32_t)set_enh;
+          if (set_edi >= 0) v = (v & ~0xf0u) | ((uint32_t)set_edi << 4);
+          if (set_seal >= 0) v = (v & ~0xf00u) | ((uint32_t)set_seal << 8);
+          *q = (uint16_t)v;
+        }
+        r += (double)naff * 2.0;
+      }
+      if (njc) {
+        if (e.njokers < 5 && jc > 0) { e.jokers = bg_set8(e.jokers, e.njokers, jc); e.njokers++; }
+        r += (double)njc * 15.0;
+      }
+      if (nitems) {
+#pragma unroll 1
+        for (int i = 0; i < nitems; i++)
+          if (n < 2) { L |= ((items >> (8 * i)) & 0xffu) << (8 * n); n++; }
+        r += (double)nitems * 5.0;
+      }
+      if (hs) e.hand_size += hs;
+    }
+    e.cons0 = L & 0xffu; e.cons1 = (L >> 8) & 0xffu; e.ncons = n;
+    o.reward = r;
+  } else { o.reward = -1.0; o.error = 8; } // :1166-1168
+  e.nsel = 0; e.sel = 0; // :1171
+}
+
 // dispatch of a VALID action (balatro_env_2.py:629-637)
 template <class DK>
 __device__ __forceinline__ void bg_env_dispatch(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr, const DK& dk,
@@ -922,21 +1130,7 @@ __device__ __forceinline__ void bg_env_dispatch(const BgDev& d, int env, Env& e,
     if (action == 0) bg_step_play_hand(d, env, e, w, sr, dk, o);
     else if (action == 1) bg_step_discard(d, env, e, w, dk, o);
     else if (action < 10) bg_toggle_select(e, action - 2);
-    else { // 10..14 _use_consumable :1066-1172, planets only (consumables.py:644-652)
-      int ci = action - 10;
-      int id = ci == 0 ? (int)e.cons0 : (int)e.cons1;
-      if (id >= 30 && id <= 41) {
-        const int PLANET_HT[12] = {1, 2, 3, 4, 5, 6, 7, 8, 0, 9, 10, 11};
-        int ht = PLANET_HT[id - 30];
-        if (ci == 0) e.cons0 = e.cons1;
-        e.cons1 = 0; e.ncons--;
-        int lv = bg_level(e, ht);
-        if (lv < 15) e.levels += 1ull << (4 * ht);          // engine.apply_planet (scoring_engine.py:82-85)
-        else e.excess += 1ull << (4 * ht);                  // state.hand_levels[...] += 1 is uncapped (:1119)
-        o.reward = 10.0;
-      } else { o.reward = -1.0; o.error = 8; }
-      e.nsel = 0; e.sel = 0;
-    }
+    else bg_use_consumable(d, env, e, w, dk, action - 10, o); // 10..14
   } else if (e.phase == 1) bg_step_shop(d, env, e, w, sr, action, o);
   else if (e.phase == 2) bg_step_blind<DK::kCards>(d, env, e, w, sr, action, o);
 }
@@ -1032,7 +1226,7 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
     jq[i] = a | (b << 16);
   }
   BG_MIX(e.cons0 | (e.cons1 << 8));
-  const uint32_t cq = (uint32_t)(e.ncons > 0 ? e.cons0 : 0) | ((uint32_t)(e.ncons > 1 ? e.cons1 : 0) << 16);
+  const uint32_t cq = (uint32_t)((e.ncons > 0 && !(e.cons0 & 0x80u)) ? e.cons0 : 0) | ((uint32_t)((e.ncons > 1 && !(e.cons1 & 0x80u)) ? e.cons1 : 0) << 16); // enum-form names map to 0 (:1570)
   // shop rows only in SHOP phase (:1534-1539)
   uint32_t it[5] = {0, 0, 0, 0, 0}, co[5] = {0, 0, 0, 0, 0};
   if (e.phase == 1 && (e.bflags & BG_BF_SHOP_EXISTS)) {

@@ -193,6 +193,10 @@ class BalatroEnv(_EnvBase):
     def inject(self, **kw):
         self._vec.inject(**kw)
 
+    def inject_consumables(self, ids, apply_now: bool = True):
+        """env.state.consumables = [names of ids] (ids as in balatro_env_2.py:1545-1567)."""
+        self._vec.inject_consumables([list(ids)], apply_now=apply_now)
+
     def inject_cards(self, cards, apply_now: bool = True):
         """cards = iterable of (deck_index, enhancement, edition, seal): env.card_states[idx] = CardState(...) (card_states=True)."""
         self._vec.inject_cards([list(cards)], apply_now=apply_now)

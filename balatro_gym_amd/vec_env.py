@@ -280,6 +280,25 @@ class BalatroVecEnv:
         if apply_now:
             self.observe()
 
+    def inject_consumables(self, consumables, mask=None, apply_now: bool = True):
+        """state.consumables per env (reset template, like `inject`): consumables[i] = up to 2 ids as in
+        `_get_consumable_ids` (balatro_env_2.py:1545-1567): tarots 1-22, planets 30-41, spectrals 50-67.  Tarot and
+        spectral cards edit card states, so they need card_states=True."""
+        n = self.num_envs
+        ids = np.zeros((n, 2), np.int32)
+        cnt = np.zeros(n, np.int32)
+        for i, cs in enumerate(consumables):
+            cnt[i] = len(cs)
+            ids[i, :len(cs)] = list(cs)[:2]
+        mk = None if mask is None else np.ascontiguousarray(np.asarray(mask, np.uint8))
+        with torch.cuda.device(self.device):
+            self._check(self._L.bg_inject_consumables(
+                self._h, ids.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p),
+                None if mk is None else mk.ctypes.data_as(C.c_void_p), 1 if apply_now else 0, self._stream()),
+                "bg_inject_consumables")
+        if apply_now:
+            self.observe()
+
     def get_state(self, env_index: int) -> bytes:
         """save_state() (balatro_env_2.py:1575-1593) as a versioned binary blob."""
         nb = int(self._L.bg_state_blob_bytes(self._h))

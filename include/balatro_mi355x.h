@@ -45,9 +45,13 @@ extern "C" {
 #define BG_ERR_VERDANT 5        /* boss_blinds.py:405 'Must play at least <n> cards' */
 #define BG_ERR_REROLL_FUNDS 6   /* shop.py:173 'Insufficient chips for reroll' */
 #define BG_ERR_JOKER_SLOTS 7    /* shop.py:196 'Joker slots full' */
-#define BG_ERR_CONSUMABLE 8     /* tarot / spectral use is outside the accelerated path */
+#define BG_ERR_CONSUMABLE 8     /* balatro_env_2.py:1166-1168 the consumable had no effect (result['success'] False), reward -1.0 */
 #define BG_ERR_MAX_ANTE 9       /* balatro_env_2.py:620 terminated 'max_ante_reached' */
 #define BG_ERR_MAX_SCORE 10     /* balatro_env_2.py:623 terminated 'max_score_reached' */
+#define BG_ERR_CONSUMABLE_RAISES 11 /* the reference RAISES here (consumables.py:246,381,418,444 list.remove of a target class;
+                                     * :496,506 assignment to a frozen dataclass): reward -1.0, state as the exception leaves it */
+#define BG_ERR_CONSUMABLE_DECK 12   /* Immolate / Cryptid change the deck length (consumables.py:519-531,581-591): not on the
+                                     * accelerated path; reward -1.0, state untouched */
 
 /* info.flags bits */
 #define BG_INFO_BEAT_BLIND 1     /* info['beat_blind'] */
@@ -224,6 +228,15 @@ int bg_inject(bg_handle* h, const int32_t* jokers_host /*[N,5] or NULL*/, const 
  * is re-applied after every reset, like bg_inject's template.  Needs BG_FLAG_CARD_STATES at bg_create. */
 int bg_inject_cards(bg_handle* h, const uint8_t* enh_host, const uint8_t* edition_host, const uint8_t* seal_host,
                     const uint8_t* mask_host, int apply_now, void* stream);
+
+/* Consumables (balatro_env_2.py:1066-1172 _use_consumable over consumables.py; BASELINE config 4): per-env reset template
+ * of state.consumables, ids as in _get_consumable_ids (balatro_env_2.py:1545-1567): tarots 1-22, planets 30-41,
+ * spectrals 50-67; ids_host is [N, 2], n_host[i] in [0, 2] (-1 = back to the reset default).  Re-applied after every
+ * reset like bg_inject's template.  Tarot / spectral cards edit card states, so they need BG_FLAG_CARD_STATES (planets do
+ * not).  In-env sources of consumables: blue seals (planets), purple seals (tarots), The Fool / High Priestess /
+ * Emperor / Judgement.  Replaces direct writes to env.state.consumables. */
+int bg_inject_consumables(bg_handle* h, const int32_t* ids_host /*[N,2]*/, const int32_t* n_host /*[N]*/,
+                          const uint8_t* mask_host, int apply_now, void* stream);
 
 /* Replaces: save_state()/load_state() (balatro_env_2.py:1575-1615).  Blob = versioned raw copy of one env's state
  * (game + all RNG streams + look-ahead rings).  bg_state_blob_bytes gives the size. */

@@ -12,7 +12,8 @@ from tests.helpers import OBS_KEYS, load_trace, trace_injection
 
 pytestmark = pytest.mark.gpu
 
-GPU_TRACES = ["c1_small_only", "c2_cycle3", "c3_jokers", "c5_uniform", "c5_uniform_rich", "cards_levels"]
+GPU_TRACES = ["c1_small_only", "c2_cycle3", "c3_jokers", "c5_uniform", "c5_uniform_rich", "cards_levels", "consumables",
+              "consumables_scorer"]
 TERMS = 8
 
 
@@ -41,7 +42,8 @@ def test_golden_trace(name):
     S, T = tr["actions"].shape
     seeds = [int(s) for s in tr["seeds"]]
     inj = [trace_injection(tr, si) for si in range(S)]
-    has_cards = any(i["cards"] for i in inj)
+    has_cons = any(i["consumables"] for i in inj)
+    has_cards = any(i["cards"] for i in inj) or has_cons  # tarot / spectral cards edit card states
     env = _vec(S, seeds, scorer_jokers=bool(tr["scorer_jokers"]), autoreset=False, max_ante=int(tr["max_ante"]),
                card_states=has_cards)
     if has_cards:  # cards.py CardState per deck index, re-applied after every reset like the other injections
@@ -56,6 +58,8 @@ def test_golden_trace(name):
                    ante=[0 if i["ante"] is None else i["ante"] for i in inj],
                    levels=levels if levels.any() else None, apply_now=True)
         env.observe()
+    if has_cons:  # state.consumables by id, re-applied after every reset
+        env.inject_consumables([i["consumables"] for i in inj], apply_now=True)
     _assert_obs(_obs_np(env), {k: tr["obs0_" + k] for k in OBS_KEYS}, f"{name} initial")
     for t in range(T):
         a = torch.from_numpy(tr["actions"][:, t].astype(np.int32)).to(env.device)
@@ -71,6 +75,7 @@ def test_golden_trace(name):
         assert np.array_equal(info["hand_type"].cpu().numpy(), tr["hand_type"][:, t]), ctx
         err = info["error"].cpu().numpy()
         assert np.array_equal((err != 0) & (err < 9), tr["error"][:, t].astype(bool) & (err < 9)), ctx
+        assert np.array_equal(err == 11, tr["error"][:, t] == 2), ctx  # steps where the reference raised
         _assert_obs(_obs_np(env), {k: tr["obs_" + k][:, t] for k in OBS_KEYS}, ctx)
         if tm.any():
             env.reset(mask=torch.from_numpy(tm).to(env.device))  # un-seeded reset() + reset template
@@ -131,13 +136,16 @@ def test_step_vs_oracle_fresh_seeds(policy, scorer):
     env.close()
 
 
-def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_index0=0, t0=0, cards=None):
+def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_index0=0, t0=0, cards=None, consumables=None):
     """SAME_STEP auto-reset rollout on the oracle; returns per-step obs/rewards/terminated and the stats dict."""
     orc = _oracle_envs(n, seeds, scorer, max_ante, jokers)
     if cards:
         for o, cs in zip(orc, cards):
             for (idx, e_, d_, s_) in cs:
                 o.set_card_state(idx, e_, d_, s_)
+    if consumables:
+        for o, cs in zip(orc, consumables):
+            o.set_consumables(cs)
     obs = {k: [] for k in OBS_KEYS}
     rewards = np.zeros((T, n)); terms = np.zeros((T, n), np.uint8); acts = np.zeros((T, n), np.int32)
     stats = {"steps": 0, "episodes": 0, "plays": 0, "score_sum": 0, "reward_bits": 0}
@@ -154,6 +162,9 @@ def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_in
                 if cards:
                     for (idx, e_, d_, s_) in cards[i]:
                         o.set_card_state(idx, e_, d_, s_)
+                if consumables:
+                    o.set_consumables(consumables[i])
+                    ob = o.obs()
                 stats["episodes"] += 1
             rewards[t, i] = r; terms[t, i] = term; acts[t, i] = a
             stats["steps"] += 1
@@ -290,6 +301,54 @@ def test_card_states_rollout_vs_oracle():
         assert np.array_equal(rb.tensors[k].contiguous().cpu().numpy(), wobs[k]), f"record key {k} differs"
     for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
         assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
+    env.close()
+
+
+@pytest.mark.parametrize("scorer", [False, True])
+def test_consumables_rollout_vs_oracle(scorer):
+    """Tarot / spectral / planet consumables (every id, two per episode) plus purple / blue seals through the fused rollout
+    with packed records: every record byte against the oracle, resets included.  Immolate / Cryptid report
+    BG_ERR_CONSUMABLE_DECK on both sides (state untouched)."""
+    from balatro_gym_amd.vec_env import RowBuffers
+    n, T = 256, 160
+    seeds = [93_000 + 5 * i for i in range(n)]
+    pool = list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68))
+    jokers = [random.Random(5000 + i).sample(list(range(1, 151)), i % 6) for i in range(n)]
+    cons = [[pool[i % len(pool)], random.Random(6000 + i).choice(pool)][: 2 - (i % 9 == 0)] for i in range(n)]
+    cards = []
+    for i in range(n):
+        rr = random.Random(7000 + i)
+        cards.append([(d, rr.choice([0, 0, 4, 8]), 0, rr.choice([0, 3, 4, 4])) for d in rr.sample(range(52), 16)] if i % 2 else [])
+    env = _vec(n, seeds, scorer_jokers=scorer, autoreset=True, max_ante=6, card_states=True)
+    env.inject(jokers=jokers, apply_now=True)
+    env.inject_cards(cards, apply_now=True)
+    env.inject_consumables(cons, apply_now=True)
+    rb = RowBuffers(n, env.device, steps=T)
+    env.rollout(T, policy=0, policy_seed=47, obs_buffers=rb)
+    env.check()
+    got_stats = env.stats()
+    wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, T, 0, 47, scorer, 6, jokers, cards=cards, consumables=cons)
+    assert np.array_equal(rb.action.cpu().numpy(), wa)
+    assert np.array_equal(rb.terminated.cpu().numpy(), wt)
+    assert np.array_equal(rb.reward.contiguous().cpu().numpy().view(np.uint64), wr.view(np.uint64))
+    for k in OBS_KEYS:
+        assert np.array_equal(rb.tensors[k].contiguous().cpu().numpy(), wobs[k]), f"record key {k} differs"
+    for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
+        assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
+    assert ((wa >= 10) & (wa <= 14)).sum() > 500  # the consumable path was really exercised
+    env.close()
+
+
+def test_inject_consumables_needs_card_states():
+    """Tarot / spectral ids are refused on a handle without card states (planets are fine): no silent divergence."""
+    from balatro_gym_amd._native import NativeError
+    env = _vec(4, [1, 2, 3, 4])
+    env.inject_consumables([[30], [41, 35], [], [38]], apply_now=True)
+    assert env.obs["consumables"].cpu().numpy()[:, :2].tolist() == [[30, 0], [41, 35], [0, 0], [38, 0]]
+    with pytest.raises(NativeError):
+        env.inject_consumables([[1], [], [], []])
+    with pytest.raises(NativeError):
+        env.inject_consumables([[23], [], [], []])
     env.close()
 
 
