@@ -941,10 +941,11 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   const char* kg = getenv("BG_KG"); const char* ks = getenv("BG_KS"); const char* kd = getenv("BG_KD");
   // Look-ahead depth = how many steps one bg_rollout launch may fuse (bg_max_fused_steps).  Deeper rings amortise the
   // refill over more steps and the end-of-launch tail (lanes that finished early wait for the slowest env of their
-  // workgroup) over more work; per env they cost 2.5 KB per global / shop slot and 64 B per deck: ~386 KB (128 fused steps),
-  // ~198 KB (64), ~105 KB (32) or ~60 KB (16) -- picked so that the state stays a modest share of the 288 GB.
-  const int dg = n_envs <= 65536 ? 49 : (n_envs <= 262144 ? 25 : (n_envs <= 1048576 ? 13 : 8));
-  const int dsd = n_envs <= 65536 ? 96 : (n_envs <= 262144 ? 48 : (n_envs <= 1048576 ? 24 : 12));
+  // workgroup) over more work: 128 -> 256 -> 372 fused steps measured +6 % / +9 % at 65 536 envs.  Per env they cost 2.5 KB
+  // per global / shop slot and 64 B per deck: ~1 MB (372 fused steps; 64 GB of the 288 at 65 536 envs), ~198 KB (64),
+  // ~105 KB (32) or ~60 KB (16).  Ring positions are bytes, so 250 is the deepest ring.
+  const int dg = n_envs <= 65536 ? 137 : (n_envs <= 262144 ? 25 : (n_envs <= 1048576 ? 13 : 8));
+  const int dsd = n_envs <= 65536 ? 248 : (n_envs <= 262144 ? 48 : (n_envs <= 1048576 ? 24 : 12));
   d.KG = kg ? atoi(kg) : dg; d.KS = ks ? atoi(ks) : dsd + 1; d.KD = kd ? atoi(kd) : dsd;
   if (d.KG < 2 || d.KS < 2 || d.KD < 1 || d.KG > 250 || d.KS > 250 || d.KD > 250) { delete h; g_create_err = "bg_create: bad ring depths"; return BG_E_ARG; }
   size_t N = (size_t)n_envs;
@@ -1075,8 +1076,13 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   static const int skip = getenv("BG_DEV_SKIP_REFILL") ? atoi(getenv("BG_DEV_SKIP_REFILL")) : 0; // development: contention experiments only (breaks the rings)
   if (!(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, d);
   if (!(skip & 2)) hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side2, d);
+  // side3: seed ring, then global blocks.  The global-block kernel would fit beside the rollout (114 VGPRs, no LDS) and
+  // queued first it is done early instead of ~100 us after the rollout -- but its HBM traffic beside the rollout costs the
+  // rollout more than the shorter gap saves (BG_GBLK_FIRST=1: -2..3 % measured), so it stays behind the seed-ring kernel.
+  static const int gblk_first = getenv("BG_GBLK_FIRST") ? atoi(getenv("BG_GBLK_FIRST")) : 0;
+  if (gblk_first && !(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
   if (!(skip & 4)) hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
-  if (!(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
+  if (!gblk_first && !(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
   BG_HIP(hipEventRecord(h->ev_deck, h->side2));
   BG_HIP(hipEventRecord(h->ev_gblk, h->side3));
   BG_HIP(hipStreamWaitEvent(s, h->ev_deck, 0));

@@ -79,8 +79,8 @@ def cpu_baseline(n_envs: int, steps: int, threads: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1024)
-    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--steps", type=int, default=7440)   # 20 launches of 372 fused steps (~0.13 s on one MI355X)
+    ap.add_argument("--warmup", type=int, default=372)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--chunk", type=int, default=0, help="fused steps per rollout call (0 = as many as the rings allow)")
     ap.add_argument("--keep-obs", type=int, default=1, help="write every step's observation to a [chunk, N] buffer")
@@ -115,7 +115,7 @@ def main():
                         max_ante=MAX_ANTE)
     env.inject(jokers=[jokers_for(g) for g in range(lo, hi)], apply_now=True)
     # chunk = steps per bg_rollout call = what the library fuses into one launch (ring depths: bg_create / BG_KG,KS,KD)
-    chunk = args.chunk or int(os.environ.get("BG_BENCH_CHUNK", "0")) or min(128, env.max_fused_steps)
+    chunk = args.chunk or int(os.environ.get("BG_BENCH_CHUNK", "0")) or min(372, env.max_fused_steps)
     ob = None
     if args.keep_obs and chunk > 1:
         ob = (RowBuffers if args.obs_layout == "rows" else ObsBuffers)(n, dev, steps=chunk)
