@@ -1422,11 +1422,12 @@ uint64_t bg_state_blob_bytes(const bg_handle* h) {
   return b;
 }
 #define BG_BLOB_MAGIC 0x42474d58u
+#define BG_BLOB_VERSION 2u // 2: stream 13 ('seal_applications') joins the card-state slices, consumables in the reset template
 int bg_get_state(bg_handle* h, int env_index, void* blob_host, uint64_t blob_bytes) {
   if (!h || !blob_host || env_index < 0 || env_index >= h->dev.N || blob_bytes < bg_state_blob_bytes(h)) return BG_E_ARG;
   BG_HIP(hipDeviceSynchronize());
   uint8_t* out = (uint8_t*)blob_host;
-  uint32_t hdr[4] = {BG_BLOB_MAGIC, 1u, (uint32_t)h->dev.KG, (uint32_t)h->dev.KS | ((uint32_t)h->dev.KD << 16)};
+  uint32_t hdr[4] = {BG_BLOB_MAGIC, BG_BLOB_VERSION, (uint32_t)h->dev.KG, (uint32_t)h->dev.KS | ((uint32_t)h->dev.KD << 16)};
   memcpy(out, hdr, 16); out += 16;
   std::vector<BgSlice> v;
   bg_slices(h, v);
@@ -1442,7 +1443,7 @@ int bg_set_state(bg_handle* h, int env_index, const void* blob_host, uint64_t bl
   const uint8_t* in = (const uint8_t*)blob_host;
   uint32_t hdr[4];
   memcpy(hdr, in, 16); in += 16;
-  if (hdr[0] != BG_BLOB_MAGIC || hdr[1] != 1u || hdr[2] != (uint32_t)h->dev.KG ||
+  if (hdr[0] != BG_BLOB_MAGIC || hdr[1] != BG_BLOB_VERSION || hdr[2] != (uint32_t)h->dev.KG ||
       hdr[3] != ((uint32_t)h->dev.KS | ((uint32_t)h->dev.KD << 16))) { h->err = "bg_set_state: blob header mismatch"; return BG_E_ARG; }
   BG_HIP(hipDeviceSynchronize());
   std::vector<BgSlice> v;

@@ -10,7 +10,9 @@ from tests.helpers import OBS_KEYS
 from tests.test_gpu_parity import _oracle_rollout
 from bench import IMPLEMENTED
 
-def run(n, T, policy, scorer, cards_on, seed0, max_ante):
+POOL = list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68))
+
+def run(n, T, policy, scorer, cards_on, seed0, max_ante, cons_on=False):
     seeds = [seed0 + 11 * i for i in range(n)]
     jokers = [random.Random(seed0 + i).sample(IMPLEMENTED if i % 2 else list(range(1, 151)), i % 6) for i in range(n)] if scorer else None
     cards = None
@@ -18,18 +20,22 @@ def run(n, T, policy, scorer, cards_on, seed0, max_ante):
         cards = []
         for i in range(n):
             rr = random.Random(seed0 * 7 + i)
-            cards.append([(d, rr.choice([0, 1, 4, 5, 6, 7, 8]), rr.choice([0, 0, 1, 2]), rr.choice([0, 0, 1, 2, 3])) for d in rr.sample(range(52), 26)])
+            cards.append([(d, rr.choice([0, 1, 4, 5, 6, 7, 8]), rr.choice([0, 0, 1, 2]), rr.choice([0, 0, 1, 2, 3, 4] if cons_on else [0, 0, 1, 2, 3])) for d in rr.sample(range(52), 26)])
     env = BalatroVecEnv(n, seeds, scorer_jokers=scorer, autoreset=True, max_ante=max_ante, card_states=cards_on)
     if jokers:
         env.inject(jokers=jokers, apply_now=True)
     if cards:
         env.inject_cards(cards, apply_now=True)
+    cons = None
+    if cons_on:  # two consumables per episode out of all 52 ids (tarots, planets, spectrals)
+        cons = [random.Random(seed0 * 13 + i).sample(POOL, 1 + (i % 5 != 0)) for i in range(n)]
+        env.inject_consumables(cons, apply_now=True)
     rb = RowBuffers(n, env.device, steps=T)
     t = time.time()
     env.rollout(T, policy=policy, policy_seed=seed0, obs_buffers=rb)
     env.check()
     st = env.stats()
-    wobs, wr, wt, wa, wst = _oracle_rollout(n, seeds, T, policy, seed0, scorer, max_ante, jokers, cards=cards)
+    wobs, wr, wt, wa, wst = _oracle_rollout(n, seeds, T, policy, seed0, scorer, max_ante, jokers, cards=cards, consumables=cons)
     assert np.array_equal(rb.action.cpu().numpy(), wa)
     assert np.array_equal(rb.terminated.cpu().numpy(), wt)
     assert np.array_equal(rb.reward.contiguous().cpu().numpy().view(np.uint64), wr.view(np.uint64))
@@ -45,6 +51,11 @@ if __name__ == "__main__":
         run(8192, 384, 0, True, True, 987001, 8)
         run(8192, 384, 2, True, False, 987002, 4)
         print("BIG STRESS OK")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "consumables":
+        run(4096, 400, 0, True, True, 987003, 8, cons_on=True)
+        run(4096, 400, 0, False, True, 987004, 0, cons_on=True)
+        print("CONSUMABLES STRESS OK")
         sys.exit(0)
     run(1000, 300, 0, True, False, 123457, 6)
     run(1000, 300, 2, True, False, 223457, 4)
