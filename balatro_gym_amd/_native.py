@@ -96,6 +96,10 @@ def load(build_if_missing: bool = True):
                 raise NativeError(f"libbalatro_mi355x.so is missing and could not be built: {exc}") from exc
     if not os.path.exists(path):
         raise NativeError(f"{path} not found: build it with `python -m balatro_gym_amd.build` (no CPU fallback exists)")
+    # PyTorch-ROCm ships its own libamdhip64 (torch/lib); the process must hold ONE HIP runtime, and device tensors come
+    # from torch, so torch's copy has to be the one that is resident when this library's libamdhip64.so.7 dependency is
+    # resolved.  (Loading this library first brought in /opt/rocm's runtime as well: bg_create then saw no device.)
+    import torch  # noqa: F401
     try:
         L = C.CDLL(path)
     except OSError as exc:

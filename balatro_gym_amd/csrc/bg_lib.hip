@@ -150,11 +150,14 @@ __device__ __forceinline__ void bg_barrier_lds() { asm volatile("s_waitcnt lgkmc
 
 struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags; }; // misc: hand_type+1 | terminated<<8 | has_shop<<9
 
+#ifndef BG_RB_ATTR
+#define BG_RB_ATTR // development: e.g. -DBG_RB_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))'
+#endif
 #ifndef BG_RB_WAVES
 #define BG_RB_WAVES 1
 #endif
 template <bool HASH, bool CARDS>
-__global__ __launch_bounds__(BG_RB, BG_RB_WAVES) void bg_rollout2_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
+__global__ __launch_bounds__(BG_RB, BG_RB_WAVES) BG_RB_ATTR void bg_rollout2_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
                                                               uint64_t env_index0, uint64_t t0, ObsPtrs obs,
                                                               int obs_stride_steps, double* reward, uint8_t* term,
                                                               int32_t* actions_out, bg_rollout_stats* stats,
