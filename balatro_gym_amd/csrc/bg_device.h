@@ -293,7 +293,7 @@ __device__ __forceinline__ double bg_lazy_random(uint32_t* S) {
 // (card, joker) pair) or of a shop generation are consecutive words of ONE block, so they are fetched with
 // independent loads up front and then consumed from LDS: the serial chain of dependent HBM round trips (one per
 // draw, ~1 us each at one wave per SIMD) becomes one batch.  Layout [word][lane] (bank = lane: conflict-free).
-#define BG_WIN 32
+#define BG_WIN 24 // the longest batch is the 24-word window of a shop inventory (bg_sprefetch); The Hook needs 16
 // Per-workgroup lookup tables in LDS (filled once per launch by bg_tables_init): per-lane-different joker ids make
 // `switch` statements fully divergent (a wave walks every case some lane takes) and constant-memory tables cost an HBM
 // round trip per lookup at one wave per SIMD; an LDS read is ~100 cycles and never diverges.

@@ -150,6 +150,9 @@ __device__ __forceinline__ void bg_barrier_lds() { asm volatile("s_waitcnt lgkmc
 
 struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags; }; // misc: hand_type+1 | terminated<<8 | has_shop<<9
 
+#ifndef BG_RB_LB
+#define BG_RB_LB BG_RB // threads per workgroup the compiler plans registers for
+#endif
 #ifndef BG_RB_ATTR
 #define BG_RB_ATTR // development: e.g. -DBG_RB_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))'
 #endif
@@ -157,7 +160,7 @@ struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags;
 #define BG_RB_WAVES 1
 #endif
 template <bool HASH, bool CARDS>
-__global__ __launch_bounds__(BG_RB, BG_RB_WAVES) BG_RB_ATTR void bg_rollout2_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
+__global__ __launch_bounds__(BG_RB_LB, BG_RB_WAVES) BG_RB_ATTR void bg_rollout2_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
                                                               uint64_t env_index0, uint64_t t0, ObsPtrs obs,
                                                               int obs_stride_steps, double* reward, uint8_t* term,
                                                               int32_t* actions_out, bg_rollout_stats* stats,
@@ -387,6 +390,286 @@ __global__ __launch_bounds__(BG_RB, BG_RB_WAVES) BG_RB_ATTR void bg_rollout2_ker
       atomicXor((unsigned long long*)&stats->reward_bits, (unsigned long long)rbits);
       atomicXor((unsigned long long*)&stats->obs_hash, (unsigned long long)ohash);
     }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused rollout with DEDICATED SERVICE WAVES (BG_ROLLOUT_V=3).
+//
+// bg_rollout2_kernel runs one wave per SIMD (341 registers) and its waves alternate between the env phases (A / C) and
+// the heavy phase B behind workgroup barriers: nothing overlaps a wave's dependent chains.  Here a workgroup is FOUR
+// waves: waves 0-1 are env waves (lane = env, 128 envs, phases A and C only), wave 2 serves the queued PLAY_HAND items
+// and wave 3 every other queued action.  The two roles sit in disjoint branches, so the register allocation is the
+// larger of the two instead of their union (<= 256: two waves per SIMD, 8 per CU), and there is NO workgroup barrier in
+// the loop: queues, completion flags and the starvation hint are LDS words with workgroup-scope acquire / release.
+//   env lane:     pack state -> s_state, s_out.misc = 0, release, slot = tail[cls]++, s_items[cls][slot & 127] = item | VALID
+//   service wave: n = tail - head; when n >= threshold (or the env waves run dry) take min(n, 64) items: wait for VALID,
+//                 clear the slot, step the env from / to LDS, s_out = result, release, s_out.misc |= DONE
+//   env lane:     polls its own s_out.misc (acquire) at the top of phase C, as before
+// A lane has at most one item in flight, so the 128-entry rings never overflow.  The service waves leave when both env
+// waves have finished.  Every spin loop sleeps and gives up after BG_SPIN_LIMIT polls (sticky device error instead of a
+// hung GPU).
+// ---------------------------------------------------------------------------------------------------------
+#define BG_ITEM_VALID 0x80000000u
+#define BG_SPIN_LIMIT (1u << 24)
+#define BG_DEVERR_SPIN 16u
+// LDS words shared between waves.  One wave's LDS instructions execute in program order, so "data, then flag" on the
+// producer side and "flag, then data" on the consumer side need no hardware fence -- only the compiler must keep the order
+// (relaxed workgroup-scope atomics + a compiler barrier).  Acquire / release atomics would also wait for the wave's global
+// stores (s_waitcnt vmcnt(0)): for an env wave that is the whole record write-out of the iteration before.
+__device__ __forceinline__ uint32_t bg_lds_load(uint32_t* p) {
+  uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  return v;
+}
+__device__ __forceinline__ void bg_lds_store(uint32_t* p, uint32_t v) {
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void bg_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } // this wave's global stores have landed
+
+template <bool HASH, bool CARDS>
+__global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
+                                                                   uint64_t env_index0, uint64_t t0, ObsPtrs obs,
+                                                                   int obs_stride_steps, double* reward, uint8_t* term,
+                                                                   int32_t* actions_out, bg_rollout_stats* stats,
+                                                                   uint32_t th_play, uint32_t th_other, uint32_t th_ready) {
+  static_assert(BG_RB == 2 * BG_BLOCK, "two env waves + two service waves per workgroup");
+  __shared__ uint4 s_state[BG_NHOT][BG_RB];
+  __shared__ uint4 s_shop[4][BG_RB];
+  __shared__ OutLds s_out[BG_RB];
+  __shared__ uint32_t s_items[2][BG_RB];   // rings: 0 = PLAY_HAND, 1 = every other deferred action
+  __shared__ uint32_t s_tail[2];           // items ever queued per class (env lanes, atomic)
+  __shared__ uint32_t s_ready[2];          // runnable lanes of each env wave (starvation hint for the service waves)
+  __shared__ uint32_t s_done;              // env waves that have finished
+  __shared__ uint32_t s_prod[BG_RB];
+  __shared__ uint32_t s_deck[16][BG_RB];
+  __shared__ uint32_t win[2][BG_WIN][BG_BLOCK];                 // RNG windows of the two service waves
+  __shared__ bg_u32x4 s_stage[2][BG_BLOCK * BG_STAGE_NP];       // record staging of the two env waves
+  __shared__ unsigned long long s_rowaddr[2][BG_BLOCK];
+  __shared__ JTables jt;
+  __builtin_amdgcn_s_setprio(3);
+  bg_tables_init(&jt);
+  const int tid = threadIdx.x;
+  const int wave = tid >> 6;
+  const int local = tid & (BG_RB - 1); // env lane index (env waves) -- service lanes use `lane`
+  const int env = blockIdx.x * BG_RB + local;
+  const bool is_env = wave < 2;
+  const bool live = is_env && env < d.N;
+  using DeckT = typename std::conditional<CARDS, DeckLdsC, DeckLds>::type;
+  if (is_env) s_prod[local] = (live && d.prod_view) ? d.prod_view[env] : 0u;
+  if (tid < 2) { s_tail[tid] = 0; s_ready[tid] = BG_BLOCK; }
+  if (tid == 0) s_done = 0;
+  if (is_env) {
+    s_items[0][local] = 0; s_items[1][local] = 0;
+    OutLds z; z.reward = 0.0; z.final_score = 0; z.misc = 0; z.flags = 0;
+    s_out[local] = z;
+  }
+  __syncthreads();
+  if (is_env) {
+    // =========================================== env waves: phases A and C ===========================================
+    uint64_t n_steps = 0, n_eps = 0, n_plays = 0, rbits = 0, ohash = 0;
+    int64_t ssum = 0;
+    Env e;
+    DeckT dk;
+    uint64_t mask = 0;
+    dk.col = (lds_u32*)&s_deck[0][local];
+    if (live) {
+      bg_load_env(d, env, e);
+#pragma unroll
+      for (int k = 0; k < BG_NDECK; k++) bg_deck_set(dk, k, d.deck[(size_t)k * d.N + env]);
+      ShopRegs sr; sr.valid = false;
+      mask = bg_action_mask(d, env, e, sr);
+      if (sr.valid) { s_shop[0][local] = sr.c3; s_shop[1][local] = sr.c4; s_shop[2][local] = sr.c5; s_shop[3][local] = sr.c6; }
+    }
+    int t = 0;
+    bool blocked = false;
+    int action = 0;
+    StepOut o;
+    bg_step_init(o);
+    const PolicyLane pl = bg_policy_lane(policy, policy_seed, env_index0 + (uint64_t)env);
+    uint32_t idle_polls = 0;
+#ifdef BG_TIMING3
+    unsigned long long q_iter = 0, q_idle = 0, q_a = 0, q_c = 0, q_lanes = 0;
+    const unsigned long long q_t0 = __builtin_readcyclecounter();
+#endif
+    for (;;) {
+#ifdef BG_TIMING3
+      const unsigned long long q_c0 = __builtin_readcyclecounter();
+#endif
+      // ---------------- phase A: policy, guards, cheap actions inline, everything else queued
+      bool fin = false;
+      if (live && !blocked && t < T) {
+        bg_step_init(o);
+        action = bg_policy_action(e, mask, policy, pl, t0 + (uint64_t)t);
+        bool deferred = false;
+        if (bg_step_guards(e, mask, action, o)) {
+          if (e.phase == 0 && action >= 2 && action < 10) bg_toggle_select(e, action - 2);
+          else if (e.phase == 1 && action == 31) { e.phase = 0; bg_draw_cards(e); }              // shop end :1247-1251
+          else deferred = true;
+        }
+        if (deferred) {
+          const int cls = (e.phase == 0 && action == 0) ? 0 : 1;
+          uint4 c[BG_NHOT];
+          bg_pack(e, c);
+#pragma unroll
+          for (int k = 0; k < BG_NHOT; k++) s_state[k][local] = c[k];
+          bg_lds_store((uint32_t*)&s_out[local].misc, 0u); // not processed yet
+          const uint32_t slot = __hip_atomic_fetch_add(&s_tail[cls], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          bg_lds_store(&s_items[cls][slot & (BG_RB - 1)], (uint32_t)local | ((uint32_t)action << 16) | BG_ITEM_VALID);
+          blocked = true;
+        } else fin = true;
+      }
+      {
+        const bool runnable_next = live && !blocked && (t + (fin ? 1 : 0)) < T;
+        const unsigned long long bal = __ballot(runnable_next);
+        if ((tid & 63) == 0) bg_lds_store(&s_ready[wave], (uint32_t)__popcll(bal));
+      }
+#ifdef BG_TIMING3
+      const unsigned long long q_c1 = __builtin_readcyclecounter();
+#endif
+      // ---------------- phase C: finish the step of every lane that took one (inline in A, or served by a service wave)
+      if (blocked && (bg_lds_load((uint32_t*)&s_out[local].misc) & 0x400u)) {
+        uint4 c[BG_NHOT];
+#pragma unroll
+        for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][local];
+        bg_unpack(c, e);
+        bg_derive_ready(e, s_prod[local]);
+        OutLds ol = s_out[local];
+        o.reward = ol.reward; o.final_score = ol.final_score; o.flags = ol.flags;
+        o.hand_type = (ol.misc & 0xff) - 1; o.terminated = (ol.misc & 0x100) != 0; o.error = ol.misc >> 16;
+        blocked = false;
+        fin = true;
+      }
+      if (fin) {
+        if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
+        if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; } // SAME_STEP auto-reset
+        // a reset zeroes the env's play counts (and re-applies its card states) in HBM, which a service wave touches a few
+        // steps later: let those stores land first.  What is still in flight here is the record write-out of the iteration
+        // BEFORE (a whole phase A old), so this wait is short -- unlike one right after the write-out
+        if (__ballot(o.terminated) != 0ull) bg_wait_vm();
+        ShopRegs sr; sr.valid = false;
+        if (e.phase == 1 && (e.bflags & BG_BF_SHOP_EXISTS)) {
+          sr.c3 = s_shop[0][local]; sr.c4 = s_shop[1][local]; sr.c5 = s_shop[2][local]; sr.c6 = s_shop[3][local]; sr.valid = true;
+        }
+        mask = bg_action_mask(d, env, e, sr);
+        size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
+        uint64_t h = bg_write_obs_impl<HASH, true>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u},
+                                                  RowStage{(lds_u4*)&s_stage[wave][0], (lds_u64*)&s_rowaddr[wave][0]});
+        if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
+        if (reward) reward[row] = o.reward;
+        if (term) term[row] = o.terminated ? 1 : 0;
+        if (actions_out) actions_out[row] = action;
+        n_steps++;
+        rbits ^= (uint64_t)__double_as_longlong(o.reward) * (2 * (uint64_t)(t0 + t) + 1);
+        if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
+        t++;
+      }
+#ifdef BG_TIMING3
+      { const unsigned long long q_c2 = __builtin_readcyclecounter(); q_a += q_c1 - q_c0; q_c += q_c2 - q_c1; q_iter++;
+        q_lanes += (unsigned long long)__popcll(__ballot(fin)); if (__ballot(fin) == 0ull) q_idle++; }
+#endif
+      if (__ballot(live && (blocked || t < T)) == 0ull) break;              // this wave has done its T steps
+      if (__ballot(fin) == 0ull) {                                           // every live lane is waiting for a service wave
+        __builtin_amdgcn_s_sleep(8);
+        if (++idle_polls > BG_SPIN_LIMIT) { if ((tid & 63) == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
+      } else idle_polls = 0;
+    }
+#ifdef BG_TIMING3
+    if ((tid & 63) == 0 && d.dbg) {
+      atomicAdd(&d.dbg[0], __builtin_readcyclecounter() - q_t0); atomicAdd(&d.dbg[1], q_iter); atomicAdd(&d.dbg[2], q_idle);
+      atomicAdd(&d.dbg[3], q_a); atomicAdd(&d.dbg[4], q_c); atomicAdd(&d.dbg[11], 1ull); atomicAdd(&d.dbg[12], q_lanes);
+    }
+#endif
+    if ((tid & 63) == 0) {
+      bg_lds_store(&s_ready[wave], 0u);
+      __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    if (live) bg_store_env(d, env, e);
+    if (stats) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        n_steps += __shfl_down(n_steps, off); n_eps += __shfl_down(n_eps, off); n_plays += __shfl_down(n_plays, off);
+        ssum += __shfl_down(ssum, off); rbits ^= __shfl_down(rbits, off); ohash ^= __shfl_down(ohash, off);
+      }
+      if ((tid & 63) == 0) {
+        atomicAdd((unsigned long long*)&stats->steps, (unsigned long long)n_steps);
+        atomicAdd((unsigned long long*)&stats->episodes, (unsigned long long)n_eps);
+        atomicAdd((unsigned long long*)&stats->plays, (unsigned long long)n_plays);
+        atomicAdd((unsigned long long*)&stats->score_sum, (unsigned long long)ssum);
+        atomicXor((unsigned long long*)&stats->reward_bits, (unsigned long long)rbits);
+        atomicXor((unsigned long long*)&stats->obs_hash, (unsigned long long)ohash);
+      }
+    }
+  } else {
+    // =========================================== service waves: phase B ===========================================
+    const int cls = wave - 2;
+    const int lane = tid & (BG_BLOCK - 1);
+    const uint32_t th = cls == 0 ? th_play : th_other;
+    uint32_t head = 0, polls = 0;
+#ifdef BG_TIMING3
+    unsigned long long q_batches = 0, q_items = 0, q_busy = 0;
+    const unsigned long long q_t0 = __builtin_readcyclecounter();
+#endif
+    for (;;) {
+      const uint32_t tail = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_tail[cls]));
+      const uint32_t n = tail - head;
+      const uint32_t ready = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_ready[0]) + bg_lds_load(&s_ready[1]));
+      if (n == 0u || (n < th && ready >= th_ready)) {
+        if (n == 0u && __builtin_amdgcn_readfirstlane(bg_lds_load(&s_done)) >= 2u) break; // both env waves are through
+        __builtin_amdgcn_s_sleep(16);
+        if (++polls > BG_SPIN_LIMIT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
+        continue;
+      }
+      polls = 0;
+      const uint32_t nb = n > BG_BLOCK ? BG_BLOCK : n;
+#ifdef BG_TIMING3
+      const unsigned long long q_b0 = __builtin_readcyclecounter();
+#endif
+      if ((uint32_t)lane < nb) {
+        uint32_t* slotp = &s_items[cls][(head + (uint32_t)lane) & (BG_RB - 1)];
+        uint32_t item = bg_lds_load(slotp);
+        uint32_t spin = 0;
+        while (!(item & BG_ITEM_VALID) && ++spin < BG_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); item = bg_lds_load(slotp); }
+        bg_lds_store(slotp, 0u);
+        if (item & BG_ITEM_VALID) {
+          const int l = (int)(item & 0xffffu), a = (int)((item >> 16) & 0x7fffu);
+          const int benv = blockIdx.x * BG_RB + l;
+          uint4 c[BG_NHOT];
+#pragma unroll
+          for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][l];
+          Env be;
+          bg_unpack(c, be);
+          bg_derive_ready(be, s_prod[l]);
+          DeckT bdk; bdk.col = (lds_u32*)&s_deck[0][l];
+          ShopRegs bsr; bsr.valid = false;
+          RngWin w;
+          bg_win_init(w, &win[cls][0][lane], &jt);
+          StepOut bo;
+          bg_step_init(bo);
+          bg_env_dispatch(d, benv, be, w, bsr, bdk, a, bo);
+          bg_pack(be, c);
+#pragma unroll
+          for (int k = 0; k < BG_NHOT; k++) s_state[k][l] = c[k];
+          if (bsr.valid) { s_shop[0][l] = bsr.c3; s_shop[1][l] = bsr.c4; s_shop[2][l] = bsr.c5; s_shop[3][l] = bsr.c6; }
+          const int32_t misc = (bo.hand_type + 1) | (bo.terminated ? 0x100 : 0) | (bsr.valid ? 0x200 : 0) | (bo.error << 16);
+          s_out[l].reward = bo.reward; s_out[l].final_score = bo.final_score; s_out[l].flags = bo.flags;
+          bg_wait_vm(); // shop inventory / play counts / card states written to HBM are read by the OTHER service wave later
+          bg_lds_store((uint32_t*)&s_out[l].misc, (uint32_t)misc | 0x400u);
+        } else atomicOr(d.err, BG_DEVERR_SPIN);
+      }
+      head += nb;
+#ifdef BG_TIMING3
+      q_busy += __builtin_readcyclecounter() - q_b0; q_batches++; q_items += nb;
+#endif
+    }
+#ifdef BG_TIMING3
+    if (lane == 0 && d.dbg) {
+      atomicAdd(&d.dbg[5 + 3 * cls], q_batches); atomicAdd(&d.dbg[6 + 3 * cls], q_items); atomicAdd(&d.dbg[7 + 3 * cls], q_busy);
+      atomicAdd(&d.dbg[13 + cls], __builtin_readcyclecounter() - q_t0);
+    }
+#endif
   }
 }
 
@@ -638,14 +921,18 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
     // seeds were drawn ahead from stream 2 into a small per-env ring
     uint32_t sm = d.smeta[env];
     int head = (int)(sm & 0xffu), cnt = (int)((sm >> 8) & 0xffu);
-    int emitted = 0;
-    while (s_ready + emitted < d.KS - 1 && cnt > 0) {
-      int slot = s_cur + 1 + s_ready + emitted; while (slot >= d.KS) slot -= d.KS;
-      uint32_t i = atomicAdd(&d.wl_count[3], 1u);
-      d.wl_shop[2 * (size_t)i] = (uint32_t)env | ((uint32_t)slot << 24);
-      d.wl_shop[2 * (size_t)i + 1] = d.sseed[(size_t)env * BG_SSEED + head];
-      head = (head + 1) & (BG_SSEED - 1); cnt--; emitted++;
-    }
+    int emitted = d.KS - 1 - s_ready;
+    if (emitted > cnt) emitted = cnt;
+    if (emitted > 0) { // ONE atomic per env (an atomic per slot was ~0.6 M serialised updates of one counter: 0.4 ms)
+      const uint32_t base = atomicAdd(&d.wl_count[3], (uint32_t)emitted);
+#pragma unroll 1
+      for (int k = 0; k < emitted; k++) {
+        int slot = s_cur + 1 + s_ready + k; while (slot >= d.KS) slot -= d.KS;
+        d.wl_shop[2 * (size_t)(base + k)] = (uint32_t)env | ((uint32_t)slot << 24);
+        d.wl_shop[2 * (size_t)(base + k) + 1] = d.sseed[(size_t)env * BG_SSEED + ((head + k) & (BG_SSEED - 1))];
+      }
+      head = (head + emitted) & (BG_SSEED - 1); cnt -= emitted;
+    } else emitted = 0;
     if (emitted) {
       d.smeta[env] = (uint32_t)head | ((uint32_t)cnt << 8);
       prod = (prod & 0xffff00ffu) | ((((prod >> 8) + (uint32_t)emitted) & 0xffu) << 8);
@@ -924,7 +1211,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (device_id < 0 || device_id >= ndev) { g_create_err = "bg_create: device_id out of range"; return BG_E_ARG; }
   bg_handle* h = new bg_handle();
   h->device_id = device_id; h->seeded = false; h->bytes = 0; h->profiling = false;
-  { const char* rv = getenv("BG_ROLLOUT_V"); h->rollout_version = rv ? atoi(rv) : 2; }
+  { const char* rv = getenv("BG_ROLLOUT_V"); h->rollout_version = rv ? atoi(rv) : 3; }
   { const char* av = getenv("BG_ASYNC_REFILL"); h->async_refill = av ? atoi(av) != 0 : true; }
   { // phase B runs when a queue reaches its threshold or fewer than th_ready lanes can still step (1/1/anything = lockstep)
     const char* a = getenv("BG_TH_PLAY"); const char* b = getenv("BG_TH_OTHER"); const char* c = getenv("BG_TH_READY");
@@ -933,6 +1220,12 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
     // partial writes, so the drift is kept short there (2.15 G -> 2.98 G env-steps/s; packed records are immune)
     h->thk_play = a ? h->th_play : (uint32_t)(BG_RB / 8); h->thk_other = b ? h->th_other : (uint32_t)(BG_RB / 8);
     h->thk_ready = c ? h->th_ready : (uint32_t)(BG_RB * 25 / 32);
+    if (h->rollout_version == 3) {
+      // dedicated service waves batch by themselves (whatever queued up while the last batch ran): no thresholds, for
+      // either output layout (16/16 -3 %, 40/40 -7 % measured)
+      h->th_play = h->thk_play = a ? h->th_play : 1u; h->th_other = h->thk_other = b ? h->th_other : 1u;
+      h->th_ready = h->thk_ready = c ? h->th_ready : 255u;
+    }
     if (h->th_play < 1) h->th_play = 1; if (h->th_other < 1) h->th_other = 1; if (h->th_ready < 1) h->th_ready = 1;
   }
   h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
@@ -1069,7 +1362,9 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   bg_ev_begin(h, h->ev_refill_t, s);
   BG_HIP(hipMemsetAsync(d.wl_count, 0, 4 * sizeof(uint32_t), s));
   hipLaunchKernelGGL(bg_refill_scan_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, d);
-  static const int dense_cap = getenv("BG_REFILL_BLOCKS") ? atoi(getenv("BG_REFILL_BLOCKS")) : 512; // two refill waves per CU per kernel
+  // v2 rollout: two refill waves per CU per kernel run BESIDE the rollout (512).  The service-wave kernel leaves no
+  // registers for a co-resident wave, so its refill runs in the gaps rollout workgroups leave when they retire: wide grids
+  static const int dense_cap = getenv("BG_REFILL_BLOCKS") ? atoi(getenv("BG_REFILL_BLOCKS")) : (h->rollout_version == 3 ? 4096 : 512);
   int dense = bg_grid(h) < dense_cap ? bg_grid(h) : dense_cap; // grid-stride over the compacted work lists
   // the three kinds of work are independent once the lists exist: run them side by side (each is a few hundred
   // latency-bound waves), join before the completion event
@@ -1225,13 +1520,13 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       if (o.boss_blind_active) o.boss_blind_active += off; if (o.boss_blind_type) o.boss_blind_type += off;
       if (o.face_down_cards) o.face_down_cards += off * 8;
     }
-    bg_ev_begin(h, h->ev_rollout_t, (hipStream_t)stream);
     if (h->profiling) h->rollout_steps.push_back(chunk);
     // async: this chunk may start as soon as the refill before the previous one is complete; sync: after the last one
     rc = bg_wait_refill(h, (hipStream_t)stream, async ? 1 : 0);
     if (rc) return rc;
     const uint32_t* view = (async && h->refill_seq >= 2) ? h->d_prod[h->refill_seq & 1] : bg_prod_latest(h);
     if (async && h->refill_seq < 2) { rc = bg_wait_refill(h, (hipStream_t)stream, 0); if (rc) return rc; }
+    bg_ev_begin(h, h->ev_rollout_t, (hipStream_t)stream); // after the waits: the events bracket the kernel, not the stream's wait for the refill
     BgDev dv = bg_dev_view(h, view);
     {
       const bool hash = (policy & BG_POLICY_HASH_OBS) != 0;
@@ -1247,8 +1542,11 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
         else hipLaunchKernelGGL(bg_rollout_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
       } else {
         dim3 g2((h->dev.N + BG_RB - 1) / BG_RB);
-#define BG_LAUNCH_R2(HASHV, CARDSV) hipLaunchKernelGGL((bg_rollout2_kernel<HASHV, CARDSV>), g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, \
-                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr)
+        const bool v3 = h->rollout_version == 3; // dedicated service waves: four waves per workgroup of 128 envs
+#define BG_LAUNCH_R2(HASHV, CARDSV) do { if (v3) hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV>), g2, dim3(2 * BG_RB), 0, st, dv, chunk, pol, policy_seed, \
+                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr); \
+  else hipLaunchKernelGGL((bg_rollout2_kernel<HASHV, CARDSV>), g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, \
+                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr); } while (0)
         const bool per_key = !rows_dev && obs && obs_stride_steps != 0; // [T, N] arrays per key
         const uint32_t thp = per_key ? h->thk_play : h->th_play, tho = per_key ? h->thk_other : h->th_other, thr = per_key ? h->thk_ready : h->th_ready;
         const bool cards = h->dev.cstate != nullptr;
@@ -1287,7 +1585,7 @@ int bg_rollout_rows(bg_handle* h, int T, int policy, uint64_t policy_seed, uint6
     h->err = "bg_rollout_rows: rows_dev must be 16-byte aligned and row_stride_bytes a multiple of 16, >= BG_ROW_BYTES";
     return BG_E_ARG;
   }
-  if (h->rollout_version == 1) { h->err = "bg_rollout_rows needs the block-compacted rollout kernel (BG_ROLLOUT_V=2)"; return BG_E_ARG; }
+  if (h->rollout_version == 1) { h->err = "bg_rollout_rows needs a block-compacted rollout kernel (BG_ROLLOUT_V=2 or 3)"; return BG_E_ARG; }
   return bg_rollout_impl(h, T, policy, policy_seed, env_index0, t0, nullptr, rows_dev, (size_t)row_stride_bytes,
                          rows_stride_steps, nullptr, nullptr, nullptr, stats_dev, stream);
 }

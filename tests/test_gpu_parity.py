@@ -358,6 +358,14 @@ def test_lane_per_env_rollout_kernel(monkeypatch):
     test_fused_rollout_vs_oracle(2, True)
 
 
+def test_barrier_rollout_kernel(monkeypatch):
+    """The barrier-phased kernel (BG_ROLLOUT_V=2: two waves per workgroup alternate between the env phases and phase B) is
+    kept for A/B comparisons with the service-wave kernel: same bits."""
+    monkeypatch.setenv("BG_ROLLOUT_V", "2")
+    test_fused_rollout_vs_oracle(2, True)
+    test_consumables_rollout_vs_oracle(True)
+
+
 def test_rollout_properties_full_size():
     """Size-independent properties at BASELINE.json's N = 65 536: determinism, chunking invariance (one T=48 call ==
     48 T=1 calls), sharding invariance (two half-size handles with env_index0 offsets == one full handle)."""
