@@ -48,7 +48,8 @@ struct BgDev {
   uint4* tmpl;
   uint4* ndeck;
   uint32_t* gblk;
-  uint32_t* sblk;
+  uint32_t* sblk;     // [N][KS][288] compact seeded shop streams (BG_SW_*)
+  uint32_t* sovf;     // [N][640] full seeded state of a shop stream that was read beyond its slot (rare)
   uint32_t* deckmt;
   uint32_t* shopgenmt;
   uint32_t* err;
@@ -196,7 +197,19 @@ __device__ __forceinline__ int bg_level(const Env& e, int ht) { return (int)((e.
 // subset of deck[0..hand_size), so the global-memory path below is the rare general case.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t* bg_gblock(const BgDev& d, int env, int slot) { return d.gblk + ((size_t)env * d.KG + slot) * BG_MTS; }
-__device__ __forceinline__ uint32_t* bg_sblock(const BgDev& d, int env, int slot) { return d.sblk + ((size_t)env * d.KS + slot) * BG_MTS; }
+// A shop-stream ring slot keeps only the part of the seeded state S a visit reads: word k of the first output block needs
+// S[k], S[k+1] and S[k+397] (k < 227), and a visit reads ~10 words per inventory -- so words 0..131 and 396..527 (k <= 130:
+// a dozen inventories) plus the seed, 1.1 KB instead of 2.5 KB.  The refill's shop kernel is bound by these writes.  A visit
+// that reads further re-seeds the FULL state into the env's overflow block once (bg_shop_overflow) and carries on there.
+#define BG_SW_A 132                // words 0..131 of S
+#define BG_SW_F (BG_MT_M - 1)      // 396: first word of the far window (396..527)
+#define BG_SW_SEED (2 * BG_SW_A)   // slot word holding the seed
+#define BG_SLOT_WORDS 288          // 264 + seed, padded to 9 x 128 B
+#define BG_S_FASTMAX 130           // largest k whose operands all sit in the slot
+#define BG_BF_SHOP_OVF 4           // bflags: the current shop stream lives in the overflow block (full state)
+__device__ __forceinline__ uint32_t* bg_sblock(const BgDev& d, int env, int slot) { return d.sblk + ((size_t)env * d.KS + slot) * BG_SLOT_WORDS; }
+__device__ __forceinline__ uint32_t* bg_sovf(const BgDev& d, int env) { return d.sovf + (size_t)env * BG_MTS; }
+__device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key); // bg_lib.hip
 __device__ __forceinline__ uint32_t* bg_deckmt(const BgDev& d, int env) { return d.deckmt + (size_t)env * BG_MTS; }
 __device__ __forceinline__ uint32_t* bg_shopgenmt(const BgDev& d, int env) { return d.shopgenmt + (size_t)env * BG_MTS; }
 
@@ -396,58 +409,79 @@ __device__ __forceinline__ void bg_gprefetch(const BgDev& d, int env, Env& e, Rn
 //   far = k < 227 ? S[k + 397] : B(k - 227),   nxt = k < 623 ? S[k + 1] : B(0)
 // i.e. at most three levels deep.  A shop visit reads ~13 words per inventory, so the window below (k + len <= 227: every
 // operand is a seeded word) covers everything but many-reroll visits, which take the slow exact path.
-__device__ __noinline__ uint32_t bg_sword_slow(const uint32_t* S, int k) {
+// S[j] of the current shop stream: `full` = the overflow block (plain indexing), else the compact slot
+__device__ __forceinline__ uint32_t bg_sget(const uint32_t* S, bool full, int j) { return S[(full || j < BG_SW_A) ? j : j - (BG_SW_F - BG_SW_A)]; }
+__device__ __noinline__ uint32_t bg_sword_slow(const uint32_t* S, bool full, int k) {
   uint32_t far;
-  if (k < BG_MT_N - BG_MT_M) far = S[k + BG_MT_M];
-  else {
+  if (k < BG_MT_N - BG_MT_M) far = bg_sget(S, full, k + BG_MT_M);
+  else { // only reachable in the full state
     const int k1 = k - (BG_MT_N - BG_MT_M); // 0..396
     uint32_t far1;
     if (k1 < BG_MT_N - BG_MT_M) far1 = S[k1 + BG_MT_M];
     else { const int k2 = k1 - (BG_MT_N - BG_MT_M); far1 = bg_twist(S[k2], S[k2 + 1], S[k2 + BG_MT_M]); } // k2 < 170
     far = bg_twist(S[k1], S[k1 + 1], far1);
   }
-  const uint32_t nxt = k < BG_MT_N - 1 ? S[k + 1] : bg_twist(S[0], S[1], S[BG_MT_M]);
-  return bg_twist(S[k], nxt, far);
+  const uint32_t nxt = k < BG_MT_N - 1 ? bg_sget(S, full, k + 1) : bg_twist(S[0], S[1], S[BG_MT_M]);
+  return bg_twist(bg_sget(S, full, k), nxt, far);
+}
+// the visit reads past what the slot holds: random.Random(seed) once more, whole state, into the env's overflow block
+__device__ __noinline__ void bg_shop_overflow(const BgDev& d, int env, Env& e) {
+  bg_mt_seed(bg_sovf(d, env), bg_sblock(d, env, e.s_cur)[BG_SW_SEED]);
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the lane reads these words back (and a later step may run in another wave)
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  e.bflags |= BG_BF_SHOP_OVF;
+}
+__device__ __forceinline__ const uint32_t* bg_sbase(const BgDev& d, int env, const Env& e, bool& full) {
+  full = (e.bflags & BG_BF_SHOP_OVF) != 0;
+  return full ? bg_sovf(d, env) : bg_sblock(d, env, e.s_cur);
 }
 __device__ __forceinline__ uint32_t bg_sdraw(const BgDev& d, int env, Env& e, RngWin& w) {
   if (e.s_idx >= BG_MT_N) { atomicOr(d.err, BG_DEVERR_SHOPBLK); return 0u; }
   uint32_t off = (uint32_t)(e.s_idx - w.s_start);
   uint32_t y;
   if (off < (uint32_t)w.s_len) y = w.lds[off * BG_BLOCK];
-  else y = bg_sword_slow(bg_sblock(d, env, e.s_cur), e.s_idx);
+  else {
+    if (e.s_idx > BG_S_FASTMAX && !(e.bflags & BG_BF_SHOP_OVF)) bg_shop_overflow(d, env, e);
+    bool full;
+    const uint32_t* S = bg_sbase(d, env, e, full);
+    y = bg_sword_slow(S, full, e.s_idx);
+  }
   e.s_idx++;
   return bg_temper(y);
 }
 // regenerate the next `count` (<= 24) words of the shop stream into the window: 14 independent 16-byte loads for a
 // fresh stream (s_idx == 0, every generate_shop), scalar loads at other positions (rerolls)
-__device__ __forceinline__ void bg_swin_fill0(lds_u32* lds, const uint32_t* S) {
+__device__ __forceinline__ void bg_swin_fill0(lds_u32* lds, const uint32_t* S) { // compact slot only (a fresh stream)
   const uint4* S4 = (const uint4*)S;
   uint32_t A[28], F[28];
 #pragma unroll
   for (int g = 0; g < 7; g++) { uint4 v = S4[g]; A[4 * g] = v.x; A[4 * g + 1] = v.y; A[4 * g + 2] = v.z; A[4 * g + 3] = v.w; }
 #pragma unroll
-  for (int g = 0; g < 7; g++) { uint4 v = S4[99 + g]; F[4 * g] = v.x; F[4 * g + 1] = v.y; F[4 * g + 2] = v.z; F[4 * g + 3] = v.w; } // words 396..423
+  for (int g = 0; g < 7; g++) { uint4 v = S4[BG_SW_A / 4 + g]; F[4 * g] = v.x; F[4 * g + 1] = v.y; F[4 * g + 2] = v.z; F[4 * g + 3] = v.w; } // words 396..423
 #pragma unroll
   for (int i = 0; i < 24; i++) lds[i * BG_BLOCK] = bg_twist(A[i], A[i + 1], F[i + 1]);
 }
-__device__ __forceinline__ void bg_swin_fill(lds_u32* lds, const uint32_t* S, int k0, int len) {
+__device__ __forceinline__ void bg_swin_fill(lds_u32* lds, const uint32_t* S, bool full, int k0, int len) {
   uint32_t A[25], F[24];
+  const uint32_t* SF = S + k0 + BG_MT_M - (full ? 0 : BG_SW_F - BG_SW_A); // &S[k0 + 397] in either layout
 #pragma unroll
   for (int j = 0; j < 25; j++) A[j] = (j <= len) ? S[k0 + j] : 0u;
 #pragma unroll
-  for (int j = 0; j < 24; j++) F[j] = (j < len) ? S[k0 + j + BG_MT_M] : 0u;
+  for (int j = 0; j < 24; j++) F[j] = (j < len) ? SF[j] : 0u;
 #pragma unroll
   for (int j = 0; j < 24; j++) if (j < len) lds[j * BG_BLOCK] = bg_twist(A[j], A[j + 1], F[j]);
 }
 __device__ __forceinline__ void bg_sprefetch(const BgDev& d, int env, Env& e, RngWin& w, int count) {
-  int len = (BG_MT_N - BG_MT_M) - e.s_idx; // stay where every operand is a seeded word
+  bool full;
+  const uint32_t* S = bg_sbase(d, env, e, full);
+  // stay where every operand is a stored seeded word: k <= 130 in the slot, k < 227 in the full state
+  int len = (full ? (BG_MT_N - BG_MT_M) : (BG_S_FASTMAX + 1)) - e.s_idx;
   if (len > count) len = count;
   if (len > 24) len = 24;
   if (len > BG_WIN) len = BG_WIN;
   if (len < 0) len = 0;
-  const uint32_t* S = bg_sblock(d, env, e.s_cur);
-  if (e.s_idx == 0 && len == 24) bg_swin_fill0(w.lds, S);
-  else if (len > 0) bg_swin_fill(w.lds, S, e.s_idx, len);
+  if (e.s_idx == 0 && len == 24 && !full) bg_swin_fill0(w.lds, S);
+  else if (len > 0) bg_swin_fill(w.lds, S, full, e.s_idx, len);
   w.s_start = e.s_idx; w.s_len = len;
   w.g_len = 0; w.g_blk = -1;
 }

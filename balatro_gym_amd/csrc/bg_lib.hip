@@ -434,7 +434,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
                                                                    uint64_t env_index0, uint64_t t0, ObsPtrs obs,
                                                                    int obs_stride_steps, double* reward, uint8_t* term,
                                                                    int32_t* actions_out, bg_rollout_stats* stats,
-                                                                   uint32_t th_play, uint32_t th_other, uint32_t th_ready) {
+                                                                   uint32_t th_play, uint32_t th_other, uint32_t th_ready, uint32_t role_mode) {
   static_assert(BG_RB == 2 * BG_BLOCK, "two env waves + two service waves per workgroup");
   __shared__ uint4 s_state[BG_NHOT][BG_RB];
   __shared__ uint4 s_shop[4][BG_RB];
@@ -452,8 +452,21 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
   __builtin_amdgcn_s_setprio(3);
   bg_tables_init(&jt);
   const int tid = threadIdx.x;
-  const int wave = tid >> 6;
-  const int local = tid & (BG_RB - 1); // env lane index (env waves) -- service lanes use `lane`
+  // Role of a wave.  The dispatcher spreads the four waves of a workgroup over the four SIMDs of the CU in order, so with
+  // fixed roles both workgroups of a CU would put their env waves (the continuously busy ones) on SIMD 0 and 1 and the
+  // mostly-waiting service waves on SIMD 2 and 3.  role_mode != 0 swaps the roles in every other workgroup: each SIMD
+  // then carries one env wave and one service wave.  (1: odd blockIdx, 2: second half of the grid, 3: hardware wave slot)
+  bool swap_roles = false;
+  if (role_mode == 1u) swap_roles = (blockIdx.x & 1u) != 0u;
+  else if (role_mode == 2u) swap_roles = blockIdx.x >= (gridDim.x + 1u) / 2u;
+  else if (role_mode == 3u) {
+    __shared__ uint32_t s_slot;
+    if (tid == 0) s_slot = (__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | ((4 - 1) << 11))) & 1u; // WAVE_ID bit 0 of wave 0
+    __syncthreads();
+    swap_roles = s_slot != 0u;
+  }
+  const int wave = (tid >> 6) ^ (swap_roles ? 2 : 0);
+  const int local = ((wave & 1) << 6) | (tid & 63); // env lane index (env waves) -- service lanes use `lane`
   const int env = blockIdx.x * BG_RB + local;
   const bool is_env = wave < 2;
   const bool live = is_env && env < d.N;
@@ -752,6 +765,40 @@ __device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) {
   p4[0] = make_uint4(0x80000000u, w1, w2, w3);
 }
 
+// The same seeding for a shop-stream ring slot: only words 0..131 and 396..527 of the state are kept (BG_SW_*), plus the seed.
+__device__ void bg_mt_seed_slot(uint32_t* __restrict__ p, uint32_t key) {
+  uint4* p4 = (uint4*)p;
+  uint32_t a = BG_GENRAND.g[0], a1 = 0;
+#pragma unroll 4
+  for (int i = 1; i < BG_MT_N; i++) {
+    a = (BG_GENRAND.g[i] ^ ((a ^ (a >> 30)) * 1664525u)) + key;
+    if (i == 1) a1 = a;
+  }
+  const uint32_t a1w = (a1 ^ ((a ^ (a >> 30)) * 1664525u)) + key;
+  a = BG_GENRAND.g[0];
+  a = (BG_GENRAND.g[1] ^ ((a ^ (a >> 30)) * 1664525u)) + key;
+  uint32_t bprev = a1w, w2 = 0, w3 = 0;
+#pragma unroll 2
+  for (int q = 0; q < BG_MT_N / 4; q++) {
+    uint32_t v[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int i = 4 * q + c;
+      if (i >= 2) {
+        a = (BG_GENRAND.g[i] ^ ((a ^ (a >> 30)) * 1664525u)) + key;
+        bprev = (a ^ ((bprev ^ (bprev >> 30)) * 1566083941u)) - (uint32_t)i;
+        v[c] = bprev;
+      }
+    }
+    if (q == 0) { w2 = v[2]; w3 = v[3]; }
+    else if (q < BG_SW_A / 4) p4[q] = make_uint4(v[0], v[1], v[2], v[3]);
+    else if (q >= BG_SW_F / 4 && q < BG_SW_F / 4 + BG_SW_A / 4) p4[q - (BG_SW_F - BG_SW_A) / 4] = make_uint4(v[0], v[1], v[2], v[3]);
+  }
+  const uint32_t w1 = (a1w ^ ((bprev ^ (bprev >> 30)) * 1566083941u)) - 1u;
+  p4[0] = make_uint4(0x80000000u, w1, w2, w3);
+  p[BG_SW_SEED] = key;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Lazy MT19937 for the streams only the refill kernels read (deck shuffles, shop seeds).  genrand_uint32() regenerates
 // all 624 words when the block is exhausted; computing word k of the next block just before it is read gives the same
@@ -1038,7 +1085,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop_kernel(BgDev d) {
   uint32_t count = d.wl_count[3];
   for (uint32_t item = blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
     uint32_t es = d.wl_shop[2 * (size_t)item], seed = d.wl_shop[2 * (size_t)item + 1];
-    bg_mt_seed(bg_sblock(d, (int)(es & 0xffffffu), (int)(es >> 24)), seed);
+    bg_mt_seed_slot(bg_sblock(d, (int)(es & 0xffffffu), (int)(es >> 24)), seed);
   }
 }
 
@@ -1252,7 +1299,8 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (e == hipSuccess) e = bg_alloc(h, &d.tmpl, BG_NTMPL * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.ndeck, (size_t)d.KD * BG_NDECK * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.gblk, (size_t)d.KG * BG_MTS * N);
-  if (e == hipSuccess) e = bg_alloc(h, &d.sblk, (size_t)d.KS * BG_MTS * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.sblk, (size_t)d.KS * BG_SLOT_WORDS * N);
+  if (e == hipSuccess) e = bg_alloc(h, &d.sovf, (size_t)BG_MTS * N);
   if (e == hipSuccess && (flags & BG_FLAG_CARD_STATES)) {
     e = bg_alloc(h, &d.cstate, (size_t)BG_NCST * N);
     if (e == hipSuccess) e = bg_alloc(h, &d.ctmpl, (size_t)BG_NCST * N);
@@ -1305,7 +1353,7 @@ int bg_destroy(bg_handle* h) {
   for (int i = 0; i < 2; i++) if (h->ev_refill[i]) (void)hipEventDestroy(h->ev_refill[i]);
   if (h->ev_rollout) (void)hipEventDestroy(h->ev_rollout);
   hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
-  hipFree(d.hot); hipFree(d.deck); hipFree(d.cold); hipFree(d.tmpl); hipFree(d.ndeck); hipFree(d.gblk); hipFree(d.sblk);
+  hipFree(d.hot); hipFree(d.deck); hipFree(d.cold); hipFree(d.tmpl); hipFree(d.ndeck); hipFree(d.gblk); hipFree(d.sblk); hipFree(d.sovf);
   hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.wl_shop); hipFree(d.sseed); hipFree(d.smeta); hipFree(d.dbg); hipFree(d.cstate); hipFree(d.ctmpl); hipFree(d.cardmt); hipFree(d.sealmt);
   delete h;
   return 0;
@@ -1543,8 +1591,9 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       } else {
         dim3 g2((h->dev.N + BG_RB - 1) / BG_RB);
         const bool v3 = h->rollout_version == 3; // dedicated service waves: four waves per workgroup of 128 envs
+        static const uint32_t role_mode = getenv("BG_ROLE_MODE") ? (uint32_t)atoi(getenv("BG_ROLE_MODE")) : 0u;
 #define BG_LAUNCH_R2(HASHV, CARDSV) do { if (v3) hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV>), g2, dim3(2 * BG_RB), 0, st, dv, chunk, pol, policy_seed, \
-                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr); \
+                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr, role_mode); \
   else hipLaunchKernelGGL((bg_rollout2_kernel<HASHV, CARDSV>), g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, \
                                                    env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr); } while (0)
         const bool per_key = !rows_dev && obs && obs_stride_steps != 0; // [T, N] arrays per key
@@ -1708,7 +1757,7 @@ static void bg_slices(bg_handle* h, std::vector<BgSlice>& v) {
   v.push_back({d.hot, BG_NHOT, 16}); v.push_back({d.deck, BG_NDECK, 16}); v.push_back({d.cold, BG_NCOLD, 16});
   v.push_back({d.tmpl, BG_NTMPL, 16}); v.push_back({d.ndeck, (size_t)d.KD * BG_NDECK, 16});
   // per-env contiguous MT blocks: one "row" of KG*2560 / KS*2560 / 2560 bytes at base + env * elem
-  v.push_back({d.gblk, 1, (size_t)d.KG * BG_MTS * 4}); v.push_back({d.sblk, 1, (size_t)d.KS * BG_MTS * 4});
+  v.push_back({d.gblk, 1, (size_t)d.KG * BG_MTS * 4}); v.push_back({d.sblk, 1, (size_t)d.KS * BG_SLOT_WORDS * 4}); v.push_back({d.sovf, 1, (size_t)BG_MTS * 4});
   v.push_back({d.deckmt, 1, (size_t)BG_MTS * 4}); v.push_back({d.shopgenmt, 1, (size_t)BG_MTS * 4});
   v.push_back({d.sseed, 1, BG_SSEED * 4}); v.push_back({d.smeta, 1, 4});
   v.push_back({bg_prod_latest(h), 1, 4});
@@ -1723,7 +1772,7 @@ uint64_t bg_state_blob_bytes(const bg_handle* h) {
   return b;
 }
 #define BG_BLOB_MAGIC 0x42474d58u
-#define BG_BLOB_VERSION 2u // 2: stream 13 ('seal_applications') joins the card-state slices, consumables in the reset template
+#define BG_BLOB_VERSION 3u // 3: compact shop-stream slots + overflow block; 2: stream 13 ('seal_applications') joins the card-state slices, consumables in the reset template
 int bg_get_state(bg_handle* h, int env_index, void* blob_host, uint64_t blob_bytes) {
   if (!h || !blob_host || env_index < 0 || env_index >= h->dev.N || blob_bytes < bg_state_blob_bytes(h)) return BG_E_ARG;
   BG_HIP(hipDeviceSynchronize());

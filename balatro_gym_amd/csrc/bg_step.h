@@ -236,7 +236,7 @@ __device__ __forceinline__ void bg_generate_shop(const BgDev& d, int env, Env& e
   e.s_cur = (e.s_cur + 1 == d.KS) ? 0 : e.s_cur + 1;
   e.s_ready--; e.s_cons = (e.s_cons + 1) & 0xff;
   e.s_idx = 0;
-  e.bflags |= BG_BF_SHOP_EXISTS;
+  e.bflags = (e.bflags & ~BG_BF_SHOP_OVF) | BG_BF_SHOP_EXISTS;
   e.shop_ante = e.ante;
   e.shop_reroll_base = 50;
   bg_shop_inventory(d, env, e, w, sr);

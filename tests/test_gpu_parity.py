@@ -136,6 +136,48 @@ def test_step_vs_oracle_fresh_seeds(policy, scorer):
     env.close()
 
 
+def test_shop_stream_beyond_slot_vs_oracle():
+    """A shop visit with dozens of rerolls reads far more of `random.Random(shop_seed)` than a ring slot keeps (words
+    0..131 and 396..527 of the seeded state): the stream is re-seeded in full into the overflow block and the visit carries
+    on there, through the two- and three-level regeneration of words beyond 227.  Every step against the oracle."""
+    import torch
+    n, T = 96, 260
+    seeds = [77_000 + 3 * i for i in range(n)]
+    env = _vec(n, seeds, autoreset=False)
+    env.inject(money=[10_000_000] * n, apply_now=True)
+    env.observe()
+    orc = _oracle_envs(n, seeds, False, 0)
+    for o in orc:
+        o.set_money(10_000_000)
+    rerolls = [0] * n
+    deepest = 0
+    for t in range(T):
+        acts = np.zeros(n, np.int32)
+        for i, o in enumerate(orc):
+            ob = o.obs()
+            if int(ob["phase"]) == 1:  # SHOP: reroll up to 10 + i % 36 times per visit, then leave
+                if ob["action_mask"][30] and rerolls[i] < 10 + i % 36:
+                    acts[i] = 30; rerolls[i] += 1
+                else:
+                    acts[i] = 31; deepest = max(deepest, rerolls[i]); rerolls[i] = 0
+            else:
+                acts[i] = o.policy_action(1, 5, i, t)  # small blind, uniform play
+        res = [o.step(int(a)) for o, a in zip(orc, acts)]
+        _, reward, term, _, info = env.step(torch.from_numpy(acts).to(env.device))
+        ctx = f"t {t}"
+        assert np.array_equal(reward.cpu().numpy().view(np.uint64), np.array([r[1] for r in res]).view(np.uint64)), ctx
+        wt = np.array([r[2] for r in res], dtype=np.uint8)
+        assert np.array_equal(term.cpu().numpy(), wt), ctx
+        _assert_obs(_obs_np(env), {k: np.stack([r[0][k] for r in res]) for k in OBS_KEYS}, ctx)
+        if wt.any():
+            for i in np.nonzero(wt)[0]:
+                orc[i].reset(); orc[i].set_money(10_000_000); rerolls[i] = 0
+            env.reset(mask=torch.from_numpy(wt).to(env.device))
+    env.check()
+    env.close()
+    assert deepest >= 30, deepest  # visits of 30+ inventories (~300+ words) really happened
+
+
 def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_index0=0, t0=0, cards=None, consumables=None):
     """SAME_STEP auto-reset rollout on the oracle; returns per-step obs/rewards/terminated and the stats dict."""
     orc = _oracle_envs(n, seeds, scorer, max_ante, jokers)
