@@ -209,7 +209,28 @@ __device__ __forceinline__ uint32_t* bg_gblock(const BgDev& d, int env, int slot
 #define BG_BF_SHOP_OVF 4           // bflags: the current shop stream lives in the overflow block (full state)
 __device__ __forceinline__ uint32_t* bg_sblock(const BgDev& d, int env, int slot) { return d.sblk + ((size_t)env * d.KS + slot) * BG_SLOT_WORDS; }
 __device__ __forceinline__ uint32_t* bg_sovf(const BgDev& d, int env) { return d.sovf + (size_t)env * BG_MTS; }
-__device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key); // bg_lib.hip
+// random.Random(key) (init_by_array([key])) as two small rolled loops through memory: ~1 ms, for the overflow path only (a
+// call to the unrolled register version would cost every kernel that contains it its stack frame and registers)
+__device__ __forceinline__ void bg_mt_seed_rolled(uint32_t* p, uint32_t key) {
+  uint32_t g = 19650218u, a = g; // init_genrand(19650218) on the fly; a = mt[i-1] of pass 1
+#pragma unroll 1
+  for (uint32_t i = 1; i < 624u; i++) {
+    g = 1812433253u * (g ^ (g >> 30)) + i;
+    a = (g ^ ((a ^ (a >> 30)) * 1664525u)) + key;
+    p[i] = a;
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+  const uint32_t m1 = (p[1] ^ ((a ^ (a >> 30)) * 1664525u)) + key; // 624th step of pass 1: mt[0] = mt[623], i = 1
+  uint32_t b = m1;
+#pragma unroll 1
+  for (uint32_t i = 2; i < 624u; i++) { // pass 2
+    b = (p[i] ^ ((b ^ (b >> 30)) * 1566083941u)) - i;
+    p[i] = b;
+  }
+  p[1] = (m1 ^ ((b ^ (b >> 30)) * 1566083941u)) - 1u; // wrapped last step: mt[0] = mt[623], i = 1
+  p[0] = 0x80000000u;
+}
 __device__ __forceinline__ uint32_t* bg_deckmt(const BgDev& d, int env) { return d.deckmt + (size_t)env * BG_MTS; }
 __device__ __forceinline__ uint32_t* bg_shopgenmt(const BgDev& d, int env) { return d.shopgenmt + (size_t)env * BG_MTS; }
 
@@ -425,8 +446,8 @@ __device__ __noinline__ uint32_t bg_sword_slow(const uint32_t* S, bool full, int
   return bg_twist(bg_sget(S, full, k), nxt, far);
 }
 // the visit reads past what the slot holds: random.Random(seed) once more, whole state, into the env's overflow block
-__device__ __noinline__ void bg_shop_overflow(const BgDev& d, int env, Env& e) {
-  bg_mt_seed(bg_sovf(d, env), bg_sblock(d, env, e.s_cur)[BG_SW_SEED]);
+__device__ __forceinline__ void bg_shop_overflow(const BgDev& d, int env, Env& e) {
+  bg_mt_seed_rolled(bg_sovf(d, env), bg_sblock(d, env, e.s_cur)[BG_SW_SEED]);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); // the lane reads these words back (and a later step may run in another wave)
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   e.bflags |= BG_BF_SHOP_OVF;

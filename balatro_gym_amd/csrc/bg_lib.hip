@@ -1413,14 +1413,18 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   // v2 rollout: two refill waves per CU per kernel run BESIDE the rollout (512).  The service-wave kernel leaves no
   // registers for a co-resident wave, so its refill runs in the gaps rollout workgroups leave when they retire: wide grids
   static const int dense_cap = getenv("BG_REFILL_BLOCKS") ? atoi(getenv("BG_REFILL_BLOCKS")) : (h->rollout_version == 3 ? 4096 : 512);
-  int dense = bg_grid(h) < dense_cap ? bg_grid(h) : dense_cap; // grid-stride over the compacted work lists
+  // grid-stride over the compacted work lists.  Beside the v2 rollout at most one refill wave per env wave makes sense; on its
+  // own (v3) a kernel of dependent chains wants several waves per SIMD however few envs there are
+  int dense = (h->rollout_version == 3 || bg_grid(h) >= dense_cap) ? dense_cap : bg_grid(h);
   // the three kinds of work are independent once the lists exist: run them side by side (each is a few hundred
   // latency-bound waves), join before the completion event
   BG_HIP(hipEventRecord(h->ev_scan, s));
   BG_HIP(hipStreamWaitEvent(h->side2, h->ev_scan, 0));
   BG_HIP(hipStreamWaitEvent(h->side3, h->ev_scan, 0));
   static const int skip = getenv("BG_DEV_SKIP_REFILL") ? atoi(getenv("BG_DEV_SKIP_REFILL")) : 0; // development: contention experiments only (breaks the rings)
-  if (!(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense), dim3(BG_BLOCK), 0, s, d);
+  static const int shop_cap = getenv("BG_REFILL_BLOCKS_SHOP") ? atoi(getenv("BG_REFILL_BLOCKS_SHOP")) : 0; // 0 = like the others
+  const int dense_shop = (shop_cap > 0 && h->rollout_version == 3) ? shop_cap : dense;
+  if (!(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d);
   if (!(skip & 2)) hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side2, d);
   // side3: seed ring, then global blocks.  The global-block kernel would fit beside the rollout (114 VGPRs, no LDS) and
   // queued first it is done early instead of ~100 us after the rollout -- but its HBM traffic beside the rollout costs the
