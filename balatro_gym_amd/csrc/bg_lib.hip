@@ -441,6 +441,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
   __shared__ OutLds s_out[BG_RB];
   __shared__ uint32_t s_items[2][BG_RB];   // rings: 0 = PLAY_HAND, 1 = every other deferred action
   __shared__ uint32_t s_tail[2];           // items ever queued per class (env lanes, atomic)
+  __shared__ uint32_t s_head[2];           // items ever taken per class (service waves; atomic when they help each other)
   __shared__ uint32_t s_ready[2];          // runnable lanes of each env wave (starvation hint for the service waves)
   __shared__ uint32_t s_done;              // env waves that have finished
   __shared__ uint32_t s_prod[BG_RB];
@@ -472,7 +473,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
   const bool live = is_env && env < d.N;
   using DeckT = typename std::conditional<CARDS, DeckLdsC, DeckLds>::type;
   if (is_env) s_prod[local] = (live && d.prod_view) ? d.prod_view[env] : 0u;
-  if (tid < 2) { s_tail[tid] = 0; s_ready[tid] = BG_BLOCK; }
+  if (tid < 2) { s_tail[tid] = 0; s_head[tid] = 0; s_ready[tid] = BG_BLOCK; }
   if (tid == 0) s_done = 0;
   if (is_env) {
     s_items[0][local] = 0; s_items[1][local] = 0;
@@ -617,23 +618,37 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
     }
   } else {
     // =========================================== service waves: phase B ===========================================
-    const int cls = wave - 2;
+    const int own = wave - 2;
     const int lane = tid & (BG_BLOCK - 1);
-    const uint32_t th = cls == 0 ? th_play : th_other;
-    uint32_t head = 0, polls = 0;
+    const uint32_t th = own == 0 ? th_play : th_other;
+    const bool help = (role_mode & 0x100u) != 0u; // an idle service wave also takes the other wave's queue
+    uint32_t polls = 0;
 #ifdef BG_TIMING3
     unsigned long long q_batches = 0, q_items = 0, q_busy = 0;
     const unsigned long long q_t0 = __builtin_readcyclecounter();
 #endif
     for (;;) {
-      const uint32_t tail = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_tail[cls]));
-      const uint32_t n = tail - head;
+      int cls = own;
+      uint32_t head = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_head[cls]));
+      uint32_t n = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_tail[cls])) - head;
       const uint32_t ready = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_ready[0]) + bg_lds_load(&s_ready[1]));
-      if (n == 0u || (n < th && ready >= th_ready)) {
-        if (n == 0u && __builtin_amdgcn_readfirstlane(bg_lds_load(&s_done)) >= 2u) break; // both env waves are through
+      if (n != 0u && n < th && ready >= th_ready) n = 0u; // batching thresholds (1 / 1 / 255 by default: never)
+      if (n == 0u && help) {
+        cls = own ^ 1;
+        head = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_head[cls]));
+        n = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_tail[cls])) - head;
+      }
+      if (n == 0u) {
+        if (__builtin_amdgcn_readfirstlane(bg_lds_load(&s_done)) >= 2u) break; // both env waves are through: every item was served
         __builtin_amdgcn_s_sleep(16);
         if (++polls > BG_SPIN_LIMIT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
         continue;
+      }
+      {
+        const uint32_t want = n > BG_BLOCK ? BG_BLOCK : n;
+        uint32_t got = 0;
+        if (lane == 0) got = atomicCAS(&s_head[cls], head, head + want) == head ? 1u : 0u; // the other wave may be claiming the same items
+        if (__builtin_amdgcn_readfirstlane(got) == 0u) continue;
       }
       polls = 0;
       const uint32_t nb = n > BG_BLOCK ? BG_BLOCK : n;
@@ -658,7 +673,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
           DeckT bdk; bdk.col = (lds_u32*)&s_deck[0][l];
           ShopRegs bsr; bsr.valid = false;
           RngWin w;
-          bg_win_init(w, &win[cls][0][lane], &jt);
+          bg_win_init(w, &win[own][0][lane], &jt);
           StepOut bo;
           bg_step_init(bo);
           bg_env_dispatch(d, benv, be, w, bsr, bdk, a, bo);
@@ -672,15 +687,14 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
           bg_lds_store((uint32_t*)&s_out[l].misc, (uint32_t)misc | 0x400u);
         } else atomicOr(d.err, BG_DEVERR_SPIN);
       }
-      head += nb;
 #ifdef BG_TIMING3
       q_busy += __builtin_readcyclecounter() - q_b0; q_batches++; q_items += nb;
 #endif
     }
 #ifdef BG_TIMING3
     if (lane == 0 && d.dbg) {
-      atomicAdd(&d.dbg[5 + 3 * cls], q_batches); atomicAdd(&d.dbg[6 + 3 * cls], q_items); atomicAdd(&d.dbg[7 + 3 * cls], q_busy);
-      atomicAdd(&d.dbg[13 + cls], __builtin_readcyclecounter() - q_t0);
+      atomicAdd(&d.dbg[5 + 3 * own], q_batches); atomicAdd(&d.dbg[6 + 3 * own], q_items); atomicAdd(&d.dbg[7 + 3 * own], q_busy);
+      atomicAdd(&d.dbg[13 + own], __builtin_readcyclecounter() - q_t0);
     }
 #endif
   }
@@ -1595,7 +1609,8 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       } else {
         dim3 g2((h->dev.N + BG_RB - 1) / BG_RB);
         const bool v3 = h->rollout_version == 3; // dedicated service waves: four waves per workgroup of 128 envs
-        static const uint32_t role_mode = getenv("BG_ROLE_MODE") ? (uint32_t)atoi(getenv("BG_ROLE_MODE")) : 0u;
+        static const uint32_t role_mode = (getenv("BG_ROLE_MODE") ? (uint32_t)atoi(getenv("BG_ROLE_MODE")) : 0u) |
+                                          ((getenv("BG_HELP") ? atoi(getenv("BG_HELP")) : 0) ? 0x100u : 0u);
 #define BG_LAUNCH_R2(HASHV, CARDSV) do { if (v3) hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV>), g2, dim3(2 * BG_RB), 0, st, dv, chunk, pol, policy_seed, \
                                                    env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr, role_mode); \
   else hipLaunchKernelGGL((bg_rollout2_kernel<HASHV, CARDSV>), g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, \

@@ -36,7 +36,7 @@ IMPLEMENTED = [1, 136, 27, 38, 61, 16, 34, 108, 23, 22, 53, 97, 50, 2, 3, 4, 5, 
                131, 132, 133, 134, 135, 48, 128, 122, 72, 140, 31, 39, 40, 41, 101, 124, 26, 33, 104, 147, 118, 119,
                116, 117]
 POLICY_CYCLE3 = 2
-TRAFFIC_FILE = {"rows": "r01_v17_hbm_traffic.json", "keys": None}  # PMC result of the default layout (none measured for per-key arrays at v17)
+TRAFFIC_FILE = {"rows": "r01_v18_hbm_traffic.json", "keys": None}  # PMC result of the default layout (none measured for per-key arrays at v18)
 POLICY_SEED = 20251001
 MAX_ANTE = 4
 
@@ -161,7 +161,7 @@ def main():
 
     if rank == 0:
         value = env_steps / elapsed
-        # roofline of the dominant kernel (bg_rollout2_kernel): algorithmic bytes per launch / mean launch duration
+        # roofline of the dominant kernel (bg_rollout3_kernel): algorithmic bytes per launch / mean launch duration
         launches = max(1, prof["rollout_launches"])
         fused = prof["rollout_fused_steps"] / launches           # mean fused steps T per launch
         a_step = OBS_BYTES + IO_BYTES + 2 * STATE_BYTES / max(1.0, fused)
@@ -195,7 +195,7 @@ def main():
                        "parallelism": f"shard{world} (independent envs, no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "bg_rollout2_kernel", "algorithmic_bytes_per_env_step": a_step,
+                         "kernel": "bg_rollout3_kernel" if os.environ.get("BG_ROLLOUT_V", "3") == "3" else "bg_rollout2_kernel", "algorithmic_bytes_per_env_step": a_step,
                          "mean_launch_us": mean_launch_s * 1e6, "launches": launches,
                          "refill_mean_launch_us": prof["refill_ms"] / max(1, prof["refill_launches"]) * 1e3},
             "episodes": int(agg[1].item()), "accepted_plays": int(agg[2].item()),

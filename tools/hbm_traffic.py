@@ -7,7 +7,7 @@ usage: hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collection.c
 import csv, json, sys
 
 
-def mean_counter(path, counter, kernel="bg_rollout2_kernel"):
+def mean_counter(path, counter, kernel="bg_rollout"):
     vals = []
     for r in csv.DictReader(open(path)):
         if kernel in r["Kernel_Name"] and r["Counter_Name"] == counter:
