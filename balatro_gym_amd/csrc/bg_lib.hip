@@ -412,6 +412,7 @@ __global__ __launch_bounds__(BG_RB_LB, BG_RB_WAVES) BG_RB_ATTR void bg_rollout2_
 // hung GPU).
 // ---------------------------------------------------------------------------------------------------------
 #define BG_ITEM_VALID 0x80000000u
+#define BG_ACT_ADVANCE 62 // internal work item: second half of a won PLAY_HAND (valid actions are < 60)
 #define BG_SPIN_LIMIT (1u << 24)
 #define BG_DEVERR_SPIN 16u
 // LDS words shared between waves.  One wave's LDS instructions execute in program order, so "data, then flag" on the
@@ -458,9 +459,9 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
   // mostly-waiting service waves on SIMD 2 and 3.  role_mode != 0 swaps the roles in every other workgroup: each SIMD
   // then carries one env wave and one service wave.  (1: odd blockIdx, 2: second half of the grid, 3: hardware wave slot)
   bool swap_roles = false;
-  if (role_mode == 1u) swap_roles = (blockIdx.x & 1u) != 0u;
-  else if (role_mode == 2u) swap_roles = blockIdx.x >= (gridDim.x + 1u) / 2u;
-  else if (role_mode == 3u) {
+  if ((role_mode & 0xffu) == 1u) swap_roles = (blockIdx.x & 1u) != 0u;
+  else if ((role_mode & 0xffu) == 2u) swap_roles = blockIdx.x >= (gridDim.x + 1u) / 2u;
+  else if ((role_mode & 0xffu) == 3u) {
     __shared__ uint32_t s_slot;
     if (tid == 0) s_slot = (__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | ((4 - 1) << 11))) & 1u; // WAVE_ID bit 0 of wave 0
     __syncthreads();
@@ -569,8 +570,13 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
         }
         mask = bg_action_mask(d, env, e, sr);
         size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
+#ifdef BG_V3_DIRECT // development: 16 bytes per lane straight to 64 rows, no LDS staging
+        uint64_t h = bg_write_obs_impl<HASH, false>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u},
+                                                   RowStage{(lds_u4*)&s_stage[wave][0], (lds_u64*)&s_rowaddr[wave][0]});
+#else
         uint64_t h = bg_write_obs_impl<HASH, true>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u},
                                                   RowStage{(lds_u4*)&s_stage[wave][0], (lds_u64*)&s_rowaddr[wave][0]});
+#endif
         if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
         if (reward) reward[row] = o.reward;
         if (term) term[row] = o.terminated ? 1 : 0;
@@ -622,6 +628,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
     const int lane = tid & (BG_BLOCK - 1);
     const uint32_t th = own == 0 ? th_play : th_other;
     const bool help = (role_mode & 0x100u) != 0u; // an idle service wave also takes the other wave's queue
+    const bool defer_adv = (role_mode & 0x200u) != 0u; // won plays leave _advance_round + shop generation to the other queue
     uint32_t polls = 0;
 #ifdef BG_TIMING3
     unsigned long long q_batches = 0, q_items = 0, q_busy = 0;
@@ -674,17 +681,34 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
           ShopRegs bsr; bsr.valid = false;
           RngWin w;
           bg_win_init(w, &win[own][0][lane], &jt);
-          StepOut bo;
-          bg_step_init(bo);
-          bg_env_dispatch(d, benv, be, w, bsr, bdk, a, bo);
-          bg_pack(be, c);
+          w.defer_adv = defer_adv;
+          if (a == BG_ACT_ADVANCE) {
+            // second half of a won play: _advance_round (+ the shop it generates); s_out already holds the play's result
+            bg_advance_round<CARDS>(d, benv, be, w, bsr);
+            bg_pack(be, c);
 #pragma unroll
-          for (int k = 0; k < BG_NHOT; k++) s_state[k][l] = c[k];
-          if (bsr.valid) { s_shop[0][l] = bsr.c3; s_shop[1][l] = bsr.c4; s_shop[2][l] = bsr.c5; s_shop[3][l] = bsr.c6; }
-          const int32_t misc = (bo.hand_type + 1) | (bo.terminated ? 0x100 : 0) | (bsr.valid ? 0x200 : 0) | (bo.error << 16);
-          s_out[l].reward = bo.reward; s_out[l].final_score = bo.final_score; s_out[l].flags = bo.flags;
-          bg_wait_vm(); // shop inventory / play counts / card states written to HBM are read by the OTHER service wave later
-          bg_lds_store((uint32_t*)&s_out[l].misc, (uint32_t)misc | 0x400u);
+            for (int k = 0; k < BG_NHOT; k++) s_state[k][l] = c[k];
+            if (bsr.valid) { s_shop[0][l] = bsr.c3; s_shop[1][l] = bsr.c4; s_shop[2][l] = bsr.c5; s_shop[3][l] = bsr.c6; }
+            const uint32_t misc = bg_lds_load((uint32_t*)&s_out[l].misc) | (bsr.valid ? 0x200u : 0u);
+            bg_wait_vm();
+            bg_lds_store((uint32_t*)&s_out[l].misc, misc | 0x400u);
+          } else {
+            StepOut bo;
+            bg_step_init(bo);
+            bg_env_dispatch(d, benv, be, w, bsr, bdk, a, bo);
+            bg_pack(be, c);
+#pragma unroll
+            for (int k = 0; k < BG_NHOT; k++) s_state[k][l] = c[k];
+            if (bsr.valid) { s_shop[0][l] = bsr.c3; s_shop[1][l] = bsr.c4; s_shop[2][l] = bsr.c5; s_shop[3][l] = bsr.c6; }
+            const int32_t misc = (bo.hand_type + 1) | (bo.terminated ? 0x100 : 0) | (bsr.valid ? 0x200 : 0) | (bo.error << 16);
+            s_out[l].reward = bo.reward; s_out[l].final_score = bo.final_score; s_out[l].flags = bo.flags & ~BG_FLAG_DEFER_ADV;
+            bg_wait_vm(); // shop inventory / play counts / card states written to HBM are read by the OTHER service wave later
+            if (bo.flags & BG_FLAG_DEFER_ADV) { // hand the env on to the other queue; DONE is set by whoever runs the second half
+              bg_lds_store((uint32_t*)&s_out[l].misc, (uint32_t)misc);
+              const uint32_t slot2 = __hip_atomic_fetch_add(&s_tail[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              bg_lds_store(&s_items[1][slot2 & (BG_RB - 1)], (uint32_t)l | ((uint32_t)BG_ACT_ADVANCE << 16) | BG_ITEM_VALID);
+            } else bg_lds_store((uint32_t*)&s_out[l].misc, (uint32_t)misc | 0x400u);
+          }
         } else atomicOr(d.err, BG_DEVERR_SPIN);
       }
 #ifdef BG_TIMING3
@@ -1610,7 +1634,8 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
         dim3 g2((h->dev.N + BG_RB - 1) / BG_RB);
         const bool v3 = h->rollout_version == 3; // dedicated service waves: four waves per workgroup of 128 envs
         static const uint32_t role_mode = (getenv("BG_ROLE_MODE") ? (uint32_t)atoi(getenv("BG_ROLE_MODE")) : 0u) |
-                                          ((getenv("BG_HELP") ? atoi(getenv("BG_HELP")) : 0) ? 0x100u : 0u);
+                                          ((getenv("BG_HELP") ? atoi(getenv("BG_HELP")) : 0) ? 0x100u : 0u) |
+                                          ((getenv("BG_DEFER_ADV") ? atoi(getenv("BG_DEFER_ADV")) : 0) ? 0x200u : 0u);
 #define BG_LAUNCH_R2(HASHV, CARDSV) do { if (v3) hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV>), g2, dim3(2 * BG_RB), 0, st, dv, chunk, pol, policy_seed, \
                                                    env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr, role_mode); \
   else hipLaunchKernelGGL((bg_rollout2_kernel<HASHV, CARDSV>), g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, \

@@ -243,6 +243,7 @@ __device__ __forceinline__ void bg_generate_shop(const BgDev& d, int env, Env& e
   e.shop_reroll_state = (int32_t)(50.0 * bg_shop_cost_mult(e, w.jt));
 }
 
+#define BG_FLAG_DEFER_ADV 0x40000000 // StepOut.flags, internal: the play was won, _advance_round is still to run
 // balatro_env_2.py:1326-1381 (card-state gold money needs card states: not on this path)
 template <bool CARDS = false>
 __device__ __forceinline__ void bg_advance_round(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr) {
@@ -746,7 +747,8 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   if (e.round_chips >= (int64_t)e.chips_needed) {
     double bonus = 25.0 + 10.0 * (double)e.ante;
     r += bonus < 50.0 ? bonus : 50.0;
-    bg_advance_round<DK::kCards>(d, env, e, w, sr);
+    if (w.defer_adv) o.flags |= BG_FLAG_DEFER_ADV; // the service-wave kernel runs _advance_round as a second work item
+    else bg_advance_round<DK::kCards>(d, env, e, w, sr);
     o.flags |= 1; // beat_blind
   } else if (e.hands_left <= 1) {
     r += -50.0 * (1.0 - new_progress);
