@@ -506,7 +506,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
     const PolicyLane pl = bg_policy_lane(policy, policy_seed, env_index0 + (uint64_t)env);
     uint32_t idle_polls = 0;
 #ifdef BG_TIMING3
-    unsigned long long q_iter = 0, q_idle = 0, q_a = 0, q_c = 0, q_lanes = 0;
+    unsigned long long q_iter = 0, q_idle = 0, q_a = 0, q_c = 0, q_lanes = 0, q_s1 = 0, q_s2 = 0, q_s3 = 0, q_s4 = 0;
     const unsigned long long q_t0 = __builtin_readcyclecounter();
 #endif
     for (;;) {
@@ -557,25 +557,40 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
         blocked = false;
         fin = true;
       }
+#ifdef BG_TIMING3
+      const unsigned long long q_m0 = __builtin_readcyclecounter();
+      unsigned long long q_m1 = q_m0, q_m2 = q_m0, q_m3 = q_m0;
+#endif
       if (fin) {
         if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
         if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; } // SAME_STEP auto-reset
         // a reset zeroes the env's play counts (and re-applies its card states) in HBM, which a service wave touches a few
         // steps later: let those stores land first.  What is still in flight here is the record write-out of the iteration
         // BEFORE (a whole phase A old), so this wait is short -- unlike one right after the write-out
+#ifndef BG_NO_RESET_WAIT // development: measure what the wait costs
         if (__ballot(o.terminated) != 0ull) bg_wait_vm();
+#endif
         ShopRegs sr; sr.valid = false;
         if (e.phase == 1 && (e.bflags & BG_BF_SHOP_EXISTS)) {
           sr.c3 = s_shop[0][local]; sr.c4 = s_shop[1][local]; sr.c5 = s_shop[2][local]; sr.c6 = s_shop[3][local]; sr.valid = true;
         }
+#ifdef BG_TIMING3
+        q_m1 = __builtin_readcyclecounter();
+#endif
         mask = bg_action_mask(d, env, e, sr);
         size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
+#ifdef BG_TIMING3
+        q_m2 = __builtin_readcyclecounter();
+#endif
 #ifdef BG_V3_DIRECT // development: 16 bytes per lane straight to 64 rows, no LDS staging
         uint64_t h = bg_write_obs_impl<HASH, false>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u},
                                                    RowStage{(lds_u4*)&s_stage[wave][0], (lds_u64*)&s_rowaddr[wave][0]});
 #else
         uint64_t h = bg_write_obs_impl<HASH, true>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u},
                                                   RowStage{(lds_u4*)&s_stage[wave][0], (lds_u64*)&s_rowaddr[wave][0]});
+#endif
+#ifdef BG_TIMING3
+        q_m3 = __builtin_readcyclecounter();
 #endif
         if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
         if (reward) reward[row] = o.reward;
@@ -588,6 +603,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
       }
 #ifdef BG_TIMING3
       { const unsigned long long q_c2 = __builtin_readcyclecounter(); q_a += q_c1 - q_c0; q_c += q_c2 - q_c1; q_iter++;
+        q_s1 += q_m0 - q_c1; q_s2 += q_m1 - q_m0; q_s3 += q_m2 - q_m1; q_s4 += q_m3 - q_m2;
         q_lanes += (unsigned long long)__popcll(__ballot(fin)); if (__ballot(fin) == 0ull) q_idle++; }
 #endif
       if (__ballot(live && (blocked || t < T)) == 0ull) break;              // this wave has done its T steps
@@ -600,6 +616,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
     if ((tid & 63) == 0 && d.dbg) {
       atomicAdd(&d.dbg[0], __builtin_readcyclecounter() - q_t0); atomicAdd(&d.dbg[1], q_iter); atomicAdd(&d.dbg[2], q_idle);
       atomicAdd(&d.dbg[3], q_a); atomicAdd(&d.dbg[4], q_c); atomicAdd(&d.dbg[11], 1ull); atomicAdd(&d.dbg[12], q_lanes);
+      atomicAdd(&d.dbg[16], q_s1); atomicAdd(&d.dbg[17], q_s2); atomicAdd(&d.dbg[18], q_s3); atomicAdd(&d.dbg[19], q_s4);
     }
 #endif
     if ((tid & 63) == 0) {

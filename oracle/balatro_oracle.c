@@ -400,7 +400,7 @@ static void new_rng(bo_env* e, int64_t seed) { /* DeterministicRNG.__init__ :87-
 static void draw_cards(bo_env* e) {
   uint64_t inhand = 0;
   for (int i = 0; i < e->nhand; i++) inhand |= 1ull << e->hand[i];
-  for (int d = 0; d < 52 && e->nhand < e->hand_size && e->nhand < BO_MAX_HAND; d++)
+  for (int d = 0; d < e->ndeck && e->nhand < e->hand_size && e->nhand < BO_MAX_HAND; d++) /* range(len(deck)): the foreign tail is out of reach */
     if (!(inhand & (1ull << d))) e->hand[e->nhand++] = d;
 }
 
@@ -422,6 +422,7 @@ void bo_reset(bo_env* e, int has_seed, int64_t seed) { /* balatro_env_2.py:505-5
   int p = 0;
   for (int s = 0; s < 4; s++) for (int r = 2; r <= 14; r++) e->deck[p++] = (uint8_t)((r - 2) * 4 + s);
   bo_mt_shuffle_u8(stream(e, ST_DECK), e->deck, 52);
+  e->ndeck = 52; e->nforeign = 0;
   /* BalatroGame() balatro_game.py:16-28 */
   e->highlighted = 0;
   /* self.shop is NOT cleared by reset; it is unobservable outside SHOP phase. */
@@ -479,9 +480,9 @@ void bo_action_mask(const bo_env* e, int8_t* mask) { /* balatro_env_2.py:1426-14
 void bo_get_obs(const bo_env* e, bo_obs* o) { /* balatro_env_2.py:1473-1541 */
   memset(o, 0, sizeof(*o));
   for (int i = 0; i < 8; i++) o->hand[i] = -1;
-  for (int i = 0; i < e->nhand && i < 8; i++) if (e->hand[i] < 52) o->hand[i] = (int8_t)e->deck[e->hand[i]];
+  for (int i = 0; i < e->nhand && i < 8; i++) if (e->hand[i] < e->ndeck) o->hand[i] = (int8_t)e->deck[e->hand[i]];
   o->hand_size = (int8_t)e->nhand;
-  o->deck_size = 52;
+  o->deck_size = (int8_t)(e->ndeck + e->nforeign); /* sum(1 for _ in state.deck) :1491 */
   for (int i = 0; i < e->nsel; i++) if (e->sel[i] < 8) o->selected_cards[e->sel[i]] = 1;
   o->chips_scored = e->chips_scored;
   o->round_chips_scored = (int32_t)e->round_chips_scored;
@@ -712,7 +713,7 @@ static void step_play_hand(bo_env* e, double* reward, uint8_t* terminated, bo_in
     int pos = e->sel[i];
     if (pos < e->nhand) {
       int ci = e->hand[pos];
-      if (ci < 52) {
+      if (ci < e->ndeck) {
         int code = e->deck[ci], rank = (code >> 2) + 2, suit = code & 3;
         int chips = bo_rank_base_chips(rank);            /* CardAdapter.to_scoring_format :287-325 */
         if (e->enh[ci] == 1) chips += 30;                /* BONUS  cards.py:122-123 */
@@ -741,7 +742,7 @@ static void step_play_hand(bo_env* e, double* reward, uint8_t* terminated, bo_in
   bo_score_out so;
   int nj = (e->flags & BO_FLAG_SCORER_JOKERS) ? e->njokers : 0; /* dict jokers are skipped */
   bo_score_hand(sc, n, sc, n, hand_type, BO_NAMES_ENV, e->hand_levels[hand_type], e->jokers, nj, e->hands_left,
-                e->discards_left, 52, &e->grand, &so);
+                e->discards_left, e->ndeck + e->nforeign, &e->grand, &so);
   int64_t base_score = so.score;
   /* :703-734 per-card enhancement / seal effects */
   int64_t extra_money = 0;
@@ -881,7 +882,7 @@ static void step_discard(bo_env* e, double* reward, bo_info* info) { /* balatro_
   int ranks[8], n = 0, purple = 0;
   for (int i = 0; i < e->nsel; i++) {
     int pos = e->sel[i];
-    if (pos < e->nhand && e->hand[pos] < 52) {
+    if (pos < e->nhand && e->hand[pos] < e->ndeck) {
       int ci = e->hand[pos];
       if (e->seal[ci] == 4) purple++;
       ranks[n++] = (e->deck[ci] >> 2) + 2;
@@ -1025,7 +1026,9 @@ static void step_blind_select(bo_env* e, int action, double* reward, bo_info* in
  *  - list.remove(target) raises ValueError (Hanged Man, Familiar, Grim, Incantation with a target) and cards.Card is a
  *    frozen dataclass (Sigil, Ouija raise after their random.choice): BO_ERR_CONSUMABLE_RAISES, reward -1.0 by harness
  *    convention, the state stays as the exception leaves it (nothing popped, selection kept);
- *  - Immolate and Cryptid change the deck length: not restated (BO_ERR_CONSUMABLE_DECK, state untouched).
+ *  - Cryptid appends two consumables.Card copies to the live deck; draws take the lowest free deck index and cards never
+ *    leave the hand for good, so the copies are only ever COUNTED (deck_size, Blue Joker); Immolate removes five sampled
+ *    cards from the live deck list, so every later deck index (hand indexes, card_states keys) now names another card.
  * --------------------------------------------------------------------------------------------------------- */
 static const int WRAITH_JOKER[14] = {137, 138, 139, 140, 0, 142, 143, 144, 145, 146, 147, 148, 149, 150}; /* consumables.py:474-476 by JOKER_LIBRARY name; 'Drivers License' is not a library name */
 static const int SOUL_JOKER[5] = {146, 147, 148, 149, 150};                                               /* :590 */
@@ -1037,14 +1040,14 @@ static void use_consumable(bo_env* e, int ci, double* reward, bo_info* info) {
   int tgt[8], nt = 0;
   for (int i = 0; i < e->nsel; i++) {
     int pos = e->sel[i];
-    if (pos < e->nhand && e->hand[pos] < 52) tgt[nt++] = e->hand[pos];
+    if (pos < e->nhand && e->hand[pos] < e->ndeck) tgt[nt++] = e->hand[pos];
   }
   bo_mt* g = &e->grand;
   int success = 0, raises = 0, unsupported = 0;
   int64_t money_gained = 0;
   int planet = -1;
   int aff[8], naff = 0, set_enh = -1, set_edi = -1, set_seal = -1; /* cards_affected + the attribute the effect changed */
-  int items[4], nitems = 0, jcreated[2], njc = 0, hs_change = 0;
+  int items[4], nitems = 0, jcreated[2], njc = 0, hs_change = 0, ncreated = 0, ndestroyed = 0;
   const int slots = e->consumable_slots;
 #define AFFECT_FIRST(n) do { for (int i_ = 0; i_ < nt && i_ < (n); i_++) aff[naff++] = tgt[i_]; } while (0)
   switch (id) {
@@ -1117,16 +1120,36 @@ static void use_consumable(bo_env* e, int ci, double* reward, bo_info* info) {
       break;
     case 56: case 57: { /* Sigil :490-498, Ouija :500-509: random.choice, then assignment to a frozen dataclass */
       int n = 0;
-      for (int i = 0; i < e->nhand; i++) n += e->hand[i] < 52;
+      for (int i = 0; i < e->nhand; i++) n += e->hand[i] < e->ndeck;
       if (n > 0) { bo_mt_randbelow(g, id == 56 ? 4 : 13); raises = 1; }
       break;
     }
     case 58: /* Ectoplasm :511-517 */
       if (e->njokers > 0) { hs_change = -1; success = 1; }
       break;
-    case 59: /* Immolate :519-531 */
-      unsupported = 1;
+    case 59: { /* Immolate :519-531: random.sample(deck, 5) by index (Lib/random.py sample(): selection set for n > 21, pool
+                * below), then deck.remove(card) for each: every later index shifts down, card_states keep their keys */
+      int n = e->ndeck + e->nforeign, k = n < 5 ? n : 5, picked[5];
+      if (n <= 21) {
+        int pool[21];
+        for (int i = 0; i < n; i++) pool[i] = i;
+        for (int i = 0; i < k; i++) { int j = (int)bo_mt_randbelow(g, (uint32_t)(n - i)); picked[i] = pool[j]; pool[j] = pool[n - i - 1]; }
+      } else
+        for (int i = 0; i < k; i++) {
+          int j, dup;
+          do { j = (int)bo_mt_randbelow(g, (uint32_t)n); dup = 0; for (int q = 0; q < i; q++) dup |= picked[q] == j; } while (dup);
+          picked[i] = j;
+        }
+      uint64_t gone = 0;
+      for (int i = 0; i < k; i++) { if (picked[i] < e->ndeck) gone |= 1ull << picked[i]; else e->nforeign--; } /* copies are a suffix of equal-class objects */
+      int w = 0;
+      uint64_t played = 0; /* The Pillar remembers card OBJECTS (id(card), boss_blinds.py:472): its marks move with the cards */
+      for (int i = 0; i < e->ndeck; i++)
+        if (!((gone >> i) & 1)) { if ((e->boss_played_cards >> i) & 1) played |= 1ull << w; e->deck[w++] = e->deck[i]; }
+      e->ndeck = w; e->boss_played_cards = played;
+      ndestroyed = k; money_gained = 20; success = 1;
       break;
+    }
     case 60: /* Ankh :533-543: the "name" is a {'name','id'} dict unless the scorer-level harness hands out names */
       if (e->njokers > 0) {
         int k = (int)bo_mt_randbelow(g, (uint32_t)e->njokers);
@@ -1137,8 +1160,8 @@ static void use_consumable(bo_env* e, int ci, double* reward, bo_info* info) {
     case 62: /* Hex :553-563 */
       if (e->njokers > 0) { bo_mt_randbelow(g, (uint32_t)e->njokers); success = 1; }
       break;
-    case 65: /* Cryptid :581-591 */
-      if (nt >= 1) unsupported = 1;
+    case 65: /* Cryptid :581-591: two consumables.Card copies appended to the live deck */
+      if (nt >= 1) { e->nforeign += 2; ncreated = 2; success = 1; }
       break;
     case 66: /* The Soul :593-601 */
       if (e->njokers < e->joker_slots) { jcreated[njc++] = SOUL_JOKER[bo_mt_randbelow(g, 5)]; success = 1; }
@@ -1173,6 +1196,8 @@ static void use_consumable(bo_env* e, int ci, double* reward, bo_info* info) {
       }
       r += (double)naff * 2.0;
     }
+    if (ncreated) r += (double)ncreated * 3.0;     /* :1140-1141 */
+    if (ndestroyed) r += (double)ndestroyed * 1.0; /* :1143-1144 */
     if (njc) {
       for (int i = 0; i < njc; i++)
         if (e->njokers < e->joker_slots && jcreated[i] > 0 && e->njokers < BO_MAX_JOKERS) e->jokers[e->njokers++] = jcreated[i];

@@ -50,7 +50,7 @@ enum {
   BO_ERR_MAX_ANTE = 9,           /* balatro_env_2.py:620 (terminated, reward 0) */
   BO_ERR_MAX_SCORE = 10,         /* balatro_env_2.py:623 */
   BO_ERR_CONSUMABLE_RAISES = 11, /* the reference raises here (consumables.py:246,381,496,506): reward -1.0 by harness convention */
-  BO_ERR_CONSUMABLE_DECK = 12    /* Immolate / Cryptid change the deck length: not restated */
+  BO_ERR_CONSUMABLE_DECK = 12    /* (unused since Immolate / Cryptid are restated) */
 };
 
 /* info.flags */
@@ -124,7 +124,9 @@ typedef struct bo_env {
   int32_t ante, round, phase;
   int64_t chips_needed, chips_scored, round_chips_scored;
   int64_t money;
-  uint8_t deck[52]; /* card code = (rank-2)*4 + suit (cards.py:103-104) */
+  uint8_t deck[52]; /* card code = (rank-2)*4 + suit (cards.py:103-104); the first `ndeck` entries are live */
+  int32_t ndeck;    /* cards.Card objects left in state.deck (52 until Immolate removes some) */
+  int32_t nforeign; /* consumables.Card copies Cryptid appended BEHIND them: never drawn (draws take the lowest free index), only counted */
   int32_t hand[BO_MAX_HAND];
   int32_t nhand;
   int32_t sel[8];

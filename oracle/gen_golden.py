@@ -263,9 +263,9 @@ def gen_traces():
 
 
 def gen_trace_consumables():
-    """Tarot / spectral / planet consumables: two injected per episode, all 52 ids but Immolate and Cryptid
-    (they change the deck length: not on the accelerated path); purple seals create more tarots on discards."""
-    pool = [i for i in list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68)) if i not in (59, 65)]
+    """Tarot / spectral / planet consumables: two injected per episode, all 52 ids (Immolate and Cryptid change
+    the deck length; Blue Joker among the jokers sees it); purple seals create more tarots on discards."""
+    pool = list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68))
 
     def cons_fn(i):
         rr = random.Random(1300 + i)
@@ -276,9 +276,9 @@ def gen_trace_consumables():
         return [(d, rr.choice([0, 0, 0, 4, 8]), 0, rr.choice([0, 0, 4, 4])) for d in range(16)] if i % 3 == 0 else []
 
     for scorer in (False, True):
-        trace("consumables_scorer" if scorer else "consumables", [(7000 if scorer else 6000) + i for i in range(50)], 320,
+        trace("consumables_scorer" if scorer else "consumables", [(7000 if scorer else 6000) + i for i in range(52)], 320,
               rh.POLICY_UNIFORM, scorer=scorer, max_ante=20, cons_fn=cons_fn, cards_fn=cards_fn,
-              jokers_fn=lambda i: random.Random(1700 + i).sample(list(range(1, 151)), i % 6),
+              jokers_fn=lambda i: ([53] if i % 6 else []) + random.Random(1700 + i).sample([j for j in range(1, 151) if j != 53], max(0, i % 6 - 1)),
               money_fn=lambda i: [None, 3, 15, 200][i % 4])
 
 

@@ -93,14 +93,23 @@ def test_env_lockstep_card_states_and_levels():
 
 def test_env_lockstep_consumables():
     """Tarot / spectral / planet use (balatro_env_2.py:1066-1172, consumables.py) incl. the cases where the reference
-    raises (harness convention: reward -1.0, state as the exception left it).  Immolate / Cryptid are not restated."""
-    pool = [i for i in list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68)) if i not in (59, 65)]
-    for s in range(25):
+    raises (harness convention: reward -1.0, state as the exception left it), and Immolate / Cryptid (deck length changes)."""
+    pool = list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68))
+    for s in range(26):
         rr = random.Random(70 + s)
         cards = [(d, rr.choice([0, 0, 4, 8]), 0, rr.choice([0, 4])) for d in range(16)] if s % 2 else None
         lockstep(9700 + s, 400, rh.POLICY_UNIFORM, scorer=bool(s & 1), env_index=s, max_ante=20, cards=cards,
                  consumables=[pool[(2 * s) % len(pool)], pool[(2 * s + 1) % len(pool)]], money=[None, 30][s % 2],
-                 jokers=rr.sample(range(1, 151), s % 6))
+                 jokers=([53] if s % 3 == 0 else []) + rr.sample(range(1, 53), s % 5))
+
+
+def test_env_lockstep_immolate_cryptid():
+    """Immolate (five sampled cards leave the live deck list: every later index shifts) and Cryptid (two foreign copies
+    appended) over and over, with The Fool copying them and Blue Joker reading len(deck)."""
+    for s in range(16):
+        lockstep(9800 + s, 500, rh.POLICY_UNIFORM, scorer=bool(s & 1), env_index=s, max_ante=20,
+                 consumables=[[59, 65], [65, 59], [59, 1], [65, 1], [59, 59], [1, 59]][s % 6], jokers=[53, 1][: 1 + s % 2],
+                 cards=[(d, [0, 7, 4][d % 3], 0, [0, 4][d % 2]) for d in range(20)] if s % 4 == 0 else None)
 
 
 def test_reseed_reproduces_first_shuffle():
