@@ -99,6 +99,7 @@ struct Env {
   int32_t g_cur, g_cons, g_valid;
   // chunk 7
   int32_t g_idx, s_idx, s_cur, s_cons, s_ready;
+  int32_t ndrop, nfo; // cards.Card objects Immolate removed from the deck (52 - ndrop are left), copies Cryptid appended behind them
   uint64_t excess; // 12 x 4-bit (state.hand_levels - engine level): planets used at the level-15 cap
 };
 
@@ -132,7 +133,7 @@ __device__ __forceinline__ void bg_unpack(const uint4 c[BG_NHOT], Env& e) {
   e.levels = (uint64_t)c[6].z | ((uint64_t)(c[6].w & 0xffffu) << 32);
   e.g_cur = bg_b(c[6].w, 2); e.g_cons = bg_b(c[6].w, 3); e.g_valid = 0;
   e.g_idx = (int32_t)(c[7].x & 0xffffu); e.s_idx = (int32_t)(c[7].x >> 16);
-  e.s_cur = bg_b(c[7].y, 0); e.s_cons = bg_b(c[7].y, 1); e.s_ready = 0;
+  e.s_cur = bg_b(c[7].y, 0); e.s_cons = bg_b(c[7].y, 1); e.s_ready = 0; e.ndrop = bg_b(c[7].y, 2); e.nfo = bg_b(c[7].y, 3);
   e.excess = (uint64_t)c[7].z | ((uint64_t)(c[7].w & 0xffffu) << 32);
 }
 
@@ -154,7 +155,7 @@ __device__ __forceinline__ void bg_pack(const Env& e, uint4 c[BG_NHOT]) {
                     bg_p4((int)(e.jokers >> 32), e.shop_ante, e.d_head, e.d_cons));
   c[6] = make_uint4((uint32_t)e.boss_cards, (uint32_t)(e.boss_cards >> 32), (uint32_t)e.levels,
                     ((uint32_t)(e.levels >> 32) & 0xffffu) | ((uint32_t)(e.g_cur & 0xff) << 16) | ((uint32_t)(e.g_cons & 0xff) << 24));
-  c[7] = make_uint4(((uint32_t)e.g_idx & 0xffffu) | ((uint32_t)e.s_idx << 16), bg_p4(e.s_cur, e.s_cons, 0, 0),
+  c[7] = make_uint4(((uint32_t)e.g_idx & 0xffffu) | ((uint32_t)e.s_idx << 16), bg_p4(e.s_cur, e.s_cons, e.ndrop, e.nfo),
                     (uint32_t)e.excess, (uint32_t)(e.excess >> 32) & 0xffffu);
 }
 
@@ -598,7 +599,7 @@ __device__ __forceinline__ void bg_draw_cards(Env& e) {
   for (int i = 0; i < e.nhand; i++) inhand |= 1ull << bg_get8(e.hand, i);
 #pragma unroll 1
   while (e.nhand < e.hand_size && e.nhand < 8) {
-    uint64_t freeset = ~inhand & ((1ull << 52) - 1);
+    uint64_t freeset = ~inhand & ((1ull << (52 - e.ndrop)) - 1); // range(len(deck)); Cryptid's copies sit behind every real card and are never reached
     if (!freeset) break;
     int dnext = __ffsll((long long)freeset) - 1;
     e.hand = bg_set8(e.hand, e.nhand, dnext);

@@ -85,6 +85,7 @@ __device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, DK
   e.boss_type = 0; e.boss_types = 0; e.boss_cards = 0; e.boss_hp = 0; e.boss_req = 5; e.face_down = 0;
   e.bflags = (e.bflags & BG_BF_SHOP_EXISTS) | BG_BF_FIRST_HAND;
   e.highlighted = 0;
+  e.ndrop = 0; e.nfo = 0; // a fresh 52-card deck (:519-525)
   e.levels = 0x111111111111ull; // ScoreEngine(): every level 1
   e.excess = 0;
   // hand_play_counts = 0 (cold chunks 0..2)
@@ -614,6 +615,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
         int c = (int)(dm >> 8);
         int madd = vk == 0 ? c : (vk == 3 ? (int)mis_of[j] : (vk == 4 ? 3 * nj : (vk == 7 ? 13 * queens : 0)));
         int cadd = vk == 1 ? c : (vk == 5 ? 30 * e.discards_left : 0);
+        if constexpr (DK::kCards) if (vk == 1u && c == 104) cadd = 2 * (52 - e.ndrop + e.nfo); // Blue Joker: 2 * len(deck) once Immolate / Cryptid changed it
         double xf = vk == 2 ? (double)c : (vk == 6 ? baron : 1.0);
         if (ok) { chips += cadd; mult += madd; x_mult *= xf; }
       }
@@ -946,7 +948,9 @@ __device__ __forceinline__ void bg_toggle_select(Env& e, int pos) {
 //  - to_dict()['consumables'] is the live list: created items are appended by the effect and again by :1157-1160;
 //    to_dict()['jokers'] is a fresh list: only :1147-1155 adds jokers (by JOKER_LIBRARY name);
 //  - The Hanged Man / Familiar / Grim / Incantation with a target and Sigil / Ouija raise: error 11, reward -1.0 (harness
-//    convention), state as the exception leaves it; Immolate / Cryptid change the deck length: error 12, state untouched.
+//    convention), state as the exception leaves it;
+//  - Cryptid's copies are appended behind the 52 real cards and draws take the lowest free index, so they are only COUNTED
+//    (deck_size, Blue Joker); Immolate removes five sampled cards from the live list (error 12 below 24 real cards).
 // Kernels built without card states keep planets only (bg_inject_consumables refuses anything else for them).
 template <class DK>
 __device__ __forceinline__ void bg_use_consumable(const BgDev& d, int env, Env& e, RngWin& w, const DK& dk, int ci, StepOut& o) {
@@ -954,7 +958,7 @@ __device__ __forceinline__ void bg_use_consumable(const BgDev& d, int env, Env& 
   uint32_t L = (e.cons0 & 0xffu) | ((e.cons1 & 0xffu) << 8); // the live list, one byte per entry (3 at most, transiently)
   int n = e.ncons;
   bool success = false;
-  int money_gained = 0, planet = -1, naff = 0, set_enh = -1, set_edi = -1, set_seal = -1, nitems = 0, njc = 0, jc = 0, hs = 0;
+  int money_gained = 0, planet = -1, naff = 0, set_enh = -1, set_edi = -1, set_seal = -1, nitems = 0, njc = 0, jc = 0, hs = 0, ncreated = 0, ndestroyed = 0;
   uint64_t aff = 0;
   uint32_t items = 0;
   if (id >= 30 && id <= 41) { planet = id - 30; success = true; } // :644-652
@@ -1055,9 +1059,44 @@ __device__ __forceinline__ void bg_use_consumable(const BgDev& d, int env, Env& 
       case 58: // Ectoplasm :511-517
         if (e.njokers > 0) { hs = -1; success = true; }
         break;
-      case 59: // Immolate :519-531
-        unsupported = true;
+      case 59: { // Immolate :519-531: random.sample(deck, 5) by index (selection set: n > 21), then deck.remove(card) for
+                 // each: every later deck index -- hand indexes, card_states keys -- now names another card
+        const int nn = 52 - e.ndrop, n = nn + e.nfo;
+        if (nn < 24) { unsupported = true; break; } // the hand's indexes (always 0..7) must stay valid
+        uint64_t gone = 0; int nfgone = 0;
+        uint32_t p0 = 0xffu, p1 = 0xffu, p2 = 0xffu, p3 = 0xffu;
+#pragma unroll 1
+        for (int i = 0; i < 5; i++) {
+          uint32_t j; int guard = 0;
+          do { j = bg_randbelow<false>(d, env, e, w, (uint32_t)n); } while ((j == p0 || j == p1 || j == p2 || j == p3) && ++guard < 4096);
+          p3 = p2; p2 = p1; p1 = p0; p0 = j;
+          if ((int)j < nn) gone |= 1ull << j; else nfgone++;
+        }
+        // compact the deck through this lane's RNG window (nothing is cached in it here), then HBM copy + kernel-local copy
+        DK& mdk = const_cast<DK&>(dk);
+        uint32_t cur = 0; int wpos = 0; uint64_t played = 0;
+#pragma unroll 1
+        for (int i = 0; i < nn; i++)
+          if (!((gone >> i) & 1ull)) {
+            cur |= (uint32_t)bg_card(d, env, dk, i) << (8 * (wpos & 3));
+            if ((e.boss_cards >> i) & 1ull) played |= 1ull << wpos; // The Pillar marks card OBJECTS (id(card)): they move along
+            wpos++;
+            if ((wpos & 3) == 0) { w.lds[((wpos >> 2) - 1) * BG_BLOCK] = cur; cur = 0; }
+          }
+#pragma unroll 1
+        while (wpos < 64) { wpos++; if ((wpos & 3) == 0) { w.lds[((wpos >> 2) - 1) * BG_BLOCK] = cur; cur = 0; } } // the partial word, then zeros
+        w.g_len = 0; w.s_len = 0; w.g_blk = -1;
+#pragma unroll
+        for (int k = 0; k < BG_NDECK; k++) {
+          const uint4 c4 = make_uint4(w.lds[(4 * k) * BG_BLOCK], w.lds[(4 * k + 1) * BG_BLOCK], w.lds[(4 * k + 2) * BG_BLOCK], w.lds[(4 * k + 3) * BG_BLOCK]);
+          d.deck[(size_t)k * d.N + env] = c4;
+          bg_deck_set(mdk, k, c4);
+        }
+        e.boss_cards = played;
+        e.ndrop += 5 - nfgone; e.nfo -= nfgone;
+        ndestroyed = 5; money_gained = 20; success = true;
         break;
+      }
       case 60: // Ankh :533-543: the "name" is a {'name','id'} dict unless the scorer-level harness hands out names
         if (e.njokers > 0) {
           uint32_t k = bg_randbelow<false>(d, env, e, w, (uint32_t)e.njokers);
@@ -1067,8 +1106,8 @@ __device__ __forceinline__ void bg_use_consumable(const BgDev& d, int env, Env& 
       case 62: // Hex :553-563
         if (e.njokers > 0) { (void)bg_randbelow<false>(d, env, e, w, (uint32_t)e.njokers); success = true; }
         break;
-      case 65: // Cryptid :581-591
-        unsupported = nt >= 1;
+      case 65: // Cryptid :581-591: two consumables.Card copies appended to the live deck (counted, never drawn)
+        if (nt >= 1) { if (e.nfo > 60) { unsupported = true; break; } e.nfo += 2; ncreated = 2; success = true; }
         break;
       case 66: // The Soul :593-601
         if (e.njokers < 5) { jc = 146 + (int)bg_randbelow<false>(d, env, e, w, 5u); njc = 1; success = true; }
@@ -1106,6 +1145,8 @@ __device__ __forceinline__ void bg_use_consumable(const BgDev& d, int env, Env& 
         }
         r += (double)naff * 2.0;
       }
+      if (ncreated) r += (double)ncreated * 3.0;     // :1140-1141
+      if (ndestroyed) r += (double)ndestroyed * 1.0; // :1143-1144
       if (njc) {
         if (e.njokers < 5 && jc > 0) { e.jokers = bg_set8(e.jokers, e.njokers, jc); e.njokers++; }
         r += (double)njc * 15.0;
@@ -1227,7 +1268,7 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
     uint32_t b = (2 * i + 1 < e.njokers && 2 * i + 1 < 8) ? (uint32_t)bg_get8(e.jokers, (2 * i + 1) & 7) : 0u;
     jq[i] = a | (b << 16);
   }
-  BG_MIX(e.cons0 | (e.cons1 << 8));
+  BG_MIX(e.cons0 | (e.cons1 << 8) | ((uint32_t)e.ndrop << 16) | ((uint32_t)e.nfo << 24));
   const uint32_t cq = (uint32_t)((e.ncons > 0 && !(e.cons0 & 0x80u)) ? e.cons0 : 0) | ((uint32_t)((e.ncons > 1 && !(e.cons1 & 0x80u)) ? e.cons1 : 0) << 16); // enum-form names map to 0 (:1570)
   // shop rows only in SHOP phase (:1534-1539)
   uint32_t it[5] = {0, 0, 0, 0, 0}, co[5] = {0, 0, 0, 0, 0};
@@ -1291,7 +1332,7 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
     w[79] = (uint32_t)(handb >> 48) | ((lv[0] & 0xffffu) << 16);                                 // 318 hand_levels i8[12]
     w[80] = (lv[0] >> 16) | (lv[1] << 16);
     w[81] = (lv[1] >> 16) | (lv[2] << 16);
-    w[82] = (lv[2] >> 16) | (((uint32_t)e.nhand & 0xffu) << 16) | (52u << 24);                   // 330 hand_size, deck_size
+    w[82] = (lv[2] >> 16) | (((uint32_t)e.nhand & 0xffu) << 16) | ((uint32_t)(52 - e.ndrop + e.nfo) << 24);                   // 330 hand_size, deck_size
     w[83] = ((uint32_t)e.round & 0xffu) | (((uint32_t)e.hands_left & 0xffu) << 8) | (((uint32_t)e.discards_left & 0xffu) << 16) |
             (((uint32_t)e.njokers & 0xffu) << 24);                                               // 332 round, hands_left, discards_left, joker_count
     w[84] = 5u | (((uint32_t)e.ncons & 0xffu) << 8) | (2u << 16) | (((uint32_t)e.phase & 0xffu) << 24); // 336 joker_slots, consumable_count, consumable_slots, phase
@@ -1335,7 +1376,7 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
   // ---- one array per key
   if (p.hand) ((uint64_t*)p.hand)[row] = handb;
   if (p.hand_size) p.hand_size[row] = (int8_t)e.nhand;
-  if (p.deck_size) p.deck_size[row] = 52;
+  if (p.deck_size) p.deck_size[row] = (int8_t)(52 - e.ndrop + e.nfo);
   if (p.selected_cards) {
     ulonglong2* q = (ulonglong2*)(p.selected_cards + row * 8);
 #pragma unroll

@@ -50,8 +50,9 @@ extern "C" {
 #define BG_ERR_MAX_SCORE 10     /* balatro_env_2.py:623 terminated 'max_score_reached' */
 #define BG_ERR_CONSUMABLE_RAISES 11 /* the reference RAISES here (consumables.py:246,381,418,444 list.remove of a target class;
                                      * :496,506 assignment to a frozen dataclass): reward -1.0, state as the exception leaves it */
-#define BG_ERR_CONSUMABLE_DECK 12   /* Immolate / Cryptid change the deck length (consumables.py:519-531,581-591): not on the
-                                     * accelerated path; reward -1.0, state untouched */
+#define BG_ERR_CONSUMABLE_DECK 12   /* Immolate on a deck of fewer than 24 real cards / Cryptid beyond 60 copies (consumables.py:519-531,
+                                     * 581-591): outside the accelerated domain (the reference's unguarded deck[i] reads would raise
+                                     * soon after); reward -1.0, state untouched */
 
 /* info.flags bits */
 #define BG_INFO_BEAT_BLIND 1     /* info['beat_blind'] */
@@ -234,7 +235,8 @@ int bg_inject_cards(bg_handle* h, const uint8_t* enh_host, const uint8_t* editio
  * spectrals 50-67; ids_host is [N, 2], n_host[i] in [0, 2] (-1 = back to the reset default).  Re-applied after every
  * reset like bg_inject's template.  Tarot / spectral cards edit card states, so they need BG_FLAG_CARD_STATES (planets do
  * not).  In-env sources of consumables: blue seals (planets), purple seals (tarots), The Fool / High Priestess /
- * Emperor / Judgement.  Replaces direct writes to env.state.consumables. */
+ * Emperor / Judgement.  All 52 ids are followed (incl. the reference's quirks: INTEGRATION.md section 6); error codes
+ * BG_ERR_CONSUMABLE / _RAISES / _DECK.  Replaces direct writes to env.state.consumables. */
 int bg_inject_consumables(bg_handle* h, const int32_t* ids_host /*[N,2]*/, const int32_t* n_host /*[N]*/,
                           const uint8_t* mask_host, int apply_now, void* stream);
 

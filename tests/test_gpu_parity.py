@@ -346,12 +346,33 @@ def test_card_states_rollout_vs_oracle():
     env.close()
 
 
+def _run_consumables_rollout(n, T, seeds, scorer, jokers, cons, cards, pseed, min_uses):
+    from balatro_gym_amd.vec_env import RowBuffers
+    env = _vec(n, seeds, scorer_jokers=scorer, autoreset=True, max_ante=6, card_states=True)
+    env.inject(jokers=jokers, apply_now=True)
+    env.inject_cards(cards, apply_now=True)
+    env.inject_consumables(cons, apply_now=True)
+    rb = RowBuffers(n, env.device, steps=T)
+    env.rollout(T, policy=0, policy_seed=pseed, obs_buffers=rb)
+    env.check()
+    got_stats = env.stats()
+    wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, T, 0, pseed, scorer, 6, jokers, cards=cards, consumables=cons)
+    assert np.array_equal(rb.action.cpu().numpy(), wa)
+    assert np.array_equal(rb.terminated.cpu().numpy(), wt)
+    assert np.array_equal(rb.reward.contiguous().cpu().numpy().view(np.uint64), wr.view(np.uint64))
+    for k in OBS_KEYS:
+        assert np.array_equal(rb.tensors[k].contiguous().cpu().numpy(), wobs[k]), f"record key {k} differs"
+    for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
+        assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
+    assert ((wa >= 10) & (wa <= 14)).sum() > min_uses  # the consumable path was really exercised
+    env.close()
+    return wobs
+
+
 @pytest.mark.parametrize("scorer", [False, True])
 def test_consumables_rollout_vs_oracle(scorer):
-    """Tarot / spectral / planet consumables (every id, two per episode) plus purple / blue seals through the fused rollout
-    with packed records: every record byte against the oracle, resets included.  Immolate / Cryptid report
-    BG_ERR_CONSUMABLE_DECK on both sides (state untouched)."""
-    from balatro_gym_amd.vec_env import RowBuffers
+    """Tarot / spectral / planet consumables (every one of the 52 ids, two per episode) plus purple / blue seals through the
+    fused rollout with packed records: every record byte against the oracle, resets included."""
     n, T = 256, 160
     seeds = [93_000 + 5 * i for i in range(n)]
     pool = list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68))
@@ -361,24 +382,21 @@ def test_consumables_rollout_vs_oracle(scorer):
     for i in range(n):
         rr = random.Random(7000 + i)
         cards.append([(d, rr.choice([0, 0, 4, 8]), 0, rr.choice([0, 3, 4, 4])) for d in rr.sample(range(52), 16)] if i % 2 else [])
-    env = _vec(n, seeds, scorer_jokers=scorer, autoreset=True, max_ante=6, card_states=True)
-    env.inject(jokers=jokers, apply_now=True)
-    env.inject_cards(cards, apply_now=True)
-    env.inject_consumables(cons, apply_now=True)
-    rb = RowBuffers(n, env.device, steps=T)
-    env.rollout(T, policy=0, policy_seed=47, obs_buffers=rb)
-    env.check()
-    got_stats = env.stats()
-    wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, T, 0, 47, scorer, 6, jokers, cards=cards, consumables=cons)
-    assert np.array_equal(rb.action.cpu().numpy(), wa)
-    assert np.array_equal(rb.terminated.cpu().numpy(), wt)
-    assert np.array_equal(rb.reward.contiguous().cpu().numpy().view(np.uint64), wr.view(np.uint64))
-    for k in OBS_KEYS:
-        assert np.array_equal(rb.tensors[k].contiguous().cpu().numpy(), wobs[k]), f"record key {k} differs"
-    for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
-        assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
-    assert ((wa >= 10) & (wa <= 14)).sum() > 500  # the consumable path was really exercised
-    env.close()
+    _run_consumables_rollout(n, T, seeds, scorer, jokers, cons, cards, 47, 500)
+
+
+def test_immolate_cryptid_rollout_vs_oracle():
+    """The two consumables that change the deck length, over and over (The Fool copies them, purple seals bring more Fools):
+    Immolate removes five sampled cards from the live deck list -- every later deck index, the hand's included, names another
+    card, The Pillar's marks move along -- and Cryptid appends copies that only deck_size and Blue Joker ever see."""
+    n, T = 192, 200
+    seeds = [95_000 + 7 * i for i in range(n)]
+    jokers = [[53, 1, 16][: 1 + i % 3] for i in range(n)]  # Blue Joker: +2 chips per card in the deck
+    cons = [[[59, 65], [65, 59], [59, 1], [65, 1], [59, 59], [1, 59]][i % 6] for i in range(n)]
+    cards = [[(d, [0, 7, 4][d % 3], 0, [0, 4][d % 2]) for d in range(20)] if i % 3 == 0 else [] for i in range(n)]
+    wobs = _run_consumables_rollout(n, T, seeds, True, jokers, cons, cards, 53, 300)
+    sizes = wobs["deck_size"]
+    assert sizes.min() <= 42 and sizes.max() >= 54, (sizes.min(), sizes.max())  # decks really shrank and grew
 
 
 def test_inject_consumables_needs_card_states():
