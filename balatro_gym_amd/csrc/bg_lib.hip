@@ -509,7 +509,17 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
     unsigned long long q_iter = 0, q_idle = 0, q_a = 0, q_c = 0, q_lanes = 0, q_s1 = 0, q_s2 = 0, q_s3 = 0, q_s4 = 0;
     const unsigned long long q_t0 = __builtin_readcyclecounter();
 #endif
+    const uint32_t th_env = (role_mode >> 16) & 0xffu; // 0 = off: an iteration starts however few lanes can take part
+    uint32_t gather_polls = 0;
     for (;;) {
+      if (th_env) {
+        // An iteration costs the wave the same whether 20 or 64 lanes take part.  Wait (a little) until enough lanes can: those
+        // that can step plus those a service wave has finished.  The service waves do not depend on this wave, so no deadlock.
+        const bool pending = live && (blocked ? (bg_lds_load((uint32_t*)&s_out[local].misc) & 0x400u) != 0u : t < T);
+        const uint32_t can = (uint32_t)__popcll(__ballot(pending)), open_ = (uint32_t)__popcll(__ballot(live && (blocked || t < T)));
+        if (can < (th_env < open_ ? th_env : open_) && gather_polls < 256u) { gather_polls++; __builtin_amdgcn_s_sleep(4); continue; }
+        gather_polls = 0;
+      }
 #ifdef BG_TIMING3
       const unsigned long long q_c0 = __builtin_readcyclecounter();
 #endif
@@ -1654,7 +1664,8 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
         const bool v3 = h->rollout_version == 3 && !per_key; // dedicated service waves: four waves per workgroup of 128 envs
         static const uint32_t role_mode = (getenv("BG_ROLE_MODE") ? (uint32_t)atoi(getenv("BG_ROLE_MODE")) : 0u) |
                                           ((getenv("BG_HELP") ? atoi(getenv("BG_HELP")) : 0) ? 0x100u : 0u) |
-                                          ((getenv("BG_DEFER_ADV") ? atoi(getenv("BG_DEFER_ADV")) : 0) ? 0x200u : 0u);
+                                          ((getenv("BG_DEFER_ADV") ? atoi(getenv("BG_DEFER_ADV")) : 0) ? 0x200u : 0u) |
+                                          (((uint32_t)(getenv("BG_TH_ENV") ? atoi(getenv("BG_TH_ENV")) : 0) & 0xffu) << 16);
 #define BG_LAUNCH_R2(HASHV, CARDSV) do { if (v3) hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV>), g2, dim3(2 * BG_RB), 0, st, dv, chunk, pol, policy_seed, \
                                                    env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr, role_mode); \
   else hipLaunchKernelGGL((bg_rollout2_kernel<HASHV, CARDSV>), g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, \
