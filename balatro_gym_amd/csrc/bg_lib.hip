@@ -498,6 +498,15 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
       mask = bg_action_mask(d, env, e, sr);
       if (sr.valid) { s_shop[0][local] = sr.c3; s_shop[1][local] = sr.c4; s_shop[2][local] = sr.c5; s_shop[3][local] = sr.c6; }
     }
+#ifdef BG_DECK_PRELOAD // development: measured -4 % (16 registers held across the whole loop cost more than the round trip)
+    // The ring's NEXT deck sits in registers before the reset that consumes it: a reset then costs no HBM round trip (some lane
+    // of a wave resets in every other iteration, and the four dependent loads were ~2.5 k of its cycles).  Slots the view calls
+    // ready were written by a refill that is complete; the refill running beside this kernel only touches the others.
+    uint4 nd[BG_NDECK];
+    bool nd_ok = live && e.d_ready > 0;
+#pragma unroll
+    for (int q = 0; q < BG_NDECK; q++) nd[q] = nd_ok ? d.ndeck[((size_t)e.d_head * BG_NDECK + q) * d.N + env] : make_uint4(0, 0, 0, 0);
+#endif
     int t = 0;
     bool blocked = false;
     int action = 0;
@@ -573,7 +582,16 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
 #endif
       if (fin) {
         if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
+#ifdef BG_DECK_PRELOAD // development: measured -4 % (16 registers held across the whole loop cost more than the round trip)
+        if (o.terminated) { // SAME_STEP auto-reset
+          bg_env_reset(d, env, e, dk, nd_ok ? nd : (const uint4*)nullptr); n_eps++;
+          nd_ok = e.d_ready > 0;
+#pragma unroll
+          for (int q = 0; q < BG_NDECK; q++) if (nd_ok) nd[q] = d.ndeck[((size_t)e.d_head * BG_NDECK + q) * d.N + env];
+        }
+#else
         if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; } // SAME_STEP auto-reset
+#endif
         // a reset zeroes the env's play counts (and re-applies its card states) in HBM, which a service wave touches a few
         // steps later: let those stores land first.  What is still in flight here is the record write-out of the iteration
         // BEFORE (a whole phase A old), so this wait is short -- unlike one right after the write-out
