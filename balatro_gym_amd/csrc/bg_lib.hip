@@ -585,9 +585,6 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
 #ifdef BG_DECK_PRELOAD // development: measured -4 % (16 registers held across the whole loop cost more than the round trip)
         if (o.terminated) { // SAME_STEP auto-reset
           bg_env_reset(d, env, e, dk, nd_ok ? nd : (const uint4*)nullptr); n_eps++;
-          nd_ok = e.d_ready > 0;
-#pragma unroll
-          for (int q = 0; q < BG_NDECK; q++) if (nd_ok) nd[q] = d.ndeck[((size_t)e.d_head * BG_NDECK + q) * d.N + env];
         }
 #else
         if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; } // SAME_STEP auto-reset
@@ -597,6 +594,13 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
         // BEFORE (a whole phase A old), so this wait is short -- unlike one right after the write-out
 #ifndef BG_NO_RESET_WAIT // development: measure what the wait costs
         if (__ballot(o.terminated) != 0ull) bg_wait_vm();
+#endif
+#ifdef BG_DECK_PRELOAD
+        if (o.terminated) { // after the wait: these loads are for the NEXT reset and must not be waited for now
+          nd_ok = e.d_ready > 0;
+#pragma unroll
+          for (int q = 0; q < BG_NDECK; q++) if (nd_ok) nd[q] = d.ndeck[((size_t)e.d_head * BG_NDECK + q) * d.N + env];
+        }
 #endif
         ShopRegs sr; sr.valid = false;
         if (e.phase == 1 && (e.bflags & BG_BF_SHOP_EXISTS)) {
