@@ -341,6 +341,7 @@ struct JTables {
   double pow115[101];  // 1.15 ** k  (shop.py:105)
   double pow15[16];    // 1.5 ** k   (Baron)
   double pow08[16];    // 0.8 ** k   (boss_blinds.py:436)
+  uint32_t inv[64];    // floor(2**32 / d): h % d without a division (bg_policy_action_fast)
 };
 // LDS pointers keep their address space in the type: a generic pointer stored in a struct compiles to FLAT loads (the
 // vector-memory path, ~1-2k cycles when nothing hides it) instead of ds_read (~100 cycles).

@@ -451,6 +451,10 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
   __shared__ bg_u32x4 s_stage[2][BG_BLOCK * BG_STAGE_NP];       // record staging of the two env waves
   __shared__ unsigned long long s_rowaddr[2][BG_BLOCK];
   __shared__ JTables jt;
+#ifdef BG_TIMING3
+  __shared__ unsigned long long s_prof[2][2];
+  if (threadIdx.x < 4) s_prof[threadIdx.x >> 1][threadIdx.x & 1] = 0;
+#endif
   __builtin_amdgcn_s_setprio(3);
   bg_tables_init(&jt);
   const int tid = threadIdx.x;
@@ -513,6 +517,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
     StepOut o;
     bg_step_init(o);
     const PolicyLane pl = bg_policy_lane(policy, policy_seed, env_index0 + (uint64_t)env);
+    uint64_t px = pl.seed_env + BG_POLICY_PSI * (t0 + 1); // the hash input of the lane's next step
     uint32_t idle_polls = 0;
 #ifdef BG_TIMING3
     unsigned long long q_iter = 0, q_idle = 0, q_a = 0, q_c = 0, q_lanes = 0, q_s1 = 0, q_s2 = 0, q_s3 = 0, q_s4 = 0;
@@ -536,13 +541,23 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
       bool fin = false;
       if (live && !blocked && t < T) {
         bg_step_init(o);
-        action = bg_policy_action(e, mask, policy, pl, t0 + (uint64_t)t);
+#ifdef BG_TIMING3
+        const unsigned long long q_a0 = __builtin_readcyclecounter();
+#endif
+        action = bg_policy_action_fast(e, mask, policy, pl, px, (lds_JTables*)&jt);
+#ifdef BG_TIMING3
+        const unsigned long long q_a1 = __builtin_readcyclecounter();
+#endif
         bool deferred = false;
         if (bg_step_guards(e, mask, action, o)) {
           if (e.phase == 0 && action >= 2 && action < 10) bg_toggle_select(e, action - 2);
           else if (e.phase == 1 && action == 31) { e.phase = 0; bg_draw_cards(e); }              // shop end :1247-1251
           else deferred = true;
         }
+#ifdef BG_TIMING3
+        const unsigned long long q_a2 = __builtin_readcyclecounter();
+        if ((tid & 63) == __builtin_ctzll(__ballot(1))) { atomicAdd(&s_prof[wave][0], q_a1 - q_a0); atomicAdd(&s_prof[wave][1], q_a2 - q_a1); }
+#endif
         if (deferred) {
           const int cls = (e.phase == 0 && action == 0) ? 0 : 1;
           uint4 c[BG_NHOT];
@@ -631,7 +646,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
         n_steps++;
         rbits ^= (uint64_t)__double_as_longlong(o.reward) * (2 * (uint64_t)(t0 + t) + 1);
         if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
-        t++;
+        t++; px += BG_POLICY_PSI;
       }
 #ifdef BG_TIMING3
       { const unsigned long long q_c2 = __builtin_readcyclecounter(); q_a += q_c1 - q_c0; q_c += q_c2 - q_c1; q_iter++;
@@ -648,7 +663,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
     if ((tid & 63) == 0 && d.dbg) {
       atomicAdd(&d.dbg[0], __builtin_readcyclecounter() - q_t0); atomicAdd(&d.dbg[1], q_iter); atomicAdd(&d.dbg[2], q_idle);
       atomicAdd(&d.dbg[3], q_a); atomicAdd(&d.dbg[4], q_c); atomicAdd(&d.dbg[11], 1ull); atomicAdd(&d.dbg[12], q_lanes);
-      atomicAdd(&d.dbg[16], q_s1); atomicAdd(&d.dbg[17], q_s2); atomicAdd(&d.dbg[18], q_s3); atomicAdd(&d.dbg[19], q_s4);
+      atomicAdd(&d.dbg[20], s_prof[wave][0]); atomicAdd(&d.dbg[21], s_prof[wave][1]); atomicAdd(&d.dbg[16], q_s1); atomicAdd(&d.dbg[17], q_s2); atomicAdd(&d.dbg[18], q_s3); atomicAdd(&d.dbg[19], q_s4);
     }
 #endif
     if ((tid & 63) == 0) {

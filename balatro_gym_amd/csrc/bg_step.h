@@ -369,6 +369,7 @@ __device__ __forceinline__ void bg_tables_init(JTables* t) {
     t->cost[id] = id < 151 ? BG_JOKER_COST[id] : 0;
     if (id < 101) t->pow115[id] = BG_POW115[id];
     if (id < 16) { t->pow15[id] = BG_POW15[id]; t->pow08[id] = id < 9 ? BG_POW08[id] : 0.0; }
+    if (id < 64) t->inv[id] = id >= 2 ? (uint32_t)(0x100000000ull / (uint64_t)id) : 0xffffffffu;
   }
   __syncthreads();
 }
@@ -931,13 +932,15 @@ __device__ __forceinline__ void bg_step_init(StepOut& o) {
 
 // :1052-1058 SELECT_CARD toggle; the selection ORDER is kept (it is the scoring / RNG order of a later play)
 __device__ __forceinline__ void bg_toggle_select(Env& e, int pos) {
-  int at = -1;
-#pragma unroll 1
-  for (int i = 0; i < e.nsel; i++) if (bg_get8(e.sel, i) == pos) at = i;
-  if (at >= 0) { e.sel = bg_del8(e.sel, at); e.nsel--; }
+  // position of `pos` among the first nsel bytes of e.sel, without a loop: zero-byte test on sel ^ (pos in every byte); the
+  // LOWEST flagged byte is exact (borrows only disturb bytes above a real zero) and a position is listed at most once
+  const uint32_t rep = (uint32_t)pos * 0x01010101u;
+  const uint64_t x = e.sel ^ (((uint64_t)rep << 32) | rep);
+  uint64_t z = (x - 0x0101010101010101ull) & ~x & 0x8080808080808080ull;
+  z &= e.nsel >= 8 ? ~0ull : ((1ull << (8 * e.nsel)) - 1ull);
+  if (z) { e.sel = bg_del8(e.sel, (__ffsll((long long)z) - 1) >> 3); e.nsel--; }
   else { e.sel = bg_set8(e.sel, e.nsel, pos); e.nsel++; }
 }
-
 
 // _use_consumable (balatro_env_2.py:1066-1172) over ConsumableManager.use_consumable (consumables.py:622-652),
 // TarotEffects.apply_tarot (:111-327) and SpectralEffects.apply_spectral (:354-613).  A consumable is held as its
@@ -1460,6 +1463,40 @@ __device__ __forceinline__ int bg_policy_action(const Env& e, uint64_t mask, int
   x ^= x >> 27; x *= 0x94D049BB133111EBull;
   x ^= x >> 31;
   uint32_t k = (uint32_t)(x >> 32) % (uint32_t)nv;
+  const uint32_t lo = (uint32_t)mask, hi = (uint32_t)(mask >> 32);
+  uint32_t c = (uint32_t)__popc(lo);
+  uint32_t w = k < c ? lo : hi;
+  int base = k < c ? 0 : 32;
+  k = k < c ? k : k - c;
+#pragma unroll
+  for (int sh = 16; sh >= 1; sh >>= 1) { // k-th set bit of w
+    c = (uint32_t)__popc(w & ((1u << sh) - 1u));
+    const bool up = k >= c;
+    w = up ? w >> sh : w;
+    base += up ? sh : 0;
+    k = up ? k - c : k;
+  }
+  return base;
+}
+
+// The same policy for a lane that keeps x0 = seed_env + psi * (t + 1) itself (+= psi per step: no 64-bit multiply for it) and
+// takes h % nv from a reciprocal table: q = umulhi(h, floor(2**32 / nv)) is the quotient or one less, so one conditional
+// subtraction makes the remainder exact.
+#define BG_POLICY_PSI 0xD1B54A32D192ED03ull
+__device__ __forceinline__ int bg_policy_action_fast(const Env& e, uint64_t mask, int policy, const PolicyLane& pl, uint64_t x0, lds_JTables* jt) {
+  if (policy != 0) {
+    if (e.phase == 2) return pl.blind;
+    if (e.phase == 1) return 31;
+  }
+  const int nv = __popcll(mask);
+  if (!nv) return 0;
+  uint64_t x = x0;
+  x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull;
+  x ^= x >> 27; x *= 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  const uint32_t h = (uint32_t)(x >> 32);
+  uint32_t k = h - __umulhi(h, jt->inv[nv]) * (uint32_t)nv;
+  k = k >= (uint32_t)nv ? k - (uint32_t)nv : k;
   const uint32_t lo = (uint32_t)mask, hi = (uint32_t)(mask >> 32);
   uint32_t c = (uint32_t)__popc(lo);
   uint32_t w = k < c ? lo : hi;

@@ -30,6 +30,7 @@ print(f"env wave: cycles {o[0]/waves:.0f}  iterations {o[1]/waves:.1f} ({o[1]/wa
 print(f"  cycles per iteration: A {o[3]/iters:.0f}  C {o[4]/iters:.0f}  total {o[0]/iters:.0f}")
 print(f"  phase C per iteration: poll+merge {o[16]/iters:.0f}  cap+reset {o[17]/iters:.0f}  mask {o[18]/iters:.0f}  record {o[19]/iters:.0f}"
       f"  stats+loop {(o[4]-o[16]-o[17]-o[18]-o[19])/iters:.0f}")
+print(f"  phase A per iteration: policy {o[20]/iters:.0f}  guards+cheap actions {o[21]/iters:.0f}  pack+enqueue+rest {(o[3]-o[20]-o[21])/iters:.0f}")
 for cls, nm in ((0, "plays"), (1, "others")):
     b = max(1, o[5 + 3 * cls])
     print(f"service {nm}: batches per wave {o[5+3*cls]/(waves/2):.1f}  items per batch {o[6+3*cls]/b:.1f}  cycles per batch {o[7+3*cls]/b:.0f}"
