@@ -595,6 +595,7 @@ __device__ __forceinline__ int bg_classify(uint64_t cards, int n) {
 
 // balatro_game.py:95-109 _draw_cards: append the lowest deck indexes not in hand until len == hand_size
 __device__ __forceinline__ void bg_draw_cards(Env& e) {
+  if (e.nhand >= e.hand_size || e.nhand >= 8) return; // nothing to draw (the usual case at the end of a shop: played cards never left the hand)
   uint64_t inhand = 0;
 #pragma unroll 1
   for (int i = 0; i < e.nhand; i++) inhand |= 1ull << bg_get8(e.hand, i);

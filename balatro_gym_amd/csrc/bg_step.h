@@ -1214,7 +1214,25 @@ struct ObsPtrs {
   uint8_t* rows;        // non-null: one BG_ROW_BYTES record per (step, env) instead of the per-key arrays
   uint32_t row_stride;  // bytes between consecutive records (multiple of 16)
 };
-struct RowExtra { double reward; int32_t action; uint32_t terminated; };
+struct RowExtra { double reward; int32_t action; uint32_t terminated; bool cached = false; float prf = 0.0f; uint64_t handb = 0; };
+// The two observation values that only change in the heavy actions (so the service-wave kernel lets the service lane compute
+// them and the env lane carry them): the hand as card codes (8 LDS byte reads) and progress_ratio (a float64 division).
+template <class DK>
+__device__ __forceinline__ uint64_t bg_obs_handb(const BgDev& d, int env, const Env& e, const DK& dk) {
+  uint64_t handb = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    int v = 0xff;
+    if (i < e.nhand) v = bg_card(d, env, dk, bg_get8(e.hand, i));
+    handb |= (uint64_t)(v & 0xff) << (8 * i);
+  }
+  return handb;
+}
+__device__ __forceinline__ float bg_obs_prf(const Env& e) { // :1497 min(2, round_chips / max(1, chips_needed)) as float32
+  int64_t need1 = e.chips_needed > 1 ? e.chips_needed : 1;
+  double pr = (double)e.round_chips / (double)need1;
+  return (float)(pr < 2.0 ? pr : 2.0);
+}
 // LDS staging of packed records (block-compacted rollout kernel): 64 slots x 6 pieces of 16 bytes + one address per slot
 typedef uint32_t bg_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bg_u32x4 lds_u4;
@@ -1244,13 +1262,7 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
   uint64_t hsh = 0x9E3779B97F4A7C15ull;
 #define BG_MIX(v) do { if (HASH) { hsh ^= (uint64_t)(v); hsh *= 0xBF58476D1CE4E5B9ull; hsh ^= hsh >> 29; } } while (0)
   // ---- values
-  uint64_t handb = 0;
-#pragma unroll
-  for (int i = 0; i < 8; i++) {
-    int v = 0xff;
-    if (i < e.nhand) v = bg_card(d, env, dk, bg_get8(e.hand, i));
-    handb |= (uint64_t)(v & 0xff) << (8 * i);
-  }
+  const uint64_t handb = rx.cached ? rx.handb : bg_obs_handb(d, env, e, dk);
   BG_MIX(handb);
   uint32_t selm = 0;
 #pragma unroll 1
@@ -1258,8 +1270,7 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
   BG_MIX(selm | ((uint64_t)e.face_down << 8) | ((uint64_t)e.nhand << 16));
   BG_MIX(e.chips_scored); BG_MIX(e.round_chips);
   int64_t need1 = e.chips_needed > 1 ? e.chips_needed : 1;
-  double pr = (double)e.round_chips / (double)need1;
-  float prf = (float)(pr < 2.0 ? pr : 2.0);
+  const float prf = rx.cached ? rx.prf : bg_obs_prf(e);
   BG_MIX(__float_as_uint(prf));
   BG_MIX(((uint64_t)(uint32_t)e.chips_needed << 32) | (uint32_t)e.money);
   BG_MIX((uint64_t)e.ante | ((uint64_t)e.round << 8) | ((uint64_t)e.hands_left << 16) | ((uint64_t)e.discards_left << 24) |
