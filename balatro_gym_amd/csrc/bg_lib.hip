@@ -148,7 +148,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, in
 // only ever passes through this CU's one vector-memory pipeline, in order; everything exchanged between waves is LDS.
 __device__ __forceinline__ void bg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags; uint64_t handb; float prf; float pad_; }; // misc: hand_type+1 | terminated<<8 | has_shop<<9; handb / prf: bg_obs_handb / bg_obs_prf of the state after the action (v3)
+struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags; uint64_t handb; float prf; uint32_t selm; }; // misc: hand_type+1 | terminated<<8 | has_shop<<9; handb / prf: bg_obs_handb / bg_obs_prf / bg_obs_selm of the state after the action (v3)
 
 #ifndef BG_RB_LB
 #define BG_RB_LB BG_RB // threads per workgroup the compiler plans registers for
@@ -482,7 +482,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
   if (tid == 0) s_done = 0;
   if (is_env) {
     s_items[0][local] = 0; s_items[1][local] = 0;
-    OutLds z; z.reward = 0.0; z.final_score = 0; z.misc = 0; z.flags = 0; z.handb = 0; z.prf = 0.0f; z.pad_ = 0.0f;
+    OutLds z; z.reward = 0.0; z.final_score = 0; z.misc = 0; z.flags = 0; z.handb = 0; z.prf = 0.0f; z.selm = 0;
     s_out[local] = z;
   }
   __syncthreads();
@@ -514,6 +514,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
     // observation values that only the heavy actions (and a reset) change: carried, not recomputed every step
     uint64_t c_handb = live ? bg_obs_handb(d, env, e, dk) : 0ull;
     float c_prf = live ? bg_obs_prf(e) : 0.0f;
+    uint32_t c_selm = live ? bg_obs_selm(e) : 0u;
     int t = 0;
     bool blocked = false;
     int action = 0;
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
 #endif
         bool deferred = false;
         if (bg_step_guards(e, mask, action, o)) {
-          if (e.phase == 0 && action >= 2 && action < 10) bg_toggle_select(e, action - 2);
+          if (e.phase == 0 && action >= 2 && action < 10) { bg_toggle_select(e, action - 2); c_selm ^= 1u << (action - 2); }
           else if (e.phase == 1 && action == 31) {                                                // shop end :1247-1251
             const int nh0 = e.nhand;
             e.phase = 0; bg_draw_cards(e);
@@ -595,7 +596,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
         OutLds ol = s_out[local];
         o.reward = ol.reward; o.final_score = ol.final_score; o.flags = ol.flags;
         o.hand_type = (ol.misc & 0xff) - 1; o.terminated = (ol.misc & 0x100) != 0; o.error = ol.misc >> 16;
-        c_handb = ol.handb; c_prf = ol.prf;
+        c_handb = ol.handb; c_prf = ol.prf; c_selm = ol.selm;
         blocked = false;
         fin = true;
       }
@@ -607,10 +608,10 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
         if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
 #ifdef BG_DECK_PRELOAD // development: measured -4 % (16 registers held across the whole loop cost more than the round trip)
         if (o.terminated) { // SAME_STEP auto-reset
-          bg_env_reset(d, env, e, dk, nd_ok ? nd : (const uint4*)nullptr); n_eps++; c_handb = ~0ull; c_prf = 0.0f;
+          bg_env_reset(d, env, e, dk, nd_ok ? nd : (const uint4*)nullptr); n_eps++; c_handb = ~0ull; c_prf = 0.0f; c_selm = 0u;
         }
 #else
-        if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; c_handb = ~0ull; c_prf = 0.0f; } // SAME_STEP auto-reset: empty hand, no chips
+        if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; c_handb = ~0ull; c_prf = 0.0f; c_selm = 0u; } // SAME_STEP auto-reset: empty hand, no chips
 #endif
         // a reset zeroes the env's play counts (and re-applies its card states) in HBM, which a service wave touches a few
         // steps later: let those stores land first.  What is still in flight here is the record write-out of the iteration
@@ -638,10 +639,10 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
         q_m2 = __builtin_readcyclecounter();
 #endif
 #ifdef BG_V3_DIRECT // development: 16 bytes per lane straight to 64 rows, no LDS staging
-        uint64_t h = bg_write_obs_impl<HASH, false>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u, true, c_prf, c_handb},
+        uint64_t h = bg_write_obs_impl<HASH, false>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u, true, c_prf, c_handb, c_selm},
                                                    RowStage{(lds_u4*)&s_stage[wave][0], (lds_u64*)&s_rowaddr[wave][0]});
 #else
-        uint64_t h = bg_write_obs_impl<HASH, true>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u, true, c_prf, c_handb},
+        uint64_t h = bg_write_obs_impl<HASH, true>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u, true, c_prf, c_handb, c_selm},
                                                   RowStage{(lds_u4*)&s_stage[wave][0], (lds_u64*)&s_rowaddr[wave][0]});
 #endif
 #ifdef BG_TIMING3
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
 #pragma unroll
             for (int k = 0; k < BG_NHOT; k++) s_state[k][l] = c[k];
             if (bsr.valid) { s_shop[0][l] = bsr.c3; s_shop[1][l] = bsr.c4; s_shop[2][l] = bsr.c5; s_shop[3][l] = bsr.c6; }
-            s_out[l].handb = bg_obs_handb(d, benv, be, bdk); s_out[l].prf = bg_obs_prf(be);
+            s_out[l].handb = bg_obs_handb(d, benv, be, bdk); s_out[l].prf = bg_obs_prf(be); s_out[l].selm = bg_obs_selm(be);
             const uint32_t misc = bg_lds_load((uint32_t*)&s_out[l].misc) | (bsr.valid ? 0x200u : 0u);
             bg_wait_vm();
             bg_lds_store((uint32_t*)&s_out[l].misc, misc | 0x400u);
@@ -775,7 +776,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
             if (bsr.valid) { s_shop[0][l] = bsr.c3; s_shop[1][l] = bsr.c4; s_shop[2][l] = bsr.c5; s_shop[3][l] = bsr.c6; }
             const int32_t misc = (bo.hand_type + 1) | (bo.terminated ? 0x100 : 0) | (bsr.valid ? 0x200 : 0) | (bo.error << 16);
             s_out[l].reward = bo.reward; s_out[l].final_score = bo.final_score; s_out[l].flags = bo.flags & ~BG_FLAG_DEFER_ADV;
-            s_out[l].handb = bg_obs_handb(d, benv, be, bdk); s_out[l].prf = bg_obs_prf(be);
+            s_out[l].handb = bg_obs_handb(d, benv, be, bdk); s_out[l].prf = bg_obs_prf(be); s_out[l].selm = bg_obs_selm(be);
             bg_wait_vm(); // shop inventory / play counts / card states written to HBM are read by the OTHER service wave later
             if (bo.flags & BG_FLAG_DEFER_ADV) { // hand the env on to the other queue; DONE is set by whoever runs the second half
               bg_lds_store((uint32_t*)&s_out[l].misc, (uint32_t)misc);

@@ -1214,7 +1214,7 @@ struct ObsPtrs {
   uint8_t* rows;        // non-null: one BG_ROW_BYTES record per (step, env) instead of the per-key arrays
   uint32_t row_stride;  // bytes between consecutive records (multiple of 16)
 };
-struct RowExtra { double reward; int32_t action; uint32_t terminated; bool cached = false; float prf = 0.0f; uint64_t handb = 0; };
+struct RowExtra { double reward; int32_t action; uint32_t terminated; bool cached = false; float prf = 0.0f; uint64_t handb = 0; uint32_t selm = 0; };
 // The two observation values that only change in the heavy actions (so the service-wave kernel lets the service lane compute
 // them and the env lane carry them): the hand as card codes (8 LDS byte reads) and progress_ratio (a float64 division).
 template <class DK>
@@ -1227,6 +1227,12 @@ __device__ __forceinline__ uint64_t bg_obs_handb(const BgDev& d, int env, const 
     handb |= (uint64_t)(v & 0xff) << (8 * i);
   }
   return handb;
+}
+__device__ __forceinline__ uint32_t bg_obs_selm(const Env& e) { // bit p = hand position p is selected
+  uint32_t selm = 0;
+#pragma unroll 1
+  for (int i = 0; i < e.nsel; i++) selm |= 1u << bg_get8(e.sel, i);
+  return selm;
 }
 __device__ __forceinline__ float bg_obs_prf(const Env& e) { // :1497 min(2, round_chips / max(1, chips_needed)) as float32
   int64_t need1 = e.chips_needed > 1 ? e.chips_needed : 1;
@@ -1264,9 +1270,7 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
   // ---- values
   const uint64_t handb = rx.cached ? rx.handb : bg_obs_handb(d, env, e, dk);
   BG_MIX(handb);
-  uint32_t selm = 0;
-#pragma unroll 1
-  for (int i = 0; i < e.nsel; i++) selm |= 1u << bg_get8(e.sel, i);
+  const uint32_t selm = rx.cached ? rx.selm : bg_obs_selm(e);
   BG_MIX(selm | ((uint64_t)e.face_down << 8) | ((uint64_t)e.nhand << 16));
   BG_MIX(e.chips_scored); BG_MIX(e.round_chips);
   int64_t need1 = e.chips_needed > 1 ? e.chips_needed : 1;
@@ -1276,12 +1280,15 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
   BG_MIX((uint64_t)e.ante | ((uint64_t)e.round << 8) | ((uint64_t)e.hands_left << 16) | ((uint64_t)e.discards_left << 24) |
          ((uint64_t)e.njokers << 32) | ((uint64_t)e.ncons << 40) | ((uint64_t)e.phase << 48));
   BG_MIX(e.jokers);
-  uint32_t jq[5];
-#pragma unroll
-  for (int i = 0; i < 5; i++) {
-    uint32_t a = (2 * i < e.njokers) ? (uint32_t)bg_get8(e.jokers, 2 * i) : 0u;
-    uint32_t b = (2 * i + 1 < e.njokers && 2 * i + 1 < 8) ? (uint32_t)bg_get8(e.jokers, (2 * i + 1) & 7) : 0u;
-    jq[i] = a | (b << 16);
+  uint32_t jq[5]; // joker_ids int16[10]: byte i of e.jokers -> halfword i (ids beyond njokers read as 0)
+  {
+    const uint64_t jm = e.jokers & (e.njokers >= 8 ? ~0ull : ((1ull << (8 * e.njokers)) - 1ull));
+    const uint32_t jl = (uint32_t)jm, jh = (uint32_t)(jm >> 32);
+    jq[0] = (jl & 0xffu) | ((jl & 0xff00u) << 8);
+    jq[1] = ((jl >> 16) & 0xffu) | ((jl >> 24) << 16);
+    jq[2] = (jh & 0xffu) | ((jh & 0xff00u) << 8);
+    jq[3] = ((jh >> 16) & 0xffu) | ((jh >> 24) << 16);
+    jq[4] = 0u;
   }
   BG_MIX(e.cons0 | (e.cons1 << 8) | ((uint32_t)e.ndrop << 16) | ((uint32_t)e.nfo << 24));
   const uint32_t cq = (uint32_t)((e.ncons > 0 && !(e.cons0 & 0x80u)) ? e.cons0 : 0) | ((uint32_t)((e.ncons > 1 && !(e.cons1 & 0x80u)) ? e.cons1 : 0) << 16); // enum-form names map to 0 (:1570)
@@ -1301,18 +1308,14 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
 #pragma unroll
   for (int i = 0; i < 5; i++) { BG_MIX(((uint64_t)it[i] << 32) | co[i]); }
   BG_MIX(e.shop_reroll_state);
-  uint32_t lv[3];
+  uint32_t lv[3]; // hand_levels int8[12]: nibble ht of (levels, excess) -> byte ht of their sum (<= 30: no carry between bytes)
 #pragma unroll
   for (int w = 0; w < 3; w++) {
-    uint32_t x = 0;
-#pragma unroll
-    for (int b = 0; b < 4; b++) {
-      int ht = w * 4 + b;
-      uint32_t l = (uint32_t)((e.levels >> (4 * ht)) & 0xf) + (uint32_t)((e.excess >> (4 * ht)) & 0xf);
-      x |= (l & 0xffu) << (8 * b);
-    }
-    lv[w] = x;
-    BG_MIX(x);
+    uint32_t a = (uint32_t)(e.levels >> (16 * w)) & 0xffffu, b = (uint32_t)(e.excess >> (16 * w)) & 0xffffu;
+    a = (a | (a << 8)) & 0x00ff00ffu; a = (a | (a << 4)) & 0x0f0f0f0fu;
+    b = (b | (b << 8)) & 0x00ff00ffu; b = (b | (b << 4)) & 0x0f0f0f0fu;
+    lv[w] = a + b;
+    BG_MIX(lv[w]);
   }
   BG_MIX(mask);
   uint32_t mq[15];
