@@ -352,9 +352,10 @@ struct RngWin {
   int g_blk, g_start, g_len; // window over the global stream: block, first index, words
   int s_start, s_len;        // window over the current shop stream
   bool defer_adv;            // a winning play leaves _advance_round (and the shop it generates) to a second work item
+  bool need_inv;             // a shop inventory is due: generated ONCE at the end of the dispatch, whichever action asked for it
 };
 __device__ __forceinline__ void bg_win_init(RngWin& w, uint32_t* lds_lane, const JTables* jt = nullptr) {
-  w.jt = (lds_JTables*)jt; w.lds = (lds_u32*)lds_lane; w.g_blk = -1; w.g_start = 0; w.g_len = 0; w.s_start = 0; w.s_len = 0; w.defer_adv = false;
+  w.jt = (lds_JTables*)jt; w.lds = (lds_u32*)lds_lane; w.g_blk = -1; w.g_start = 0; w.g_len = 0; w.s_start = 0; w.s_len = 0; w.defer_adv = false; w.need_inv = false;
 }
 __device__ __noinline__ void bg_win_fill(lds_u32* lds, const uint32_t* src, int len) {
 #pragma unroll 1

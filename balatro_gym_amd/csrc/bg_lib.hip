@@ -758,6 +758,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
           if (a == BG_ACT_ADVANCE) {
             // second half of a won play: _advance_round (+ the shop it generates); s_out already holds the play's result
             bg_advance_round<CARDS>(d, benv, be, w, bsr);
+            if (w.need_inv) { bg_shop_inventory(d, benv, be, w, bsr); w.need_inv = false; }
             bg_pack(be, c);
 #pragma unroll
             for (int k = 0; k < BG_NHOT; k++) s_state[k][l] = c[k];

@@ -241,7 +241,8 @@ __device__ __forceinline__ void bg_generate_shop(const BgDev& d, int env, Env& e
   e.bflags = (e.bflags & ~BG_BF_SHOP_OVF) | BG_BF_SHOP_EXISTS;
   e.shop_ante = e.ante;
   e.shop_reroll_base = 50;
-  bg_shop_inventory(d, env, e, w, sr);
+  w.need_inv = true; // Shop.__init__ -> _generate_inventory (shop.py:101): run by bg_env_dispatch, one code site for a wave whose
+                     // lanes reach it from a won play, a skipped blind and a reroll
   e.shop_reroll_state = (int32_t)(50.0 * bg_shop_cost_mult(e, w.jt));
 }
 
@@ -850,7 +851,7 @@ __device__ __forceinline__ void bg_step_shop(const BgDev& d, int env, Env& e, Rn
     if (e.money < cost) { o.reward = -1.0; o.error = 6; return; }
     e.money -= cost;
     e.shop_reroll_base = (int32_t)((double)e.shop_reroll_base * 1.35);
-    bg_shop_inventory(d, env, e, w, sr);
+    w.need_inv = true;
     o.reward = 0.0;
     return;
   }
@@ -1180,6 +1181,7 @@ __device__ __forceinline__ void bg_env_dispatch(const BgDev& d, int env, Env& e,
     else bg_use_consumable(d, env, e, w, dk, action - 10, o); // 10..14
   } else if (e.phase == 1) bg_step_shop(d, env, e, w, sr, action, o);
   else if (e.phase == 2) bg_step_blind<DK::kCards>(d, env, e, w, sr, action, o);
+  if (w.need_inv) { bg_shop_inventory(d, env, e, w, sr); w.need_inv = false; }
 }
 
 // the guards in front of the dispatch (balatro_env_2.py:619-627); returns true when the action must be dispatched
