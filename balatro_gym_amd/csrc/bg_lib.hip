@@ -1402,8 +1402,9 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   // workgroup) over more work: 128 -> 256 -> 372 fused steps measured +6 % / +9 % at 65 536 envs.  Per env they cost 2.5 KB
   // per global / shop slot and 64 B per deck: ~1 MB (372 fused steps; 64 GB of the 288 at 65 536 envs), ~198 KB (64),
   // ~105 KB (32) or ~60 KB (16).  Ring positions are bytes, so 250 is the deepest ring.
-  const int dg = n_envs <= 65536 ? 137 : (n_envs <= 262144 ? 25 : (n_envs <= 1048576 ? 13 : 8));
-  const int dsd = n_envs <= 65536 ? 248 : (n_envs <= 262144 ? 48 : (n_envs <= 1048576 ? 24 : 12));
+  // (0.66 MB per env at full depth since the shop-stream slots are compact: 43 GB at 65 536 envs, 86 GB at 131 072)
+  const int dg = n_envs <= 131072 ? 137 : (n_envs <= 262144 ? 73 : (n_envs <= 1048576 ? 13 : 8));
+  const int dsd = n_envs <= 131072 ? 248 : (n_envs <= 262144 ? 124 : (n_envs <= 1048576 ? 24 : 12));
   d.KG = kg ? atoi(kg) : dg; d.KS = ks ? atoi(ks) : dsd + 1; d.KD = kd ? atoi(kd) : dsd;
   if (d.KG < 2 || d.KS < 2 || d.KD < 1 || d.KG > 250 || d.KS > 250 || d.KD > 250) { delete h; g_create_err = "bg_create: bad ring depths"; return BG_E_ARG; }
   size_t N = (size_t)n_envs;
