@@ -290,6 +290,16 @@ __device__ __forceinline__ int bg_card(const BgDev& d, int env, const Deck0& k, 
   const uint8_t* p = (const uint8_t*)&d.deck[(size_t)(idx >> 4) * d.N + env];
   return p[idx & 15];
 }
+// workgroup decks with the row stride as a parameter (bg_rollout3_kernel: 128 or 256 envs per workgroup)
+template <int S, bool C> struct DeckLdsS { lds_u32* col; static constexpr bool kCards = C; };
+template <int S, bool C>
+__device__ __forceinline__ void bg_deck_set(DeckLdsS<S, C>& dk, int k, uint4 c) {
+  dk.col[(4 * k) * S] = c.x; dk.col[(4 * k + 1) * S] = c.y; dk.col[(4 * k + 2) * S] = c.z; dk.col[(4 * k + 3) * S] = c.w;
+}
+template <int S, bool C>
+__device__ __forceinline__ int bg_card(const BgDev& d, int env, const DeckLdsS<S, C>& k, int idx) {
+  return (int)((const lds_u8*)k.col)[(idx >> 2) * (S * 4) + (idx & 3)];
+}
 __device__ __forceinline__ int bg_card(const BgDev& d, int env, const DeckLds& k, int idx) {
   return (int)((const lds_u8*)k.col)[(idx >> 2) * (BG_RB * 4) + (idx & 3)];
 }

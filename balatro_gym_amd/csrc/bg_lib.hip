@@ -430,30 +430,33 @@ __device__ __forceinline__ void bg_lds_store(uint32_t* p, uint32_t v) {
 }
 __device__ __forceinline__ void bg_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } // this wave's global stores have landed
 
-template <bool HASH, bool CARDS>
-__global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
+// EW = env waves per workgroup (2: 128 envs, two workgroups per CU; 4: 256 envs, ONE workgroup per CU whose two play waves and
+// two other waves share the queues of all 256 envs) -- as many service waves as env waves, half of them per class
+template <bool HASH, bool CARDS, int EW>
+__global__ __launch_bounds__(2 * EW * BG_BLOCK, 2) void bg_rollout3_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
                                                                    uint64_t env_index0, uint64_t t0, ObsPtrs obs,
                                                                    int obs_stride_steps, double* reward, uint8_t* term,
                                                                    int32_t* actions_out, bg_rollout_stats* stats,
                                                                    uint32_t th_play, uint32_t th_other, uint32_t th_ready, uint32_t role_mode) {
-  static_assert(BG_RB == 2 * BG_BLOCK, "two env waves + two service waves per workgroup");
-  __shared__ uint4 s_state[BG_NHOT][BG_RB];
-  __shared__ uint4 s_shop[4][BG_RB];
-  __shared__ OutLds s_out[BG_RB];
-  __shared__ uint32_t s_items[2][BG_RB];   // rings: 0 = PLAY_HAND, 1 = every other deferred action
+  static_assert(EW == 2 || EW == 4, "2 or 4 env waves per workgroup");
+  constexpr int NE = EW * BG_BLOCK;        // envs per workgroup
+  __shared__ uint4 s_state[BG_NHOT][NE];
+  __shared__ uint4 s_shop[4][NE];
+  __shared__ OutLds s_out[NE];
+  __shared__ uint32_t s_items[2][NE];      // rings: 0 = PLAY_HAND, 1 = every other deferred action
   __shared__ uint32_t s_tail[2];           // items ever queued per class (env lanes, atomic)
   __shared__ uint32_t s_head[2];           // items ever taken per class (service waves; atomic when they help each other)
-  __shared__ uint32_t s_ready[2];          // runnable lanes of each env wave (starvation hint for the service waves)
+  __shared__ uint32_t s_ready[EW];         // runnable lanes of each env wave (starvation hint for the service waves)
   __shared__ uint32_t s_done;              // env waves that have finished
-  __shared__ uint32_t s_prod[BG_RB];
-  __shared__ uint32_t s_deck[16][BG_RB];
-  __shared__ uint32_t win[2][BG_WIN][BG_BLOCK];                 // RNG windows of the two service waves
-  __shared__ bg_u32x4 s_stage[2][BG_BLOCK * BG_STAGE_NP];       // record staging of the two env waves
-  __shared__ unsigned long long s_rowaddr[2][BG_BLOCK];
+  __shared__ uint32_t s_prod[NE];
+  __shared__ uint32_t s_deck[16][NE];
+  __shared__ uint32_t win[EW][BG_WIN][BG_BLOCK];                // RNG windows of the service waves
+  __shared__ bg_u32x4 s_stage[EW][BG_BLOCK * BG_STAGE_NP];      // record staging of the env waves
+  __shared__ unsigned long long s_rowaddr[EW][BG_BLOCK];
   __shared__ JTables jt;
 #ifdef BG_TIMING3
-  __shared__ unsigned long long s_prof[2][2];
-  if (threadIdx.x < 4) s_prof[threadIdx.x >> 1][threadIdx.x & 1] = 0;
+  __shared__ unsigned long long s_prof[EW][2];
+  if (threadIdx.x < 2 * EW) s_prof[threadIdx.x >> 1][threadIdx.x & 1] = 0;
 #endif
   __builtin_amdgcn_s_setprio(3);
   bg_tables_init(&jt);
@@ -463,7 +466,8 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
   // mostly-waiting service waves on SIMD 2 and 3.  role_mode != 0 swaps the roles in every other workgroup: each SIMD
   // then carries one env wave and one service wave.  (1: odd blockIdx, 2: second half of the grid, 3: hardware wave slot)
   bool swap_roles = false;
-  if ((role_mode & 0xffu) == 1u) swap_roles = (blockIdx.x & 1u) != 0u;
+  if (EW != 2) { /* one workgroup per CU: nothing to alternate */ }
+  else if ((role_mode & 0xffu) == 1u) swap_roles = (blockIdx.x & 1u) != 0u;
   else if ((role_mode & 0xffu) == 2u) swap_roles = blockIdx.x >= (gridDim.x + 1u) / 2u;
   else if ((role_mode & 0xffu) == 3u) {
     __shared__ uint32_t s_slot;
@@ -472,13 +476,14 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
     swap_roles = s_slot != 0u;
   }
   const int wave = (tid >> 6) ^ (swap_roles ? 2 : 0);
-  const int local = ((wave & 1) << 6) | (tid & 63); // env lane index (env waves) -- service lanes use `lane`
-  const int env = blockIdx.x * BG_RB + local;
-  const bool is_env = wave < 2;
+  const int local = ((wave & (EW - 1)) << 6) | (tid & 63); // env lane index (env waves) -- service lanes use `lane`
+  const int env = blockIdx.x * NE + local;
+  const bool is_env = wave < EW;
   const bool live = is_env && env < d.N;
-  using DeckT = typename std::conditional<CARDS, DeckLdsC, DeckLds>::type;
+  using DeckT = DeckLdsS<NE, CARDS>;
   if (is_env) s_prod[local] = (live && d.prod_view) ? d.prod_view[env] : 0u;
-  if (tid < 2) { s_tail[tid] = 0; s_head[tid] = 0; s_ready[tid] = BG_BLOCK; }
+  if (tid < 2) { s_tail[tid] = 0; s_head[tid] = 0; }
+  if (tid < EW) s_ready[tid] = BG_BLOCK;
   if (tid == 0) s_done = 0;
   if (is_env) {
     s_items[0][local] = 0; s_items[1][local] = 0;
@@ -574,7 +579,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
           for (int k = 0; k < BG_NHOT; k++) s_state[k][local] = c[k];
           bg_lds_store((uint32_t*)&s_out[local].misc, 0u); // not processed yet
           const uint32_t slot = __hip_atomic_fetch_add(&s_tail[cls], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          bg_lds_store(&s_items[cls][slot & (BG_RB - 1)], (uint32_t)local | ((uint32_t)action << 16) | BG_ITEM_VALID);
+          bg_lds_store(&s_items[cls][slot & (NE - 1)], (uint32_t)local | ((uint32_t)action << 16) | BG_ITEM_VALID);
           blocked = true;
         } else fin = true;
       }
@@ -697,7 +702,8 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
     }
   } else {
     // =========================================== service waves: phase B ===========================================
-    const int own = wave - 2;
+    const int own = (wave - EW) & 1;     // class this wave serves first
+    const int wslot = wave - EW;          // its RNG window
     const int lane = tid & (BG_BLOCK - 1);
     const uint32_t th = own == 0 ? th_play : th_other;
     const bool help = (role_mode & 0x100u) != 0u; // an idle service wave also takes the other wave's queue
@@ -711,7 +717,9 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
       int cls = own;
       uint32_t head = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_head[cls]));
       uint32_t n = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_tail[cls])) - head;
-      const uint32_t ready = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_ready[0]) + bg_lds_load(&s_ready[1]));
+      uint32_t ready = 0;
+#pragma unroll
+      for (int q = 0; q < EW; q++) ready += __builtin_amdgcn_readfirstlane(bg_lds_load(&s_ready[q]));
       if (n != 0u && n < th && ready >= th_ready) n = 0u; // batching thresholds (1 / 1 / 255 by default: never)
       if (n == 0u && help) {
         cls = own ^ 1;
@@ -719,7 +727,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
         n = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_tail[cls])) - head;
       }
       if (n == 0u) {
-        if (__builtin_amdgcn_readfirstlane(bg_lds_load(&s_done)) >= 2u) break; // both env waves are through: every item was served
+        if (__builtin_amdgcn_readfirstlane(bg_lds_load(&s_done)) >= (uint32_t)EW) break; // all env waves are through: every item was served
         __builtin_amdgcn_s_sleep(16);
         if (++polls > BG_SPIN_LIMIT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
         continue;
@@ -736,14 +744,14 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
       const unsigned long long q_b0 = __builtin_readcyclecounter();
 #endif
       if ((uint32_t)lane < nb) {
-        uint32_t* slotp = &s_items[cls][(head + (uint32_t)lane) & (BG_RB - 1)];
+        uint32_t* slotp = &s_items[cls][(head + (uint32_t)lane) & (NE - 1)];
         uint32_t item = bg_lds_load(slotp);
         uint32_t spin = 0;
         while (!(item & BG_ITEM_VALID) && ++spin < BG_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); item = bg_lds_load(slotp); }
         bg_lds_store(slotp, 0u);
         if (item & BG_ITEM_VALID) {
           const int l = (int)(item & 0xffffu), a = (int)((item >> 16) & 0x7fffu);
-          const int benv = blockIdx.x * BG_RB + l;
+          const int benv = blockIdx.x * NE + l;
           uint4 c[BG_NHOT];
 #pragma unroll
           for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][l];
@@ -753,7 +761,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
           DeckT bdk; bdk.col = (lds_u32*)&s_deck[0][l];
           ShopRegs bsr; bsr.valid = false;
           RngWin w;
-          bg_win_init(w, &win[own][0][lane], &jt);
+          bg_win_init(w, &win[wslot][0][lane], &jt);
           w.defer_adv = defer_adv;
           if (a == BG_ACT_ADVANCE) {
             // second half of a won play: _advance_round (+ the shop it generates); s_out already holds the play's result
@@ -782,7 +790,7 @@ __global__ __launch_bounds__(2 * BG_RB, 2) void bg_rollout3_kernel(BgDev d, int 
             if (bo.flags & BG_FLAG_DEFER_ADV) { // hand the env on to the other queue; DONE is set by whoever runs the second half
               bg_lds_store((uint32_t*)&s_out[l].misc, (uint32_t)misc);
               const uint32_t slot2 = __hip_atomic_fetch_add(&s_tail[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              bg_lds_store(&s_items[1][slot2 & (BG_RB - 1)], (uint32_t)l | ((uint32_t)BG_ACT_ADVANCE << 16) | BG_ITEM_VALID);
+              bg_lds_store(&s_items[1][slot2 & (NE - 1)], (uint32_t)l | ((uint32_t)BG_ACT_ADVANCE << 16) | BG_ITEM_VALID);
             } else bg_lds_store((uint32_t*)&s_out[l].misc, (uint32_t)misc | 0x400u);
           }
         } else atomicOr(d.err, BG_DEVERR_SPIN);
@@ -1716,7 +1724,16 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
                                           ((getenv("BG_HELP") ? atoi(getenv("BG_HELP")) : 0) ? 0x100u : 0u) |
                                           ((getenv("BG_DEFER_ADV") ? atoi(getenv("BG_DEFER_ADV")) : 0) ? 0x200u : 0u) |
                                           (((uint32_t)(getenv("BG_TH_ENV") ? atoi(getenv("BG_TH_ENV")) : 0) & 0xffu) << 16);
-#define BG_LAUNCH_R2(HASHV, CARDSV) do { if (v3) hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV>), g2, dim3(2 * BG_RB), 0, st, dv, chunk, pol, policy_seed, \
+        // envs per v3 workgroup.  256 (one workgroup per CU: its two play waves and two other waves pool the queues of 256 envs,
+        // so a queued action waits half as long for a free wave) makes the kernel 5-7 % faster than 128 (two workgroups per CU)
+        // once the env count fills every CU that way; it also ends more evenly, which leaves the refill less of a tail to hide in
+        // (whole-job rate -2 %).  Smaller jobs keep 128 so that they spread over twice as many CUs.
+        static const int wg_override = getenv("BG_WG_ENVS") ? atoi(getenv("BG_WG_ENVS")) : 0;
+        const int wg_envs = wg_override ? wg_override : (h->dev.N >= 65536 ? 256 : 128);
+        dim3 g4((h->dev.N + 4 * BG_BLOCK - 1) / (4 * BG_BLOCK));
+#define BG_LAUNCH_R2(HASHV, CARDSV) do { if (v3 && wg_envs == 256) hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV, 4>), g4, dim3(8 * BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, \
+                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr, role_mode); \
+  else if (v3) hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV, 2>), g2, dim3(2 * BG_RB), 0, st, dv, chunk, pol, policy_seed, \
                                                    env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr, role_mode); \
   else hipLaunchKernelGGL((bg_rollout2_kernel<HASHV, CARDSV>), g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, \
                                                    env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr); } while (0)

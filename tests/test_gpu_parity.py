@@ -426,6 +426,15 @@ def test_barrier_rollout_kernel(monkeypatch):
     test_consumables_rollout_vs_oracle(True)
 
 
+def test_wide_workgroup_rollout_kernel(monkeypatch):
+    """The service-wave kernel with 256 envs per workgroup (the default from 65 536 envs on: four env waves, two play waves and
+    two other waves that share the queues) at a small env count, incl. a last workgroup that is not full: same bits."""
+    monkeypatch.setenv("BG_WG_ENVS", "256")
+    test_fused_rollout_vs_oracle(2, True)
+    test_consumables_rollout_vs_oracle(True)
+    test_immolate_cryptid_rollout_vs_oracle()
+
+
 def test_rollout_properties_full_size():
     """Size-independent properties at BASELINE.json's N = 65 536: determinism, chunking invariance (one T=48 call ==
     48 T=1 calls), sharding invariance (two half-size handles with env_index0 offsets == one full handle)."""
