@@ -36,7 +36,7 @@ IMPLEMENTED = [1, 136, 27, 38, 61, 16, 34, 108, 23, 22, 53, 97, 50, 2, 3, 4, 5, 
                131, 132, 133, 134, 135, 48, 128, 122, 72, 140, 31, 39, 40, 41, 101, 124, 26, 33, 104, 147, 118, 119,
                116, 117]
 POLICY_CYCLE3 = 2
-TRAFFIC_FILE = {"rows": "r01_v20_hbm_traffic.json", "keys": None}  # PMC result of the default layout (none measured for per-key arrays at v20)
+TRAFFIC_FILE = {"rows": "r01_v21_hbm_traffic.json", "keys": None}  # PMC result of the default layout (none measured for per-key arrays at v21)
 POLICY_SEED = 20251001
 MAX_ANTE = 4
 
