@@ -1728,7 +1728,7 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
         // so a queued action waits half as long for a free wave) makes the kernel 5-7 % faster than 128 (two workgroups per CU)
         // once the env count fills every CU that way; it also ends more evenly, which leaves the refill less of a tail to hide in
         // (whole-job rate -2 %).  Smaller jobs keep 128 so that they spread over twice as many CUs.
-        static const int wg_override = getenv("BG_WG_ENVS") ? atoi(getenv("BG_WG_ENVS")) : 0;
+        const int wg_override = getenv("BG_WG_ENVS") ? atoi(getenv("BG_WG_ENVS")) : 0; // read per launch (tests switch it)
         const int wg_envs = wg_override ? wg_override : (h->dev.N >= 65536 ? 256 : 128);
         dim3 g4((h->dev.N + 4 * BG_BLOCK - 1) / (4 * BG_BLOCK));
 #define BG_LAUNCH_R2(HASHV, CARDSV) do { if (v3 && wg_envs == 256) hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV, 4>), g4, dim3(8 * BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, \
