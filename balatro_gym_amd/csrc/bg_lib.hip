@@ -479,6 +479,9 @@ __global__ __launch_bounds__(2 * EW * BG_BLOCK, 2) void bg_rollout3_kernel(BgDev
   const int local = ((wave & (EW - 1)) << 6) | (tid & 63); // env lane index (env waves) -- service lanes use `lane`
   const int env = blockIdx.x * NE + local;
   const bool is_env = wave < EW;
+#ifdef BG_PRIO_SERVICE // development: service waves issue ahead of the env wave they share a SIMD with
+  if (is_env) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
+#endif
   const bool live = is_env && env < d.N;
   using DeckT = DeckLdsS<NE, CARDS>;
   if (is_env) s_prod[local] = (live && d.prod_view) ? d.prod_view[env] : 0u;
