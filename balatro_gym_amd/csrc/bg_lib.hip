@@ -1119,7 +1119,9 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
 // 16-byte groups per lazy window of the deck stream: >= 37 words, a shuffle reads ~70 (two or three windows).  Sized so
 // that the kernel needs <= 168 VGPRs: its waves must fit on SIMDs that already hold a rollout wave (~336 of the 512
 // registers) -- with a 256-register build the kernel only ran in the gaps between rollout launches (7x longer).
+#ifndef BG_DECK_G
 #define BG_DECK_G 10
+#endif
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
   __shared__ uint8_t sdeck[52][BG_BLOCK];
   __shared__ uint32_t rwin[4 * BG_DECK_G][BG_BLOCK], rold[4 * BG_DECK_G][BG_BLOCK];
