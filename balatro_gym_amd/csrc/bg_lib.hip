@@ -1285,7 +1285,8 @@ struct bg_handle {
   uint32_t thk_play, thk_other, thk_ready; // the same when the output is one array per key (lighter batching: less step drift)
   bool async_refill;     // BG_ASYNC_REFILL (default on): bg_rollout overlaps refill #i with rollout chunk i+1
   hipStream_t side, side2, side3; // side: overlapped refills; side2/3: the deck and block kernels of one refill run beside the shop kernel
-  hipEvent_t ev_scan, ev_deck, ev_gblk;
+  hipEvent_t ev_scan, ev_deck, ev_gblk, ev_gblk2;
+  hipStream_t side4;     // the global-block kernel of a refill when it runs beside the seed-ring kernel instead of behind it
   hipEvent_t ev_refill[2];
   hipEvent_t ev_rollout;
   std::vector<hipEvent_t> ev_rollout_t, ev_refill_t, ev_step_t; // start/stop pairs
@@ -1403,7 +1404,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
     }
     if (h->th_play < 1) h->th_play = 1; if (h->th_other < 1) h->th_other = 1; if (h->th_ready < 1) h->th_ready = 1;
   }
-  h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
+  h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = h->ev_gblk2 = nullptr; h->side4 = nullptr;
   h->ev_refill[0] = h->ev_refill[1] = nullptr; h->ev_rollout = nullptr;
   h->d_seeds = nullptr; h->d_mask = nullptr;
   memset(&h->dev, 0, sizeof(h->dev));
@@ -1451,6 +1452,8 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_scan, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_deck, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_gblk, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_gblk2, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side4, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_refill[0], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_refill[1], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_rollout, hipEventDisableTiming);
@@ -1479,6 +1482,8 @@ int bg_destroy(bg_handle* h) {
   if (h->ev_scan) (void)hipEventDestroy(h->ev_scan);
   if (h->ev_deck) (void)hipEventDestroy(h->ev_deck);
   if (h->ev_gblk) (void)hipEventDestroy(h->ev_gblk);
+  if (h->ev_gblk2) (void)hipEventDestroy(h->ev_gblk2);
+  if (h->side4) (void)hipStreamDestroy(h->side4);
   for (int i = 0; i < 2; i++) if (h->ev_refill[i]) (void)hipEventDestroy(h->ev_refill[i]);
   if (h->ev_rollout) (void)hipEventDestroy(h->ev_rollout);
   hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
@@ -1561,7 +1566,16 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   static const int gblk_first = getenv("BG_GBLK_FIRST") ? atoi(getenv("BG_GBLK_FIRST")) : 0;
   if (gblk_first && !(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
   if (!(skip & 4)) hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
-  if (!gblk_first && !(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
+  // development: the global blocks side by side with the seed ring on a stream of their own (BG_GBLK_OWN=1: no change measured)
+  static const int gblk_own = getenv("BG_GBLK_OWN") ? atoi(getenv("BG_GBLK_OWN")) : 0;
+  if (!gblk_first && !(skip & 8)) {
+    if (gblk_own) {
+      BG_HIP(hipStreamWaitEvent(h->side4, h->ev_scan, 0));
+      hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side4, d);
+      BG_HIP(hipEventRecord(h->ev_gblk2, h->side4));
+      BG_HIP(hipStreamWaitEvent(s, h->ev_gblk2, 0));
+    } else hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
+  }
   BG_HIP(hipEventRecord(h->ev_deck, h->side2));
   BG_HIP(hipEventRecord(h->ev_gblk, h->side3));
   BG_HIP(hipStreamWaitEvent(s, h->ev_deck, 0));
