@@ -101,6 +101,7 @@ struct Env {
   int32_t g_idx, s_idx, s_cur, s_cons, s_ready;
   int32_t ndrop, nfo; // cards.Card objects Immolate removed from the deck (52 - ndrop are left), copies Cryptid appended behind them
   uint64_t excess; // 12 x 4-bit (state.hand_levels - engine level): planets used at the level-15 cap
+  int32_t max_ante; // CurriculumBalatroEnv.current_max_ante of this env (train_balatro_agent.py:126-152), 0 = no cap; survives reset()
 };
 
 #define BG_BF_FIRST_HAND 1
@@ -135,6 +136,7 @@ __device__ __forceinline__ void bg_unpack(const uint4 c[BG_NHOT], Env& e) {
   e.g_idx = (int32_t)(c[7].x & 0xffffu); e.s_idx = (int32_t)(c[7].x >> 16);
   e.s_cur = bg_b(c[7].y, 0); e.s_cons = bg_b(c[7].y, 1); e.s_ready = 0; e.ndrop = bg_b(c[7].y, 2); e.nfo = bg_b(c[7].y, 3);
   e.excess = (uint64_t)c[7].z | ((uint64_t)(c[7].w & 0xffffu) << 32);
+  e.max_ante = (int32_t)(c[7].w >> 16) & 0xff;
 }
 
 __device__ __forceinline__ uint32_t bg_p4(int a, int b, int c, int d) {
@@ -156,7 +158,7 @@ __device__ __forceinline__ void bg_pack(const Env& e, uint4 c[BG_NHOT]) {
   c[6] = make_uint4((uint32_t)e.boss_cards, (uint32_t)(e.boss_cards >> 32), (uint32_t)e.levels,
                     ((uint32_t)(e.levels >> 32) & 0xffffu) | ((uint32_t)(e.g_cur & 0xff) << 16) | ((uint32_t)(e.g_cons & 0xff) << 24));
   c[7] = make_uint4(((uint32_t)e.g_idx & 0xffffu) | ((uint32_t)e.s_idx << 16), bg_p4(e.s_cur, e.s_cons, e.ndrop, e.nfo),
-                    (uint32_t)e.excess, (uint32_t)(e.excess >> 32) & 0xffffu);
+                    (uint32_t)e.excess, ((uint32_t)(e.excess >> 32) & 0xffffu) | ((uint32_t)(e.max_ante & 0xff) << 16));
 }
 
 // ring fill levels as this kernel may see them: producer counters of a COMPLETED refill minus own consumer counters

@@ -2,7 +2,7 @@
 //
 // Kernels (one lane = one env, env index fastest in every array => every wave access is one coalesced request):
 //   bg_step_kernel     one lockstep step() of all envs + observation / mask / reward / info
-//   bg_rollout_kernel  T fused steps with the counter-hash policy on device, state resident in registers
+//   bg_rollout3_kernel T fused steps with the counter-hash policy on device (env waves + dedicated service waves)
 //   bg_reset_kernel    masked reset() + observation
 //   bg_observe_kernel  observation only
 //   bg_seed_kernel     DeterministicRNG(seed): CPython init_by_array for streams 0, 2 and the per-env global stream
@@ -73,326 +73,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_step_kernel(BgDev d, const int32_
   bg_emit(d, env, (size_t)env, o, reward, term, trunc, info);
 }
 
-template <bool HASH>
-__global__ __launch_bounds__(BG_BLOCK) void bg_rollout_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
-                                                             uint64_t env_index0, uint64_t t0, ObsPtrs obs,
-                                                             int obs_stride_steps, double* reward, uint8_t* term,
-                                                             int32_t* actions_out, bg_rollout_stats* stats) {
-  int env = blockIdx.x * BG_BLOCK + threadIdx.x;
-  uint64_t n_steps = 0, n_eps = 0, n_plays = 0, rbits = 0, ohash = 0;
-  int64_t ssum = 0;
-  __shared__ uint32_t win[BG_WIN][BG_BLOCK];
-  __shared__ JTables jt;
-  bg_tables_init(&jt);
-  if (env < d.N) {
-    RngWin w;
-    bg_win_init(w, &win[0][threadIdx.x], &jt);
-    Env e;
-    bg_load_env(d, env, e);
-    Deck0 dk = bg_load_deck0(d, env);
-    ShopRegs sr; sr.valid = false;
-    uint64_t mask = bg_action_mask(d, env, e, sr);
-    for (int t = 0; t < T; t++) {
-      int action = bg_policy_action(e, mask, policy, policy_seed, env_index0 + (uint64_t)env, t0 + (uint64_t)t);
-      StepOut o;
-      bg_env_step(d, env, e, w, sr, dk, mask, action, o);
-      if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; } // SAME_STEP auto-reset
-      mask = bg_action_mask(d, env, e, sr);
-      size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
-      uint64_t h = bg_write_obs<HASH>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u});
-      if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
-      if (reward) reward[row] = o.reward;
-      if (term) term[row] = o.terminated ? 1 : 0;
-      if (actions_out) actions_out[row] = action;
-      n_steps++;
-      rbits ^= (uint64_t)__double_as_longlong(o.reward) * (2 * (uint64_t)(t0 + t) + 1);
-      if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
-    }
-    bg_store_env(d, env, e);
-  }
-  if (stats) {
-    // wave reduction (64 lanes) with DPP/shuffle intrinsics, then one atomic per wave
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      n_steps += __shfl_down(n_steps, off); n_eps += __shfl_down(n_eps, off); n_plays += __shfl_down(n_plays, off);
-      ssum += __shfl_down(ssum, off); rbits ^= __shfl_down(rbits, off); ohash ^= __shfl_down(ohash, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd((unsigned long long*)&stats->steps, (unsigned long long)n_steps);
-      atomicAdd((unsigned long long*)&stats->episodes, (unsigned long long)n_eps);
-      atomicAdd((unsigned long long*)&stats->plays, (unsigned long long)n_plays);
-      atomicAdd((unsigned long long*)&stats->score_sum, (unsigned long long)ssum);
-      atomicXor((unsigned long long*)&stats->reward_bits, (unsigned long long)rbits);
-      atomicXor((unsigned long long*)&stats->obs_hash, (unsigned long long)ohash);
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Fused rollout, block-compacted (the bench path).
-//
-// A step of the lane-per-env kernel above costs a wave the UNION of every branch some lane takes (a random policy
-// plays a hand on 8% of the steps, so practically every wave pays for the whole play path at ~13% lane utilisation),
-// and at 65 536 envs = 1 wave per SIMD nothing hides it.  Here a workgroup owns 256 envs and each step runs in three
-// phases separated by workgroup barriers:
-//   A  lane = env (4 waves): action mask, counter-hash policy, guards; the cheap, common actions (card-select toggles,
-//      shop end, small/big blind) are applied in registers; everything else (PLAY_HAND, DISCARD, boss blind, skip, shop
-//      buy/reroll/sell, consumables) is DEFERRED: the env's packed state goes to LDS and its index to an LDS work list
-//   B  lane = work item (dense): the deferred envs are stepped from / back to LDS by as few waves as needed
-//   C  lane = env: merge, curriculum cap, SAME_STEP auto-reset, observation / reward / terminated stores, statistics
-// State stays in registers (lane = env) across the T fused steps; LDS is only the exchange between the two lane maps.
-// ---------------------------------------------------------------------------------------------------------
-// Workgroup barrier that orders LDS only.  __syncthreads() also drains the wave's outstanding global stores
-// (s_waitcnt vmcnt(0)): right after phase C that exposes the whole record write-out (~90 KB per CU per iteration through
-// a ~16 B/clk store path).  No lane reads another wave's global stores inside the kernel except an env's own state, which
-// only ever passes through this CU's one vector-memory pipeline, in order; everything exchanged between waves is LDS.
-__device__ __forceinline__ void bg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags; uint64_t handb; float prf; uint32_t selm; }; // misc: hand_type+1 | terminated<<8 | has_shop<<9; handb / prf: bg_obs_handb / bg_obs_prf / bg_obs_selm of the state after the action (v3)
-
-#ifndef BG_RB_LB
-#define BG_RB_LB BG_RB // threads per workgroup the compiler plans registers for
-#endif
-#ifndef BG_RB_ATTR
-#define BG_RB_ATTR // development: e.g. -DBG_RB_ATTR='__attribute__((amdgpu_waves_per_eu(2,2)))'
-#endif
-#ifndef BG_RB_WAVES
-#define BG_RB_WAVES 1
-#endif
-template <bool HASH, bool CARDS>
-__global__ __launch_bounds__(BG_RB_LB, BG_RB_WAVES) BG_RB_ATTR void bg_rollout2_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
-                                                              uint64_t env_index0, uint64_t t0, ObsPtrs obs,
-                                                              int obs_stride_steps, double* reward, uint8_t* term,
-                                                              int32_t* actions_out, bg_rollout_stats* stats,
-                                                              uint32_t th_play, uint32_t th_other, uint32_t th_ready) {
-  __shared__ uint4 s_state[BG_NHOT][BG_RB];
-  __shared__ uint4 s_shop[4][BG_RB];
-  __shared__ OutLds s_out[BG_RB];
-  __shared__ uint32_t s_items[2][BG_RB]; // work queues: 0 = PLAY_HAND, 1 = every other deferred action
-  __shared__ uint32_t s_nitems[2];
-  __shared__ uint32_t s_nready;
-  __shared__ uint32_t s_more[2];
-  __shared__ uint32_t s_prod[BG_RB];
-  __shared__ uint32_t s_deck[16][BG_RB];        // every env's 52 card codes (Deck0::lds)
-  // one storage, two uses that never overlap in time (a workgroup barrier separates them): phase B's two RNG windows
-  // ([2][BG_WIN][64] words) and phase C's record staging (per wave 64 x BG_STAGE_NP pieces of 16 bytes, bg_write_obs_impl)
-  constexpr int kWinBytes = 2 * BG_WIN * BG_BLOCK * 4, kStageBytes = (BG_RB / BG_BLOCK) * BG_BLOCK * BG_STAGE_NP * 16;
-  __shared__ bg_u32x4 s_scratch[(kWinBytes > kStageBytes ? kWinBytes : kStageBytes) / 16];
-  uint32_t (*win)[BG_WIN][BG_BLOCK] = (uint32_t (*)[BG_WIN][BG_BLOCK])s_scratch;
-  bg_u32x4 (*s_stage)[BG_BLOCK * BG_STAGE_NP] = (bg_u32x4 (*)[BG_BLOCK * BG_STAGE_NP])s_scratch;
-  __shared__ unsigned long long s_rowaddr[BG_RB / BG_BLOCK][BG_BLOCK];
-  __shared__ JTables jt;
-  BG_PROBE_INIT();
-  // the refill kernels of the previous launch run beside this kernel and their (ALU-bound) waves land on the same SIMDs as
-  // the latency-critical one-wave phases here: let this kernel's waves issue first
-  __builtin_amdgcn_s_setprio(3);
-  bg_tables_init(&jt);
-  const int local = threadIdx.x;
-  const int env = blockIdx.x * BG_RB + local;
-  const bool live = env < d.N;
-  uint64_t n_steps = 0, n_eps = 0, n_plays = 0, rbits = 0, ohash = 0;
-  int64_t ssum = 0;
-  using DeckT = typename std::conditional<CARDS, DeckLdsC, DeckLds>::type;
-  Env e;
-  DeckT dk;
-  uint64_t mask = 0;
-  s_prod[local] = (live && d.prod_view) ? d.prod_view[env] : 0u;
-  if (local < 2) s_nitems[local] = 0;
-  if (local == 0) s_nready = 0;
-  if (local < 2) s_more[local] = 0;
-  uint32_t iter_no = 0;
-  dk.col = (lds_u32*)&s_deck[0][local];
-  if (live) {
-    bg_load_env(d, env, e);
-#pragma unroll
-    for (int k = 0; k < BG_NDECK; k++) bg_deck_set(dk, k, d.deck[(size_t)k * d.N + env]);
-    // s_shop[.][lane] always holds the shop of a lane that is in the shop phase (phase B keeps it current), so no lane
-    // carries the 16 shop registers through the kernel
-    ShopRegs sr; sr.valid = false;
-    mask = bg_action_mask(d, env, e, sr);
-    if (sr.valid) { s_shop[0][local] = sr.c3; s_shop[1][local] = sr.c4; s_shop[2][local] = sr.c5; s_shop[3][local] = sr.c6; }
-  }
-#ifdef BG_TIMING
-  unsigned long long tA = 0, tB = 0, tC = 0, tBitems = 0, tIter = 0, tRounds = 0;
-#define BG_TICK() __builtin_readcyclecounter()
-#endif
-  // Envs are independent, so the lanes of a workgroup need not sit on the same step: every lane carries its own step
-  // counter t.  An iteration lets every runnable lane take ONE step; lanes whose action needs the heavy code park their
-  // state in LDS and wait.  Phase B only runs once a queue holds enough items to fill its wave (or too few lanes are
-  // still runnable), so the ~40k-cycle latency of the play path is paid per ~60 plays instead of per ~20.
-  int t = 0;
-  bool blocked = false;
-  int action = 0;
-  StepOut o;
-  bg_step_init(o);
-  const PolicyLane pl = bg_policy_lane(policy, policy_seed, env_index0 + (uint64_t)env);
-  __syncthreads();
-  for (;;) {
-#ifdef BG_TIMING
-    unsigned long long c0 = BG_TICK();
-#endif
-    // ---------------- phase A: policy, guards, cheap actions inline, everything else queued
-    bool fin = false;
-    if (live && !blocked && t < T) {
-      BG_PROBE_BEGIN();
-      bg_step_init(o);
-      action = bg_policy_action(e, mask, policy, pl, t0 + (uint64_t)t);
-      BG_PROBE(20);
-      bool deferred = false;
-      if (bg_step_guards(e, mask, action, o)) {
-        if (e.phase == 0 && action >= 2 && action < 10) bg_toggle_select(e, action - 2);
-        else if (e.phase == 1 && action == 31) { e.phase = 0; bg_draw_cards(e); }              // shop end :1247-1251
-        else deferred = true;
-      }
-      if (deferred) {
-        const int cls = (e.phase == 0 && action == 0) ? 0 : 1;
-        uint32_t slot = atomicAdd(&s_nitems[cls], 1u);
-        s_items[cls][slot] = (uint32_t)local | ((uint32_t)action << 16);
-        uint4 c[BG_NHOT];
-        bg_pack(e, c);
-#pragma unroll
-        for (int k = 0; k < BG_NHOT; k++) s_state[k][local] = c[k];
-        s_out[local].misc = 0; // not processed yet
-        blocked = true;
-      } else fin = true;
-      BG_PROBE(21);
-    }
-    {
-      const bool runnable_next = live && !blocked && (t + (fin ? 1 : 0)) < T;
-      const unsigned long long bal = __ballot(runnable_next);
-      if ((local & 63) == 0 && bal) atomicAdd(&s_nready, (uint32_t)__popcll(bal));
-    }
-    bg_barrier_lds();
-#ifdef BG_TIMING
-    unsigned long long c1 = BG_TICK();
-#endif
-    const uint32_t nq0 = s_nitems[0], nq1 = s_nitems[1], nready = s_nready;
-    const bool run_b = (nq0 + nq1) > 0 && (nq0 >= th_play || nq1 >= th_other || nready < th_ready);
-    const uint32_t rem0 = run_b ? (nq0 > BG_BLOCK ? nq0 - BG_BLOCK : 0u) : nq0;
-    const uint32_t rem1 = run_b ? (nq1 > BG_BLOCK ? nq1 - BG_BLOCK : 0u) : nq1;
-    // ---------------- phase B: one batch of up to 64 items per queue; wave 0 takes the plays, wave 1 everything else,
-    // side by side (one code path: a wave only walks the branches its own class takes)
-    if (run_b) {
-      const int cls = local >> 6;
-      const int lane = local & (BG_BLOCK - 1);
-      const uint32_t nitems = cls == 0 ? nq0 : (cls == 1 ? nq1 : 0u);
-      const uint32_t nb = nitems > BG_BLOCK ? BG_BLOCK : nitems;
-      if (cls < 2 && (uint32_t)lane < nb) {
-        uint32_t item = s_items[cls][lane];
-        int l = (int)(item & 0xffffu), a = (int)(item >> 16);
-        int benv = blockIdx.x * BG_RB + l;
-        uint4 c[BG_NHOT];
-#pragma unroll
-        for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][l];
-        Env be;
-        bg_unpack(c, be);
-        bg_derive_ready(be, s_prod[l]);
-        DeckT bdk; bdk.col = (lds_u32*)&s_deck[0][l];
-        ShopRegs bsr; bsr.valid = false;
-        RngWin w;
-        bg_win_init(w, &win[cls][0][lane], &jt);
-        StepOut bo;
-        bg_step_init(bo);
-        bg_env_dispatch(d, benv, be, w, bsr, bdk, a, bo);
-        bg_pack(be, c);
-#pragma unroll
-        for (int k = 0; k < BG_NHOT; k++) s_state[k][l] = c[k];
-        if (bsr.valid) { s_shop[0][l] = bsr.c3; s_shop[1][l] = bsr.c4; s_shop[2][l] = bsr.c5; s_shop[3][l] = bsr.c6; }
-        OutLds ol;
-        ol.reward = bo.reward; ol.final_score = bo.final_score;
-        ol.misc = (bo.hand_type + 1) | (bo.terminated ? 0x100 : 0) | (bsr.valid ? 0x200 : 0) | 0x400 | (bo.error << 16);
-        ol.flags = bo.flags;
-        s_out[l] = ol;
-      }
-      // items beyond the batch move to the front of their queue (only this wave touches the queue during phase B)
-      if (cls < 2 && nitems > nb) {
-        for (uint32_t i = (uint32_t)lane; i < nitems - nb; i += BG_BLOCK) {
-          uint32_t v = s_items[cls][i + nb];
-          s_items[cls][i] = v;
-        }
-      }
-    }
-    if (run_b) __syncthreads(); else bg_barrier_lds();
-#ifdef BG_TIMING
-    unsigned long long c2 = BG_TICK();
-    if (run_b) { tBitems += (nq0 - rem0) + (nq1 - rem1); tRounds++; }
-    tIter++;
-#endif
-    if (local == 0) { s_nready = 0; s_nitems[0] = rem0; s_nitems[1] = rem1; }
-    const uint32_t par = iter_no & 1u;
-    // ---------------- phase C: finish the step of every lane that took one (inline in A, or just served by phase B)
-    BG_PROBE_BEGIN();
-    if (blocked && (s_out[local].misc & 0x400)) {
-      uint4 c[BG_NHOT];
-#pragma unroll
-      for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][local];
-      bg_unpack(c, e);
-      bg_derive_ready(e, s_prod[local]);
-      OutLds ol = s_out[local];
-      o.reward = ol.reward; o.final_score = ol.final_score; o.flags = ol.flags;
-      o.hand_type = (ol.misc & 0xff) - 1; o.terminated = (ol.misc & 0x100) != 0; o.error = ol.misc >> 16;
-      blocked = false;
-      fin = true;
-    }
-    BG_PROBE(16);
-    if (fin) {
-      if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
-      if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; } // SAME_STEP auto-reset
-      BG_PROBE(17);
-      ShopRegs sr; sr.valid = false;
-      if (e.phase == 1 && (e.bflags & BG_BF_SHOP_EXISTS)) {
-        sr.c3 = s_shop[0][local]; sr.c4 = s_shop[1][local]; sr.c5 = s_shop[2][local]; sr.c6 = s_shop[3][local]; sr.valid = true;
-      }
-      mask = bg_action_mask(d, env, e, sr);
-      BG_PROBE(18);
-      size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
-      uint64_t h = bg_write_obs_impl<HASH, true>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u},
-                                                RowStage{(lds_u4*)&s_stage[local >> 6][0], (lds_u64*)&s_rowaddr[local >> 6][0]});
-      BG_PROBE(19);
-      if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
-      if (reward) reward[row] = o.reward;
-      if (term) term[row] = o.terminated ? 1 : 0;
-      if (actions_out) actions_out[row] = action;
-      n_steps++;
-      rbits ^= (uint64_t)__double_as_longlong(o.reward) * (2 * (uint64_t)(t0 + t) + 1);
-      if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
-      t++;
-    }
-    // any lane with steps left?  (flag per iteration parity: written here, read after the barrier, cleared one iteration later)
-    if (__ballot(live && (blocked || t < T)) != 0ull && (local & 63) == 0) s_more[par] = 1u;
-    bg_barrier_lds();
-    const uint32_t more = s_more[par];
-    if (local == 0) s_more[par ^ 1u] = 0u;
-    iter_no++;
-#ifdef BG_TIMING
-    unsigned long long c3 = BG_TICK();
-    tA += c1 - c0; tB += c2 - c1; tC += c3 - c2;
-#endif
-    if (!more) break; // every lane has done its T steps
-  }
-#ifdef BG_TIMING
-  if (local == 0) { bg_probe_lds[0] = tA; bg_probe_lds[1] = tB; bg_probe_lds[2] = tC; bg_probe_lds[3] = tBitems; bg_probe_lds[4] = (unsigned long long)T; bg_probe_lds[15] = tIter | (tRounds << 32); }
-  BG_PROBE_FLUSH(d);
-  if (local == 0 && d.dbg) { atomicMax(&d.dbg[24], tIter); atomicMin(&d.dbg[25], ~tIter); atomicAdd(&d.dbg[26], 1ull); } // iterations per workgroup: max, ~min, count
-#endif
-  if (live) bg_store_env(d, env, e);
-  if (stats) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      n_steps += __shfl_down(n_steps, off); n_eps += __shfl_down(n_eps, off); n_plays += __shfl_down(n_plays, off);
-      ssum += __shfl_down(ssum, off); rbits ^= __shfl_down(rbits, off); ohash ^= __shfl_down(ohash, off);
-    }
-    if ((threadIdx.x & 63) == 0) {
-      atomicAdd((unsigned long long*)&stats->steps, (unsigned long long)n_steps);
-      atomicAdd((unsigned long long*)&stats->episodes, (unsigned long long)n_eps);
-      atomicAdd((unsigned long long*)&stats->plays, (unsigned long long)n_plays);
-      atomicAdd((unsigned long long*)&stats->score_sum, (unsigned long long)ssum);
-      atomicXor((unsigned long long*)&stats->reward_bits, (unsigned long long)rbits);
-      atomicXor((unsigned long long*)&stats->obs_hash, (unsigned long long)ohash);
-    }
-  }
-}
-
+struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags; uint64_t handb; float prf; uint32_t selm; }; // misc: hand_type+1 | terminated<<8 | has_shop<<9; handb / prf: bg_obs_handb / bg_obs_prf / bg_obs_selm of the state after the action
 
 // ---------------------------------------------------------------------------------------------------------
 // Fused rollout with DEDICATED SERVICE WAVES (BG_ROLLOUT_V=3).
@@ -613,7 +294,7 @@ __global__ __launch_bounds__(2 * EW * BG_BLOCK, 2) void bg_rollout3_kernel(BgDev
       unsigned long long q_m1 = q_m0, q_m2 = q_m0, q_m3 = q_m0;
 #endif
       if (fin) {
-        if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
+        if (e.max_ante > 0 && e.ante > e.max_ante) { o.terminated = true; o.flags |= 256; }
 #ifdef BG_DECK_PRELOAD // development: measured -4 % (16 registers held across the whole loop cost more than the round trip)
         if (o.terminated) { // SAME_STEP auto-reset
           bg_env_reset(d, env, e, dk, nd_ok ? nd : (const uint4*)nullptr); n_eps++; c_handb = ~0ull; c_prf = 0.0f; c_selm = 0u;
@@ -1010,6 +691,8 @@ __device__ void bg_mt_twist(const uint32_t* src, uint32_t* dst) {
   }
 }
 
+#include "bg_ops.h" // operator-level batch kernels (classify / score_hand / balatro_sim): need bg_mt_seed, bg_mt_twist
+
 // DeterministicRNG(seed) (balatro_env_2.py:84-106) for streams 0 ('deck_shuffle') and 2 ('shop_generation'), plus the
 // per-env global stream seeded G(seed).  Streams are seeded `(master + 1000 * i) % 2**32` (:105).
 __global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_t* __restrict__ seeds,
@@ -1263,6 +946,23 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_inject_kernel(BgDev d, const uint
   bg_store_env(d, env, e);
 }
 
+// harness injection of the live deck order (bg_inject_deck) and of the per-env curriculum cap (bg_set_max_ante)
+__global__ __launch_bounds__(BG_BLOCK) void bg_inject_deck_kernel(BgDev d, const uint4* __restrict__ decks, const uint8_t* __restrict__ mask_in) {
+  int env = blockIdx.x * BG_BLOCK + threadIdx.x;
+  if (env >= d.N) return;
+  if (mask_in && !mask_in[env]) return;
+#pragma unroll
+  for (int k = 0; k < BG_NDECK; k++) d.deck[(size_t)k * d.N + env] = decks[(size_t)env * BG_NDECK + k];
+}
+__global__ __launch_bounds__(BG_BLOCK) void bg_set_cap_kernel(BgDev d, const int32_t* __restrict__ caps, int scalar, const uint8_t* __restrict__ mask_in) {
+  int env = blockIdx.x * BG_BLOCK + threadIdx.x;
+  if (env >= d.N) return;
+  if (mask_in && !mask_in[env]) return;
+  uint32_t* w = ((uint32_t*)&d.hot[(size_t)7 * d.N + env]) + 3; // chunk 7, word 3: excess (low half) | cap << 16
+  const int cap = caps ? caps[env] : scalar;
+  *w = (*w & 0xffffu) | ((uint32_t)(cap & 0xff) << 16);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------
@@ -1277,12 +977,11 @@ struct bg_handle {
   std::string err;
   // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
   bool profiling;
-  int rollout_version; // 1 = lane-per-env kernel, 2 = block-compacted kernel (BG_ROLLOUT_V)
+  int rollout_version; // 3 = service-wave kernel (BG_ROLLOUT_V)
   // refill pipeline: double-buffered producer counters, a side stream and per-parity completion events
   uint32_t* d_prod[2];
   long refill_seq;       // refills launched so far; refill #i writes d_prod[i & 1]
-  uint32_t th_play, th_other, th_ready; // phase-B batching thresholds of bg_rollout2_kernel (BG_TH_PLAY / _OTHER / _READY)
-  uint32_t thk_play, thk_other, thk_ready; // the same when the output is one array per key (lighter batching: less step drift)
+  uint32_t th_play, th_other, th_ready; // service-wave batching thresholds (BG_TH_PLAY / _OTHER / _READY)
   bool async_refill;     // BG_ASYNC_REFILL (default on): bg_rollout overlaps refill #i with rollout chunk i+1
   hipStream_t side, side2, side3; // side: overlapped refills; side2/3: the deck and block kernels of one refill run beside the shop kernel
   hipEvent_t ev_scan, ev_deck, ev_gblk, ev_gblk2;
@@ -1291,9 +990,24 @@ struct bg_handle {
   hipEvent_t ev_rollout;
   std::vector<hipEvent_t> ev_rollout_t, ev_refill_t, ev_step_t; // start/stop pairs
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
+  // tunables read ONCE per handle in bg_create (environment variables)
+  int refill_blocks, refill_blocks_shop, dev_skip_refill, gblk_first, gblk_own, wg_envs;
+  uint32_t role_mode;
 };
 
 static std::string g_create_err;
+
+// Every entry point works on the handle's device, whatever the caller's current device is, and leaves the caller's current
+// device as it found it (a process may hold handles on several GPUs; torch's current device must not change under it).
+struct BgDeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  explicit BgDeviceGuard(int dev) {
+    if (hipGetDevice(&prev) == hipSuccess && prev != dev) switched = hipSetDevice(dev) == hipSuccess;
+  }
+  ~BgDeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+};
+#define BG_GUARD(h) BgDeviceGuard _guard((h)->device_id)
 
 #define BG_HIP(call)                                                                                   \
   do {                                                                                                 \
@@ -1342,6 +1056,7 @@ extern "C" {
 // development hook: copy (and clear) the 16 phase counters written by -DBG_TIMING builds
 int bg_debug_counters(bg_handle* h, unsigned long long* out16) {
   if (!h || !out16) return BG_E_ARG;
+  BG_GUARD(h);
   BG_HIP(hipDeviceSynchronize());
   BG_HIP(hipMemcpy(out16, h->dev.dbg, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
   BG_HIP(hipMemset(h->dev.dbg, 0, 32 * sizeof(unsigned long long)));
@@ -1351,6 +1066,7 @@ int bg_debug_counters(bg_handle* h, unsigned long long* out16) {
 // development aid: the four work-list lengths of the most recent refill (decks, seed rings, global blocks, shop streams)
 int bg_debug_worklists(bg_handle* h, unsigned int* out4) {
   if (!h || !out4) return BG_E_ARG;
+  BG_GUARD(h);
   BG_HIP(hipDeviceSynchronize());
   BG_HIP(hipMemcpy(out4, h->dev.wl_count, 4 * sizeof(unsigned int), hipMemcpyDeviceToHost));
   return 0;
@@ -1365,6 +1081,7 @@ int bg_set_profiling(bg_handle* h, int enable) {
 // out[0..5] = rollout kernel ms, launches, fused env-steps per env summed over launches; refill ms, launches; step ms
 int bg_get_profile(bg_handle* h, double* out8) {
   if (!h || !out8) return BG_E_ARG;
+  BG_GUARD(h);
   BG_HIP(hipDeviceSynchronize());
   double nr = (double)(h->ev_rollout_t.size() / 2), nf = (double)(h->ev_refill_t.size() / 2), ns = (double)(h->ev_step_t.size() / 2);
   double steps = 0;
@@ -1387,22 +1104,20 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   bg_handle* h = new bg_handle();
   h->device_id = device_id; h->seeded = false; h->bytes = 0; h->profiling = false;
   { const char* rv = getenv("BG_ROLLOUT_V"); h->rollout_version = rv ? atoi(rv) : 3; }
+  if (h->rollout_version != 3) { delete h; g_create_err = "bg_create: BG_ROLLOUT_V must be 3 (the lane-per-env and barrier-phased kernels were retired)"; return BG_E_ARG; }
   { const char* av = getenv("BG_ASYNC_REFILL"); h->async_refill = av ? atoi(av) != 0 : true; }
-  { // phase B runs when a queue reaches its threshold or fewer than th_ready lanes can still step (1/1/anything = lockstep)
+  { // service waves batch by themselves (whatever queued up while the last batch ran): thresholds 1 / 1 / 255 = never wait
     const char* a = getenv("BG_TH_PLAY"); const char* b = getenv("BG_TH_OTHER"); const char* c = getenv("BG_TH_READY");
-    h->th_play = a ? (uint32_t)atoi(a) : (uint32_t)(BG_RB * 5 / 16); h->th_other = b ? (uint32_t)atoi(b) : (uint32_t)(BG_RB * 5 / 16); h->th_ready = c ? (uint32_t)atoi(c) : (uint32_t)(BG_RB * 3 / 16);
-    // per-key [T, N] arrays: envs that drift apart in time complete the 32-byte sectors of the narrow keys with several
-    // partial writes, so the drift is kept short there (2.15 G -> 2.98 G env-steps/s; packed records are immune)
-    h->thk_play = a ? h->th_play : (uint32_t)(BG_RB / 8); h->thk_other = b ? h->th_other : (uint32_t)(BG_RB / 8);
-    h->thk_ready = c ? h->th_ready : (uint32_t)(BG_RB * 25 / 32);
-    if (h->rollout_version == 3) {
-      // dedicated service waves batch by themselves (whatever queued up while the last batch ran): no thresholds, for
-      // either output layout (16/16 -3 %, 40/40 -7 % measured)
-      h->th_play = a ? h->th_play : 1u; h->th_other = b ? h->th_other : 1u; h->th_ready = c ? h->th_ready : 255u;
-      // (one array per key keeps the barrier-phased kernel and its light batching: without barriers the lanes of a workgroup
-      //  drift further apart in time, and that layout pays for drift with partial-sector writes: 2.3 G vs 2.9 G env-steps/s)
-    }
+    h->th_play = a ? (uint32_t)atoi(a) : 1u; h->th_other = b ? (uint32_t)atoi(b) : 1u; h->th_ready = c ? (uint32_t)atoi(c) : 255u;
     if (h->th_play < 1) h->th_play = 1; if (h->th_other < 1) h->th_other = 1; if (h->th_ready < 1) h->th_ready = 1;
+  }
+  { // every tunable is read here, once per handle (a process may A/B two handles with different settings)
+    auto geti = [](const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; };
+    h->refill_blocks = geti("BG_REFILL_BLOCKS", 4096); h->refill_blocks_shop = geti("BG_REFILL_BLOCKS_SHOP", 0);
+    h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0); h->gblk_first = geti("BG_GBLK_FIRST", 0); h->gblk_own = geti("BG_GBLK_OWN", 0);
+    h->wg_envs = geti("BG_WG_ENVS", 0);
+    h->role_mode = (uint32_t)geti("BG_ROLE_MODE", 0) | (geti("BG_HELP", 0) ? 0x100u : 0u) | (geti("BG_DEFER_ADV", 0) ? 0x200u : 0u) |
+                   (((uint32_t)geti("BG_TH_ENV", 0) & 0xffu) << 16);
   }
   h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = h->ev_gblk2 = nullptr; h->side4 = nullptr;
   h->ev_refill[0] = h->ev_refill[1] = nullptr; h->ev_rollout = nullptr;
@@ -1422,7 +1137,8 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   d.KG = kg ? atoi(kg) : dg; d.KS = ks ? atoi(ks) : dsd + 1; d.KD = kd ? atoi(kd) : dsd;
   if (d.KG < 2 || d.KS < 2 || d.KD < 1 || d.KG > 250 || d.KS > 250 || d.KD > 250) { delete h; g_create_err = "bg_create: bad ring depths"; return BG_E_ARG; }
   size_t N = (size_t)n_envs;
-  hipError_t e = hipSetDevice(device_id);
+  BG_GUARD(h); // the caller's current device is restored on return
+  hipError_t e = hipSuccess;
   if (e == hipSuccess) e = bg_alloc(h, &d.hot, BG_NHOT * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.deck, BG_NDECK * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.cold, BG_NCOLD * N);
@@ -1468,12 +1184,18 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   }
   d.prod_view = h->d_prod[0]; d.prod_in = h->d_prod[0]; d.prod_out = h->d_prod[1];
   h->h_tmpl.assign(BG_NTMPL * N, make_uint4(0, 0, 0, 0));
+  if (max_ante < 0 || max_ante > 255) { g_create_err = "bg_create: max_ante must be in [0, 255]"; bg_destroy(h); return BG_E_ARG; }
+  if (max_ante > 0) { // the cap lives in each env's state (bg_set_max_ante changes it later: a rising curriculum)
+    hipLaunchKernelGGL(bg_set_cap_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, 0, d, (const int32_t*)nullptr, max_ante, (const uint8_t*)nullptr);
+    if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { g_create_err = "bg_create: cap kernel failed"; bg_destroy(h); return BG_E_HIP; }
+  }
   *out = h;
   return 0;
 }
 
 int bg_destroy(bg_handle* h) {
   if (!h) return 0;
+  { BG_GUARD(h);
   BgDev& d = h->dev;
   (void)hipDeviceSynchronize();
   if (h->side) (void)hipStreamDestroy(h->side);
@@ -1489,6 +1211,7 @@ int bg_destroy(bg_handle* h) {
   hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
   hipFree(d.hot); hipFree(d.deck); hipFree(d.cold); hipFree(d.tmpl); hipFree(d.ndeck); hipFree(d.gblk); hipFree(d.sblk); hipFree(d.sovf);
   hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.wl_shop); hipFree(d.sseed); hipFree(d.smeta); hipFree(d.dbg); hipFree(d.cstate); hipFree(d.ctmpl); hipFree(d.cardmt); hipFree(d.sealmt);
+  }
   delete h;
   return 0;
 }
@@ -1544,30 +1267,27 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   bg_ev_begin(h, h->ev_refill_t, s);
   BG_HIP(hipMemsetAsync(d.wl_count, 0, 4 * sizeof(uint32_t), s));
   hipLaunchKernelGGL(bg_refill_scan_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, d);
-  // v2 rollout: two refill waves per CU per kernel run BESIDE the rollout (512).  The service-wave kernel leaves no
-  // registers for a co-resident wave, so its refill runs in the gaps rollout workgroups leave when they retire: wide grids
-  static const int dense_cap = getenv("BG_REFILL_BLOCKS") ? atoi(getenv("BG_REFILL_BLOCKS")) : (h->rollout_version == 3 ? 4096 : 512);
-  // grid-stride over the compacted work lists.  Beside the v2 rollout at most one refill wave per env wave makes sense; on its
-  // own (v3) a kernel of dependent chains wants several waves per SIMD however few envs there are
-  int dense = (h->rollout_version == 3 || bg_grid(h) >= dense_cap) ? dense_cap : bg_grid(h);
+  // The rollout kernel leaves no registers for a co-resident wave, so the refill runs in the gaps rollout workgroups leave
+  // when they retire: wide grids
+  // grid-stride over the compacted work lists: kernels of dependent chains want several waves per SIMD however few envs there are
+  const int dense = h->refill_blocks;
   // the three kinds of work are independent once the lists exist: run them side by side (each is a few hundred
   // latency-bound waves), join before the completion event
   BG_HIP(hipEventRecord(h->ev_scan, s));
   BG_HIP(hipStreamWaitEvent(h->side2, h->ev_scan, 0));
   BG_HIP(hipStreamWaitEvent(h->side3, h->ev_scan, 0));
-  static const int skip = getenv("BG_DEV_SKIP_REFILL") ? atoi(getenv("BG_DEV_SKIP_REFILL")) : 0; // development: contention experiments only (breaks the rings)
-  static const int shop_cap = getenv("BG_REFILL_BLOCKS_SHOP") ? atoi(getenv("BG_REFILL_BLOCKS_SHOP")) : 0; // 0 = like the others
-  const int dense_shop = (shop_cap > 0 && h->rollout_version == 3) ? shop_cap : dense;
+  const int skip = h->dev_skip_refill; // development: contention experiments only (breaks the rings)
+  const int dense_shop = h->refill_blocks_shop > 0 ? h->refill_blocks_shop : dense;
   if (!(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d);
   if (!(skip & 2)) hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side2, d);
   // side3: seed ring, then global blocks.  The global-block kernel would fit beside the rollout (114 VGPRs, no LDS) and
   // queued first it is done early instead of ~100 us after the rollout -- but its HBM traffic beside the rollout costs the
   // rollout more than the shorter gap saves (BG_GBLK_FIRST=1: -2..3 % measured), so it stays behind the seed-ring kernel.
-  static const int gblk_first = getenv("BG_GBLK_FIRST") ? atoi(getenv("BG_GBLK_FIRST")) : 0;
+  const int gblk_first = h->gblk_first;
   if (gblk_first && !(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
   if (!(skip & 4)) hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
   // development: the global blocks side by side with the seed ring on a stream of their own (BG_GBLK_OWN=1: no change measured)
-  static const int gblk_own = getenv("BG_GBLK_OWN") ? atoi(getenv("BG_GBLK_OWN")) : 0;
+  const int gblk_own = h->gblk_own;
   if (!gblk_first && !(skip & 8)) {
     if (gblk_own) {
       BG_HIP(hipStreamWaitEvent(h->side4, h->ev_scan, 0));
@@ -1590,6 +1310,7 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
 // synchronous flavour: ordered after everything on `stream`, and everything later on `stream` is ordered after it
 int bg_refill(bg_handle* h, void* stream) {
   if (!h) return BG_E_ARG;
+  BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;
   int rc = bg_wait_refill(h, s, 0); // the previous refill may still be running on the side stream
   if (rc) return rc;
@@ -1598,6 +1319,7 @@ int bg_refill(bg_handle* h, void* stream) {
 
 int bg_check(bg_handle* h, void* stream) {
   if (!h) return BG_E_ARG;
+  BG_GUARD(h);
   uint32_t w = 0;
   BG_HIP(hipMemcpyAsync(&w, h->dev.err, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream));
   BG_HIP(hipStreamSynchronize((hipStream_t)stream));
@@ -1612,6 +1334,7 @@ int bg_check(bg_handle* h, void* stream) {
 
 int bg_seed(bg_handle* h, const int64_t* seeds_host, const uint8_t* mask_host, int reseed_global, void* stream) {
   if (!h || !seeds_host) return BG_E_ARG;
+  BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;
   size_t N = h->dev.N;
   BG_HIP(hipMemcpyAsync(h->d_seeds, seeds_host, N * sizeof(int64_t), hipMemcpyHostToDevice, s));
@@ -1651,6 +1374,7 @@ static InfoPtrs bg_info(const bg_info_ptrs* o) {
 int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void* stream) {
   int rc = bg_require_seeded(h);
   if (rc) return rc;
+  BG_GUARD(h);
   rc = bg_wait_refill(h, (hipStream_t)stream, 0);
   if (rc) return rc;
   if (h->dev.cstate) hipLaunchKernelGGL(bg_reset_kernel<true>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), mask_dev, bg_obs(obs));
@@ -1663,6 +1387,7 @@ int bg_step(bg_handle* h, const int32_t* actions_dev, const bg_obs_ptrs* obs, do
             uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream) {
   int rc = bg_require_seeded(h);
   if (rc) return rc;
+  BG_GUARD(h);
   if (!actions_dev) return BG_E_ARG;
   rc = bg_wait_refill(h, (hipStream_t)stream, 0);
   if (rc) return rc;
@@ -1678,6 +1403,7 @@ int bg_step(bg_handle* h, const int32_t* actions_dev, const bg_obs_ptrs* obs, do
 
 int bg_observe(bg_handle* h, const bg_obs_ptrs* obs, void* stream) {
   if (!h) return BG_E_ARG;
+  BG_GUARD(h);
   hipLaunchKernelGGL(bg_observe_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), bg_obs(obs));
   BG_HIP(hipGetLastError());
   return 0;
@@ -1689,6 +1415,7 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
                            bg_rollout_stats* stats_dev, void* stream) {
   int rc = bg_require_seeded(h);
   if (rc) return rc;
+  BG_GUARD(h);
   if (T <= 0) return BG_E_ARG;
   bool async = false;
   const int max_chunk = bg_chunk_limit(h, &async);
@@ -1731,36 +1458,21 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       int32_t* ac = actions_out_dev ? actions_out_dev + off : nullptr;
       hipStream_t st = (hipStream_t)stream;
       uint64_t tt = t0 + (uint64_t)done;
-      if (h->rollout_version == 1) {
-        if (h->dev.cstate) { h->err = "card states need the block-compacted rollout kernel (BG_ROLLOUT_V=2)"; return BG_E_ARG; }
-        if (hash) hipLaunchKernelGGL(bg_rollout_kernel<true>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
-        else hipLaunchKernelGGL(bg_rollout_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev);
-      } else {
-        dim3 g2((h->dev.N + BG_RB - 1) / BG_RB);
-        const bool per_key = !rows_dev && obs && obs_stride_steps != 0; // [T, N] arrays per key
-        const bool v3 = h->rollout_version == 3 && !per_key; // dedicated service waves: four waves per workgroup of 128 envs
-        static const uint32_t role_mode = (getenv("BG_ROLE_MODE") ? (uint32_t)atoi(getenv("BG_ROLE_MODE")) : 0u) |
-                                          ((getenv("BG_HELP") ? atoi(getenv("BG_HELP")) : 0) ? 0x100u : 0u) |
-                                          ((getenv("BG_DEFER_ADV") ? atoi(getenv("BG_DEFER_ADV")) : 0) ? 0x200u : 0u) |
-                                          (((uint32_t)(getenv("BG_TH_ENV") ? atoi(getenv("BG_TH_ENV")) : 0) & 0xffu) << 16);
-        // envs per v3 workgroup.  256 (one workgroup per CU: its two play waves and two other waves pool the queues of 256 envs,
+      {
+        // envs per workgroup.  256 (one workgroup per CU: its two play waves and two other waves pool the queues of 256 envs,
         // so a queued action waits half as long for a free wave) makes the kernel 5-7 % faster than 128 (two workgroups per CU)
-        // once the env count fills every CU that way; it also ends more evenly, which leaves the refill less of a tail to hide in
-        // (whole-job rate -2 %).  Smaller jobs keep 128 so that they spread over twice as many CUs.
-        const int wg_override = getenv("BG_WG_ENVS") ? atoi(getenv("BG_WG_ENVS")) : 0; // read per launch (tests switch it)
-        const int wg_envs = wg_override ? wg_override : (h->dev.N >= 65536 ? 256 : 128);
-        dim3 g4((h->dev.N + 4 * BG_BLOCK - 1) / (4 * BG_BLOCK));
-#define BG_LAUNCH_R2(HASHV, CARDSV) do { if (v3 && wg_envs == 256) hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV, 4>), g4, dim3(8 * BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, \
+        // once the env count fills every CU that way.  Smaller jobs keep 128 so that they spread over twice as many CUs.
+        const int wg_envs = h->wg_envs ? h->wg_envs : (h->dev.N >= 65536 ? 256 : 128);
+        dim3 g2((h->dev.N + 2 * BG_BLOCK - 1) / (2 * BG_BLOCK)), g4((h->dev.N + 4 * BG_BLOCK - 1) / (4 * BG_BLOCK));
+        const uint32_t thp = h->th_play, tho = h->th_other, thr = h->th_ready, role_mode = h->role_mode;
+#define BG_LAUNCH_R3(HASHV, CARDSV) do { if (wg_envs == 256) hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV, 4>), g4, dim3(8 * BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, \
                                                    env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr, role_mode); \
-  else if (v3) hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV, 2>), g2, dim3(2 * BG_RB), 0, st, dv, chunk, pol, policy_seed, \
-                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr, role_mode); \
-  else hipLaunchKernelGGL((bg_rollout2_kernel<HASHV, CARDSV>), g2, dim3(BG_RB), 0, st, dv, chunk, pol, policy_seed, \
-                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr); } while (0)
-        const uint32_t thp = per_key ? h->thk_play : h->th_play, tho = per_key ? h->thk_other : h->th_other, thr = per_key ? h->thk_ready : h->th_ready;
+  else hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV, 2>), g2, dim3(4 * BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, \
+                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr, role_mode); } while (0)
         const bool cards = h->dev.cstate != nullptr;
-        if (hash && cards) BG_LAUNCH_R2(true, true); else if (hash) BG_LAUNCH_R2(true, false);
-        else if (cards) BG_LAUNCH_R2(false, true); else BG_LAUNCH_R2(false, false);
-#undef BG_LAUNCH_R2
+        if (hash && cards) BG_LAUNCH_R3(true, true); else if (hash) BG_LAUNCH_R3(true, false);
+        else if (cards) BG_LAUNCH_R3(false, true); else BG_LAUNCH_R3(false, false);
+#undef BG_LAUNCH_R3
       }
     }
     bg_ev_end(h, h->ev_rollout_t, (hipStream_t)stream);
@@ -1793,7 +1505,6 @@ int bg_rollout_rows(bg_handle* h, int T, int policy, uint64_t policy_seed, uint6
     h->err = "bg_rollout_rows: rows_dev must be 16-byte aligned and row_stride_bytes a multiple of 16, >= BG_ROW_BYTES";
     return BG_E_ARG;
   }
-  if (h->rollout_version == 1) { h->err = "bg_rollout_rows needs a block-compacted rollout kernel (BG_ROLLOUT_V=2 or 3)"; return BG_E_ARG; }
   return bg_rollout_impl(h, T, policy, policy_seed, env_index0, t0, nullptr, rows_dev, (size_t)row_stride_bytes,
                          rows_stride_steps, nullptr, nullptr, nullptr, stats_dev, stream);
 }
@@ -1815,6 +1526,7 @@ int bg_inject_cards(bg_handle* h, const uint8_t* enh_host, const uint8_t* editio
                     const uint8_t* mask_host, int apply_now, void* stream) {
   if (!h) return BG_E_ARG;
   if (!h->dev.cstate) { h->err = "bg_inject_cards: the handle was created without BG_FLAG_CARD_STATES"; return BG_E_ARG; }
+  BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;
   const size_t N = h->dev.N;
   std::vector<uint16_t> packed(N * 56, 0);
@@ -1839,6 +1551,7 @@ int bg_inject_cards(bg_handle* h, const uint8_t* enh_host, const uint8_t* editio
 int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_host, const int64_t* money_host,
               const int32_t* ante_host, const uint8_t* levels_host, const uint8_t* mask_host, int apply_now, void* stream) {
   if (!h) return BG_E_ARG;
+  BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;
   size_t N = h->dev.N;
   for (size_t i = 0; i < N; i++) {
@@ -1859,7 +1572,12 @@ int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_h
       t0.x = lo; nj = (uint32_t)n; fl |= 0x80u;
     }
     if (money_host) { if (money_host[i] >= 0) { t0.z = (uint32_t)(int32_t)money_host[i]; fl |= 0x40u; } else fl &= ~0x40u; }
-    if (ante_host) { if (ante_host[i] > 0) { an = (uint32_t)ante_host[i] & 0xffu; fl |= 0x20u; } else fl &= ~0x20u; }
+    if (ante_host) {
+      // an env that resets into ante > cap ends every episode on its first step: one pre-shuffled deck per STEP, three times
+      // what the look-ahead rings are sized for (bg_chunk_limit)
+      if (ante_host[i] > 255 || (h->dev.max_ante > 0 && ante_host[i] > h->dev.max_ante)) { h->err = "bg_inject: template ante above the curriculum cap (max_ante)"; return BG_E_ARG; }
+      if (ante_host[i] > 0) { an = (uint32_t)ante_host[i] & 0xffu; fl |= 0x20u; } else fl &= ~0x20u;
+    }
     if (levels_host) {
       uint64_t lv = 0; bool any = false;
       for (int k = 0; k < 12; k++) { int l = levels_host[i * 12 + k]; if (l) any = true; if (l < 1) l = 1; if (l > 15) l = 15; lv |= (uint64_t)l << (4 * k); }
@@ -1881,6 +1599,7 @@ int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_h
 int bg_inject_consumables(bg_handle* h, const int32_t* ids_host, const int32_t* n_host, const uint8_t* mask_host, int apply_now,
                           void* stream) {
   if (!h || !ids_host || !n_host) return BG_E_ARG;
+  BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;
   size_t N = h->dev.N;
   for (size_t i = 0; i < N; i++) {
@@ -1931,12 +1650,28 @@ uint64_t bg_state_blob_bytes(const bg_handle* h) {
   return b;
 }
 #define BG_BLOB_MAGIC 0x42474d58u
-#define BG_BLOB_VERSION 3u // 3: compact shop-stream slots + overflow block; 2: stream 13 ('seal_applications') joins the card-state slices, consumables in the reset template
+#define BG_BLOB_VERSION 4u // 4: the curriculum cap in the hot state, card-state flag in the header; 3: compact shop-stream slots + overflow block; 2: stream 13 ('seal_applications') joins the card-state slices, consumables in the reset template
+// what is wrong with a blob handed to bg_set_state (or with the buffer handed to bg_get_state), as text
+static int bg_blob_args(bg_handle* h, const char* fn, int env_index, const void* blob, uint64_t blob_bytes) {
+  if (!h) return BG_E_ARG;
+  char buf[200];
+  if (!blob) { h->err = std::string(fn) + ": null blob"; return BG_E_ARG; }
+  if (env_index < 0 || env_index >= h->dev.N) { snprintf(buf, sizeof(buf), "%s: env_index %d out of range [0, %d)", fn, env_index, h->dev.N); h->err = buf; return BG_E_ARG; }
+  const uint64_t want = bg_state_blob_bytes(h);
+  if (blob_bytes < want) {
+    snprintf(buf, sizeof(buf), "%s: blob of %llu bytes, this handle's blobs are %llu bytes (ring depths and card-state flag decide the size)", fn,
+             (unsigned long long)blob_bytes, (unsigned long long)want);
+    h->err = buf; return BG_E_ARG;
+  }
+  return 0;
+}
 int bg_get_state(bg_handle* h, int env_index, void* blob_host, uint64_t blob_bytes) {
-  if (!h || !blob_host || env_index < 0 || env_index >= h->dev.N || blob_bytes < bg_state_blob_bytes(h)) return BG_E_ARG;
+  int rc = bg_blob_args(h, "bg_get_state", env_index, blob_host, blob_bytes);
+  if (rc) return rc;
+  BG_GUARD(h);
   BG_HIP(hipDeviceSynchronize());
   uint8_t* out = (uint8_t*)blob_host;
-  uint32_t hdr[4] = {BG_BLOB_MAGIC, BG_BLOB_VERSION, (uint32_t)h->dev.KG, (uint32_t)h->dev.KS | ((uint32_t)h->dev.KD << 16)};
+  uint32_t hdr[4] = {BG_BLOB_MAGIC, BG_BLOB_VERSION, (uint32_t)h->dev.KG | (h->dev.cstate ? 0x10000u : 0u), (uint32_t)h->dev.KS | ((uint32_t)h->dev.KD << 16)};
   memcpy(out, hdr, 16); out += 16;
   std::vector<BgSlice> v;
   bg_slices(h, v);
@@ -1948,18 +1683,28 @@ int bg_get_state(bg_handle* h, int env_index, void* blob_host, uint64_t blob_byt
   return 0;
 }
 int bg_set_state(bg_handle* h, int env_index, const void* blob_host, uint64_t blob_bytes) {
-  if (!h || !blob_host || env_index < 0 || env_index >= h->dev.N || blob_bytes < bg_state_blob_bytes(h)) return BG_E_ARG;
+  int rc = bg_blob_args(h, "bg_set_state", env_index, blob_host, blob_bytes);
+  if (rc) return rc;
+  BG_GUARD(h);
   const uint8_t* in = (const uint8_t*)blob_host;
   uint32_t hdr[4];
   memcpy(hdr, in, 16); in += 16;
-  if (hdr[0] != BG_BLOB_MAGIC || hdr[1] != BG_BLOB_VERSION || hdr[2] != (uint32_t)h->dev.KG ||
-      hdr[3] != ((uint32_t)h->dev.KS | ((uint32_t)h->dev.KD << 16))) { h->err = "bg_set_state: blob header mismatch"; return BG_E_ARG; }
+  char buf[200];
+  if (hdr[0] != BG_BLOB_MAGIC) { h->err = "bg_set_state: not a state blob (bad magic)"; return BG_E_ARG; }
+  if (hdr[1] != BG_BLOB_VERSION) { snprintf(buf, sizeof(buf), "bg_set_state: blob version %u, this library reads version %u", hdr[1], BG_BLOB_VERSION); h->err = buf; return BG_E_ARG; }
+  if (hdr[2] != ((uint32_t)h->dev.KG | (h->dev.cstate ? 0x10000u : 0u)) || hdr[3] != ((uint32_t)h->dev.KS | ((uint32_t)h->dev.KD << 16))) {
+    snprintf(buf, sizeof(buf), "bg_set_state: the blob was saved with ring depths %u/%u/%u%s, this handle has %d/%d/%d%s", hdr[2] & 0xffffu, hdr[3] & 0xffffu, hdr[3] >> 16,
+             (hdr[2] & 0x10000u) ? " + card states" : "", h->dev.KG, h->dev.KS, h->dev.KD, h->dev.cstate ? " + card states" : "");
+    h->err = buf; return BG_E_ARG;
+  }
   BG_HIP(hipDeviceSynchronize());
   std::vector<BgSlice> v;
   bg_slices(h, v);
   size_t N = h->dev.N;
   for (auto& s : v) {
     BG_HIP(hipMemcpy2D((uint8_t*)s.base + (size_t)env_index * s.elem, N * s.elem, in, s.elem, s.elem, s.rows, hipMemcpyHostToDevice));
+    if (s.base == (void*)h->dev.tmpl) // the host mirror of the reset template follows (later bg_inject calls upload the whole mirror)
+      for (size_t r = 0; r < s.rows; r++) memcpy(&h->h_tmpl[r * N + (size_t)env_index], in + r * s.elem, sizeof(uint4));
     in += s.rows * s.elem;
   }
   { // both producer-counter buffers must agree for this env (an overlapped rollout reads the older one)
@@ -1969,6 +1714,135 @@ int bg_set_state(bg_handle* h, int env_index, const void* blob_host, uint64_t bl
     BG_HIP(hipMemcpy(h->d_prod[1] + env_index, &w, 4, hipMemcpyHostToDevice));
   }
   h->seeded = true;
+  return 0;
+}
+
+// ---- harness injection of the LIVE deck order and of the curriculum cap ----
+int bg_inject_deck(bg_handle* h, const uint8_t* decks_host, const uint8_t* mask_host, void* stream) {
+  if (!h || !decks_host) return BG_E_ARG;
+  BG_GUARD(h);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t N = h->dev.N;
+  std::vector<uint8_t> packed(N * 64, 0);
+  for (size_t i = 0; i < N; i++) {
+    if (mask_host && !mask_host[i]) continue;
+    uint64_t seen = 0;
+    for (int c = 0; c < 52; c++) {
+      const uint8_t v = decks_host[i * 52 + c];
+      if (v >= 52 || ((seen >> v) & 1ull)) { h->err = "bg_inject_deck: every deck must be a permutation of the 52 card codes (rank-2)*4+suit"; return BG_E_ARG; }
+      seen |= 1ull << v;
+      packed[i * 64 + c] = v;
+    }
+  }
+  uint4* dd = nullptr;
+  BG_HIP(hipMalloc((void**)&dd, packed.size()));
+  BG_HIP(hipMemcpyAsync(dd, packed.data(), packed.size(), hipMemcpyHostToDevice, s));
+  if (mask_host) BG_HIP(hipMemcpyAsync(h->d_mask, mask_host, N, hipMemcpyHostToDevice, s));
+  { int rcw = bg_wait_refill(h, s, 0); if (rcw) { (void)hipFree(dd); return rcw; } }
+  hipLaunchKernelGGL(bg_inject_deck_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, h->dev, (const uint4*)dd,
+                     mask_host ? (const uint8_t*)h->d_mask : (const uint8_t*)nullptr);
+  BG_HIP(hipGetLastError());
+  BG_HIP(hipStreamSynchronize(s));
+  BG_HIP(hipFree(dd));
+  return 0;
+}
+
+int bg_set_max_ante(bg_handle* h, int max_ante, const int32_t* per_env_host, const uint8_t* mask_host, void* stream) {
+  if (!h) return BG_E_ARG;
+  BG_GUARD(h);
+  hipStream_t s = (hipStream_t)stream;
+  const size_t N = h->dev.N;
+  if (!per_env_host && (max_ante < 0 || max_ante > 255)) { h->err = "bg_set_max_ante: the cap must be in [0, 255] (0 = none)"; return BG_E_ARG; }
+  int32_t* dc = nullptr;
+  if (per_env_host) {
+    for (size_t i = 0; i < N; i++)
+      if ((!mask_host || mask_host[i]) && (per_env_host[i] < 0 || per_env_host[i] > 255)) { h->err = "bg_set_max_ante: every cap must be in [0, 255] (0 = none)"; return BG_E_ARG; }
+    BG_HIP(hipMalloc((void**)&dc, N * sizeof(int32_t)));
+    BG_HIP(hipMemcpyAsync(dc, per_env_host, N * sizeof(int32_t), hipMemcpyHostToDevice, s));
+  }
+  if (mask_host) BG_HIP(hipMemcpyAsync(h->d_mask, mask_host, N, hipMemcpyHostToDevice, s));
+  hipLaunchKernelGGL(bg_set_cap_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, h->dev, (const int32_t*)dc, max_ante,
+                     mask_host ? (const uint8_t*)h->d_mask : (const uint8_t*)nullptr);
+  BG_HIP(hipGetLastError());
+  BG_HIP(hipStreamSynchronize(s));
+  if (dc) BG_HIP(hipFree(dc));
+  if (!per_env_host && !mask_host) h->dev.max_ante = max_ante; // what bg_inject validates template antes against
+  else if (h->dev.max_ante) h->dev.max_ante = 255;               // mixed caps: only the representable range is checked
+  return 0;
+}
+
+// ---- operator-level entry points (no handle: they run on the CURRENT device, on caller-owned device buffers) ----
+#define BG_HIP0(call)                                                                                  \
+  do {                                                                                                 \
+    hipError_t _e = (call);                                                                            \
+    if (_e != hipSuccess) {                                                                            \
+      g_create_err = std::string(#call) + ": " + hipGetErrorString(_e);                                \
+      return BG_E_HIP;                                                                                 \
+    }                                                                                                  \
+  } while (0)
+
+// ---- measurement hook: streaming copy (bench.py's `peak_measured`: what this GPU's HBM sustains for a plain 16-byte-per-lane
+// copy, the yardstick SURVEY 8(d) asks the roofline fraction to be quoted against beside the 8 TB/s nominal) ----
+__global__ __launch_bounds__(256) void bg_stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n16; i += stride) {
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (i + (size_t)k * 256 < n16) v[k] = src[i + (size_t)k * 256];
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (i + (size_t)k * 256 < n16) dst[i + (size_t)k * 256] = v[k];
+  }
+}
+int bg_bench_copy(const void* src_dev, void* dst_dev, uint64_t bytes, int iters, double* gbps_out, void* stream) {
+  if (!src_dev || !dst_dev || !gbps_out || bytes < 16 || iters < 1 || ((uintptr_t)src_dev & 15) || ((uintptr_t)dst_dev & 15)) { g_create_err = "bg_bench_copy: bad arguments"; return BG_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n16 = bytes / 16;
+  const int grid = 256 * 16; // 16 workgroups per CU
+  hipEvent_t a, b;
+  BG_HIP0(hipEventCreate(&a)); BG_HIP0(hipEventCreate(&b));
+  hipLaunchKernelGGL(bg_stream_copy_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)src_dev, (uint4*)dst_dev, n16); // warm-up
+  BG_HIP0(hipEventRecord(a, s));
+  for (int i = 0; i < iters; i++) hipLaunchKernelGGL(bg_stream_copy_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)src_dev, (uint4*)dst_dev, n16);
+  BG_HIP0(hipEventRecord(b, s));
+  BG_HIP0(hipGetLastError());
+  BG_HIP0(hipEventSynchronize(b));
+  float ms = 0;
+  BG_HIP0(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  *gbps_out = ms > 0 ? 2.0 * (double)(n16 * 16) * iters / (ms * 1e-3) / 1e9 : 0.0; // bytes read + bytes written
+  return 0;
+}
+
+int bg_classify_batch(const uint8_t* cards_dev, const uint8_t* n_dev, uint8_t* hand_type_dev, int64_t m, void* stream) {
+  if (!cards_dev || !n_dev || !hand_type_dev || m < 0 || ((uintptr_t)cards_dev & 7)) { g_create_err = "bg_classify_batch: bad arguments (cards_dev must be 8-byte aligned)"; return BG_E_ARG; }
+  if (m == 0) return 0;
+  hipLaunchKernelGGL(bg_classify_batch_kernel, dim3((unsigned)((m + BG_BLOCK - 1) / BG_BLOCK)), dim3(BG_BLOCK), 0, (hipStream_t)stream,
+                     cards_dev, n_dev, hand_type_dev, (long long)m);
+  BG_HIP0(hipGetLastError());
+  return 0;
+}
+
+int bg_score_hand_batch(const int32_t* cases_dev, int64_t* out_dev, int m, void* stream) {
+  if (!cases_dev || !out_dev || m < 0) { g_create_err = "bg_score_hand_batch: bad arguments"; return BG_E_ARG; }
+  if (m == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  BgDev d;
+  memset(&d, 0, sizeof(d));
+  d.N = m; d.flags = BG_FLAG_SCORER_JOKERS; d.KG = 2; d.KS = 2; d.KD = 1;
+  uint32_t* scratch = nullptr; // two MT19937 blocks per case + the error word
+  BG_HIP0(hipMalloc((void**)&scratch, ((size_t)m * 2 * BG_MTS + 4) * sizeof(uint32_t)));
+  d.gblk = scratch; d.err = scratch + (size_t)m * 2 * BG_MTS;
+  hipError_t e = hipMemsetAsync(d.err, 0, 4 * sizeof(uint32_t), s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(bg_score_hand_batch_kernel, dim3((m + BG_BLOCK - 1) / BG_BLOCK), dim3(BG_BLOCK), 0, s, d, cases_dev, out_dev);
+    e = hipGetLastError();
+  }
+  uint32_t errw = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&errw, d.err, sizeof(errw), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(scratch);
+  if (e != hipSuccess) { g_create_err = std::string("bg_score_hand_batch: ") + hipGetErrorString(e); return BG_E_HIP; }
+  if (errw) { g_create_err = "bg_score_hand_batch: a case drew more than two blocks of the global stream"; return BG_E_INTERNAL; }
   return 0;
 }
 

@@ -277,9 +277,11 @@ struct JEff { int chips, mult; double x; };
 // complete_joker_effects.py:35-129 (main 'scoring' phase) as a descriptor per joker id:
 //   bits 0..4 condition index into a per-play condition bit set, 5..7 value kind, 8..23 constant.
 // conditions: 0 always | 1 <= 3 scoring cards | 2 hands_left == 1 | 3 discards_left == 0 | 4..7 a scoring card of suit
-//   C,D,H,S | 8 Blackboard | 9 Seeing Double | 10 Flower Pot | 11 a King played | 12 a Queen played | 16+t hand type == t
-//   (the env's names 'One Pair'/'Three Kind'/'Four Kind' never match 'Pair'/'Three of a Kind'/'Four of a Kind', SURVEY
-//   Q11, so only Two Pair / Straight / Flush jokers get a type condition) | 31 never.
+//   C,D,H,S | 8 Blackboard | 9 Seeing Double | 10 Flower Pot | 11 a King played | 12 a Queen played | 13 / 14 / 15 the hand
+//   is called 'Pair' / 'Three of a Kind' / 'Four of a Kind' | 16+t hand type == t | 31 never.
+//   The env's names are 'One Pair' / 'Three Kind' / 'Four Kind' (balatro_env_2.py:674): conditions 13..15 are
+//   never set on the step path, only by the operator-level entry point bg_score_hand_batch when a case uses the
+//   balatro_sim-style names (unified_scoring.py:313-351 called directly).
 // values: 0 +mult c | 1 +chips c | 2 x c | 3 +mult randint(0,23) (Misprint) | 4 +mult 3*len(jokers) | 5 +chips 30*discards
 //   | 6 x 1.5**kings | 7 +mult 13*queens.
 #define BG_JM(cond, vk, c) ((uint32_t)(cond) | ((uint32_t)(vk) << 5) | ((uint32_t)(c) << 8))
@@ -302,6 +304,13 @@ __device__ __forceinline__ uint32_t bg_jmain_desc(int id) {
     case 3: return BG_JM(6, 0, 3);      // Lusty (Hearts)
     case 4: return BG_JM(7, 0, 3);      // Wrathful (Spades)
     case 5: return BG_JM(4, 0, 3);      // Gluttonous (Clubs)
+    case 6: return BG_JM(13, 0, 8);        // Jolly Joker ('Pair')
+    case 7: return BG_JM(14, 0, 12);       // Zany Joker ('Three of a Kind')
+    case 11: return BG_JM(13, 1, 50);      // Sly Joker
+    case 12: return BG_JM(14, 1, 100);     // Wily Joker
+    case 131: return BG_JM(13, 2, 2);      // The Duo
+    case 132: return BG_JM(14, 2, 3);      // The Trio
+    case 133: return BG_JM(15, 2, 4);      // The Family ('Four of a Kind')
     case 8: return BG_JM(16 + 2, 0, 10);   // Mad Joker (Two Pair)
     case 9: return BG_JM(16 + 4, 0, 12);   // Crazy Joker (Straight)
     case 10: return BG_JM(16 + 5, 0, 10);  // Droll Joker (Flush)
@@ -417,6 +426,170 @@ __device__ __forceinline__ void bg_boss_on_hand_drawn(const BgDev& d, int env, E
   }
 }
 
+// unified_scoring.py:174-244: the joker chain of one scored hand -- individual phase (card-major, joker-minor), then the
+// main phase in joker order -- with the eager RNG draws of complete_joker_effects.py:42,161.  What it needs of
+// the hand is a few small histograms (ChainIn).  GENERAL = false is the step path (bg_step_play_hand: scoring cards == cards,
+// the env's hand-type names, money reported to a throw-away dict); GENERAL = true is the operator-level entry point
+// bg_score_hand_batch (UnifiedScorer.score_hand called directly: either name style, `cards` != `scoring_cards`, deck length and
+// money as given).  Both instantiate THIS function.
+struct ChainIn {
+  uint64_t phist;   // 15 x 4-bit counts per rank of the SCORING cards (rank 0 = a STONE card)
+  uint64_t pcodes;  // their card codes, one byte each (rank and suit of a STONE card are ignored)
+  uint32_t scnt;    // 5 x 4-bit counts per suit of the scoring cards (C, D, H, S, 'Stone')
+  uint32_t stone;   // bit per scoring-card index
+  int n, ht;        // scoring cards, hand type
+  int kings, queens; // of context['cards'] (Baron :116-120, Shoot the Moon :122-126)
+  bool all_black;   // GENERAL: every card of context['cards'] is a Spade or a Club (Blackboard)
+  int deck_len, style; // GENERAL: len(game_state['deck']), 1 = 'Pair' / 'Three of a Kind' / 'Four of a Kind' names
+};
+template <bool GENERAL, class DK>
+__device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, RngWin& w, const ChainIn& in, int64_t& chips,
+                                               int64_t& mult, double& x_mult, int& money) {
+  BG_PROBE_BEGIN();
+  // unified_scoring.py:174-209 individual phase.  Totals do not depend on the (card-major, joker-minor) order: chips
+  // and mult add up, and every x factor is exactly 2.0.
+  const int nj = e.njokers, n = in.n, ht = in.ht;
+  const uint64_t phist = in.phist, pcodes = in.pcodes;
+  const uint32_t scnt = in.scnt, stone = in.stone;
+  const int kings = in.kings, queens = in.queens;
+  int ic = 0, im = 0, xexp = 0, j8 = -1, jb = -1;
+  // all table reads first (independent LDS reads), then straight-line arithmetic per joker slot
+  uint64_t jds[5], jrs[5];
+  uint32_t dms[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    int id = j < nj ? (int)((e.jokers >> (8 * j)) & 0xff) : 0;
+    jds[j] = w.jt->jd[id]; jrs[j] = w.jt->jr[id]; dms[j] = w.jt->jm[id];
+  }
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    uint64_t dsc = jds[j];
+    uint32_t sp = (uint32_t)(dsc >> 20) & 3u;
+    if (sp == 1u) j8 = j;
+    if (sp == 2u) jb = j;
+    // matching cards = sum of the histogram nibbles selected by the rank mask, or the suit's count
+    uint64_t x = phist & jrs[j];
+    uint32_t y = (uint32_t)(x & 0x0f0f0f0f0f0f0f0full) + (uint32_t)((x >> 4) & 0x0f0f0f0f0f0f0f0full) +
+                 (uint32_t)((x & 0x0f0f0f0f0f0f0f0full) >> 32) + (uint32_t)(((x >> 4) & 0x0f0f0f0f0f0f0f0full) >> 32);
+    y += y >> 16;
+    int cnt = (int)((y + (y >> 8)) & 0xffu);
+    uint32_t suit1 = (uint32_t)(dsc >> 16) & 7u;
+    if (suit1) cnt = (int)((scnt >> (4 * (suit1 - 1))) & 0xfu);
+    if (sp == 2u) cnt = 0; // Bloodstone is settled card by card below
+    ic += cnt * (int)((dsc >> 24) & 0xffu); im += cnt * (int)((dsc >> 32) & 0xffu);
+    if constexpr (GENERAL) if (j < nj && (int)((e.jokers >> (8 * j)) & 0xff) == 116) money += (int)((scnt >> 4) & 0xfu); // Rough Gem: $1 per Diamond (:160)
+    if ((dsc >> 22) & 1u) xexp += cnt;
+  }
+  BG_PROBE(7);
+  bg_gnorm(d, e);
+  int n8 = j8 >= 0 ? (int)((phist >> 32) & 0xf) : 0; // 8 Ball: one extra random() per played 8 (:167)
+  int consumed = 2 * n * nj + 2 * n8;
+  // Every RNG word the chain looks at is requested in ONE batch of independent loads: Bloodstone's two words per played
+  // Heart, and the 12 words that follow the individual phase's `consumed` (eagerly drawn, never looked at) words, where
+  // the main phase's randint draws will fall (5 accepted among 12 words fails once in ~3000 plays: then the loop).
+  const bool blood = jb >= 0 && ((scnt >> 8) & 0xfu);
+  int boff[8];
+  {
+    // Bloodstone on a Heart: x2 iff the pair's random() < 0.5.  Pair (c, jb) sits 2*(c*nj + jb) words ahead, plus 2
+    // for every extra 8-Ball draw that precedes it in card-major order.
+    int eights = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      int code = (int)((pcodes >> (8 * c)) & 0xff);
+      int rk = (code >> 2) + 2;
+      const bool st = (stone >> c) & 1u; // a STONE card has no rank and no suit for the jokers
+      boff[c] = (blood && c < n && !st && (code & 3) == 2) ? 2 * (c * nj + jb) + 2 * (eights + ((j8 >= 0 && j8 < jb && !st && rk == 8) ? 1 : 0)) : -1;
+      if (c < n && j8 >= 0 && !st && rk == 8) eights++;
+    }
+  }
+  // random() < 0.5 for random() = ((a >> 5) * 2**26 + (b >> 6)) / 2**53 is decided by the top bit of the FIRST word
+  // alone ((a >> 5) < 2**26), so one word per Heart is read and no float arithmetic is needed.
+  uint32_t ra[8], mw[12];
+  uint32_t avail = 0; // main-phase words the ring already holds
+#pragma unroll
+  for (int c = 0; c < 8; c++) { ra[c] = 0x80000000u; if (boff[c] >= 0) ra[c] = bg_gpeek(d, env, e, boff[c]); }
+  bg_gpeek12(d, env, e, consumed, mw, avail);
+#pragma unroll
+  for (int c = 0; c < 8; c++) xexp += (int)((ra[c] >> 31) ^ 1u);
+  bg_gskip(d, e, consumed);
+  chips += ic; mult += im;
+  x_mult *= (double)(1ull << xexp);
+  // :216-244 main phase, joker order; one randint(0, 23) per joker
+  // bit 4 = 'Stone': complete_joker_effects.py:98-114 compare suit STRINGS, so a STONE card is a fifth kind of suit for
+  // Blackboard / Seeing Double / Flower Pot (and no suit at all for the four suit jokers)
+  uint32_t suits = ((scnt & 0xfu) ? 1u : 0u) | ((scnt & 0xf0u) ? 2u : 0u) | ((scnt & 0xf00u) ? 4u : 0u) | ((scnt & 0xf000u) ? 8u : 0u) |
+                   ((scnt & 0xf0000u) ? 16u : 0u);
+  // Blackboard (complete_joker_effects.py:98-102) looks at context['cards'], the other suit jokers at the scoring cards; on
+  // the step path the two lists are the same one (balatro_env_2.py:683-689)
+  const bool blackboard = GENERAL ? in.all_black : (suits & ~9u) == 0;
+  uint32_t cond = 1u | (n <= 3 ? 2u : 0u) | (e.hands_left == 1 ? 4u : 0u) | (e.discards_left == 0 ? 8u : 0u) | ((suits & 15u) << 4) |
+                  (blackboard ? 1u << 8 : 0u) | (((suits & 1u) && __popc(suits) > 1) ? 1u << 9 : 0u) |
+                  (__popc(suits) == 4 ? 1u << 10 : 0u) | (kings > 0 ? 1u << 11 : 0u) | (queens > 0 ? 1u << 12 : 0u) | (1u << (16 + ht));
+  if constexpr (GENERAL) // 'Pair' / 'Three of a Kind' / 'Four of a Kind' (complete_joker_effects.py:64-80) only exist in the sim-style names
+    if (in.style == 1) cond |= (ht == 1 ? 1u << 13 : 0u) | (ht == 3 ? 1u << 14 : 0u) | (ht == 7 ? 1u << 15 : 0u);
+  double baron = w.jt->pow15[kings];
+  BG_PROBE(8);
+  BG_PROBE(13);
+  // The nj draws are `_randbelow(24)`: 5-bit words, rejected when >= 24.  Instead of a rejection loop per joker (a wave
+  // iterates until its unluckiest lane is done), look at the next 12 words at once: the j-th ACCEPTED word is joker
+  // j's draw.  Only Misprint uses the value.
+  uint32_t mis_of[5] = {0, 0, 0, 0, 0};
+  {
+    bg_gnorm(d, e);
+    uint32_t acc = 0;
+    uint64_t r5lo = 0, r5hi = 0; // the twelve 5-bit candidates, one per byte
+#pragma unroll
+    for (int i = 0; i < 12; i++) {
+      const uint32_t r5 = mw[i] >> 27;
+      acc |= (r5 < 24u ? 1u : 0u) << i;
+      if (i < 8) r5lo |= (uint64_t)r5 << (8 * i); else r5hi |= (uint64_t)r5 << (8 * (i - 8));
+    }
+    // usable only up to the last word the ring holds, and only if the nj-th accepted word lies inside
+    uint32_t usable = acc & avail;
+    bool fast = avail == 0xfffu ? __popc(acc) >= nj : false;
+    if (!fast && avail) { // ring ends inside the 12 words: accepted words must all come before the first missing one
+      const int first_missing = __ffs((int)(~avail & 0xfffu)) - 1;
+      usable = acc & ((1u << first_missing) - 1u);
+      fast = __popc(usable) >= nj;
+    }
+    if (fast) {
+      uint32_t m = usable;
+      int last = 0;
+#pragma unroll
+      for (int j = 0; j < 5; j++)
+        if (j < nj) {
+          last = __ffs((int)m) - 1;
+          m &= m - 1;
+          if (((dms[j] >> 5) & 7u) == 3u) mis_of[j] = (uint32_t)(((last < 8 ? r5lo : r5hi) >> (8 * (last & 7))) & 0x1fu);
+        }
+      e.g_idx += last + 1;
+    } else {
+#pragma unroll 1
+      for (int j = 0; j < nj; j++) {
+        uint32_t v = bg_randbelow<false>(d, env, e, w, 24u);
+#pragma unroll
+        for (int q = 0; q < 5; q++) if (q == j) mis_of[q] = v;
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    if (j < nj) {
+      uint32_t dm = dms[j];
+      bool ok = (cond >> (dm & 31u)) & 1u;
+      uint32_t vk = (dm >> 5) & 7u;
+      int c = (int)(dm >> 8);
+      int madd = vk == 0 ? c : (vk == 3 ? (int)mis_of[j] : (vk == 4 ? 3 * nj : (vk == 7 ? 13 * queens : 0)));
+      int cadd = vk == 1 ? c : (vk == 5 ? 30 * e.discards_left : 0);
+      if constexpr (GENERAL) { if (vk == 1u && c == 104) cadd = 2 * in.deck_len; } // Blue Joker: 2 * len(deck)
+      else if constexpr (DK::kCards) if (vk == 1u && c == 104) cadd = 2 * (52 - e.ndrop + e.nfo); // ... once Immolate / Cryptid changed it
+      double xf = vk == 2 ? (double)c : (vk == 6 ? baron : 1.0);
+      if (ok) { chips += cadd; mult += madd; x_mult *= xf; }
+    }
+  }
+  BG_PROBE(14);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // PLAY_HAND  balatro_env_2.py:645-960
 // ---------------------------------------------------------------------------------------------------------
@@ -492,138 +665,11 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   int64_t chips = bchips + chip_sum, mult = bmult;
   double x_mult = 1.0;
   if ((d.flags & 1u) && e.njokers > 0) { // scorer-level joker names (BG_FLAG_SCORER_JOKERS); dict jokers are inert (Q6)
-    // unified_scoring.py:174-209 individual phase.  Totals do not depend on the (card-major, joker-minor) order: chips
-    // and mult add up, and every x factor is exactly 2.0.
-    const int nj = e.njokers;
-    int ic = 0, im = 0, xexp = 0, j8 = -1, jb = -1;
-    // all table reads first (independent LDS reads), then straight-line arithmetic per joker slot
-    uint64_t jds[5], jrs[5];
-    uint32_t dms[5];
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      int id = j < nj ? (int)((e.jokers >> (8 * j)) & 0xff) : 0;
-      jds[j] = w.jt->jd[id]; jrs[j] = w.jt->jr[id]; dms[j] = w.jt->jm[id];
-    }
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      uint64_t dsc = jds[j];
-      uint32_t sp = (uint32_t)(dsc >> 20) & 3u;
-      if (sp == 1u) j8 = j;
-      if (sp == 2u) jb = j;
-      // matching cards = sum of the histogram nibbles selected by the rank mask, or the suit's count
-      uint64_t x = phist & jrs[j];
-      uint32_t y = (uint32_t)(x & 0x0f0f0f0f0f0f0f0full) + (uint32_t)((x >> 4) & 0x0f0f0f0f0f0f0f0full) +
-                   (uint32_t)((x & 0x0f0f0f0f0f0f0f0full) >> 32) + (uint32_t)(((x >> 4) & 0x0f0f0f0f0f0f0f0full) >> 32);
-      y += y >> 16;
-      int cnt = (int)((y + (y >> 8)) & 0xffu);
-      uint32_t suit1 = (uint32_t)(dsc >> 16) & 7u;
-      if (suit1) cnt = (int)((scnt >> (4 * (suit1 - 1))) & 0xfu);
-      if (sp == 2u) cnt = 0; // Bloodstone is settled card by card below
-      ic += cnt * (int)((dsc >> 24) & 0xffu); im += cnt * (int)((dsc >> 32) & 0xffu);
-      if ((dsc >> 22) & 1u) xexp += cnt;
-    }
-    BG_PROBE(7);
-    bg_gnorm(d, e);
-    int n8 = j8 >= 0 ? (int)((phist >> 32) & 0xf) : 0; // 8 Ball: one extra random() per played 8 (:167)
-    int consumed = 2 * n * nj + 2 * n8;
-    // Every RNG word the chain looks at is requested in ONE batch of independent loads: Bloodstone's two words per played
-    // Heart, and the 12 words that follow the individual phase's `consumed` (eagerly drawn, never looked at) words, where
-    // the main phase's randint draws will fall (5 accepted among 12 words fails once in ~3000 plays: then the loop).
-    const bool blood = jb >= 0 && ((scnt >> 8) & 0xfu);
-    int boff[8];
-    {
-      // Bloodstone on a Heart: x2 iff the pair's random() < 0.5.  Pair (c, jb) sits 2*(c*nj + jb) words ahead, plus 2
-      // for every extra 8-Ball draw that precedes it in card-major order.
-      int eights = 0;
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        int code = (int)((pcodes >> (8 * c)) & 0xff);
-        int rk = (code >> 2) + 2;
-        const bool st = (stone >> c) & 1u; // a STONE card has no rank and no suit for the jokers
-        boff[c] = (blood && c < n && !st && (code & 3) == 2) ? 2 * (c * nj + jb) + 2 * (eights + ((j8 >= 0 && j8 < jb && !st && rk == 8) ? 1 : 0)) : -1;
-        if (c < n && j8 >= 0 && !st && rk == 8) eights++;
-      }
-    }
-    // random() < 0.5 for random() = ((a >> 5) * 2**26 + (b >> 6)) / 2**53 is decided by the top bit of the FIRST word
-    // alone ((a >> 5) < 2**26), so one word per Heart is read and no float arithmetic is needed.
-    uint32_t ra[8], mw[12];
-    uint32_t avail = 0; // main-phase words the ring already holds
-#pragma unroll
-    for (int c = 0; c < 8; c++) { ra[c] = 0x80000000u; if (boff[c] >= 0) ra[c] = bg_gpeek(d, env, e, boff[c]); }
-    bg_gpeek12(d, env, e, consumed, mw, avail);
-#pragma unroll
-    for (int c = 0; c < 8; c++) xexp += (int)((ra[c] >> 31) ^ 1u);
-    bg_gskip(d, e, consumed);
-    chips += ic; mult += im;
-    x_mult *= (double)(1ull << xexp);
-    // :216-244 main phase, joker order; one randint(0, 23) per joker
-    // bit 4 = 'Stone': complete_joker_effects.py:98-114 compare suit STRINGS, so a STONE card is a fifth kind of suit for
-    // Blackboard / Seeing Double / Flower Pot (and no suit at all for the four suit jokers)
-    uint32_t suits = ((scnt & 0xfu) ? 1u : 0u) | ((scnt & 0xf0u) ? 2u : 0u) | ((scnt & 0xf00u) ? 4u : 0u) | ((scnt & 0xf000u) ? 8u : 0u) |
-                     ((scnt & 0xf0000u) ? 16u : 0u);
-    uint32_t cond = 1u | (n <= 3 ? 2u : 0u) | (e.hands_left == 1 ? 4u : 0u) | (e.discards_left == 0 ? 8u : 0u) | ((suits & 15u) << 4) |
-                    ((suits & ~9u) == 0 ? 1u << 8 : 0u) | (((suits & 1u) && __popc(suits) > 1) ? 1u << 9 : 0u) |
-                    (__popc(suits) == 4 ? 1u << 10 : 0u) | (kings > 0 ? 1u << 11 : 0u) | (queens > 0 ? 1u << 12 : 0u) | (1u << (16 + ht));
-    double baron = w.jt->pow15[kings];
-    BG_PROBE(8);
-    BG_PROBE(13);
-    // The nj draws are `_randbelow(24)`: 5-bit words, rejected when >= 24.  Instead of a rejection loop per joker (a wave
-    // iterates until its unluckiest lane is done), look at the next 12 words at once: the j-th ACCEPTED word is joker
-    // j's draw.  Only Misprint uses the value.
-    uint32_t mis_of[5] = {0, 0, 0, 0, 0};
-    {
-      bg_gnorm(d, e);
-      uint32_t acc = 0;
-      uint64_t r5lo = 0, r5hi = 0; // the twelve 5-bit candidates, one per byte
-#pragma unroll
-      for (int i = 0; i < 12; i++) {
-        const uint32_t r5 = mw[i] >> 27;
-        acc |= (r5 < 24u ? 1u : 0u) << i;
-        if (i < 8) r5lo |= (uint64_t)r5 << (8 * i); else r5hi |= (uint64_t)r5 << (8 * (i - 8));
-      }
-      // usable only up to the last word the ring holds, and only if the nj-th accepted word lies inside
-      uint32_t usable = acc & avail;
-      bool fast = avail == 0xfffu ? __popc(acc) >= nj : false;
-      if (!fast && avail) { // ring ends inside the 12 words: accepted words must all come before the first missing one
-        const int first_missing = __ffs((int)(~avail & 0xfffu)) - 1;
-        usable = acc & ((1u << first_missing) - 1u);
-        fast = __popc(usable) >= nj;
-      }
-      if (fast) {
-        uint32_t m = usable;
-        int last = 0;
-#pragma unroll
-        for (int j = 0; j < 5; j++)
-          if (j < nj) {
-            last = __ffs((int)m) - 1;
-            m &= m - 1;
-            if (((dms[j] >> 5) & 7u) == 3u) mis_of[j] = (uint32_t)(((last < 8 ? r5lo : r5hi) >> (8 * (last & 7))) & 0x1fu);
-          }
-        e.g_idx += last + 1;
-      } else {
-#pragma unroll 1
-        for (int j = 0; j < nj; j++) {
-          uint32_t v = bg_randbelow<false>(d, env, e, w, 24u);
-#pragma unroll
-          for (int q = 0; q < 5; q++) if (q == j) mis_of[q] = v;
-        }
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 5; j++) {
-      if (j < nj) {
-        uint32_t dm = dms[j];
-        bool ok = (cond >> (dm & 31u)) & 1u;
-        uint32_t vk = (dm >> 5) & 7u;
-        int c = (int)(dm >> 8);
-        int madd = vk == 0 ? c : (vk == 3 ? (int)mis_of[j] : (vk == 4 ? 3 * nj : (vk == 7 ? 13 * queens : 0)));
-        int cadd = vk == 1 ? c : (vk == 5 ? 30 * e.discards_left : 0);
-        if constexpr (DK::kCards) if (vk == 1u && c == 104) cadd = 2 * (52 - e.ndrop + e.nfo); // Blue Joker: 2 * len(deck) once Immolate / Cryptid changed it
-        double xf = vk == 2 ? (double)c : (vk == 6 ? baron : 1.0);
-        if (ok) { chips += cadd; mult += madd; x_mult *= xf; }
-      }
-    }
-    BG_PROBE(14);
+    ChainIn in;
+    in.phist = phist; in.pcodes = pcodes; in.scnt = scnt; in.stone = stone; in.n = n; in.ht = ht; in.kings = kings; in.queens = queens;
+    in.all_black = false; in.deck_len = 52; in.style = 0;
+    int chain_money = 0; // game_state is state.to_dict(): the scorer's money goes nowhere (unified_scoring.py:292-294)
+    bg_joker_chain<false, DK>(d, env, e, w, in, chips, mult, x_mult, chain_money);
   }
   int64_t final_score = (int64_t)((double)(chips * mult) * x_mult); // unified_scoring.py:286
   int retriggers = 0;
@@ -1198,7 +1244,7 @@ __device__ __forceinline__ void bg_env_step(const BgDev& d, int env, Env& e, Rng
                                             int action, StepOut& o) {
   bg_step_init(o);
   if (bg_step_guards(e, mask, action, o)) bg_env_dispatch(d, env, e, w, sr, dk, action, o);
-  if (d.max_ante > 0 && e.ante > d.max_ante) { o.terminated = true; o.flags |= 256; }
+  if (e.max_ante > 0 && e.ante > e.max_ante) { o.terminated = true; o.flags |= 256; }
 }
 
 // ---------------------------------------------------------------------------------------------------------

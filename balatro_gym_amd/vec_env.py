@@ -234,6 +234,9 @@ class BalatroVecEnv:
         return self._stats
 
     def stats(self) -> Dict[str, int]:
+        """Aggregate counters of the rollouts since the last zeroing.  Also checks the device error word (a look-ahead ring
+        that ran dry would otherwise go unnoticed behind a return code of 0)."""
+        self.check()
         s = self._stats.cpu().numpy()
         u = s.view(np.uint64)
         return {"steps": int(u[0]), "episodes": int(u[1]), "plays": int(u[2]), "score_sum": int(s[3]),
@@ -263,6 +266,35 @@ class BalatroVecEnv:
         with torch.cuda.device(self.device):
             self._check(self._L.bg_inject(self._h, jptr, nptr, mptr, aptr, lptr, kptr, 1 if apply_now else 0,
                                           self._stream()), "bg_inject")
+
+    def set_max_ante(self, max_ante, mask=None):
+        """`CurriculumBalatroEnv.current_max_ante` (train_balatro_agent.py:129-166): one int for every (masked) env, or one
+        per env.  0 = no cap.  Takes effect from the next step on; survives reset()."""
+        mk = None if mask is None else np.ascontiguousarray(np.asarray(mask, np.uint8))
+        per = None
+        if not np.isscalar(max_ante):
+            per = np.ascontiguousarray(np.asarray(max_ante, np.int32))
+            if per.shape != (self.num_envs,):
+                raise ValueError(f"per-env caps must have shape ({self.num_envs},)")
+        with torch.cuda.device(self.device):
+            self._check(self._L.bg_set_max_ante(
+                self._h, 0 if per is not None else int(max_ante), None if per is None else per.ctypes.data_as(C.c_void_p),
+                None if mk is None else mk.ctypes.data_as(C.c_void_p), self._stream()), "bg_set_max_ante")
+        if per is None and mask is None:
+            self.max_ante = int(max_ante)
+
+    def inject_deck(self, decks, mask=None):
+        """The live deck order per env ([N, 52] card codes (rank-2)*4+suit, each row a permutation): what a harness does by
+        writing env.state.deck (balatro_env_2.py:528-531).  The next reset() reshuffles."""
+        da = np.ascontiguousarray(np.asarray(decks, np.uint8))
+        if da.shape != (self.num_envs, 52):
+            raise ValueError(f"decks must have shape ({self.num_envs}, 52)")
+        mk = None if mask is None else np.ascontiguousarray(np.asarray(mask, np.uint8))
+        with torch.cuda.device(self.device):
+            self._check(self._L.bg_inject_deck(self._h, da.ctypes.data_as(C.c_void_p),
+                                               None if mk is None else mk.ctypes.data_as(C.c_void_p), self._stream()),
+                        "bg_inject_deck")
+        self.observe()
 
     def inject_cards(self, cards, mask=None, apply_now: bool = True):
         """Card states (cards.py CardState) per env: cards[i] = iterable of (deck_index, enhancement, edition, seal) codes.
@@ -325,3 +357,37 @@ class BalatroVecEnv:
         """Raise if the device reported an internal invariant violation (RNG look-ahead underflow)."""
         with torch.cuda.device(self.device):
             self._check(self._L.bg_check(self._h, self._stream()), "bg_check")
+
+
+# ---------------------------------------------------------------------- operator-level entry points
+def classify_batch(cards: torch.Tensor, n: torch.Tensor) -> torch.Tensor:
+    """`BalatroGame._classify_hand` (balatro_game.py:40-93) for M hands at once: cards uint8 [M, 8] card codes
+    (rank-2)*4+suit, n uint8 [M] valid cards per row -> uint8 [M] HandType values.  Device tensors in, device tensor out."""
+    L = nat.load()
+    if cards.dtype != torch.uint8 or n.dtype != torch.uint8 or cards.dim() != 2 or cards.shape[1] != 8 or not cards.is_cuda:
+        raise ValueError("cards must be a uint8 [M, 8] device tensor, n a uint8 [M] device tensor")
+    cards, n = cards.contiguous(), n.contiguous()
+    out = torch.empty(cards.shape[0], dtype=torch.uint8, device=cards.device)
+    with torch.cuda.device(cards.device):
+        rc = L.bg_classify_batch(C.c_void_p(cards.data_ptr()), C.c_void_p(n.data_ptr()), C.c_void_p(out.data_ptr()),
+                                 C.c_int64(cards.shape[0]), C.c_void_p(torch.cuda.current_stream(cards.device).cuda_stream))
+    if rc != 0:
+        raise nat.NativeError(f"bg_classify_batch failed ({rc}): {L.bg_last_error(None).decode()}")
+    return out
+
+
+def score_hand_batch(cases: torch.Tensor) -> torch.Tensor:
+    """`UnifiedScorer.score_hand` (unified_scoring.py:111-299) with joker NAMES for M cases at once: cases int32
+    [M, 40] (layout: include/balatro_mi355x.h bg_score_hand_batch) -> int64 [M, 8] (score, chips, mult, x_mult bits, money,
+    global-stream words consumed, next getrandbits(32), 0)."""
+    L = nat.load()
+    if cases.dtype != torch.int32 or cases.dim() != 2 or cases.shape[1] != nat.SCORE_CASE_WORDS or not cases.is_cuda:
+        raise ValueError(f"cases must be an int32 [M, {nat.SCORE_CASE_WORDS}] device tensor")
+    cases = cases.contiguous()
+    out = torch.zeros((cases.shape[0], nat.SCORE_OUT_WORDS), dtype=torch.int64, device=cases.device)
+    with torch.cuda.device(cases.device):
+        rc = L.bg_score_hand_batch(C.c_void_p(cases.data_ptr()), C.c_void_p(out.data_ptr()), int(cases.shape[0]),
+                                   C.c_void_p(torch.cuda.current_stream(cases.device).cuda_stream))
+    if rc != 0:
+        raise nat.NativeError(f"bg_score_hand_batch failed ({rc}): {L.bg_last_error(None).decode()}")
+    return out

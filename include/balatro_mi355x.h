@@ -132,8 +132,15 @@ typedef struct bg_rollout_stats {
 } bg_rollout_stats;
 
 /* Replaces: constructing n_envs `BalatroEnv` objects (balatro_env_2.py:359-384) + SB3 SubprocVecEnv (hpc_train.py:60-65).
- * max_ante > 0 applies the CurriculumBalatroEnv cap (train_balatro_agent.py:146-152). */
+ * max_ante > 0 applies the CurriculumBalatroEnv cap (train_balatro_agent.py:146-152) to every env; bg_set_max_ante changes it
+ * later.  Every entry point runs on the handle's device and leaves the caller's current device unchanged. */
 int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle** out);
+/* Replaces: `CurriculumBalatroEnv.current_max_ante` (train_balatro_agent.py:129-166: one wrapper, hence one cap, per env; the
+ * cap rises by ante_increment when 80 % of the last 100 episodes reached it).  The cap is part of an env's state: it survives
+ * reset() and travels in state blobs.  per_env_host == NULL sets `max_ante` for the masked envs (mask_host NULL = all),
+ * otherwise per_env_host[i]; 0 = no cap; caps are in [0, 255].  The host decides WHEN to raise a cap (the statistics it needs
+ * are the terminated flags and the ante of the finished episodes); see balatro_gym_amd/sb3_adapter.py CurriculumTracker. */
+int bg_set_max_ante(bg_handle* h, int max_ante, const int32_t* per_env_host /*[N] or NULL*/, const uint8_t* mask_host, void* stream);
 int bg_destroy(bg_handle* h);
 const char* bg_last_error(const bg_handle* h); /* also valid with h == NULL after a failed bg_create */
 int bg_num_envs(const bg_handle* h);
@@ -220,6 +227,12 @@ int bg_inject(bg_handle* h, const int32_t* jokers_host /*[N,5] or NULL*/, const 
               const int64_t* money_host /*[N] or NULL*/, const int32_t* ante_host /*[N] or NULL*/,
               const uint8_t* levels_host /*[N,12] or NULL*/, const uint8_t* mask_host, int apply_now, void* stream);
 
+/* The LIVE deck order of the masked envs: decks_host is [N, 52] card codes (rank-2)*4+suit, each row a permutation of 0..51.
+ * Replaces direct writes to env.state.deck / env.game.deck (one aliased list, balatro_env_2.py:528-531), which is how a harness
+ * or a test puts chosen cards under the hand's deck indexes (e.g. a straight flush at deck[0..4]: classification reads
+ * deck[position]).  The next reset() reshuffles as always. */
+int bg_inject_deck(bg_handle* h, const uint8_t* decks_host /*[N,52]*/, const uint8_t* mask_host, void* stream);
+
 /* Card states (cards.py:62-139 CardState; the reference sets them through tarot cards -- not on this path -- the harness
  * injects them directly, like env.card_states[idx] = CardState(...)): per env and deck INDEX (position in the shuffled
  * deck, 0..51) the enhancement (0 none, 1 BONUS, 2 MULT, 3 WILD, 4 GLASS, 5 STEEL, 6 STONE, 7 GOLD, 8 LUCKY), edition
@@ -256,8 +269,35 @@ int bg_refill(bg_handle* h, void* stream);
 int bg_set_profiling(bg_handle* h, int enable);
 int bg_get_profile(bg_handle* h, double* out8);
 
+/* Measurement hook (bench.py `roofline.peak_measured`): a plain streaming copy of `bytes` (16 B per lane, src -> dst, both
+ * 16-byte aligned device buffers) repeated `iters` times; *gbps_out = (bytes read + bytes written) / time.  SURVEY 8(d): the
+ * roofline fraction is quoted against the nominal 8 TB/s AND against what a copy kernel reaches on the same GPU. */
+int bg_bench_copy(const void* src_dev, void* dst_dev, uint64_t bytes, int iters, double* gbps_out, void* stream);
+
 /* Check the sticky device error word (synchronises the stream). */
 int bg_check(bg_handle* h, void* stream);
+
+/* ---- Operator-level entry points: the units the reference exposes as callables of their own, batched (lane = case).  They
+ * need no handle: they run on the CURRENT device, on caller-owned device buffers, and call the same device functions as the
+ * step path.  bg_last_error(NULL) gives the text of a failure. ---- */
+
+/* Replaces: `BalatroGame._classify_hand(cards)` (balatro_game.py:40-93).  cards_dev is [M, 8] card codes (rank-2)*4+suit
+ * (8-byte aligned), n_dev[i] in [0, 8] of them are valid; hand_type_dev[i] = HandType value 0..8 (scoring_engine.py:12-24). */
+int bg_classify_batch(const uint8_t* cards_dev, const uint8_t* n_dev, uint8_t* hand_type_dev, int64_t m, void* stream);
+
+/* Replaces: `UnifiedScorer.score_hand(ctx)` (unified_scoring.py:111-299) called with game_state['jokers'] = joker NAMES (as
+ * unified_scoring.py:313-351 does) after random.seed(gseed).  One int32[BG_SCORE_CASE_WORDS] record per case:
+ *   [0..23] 8 x (rank 2..14 | 0 for a STONE card, suit 0..3 = C D H S | 4 = 'Stone', chip_value()) = context.cards
+ *   [24] len(cards)  [25] the first nscoring of them are context.scoring_cards  [26] hand type 0..11
+ *   [27] name style: 0 = balatro_env_2.py:674 ('One Pair', 'Three Kind', 'Four Kind'), 1 = balatro_sim ('Pair', ...)
+ *   [28] hand level  [29] number of jokers  [30..34] joker ids (jokers.py)  [35] hands_left  [36] discards_left
+ *   [37] len(game_state['deck'])  [38] gseed (< 2**32)  [39] 0
+ * and one int64[BG_SCORE_OUT_WORDS] result: score, final chips, final mult, bits of the float64 x_mult, money gained, words
+ * of the global stream consumed, the word the NEXT getrandbits(32) would return (identifies the stream position), 0.
+ * Synchronises the stream. */
+#define BG_SCORE_CASE_WORDS 40
+#define BG_SCORE_OUT_WORDS 8
+int bg_score_hand_batch(const int32_t* cases_dev, int64_t* out_dev, int m, void* stream);
 
 #ifdef __cplusplus
 }

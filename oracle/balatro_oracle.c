@@ -453,6 +453,9 @@ void bo_set_consumables(bo_env* e, const int32_t* ids, int n) {
   e->nconsumables = e->tmpl_ncons;
   for (int i = 0; i < e->tmpl_ncons; i++) e->consumables[i] = ids[i];
 }
+/* harness injection: state.deck / game.deck (one aliased list, balatro_env_2.py:528-531) given a new order; the hand keeps its deck INDEXES */
+void bo_set_deck(bo_env* e, const uint8_t* codes52) { memcpy(e->deck, codes52, 52); }
+void bo_set_max_ante(bo_env* e, int max_ante) { e->max_ante = max_ante; } /* CurriculumBalatroEnv.current_max_ante (train_balatro_agent.py:129-166) */
 void bo_set_money(bo_env* e, int64_t money) { e->money = money; }
 void bo_set_ante(bo_env* e, int ante) { e->ante = ante; }
 void bo_set_hand_level(bo_env* e, int ht, int level) { e->hand_levels[ht] = (uint8_t)(level < 1 ? 1 : level > 15 ? 15 : level); e->obs_levels[ht] = e->hand_levels[ht]; }

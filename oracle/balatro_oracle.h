@@ -201,6 +201,8 @@ void bo_set_card_state(bo_env* e, int deck_idx, int enh, int edi, int seal);
 void bo_set_hand_level(bo_env* e, int hand_type, int level);
 void bo_set_template_jokers(bo_env* e, const int32_t* ids, int n); /* jokers now + after every reset in bo_rollout */
 void bo_set_consumables(bo_env* e, const int32_t* ids, int n);     /* harness injection: state.consumables by id (config 4) */
+void bo_set_deck(bo_env* e, const uint8_t* codes52); /* harness injection: the live deck order (state.deck) */
+void bo_set_max_ante(bo_env* e, int max_ante); /* the curriculum cap of this env (0 = none) */
 void bo_set_money(bo_env* e, int64_t money);   /* harness injection: state.money */
 void bo_set_ante(bo_env* e, int ante);         /* harness injection: state.ante */
 int bo_policy_action(const bo_env* e, int policy, uint64_t policy_seed, uint64_t env_index, uint64_t t);

@@ -108,6 +108,8 @@ def lib():
         L.bo_set_hand_level.argtypes = [C.c_void_p, C.c_int, C.c_int]
         L.bo_set_template_jokers.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.bo_set_money.argtypes = [C.c_void_p, C.c_int64]
+        L.bo_set_deck.argtypes = [C.c_void_p, C.POINTER(C.c_uint8)]
+        L.bo_set_max_ante.argtypes = [C.c_void_p, C.c_int]
         L.bo_set_consumables.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.c_int]
         L.bo_set_ante.argtypes = [C.c_void_p, C.c_int]
         L.bo_policy_action.restype = C.c_int
@@ -203,6 +205,13 @@ class OracleEnv:
     def set_consumables(self, ids):
         arr = (C.c_int32 * max(1, len(ids)))(*ids)
         self._L.bo_set_consumables(self._h, arr, len(ids))
+
+    def set_deck(self, codes):
+        arr = (C.c_uint8 * 52)(*codes)
+        self._L.bo_set_deck(self._h, arr)
+
+    def set_max_ante(self, max_ante):
+        self._L.bo_set_max_ante(self._h, int(max_ante))
 
     def set_money(self, money):
         self._L.bo_set_money(self._h, money)

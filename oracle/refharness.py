@@ -204,6 +204,12 @@ class RefEnv:
         """state.consumables by the ids of _get_consumable_ids (balatro_env_2.py:1545-1567)."""
         self.env.state.consumables = [self.CONSUMABLE_NAMES[i] for i in ids]
 
+    def set_deck(self, codes):
+        """state.deck / game.deck (ONE aliased list, balatro_env_2.py:528-531) re-ordered in place: codes are (rank-2)*4+suit."""
+        c = self.ref["cards"]
+        self.env.state.deck[:] = [c.Card(rank=c.Rank(v // 4 + 2), suit=c.Suit(v % 4)) for v in codes]
+        assert self.env.game.deck is self.env.state.deck
+
     def set_money(self, money):
         self.env.state.money = money
 

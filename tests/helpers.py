@@ -51,3 +51,63 @@ def assert_obs_equal(got, want, ctx):
         assert g.shape == w.shape, f"{ctx}: obs[{k}] shape {g.shape} vs {w.shape}"
         if not np.array_equal(g, w):
             raise AssertionError(f"{ctx}: obs[{k}] got {g} want {w}")
+
+
+# ---------------------------------------------------------------------- forced hands (rare hand types on purpose)
+def _code(rank, suit):
+    return (rank - 2) * 4 + suit
+
+
+def forced_hand_cards(ht, rr):
+    """Card codes (1..5 of them) that BalatroGame._classify_hand (balatro_game.py:40-93) calls hand type `ht`."""
+    suits = list(range(4))
+    rr.shuffle(suits)
+    if ht == 8:  # straight flush (incl. the wheel A-2-3-4-5)
+        lo = rr.randint(1, 10)
+        ranks = [14, 2, 3, 4, 5] if lo == 1 else list(range(lo, lo + 5))
+        return [_code(r, suits[0]) for r in ranks]
+    if ht == 7:  # four of a kind, with or without a kicker
+        r = rr.randint(2, 14)
+        cards = [_code(r, s) for s in range(4)]
+        if rr.random() < 0.5:
+            cards.append(_code(rr.choice([x for x in range(2, 15) if x != r]), rr.randrange(4)))
+        return cards
+    if ht == 6:  # full house
+        a, b = rr.sample(range(2, 15), 2)
+        return [_code(a, s) for s in rr.sample(range(4), 3)] + [_code(b, s) for s in rr.sample(range(4), 2)]
+    if ht == 5:  # flush that is not a straight
+        while True:
+            ranks = sorted(rr.sample(range(2, 15), 5))
+            if ranks[4] - ranks[0] != 4 and ranks != [2, 3, 4, 5, 14]:
+                return [_code(r, suits[0]) for r in ranks]
+    if ht == 4:  # straight in at least two suits
+        lo = rr.randint(1, 10)
+        ranks = [14, 2, 3, 4, 5] if lo == 1 else list(range(lo, lo + 5))
+        ss = [suits[0], suits[1]] + [rr.randrange(4) for _ in range(3)]
+        return [_code(r, s) for r, s in zip(ranks, ss)]
+    if ht == 3:
+        r = rr.randint(2, 14)
+        return [_code(r, s) for s in rr.sample(range(4), 3)]
+    if ht == 2:
+        a, b = rr.sample(range(2, 15), 2)
+        return [_code(a, s) for s in rr.sample(range(4), 2)] + [_code(b, s) for s in rr.sample(range(4), 2)]
+    if ht == 1:
+        r = rr.randint(2, 14)
+        return [_code(r, s) for s in rr.sample(range(4), 2)]
+    return [_code(rr.randint(2, 14), rr.randrange(4))]
+
+
+def forced_deck(ht, rr):
+    """A 52-card deck whose first k cards form hand type `ht` (the hand after the blind choice is deck[0..7], and the
+    classifier reads deck[position]): returns (deck codes, k)."""
+    head = forced_hand_cards(ht, rr)
+    rest = [c for c in range(52) if c not in head]
+    rr.shuffle(rest)
+    return head + rest, len(head)
+
+
+def forced_hand_script(k, rr, blind=45):
+    """Actions of a forced-hand episode start: choose the blind, select positions 0..k-1 (in a random order), play."""
+    order = list(range(k))
+    rr.shuffle(order)
+    return [blind] + [2 + p for p in order] + [0]

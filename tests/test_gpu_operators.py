@@ -1,0 +1,182 @@
+"""GPU parity tests of the OPERATOR-level entry points (run with -m gpu): the units the reference exposes as callables of
+their own -- BalatroGame._classify_hand, UnifiedScorer.score_hand, BalatroSimulator.evaluate_hand / calculate_score -- batched
+through the C ABI, against the golden vectors generated from the Python reference (tests/golden/, oracle/gen_golden.py).
+These are the same device functions the step path runs, so hand types and joker combinations a random env almost never
+reaches (STRAIGHT_FLUSH, FLUSH, FOUR_KIND ...) get their GPU evidence here.  Everything is bit-exact (tolerance 0).
+"""
+import json
+import os
+import random
+import zlib
+from itertools import combinations
+
+import numpy as np
+import pytest
+
+from tests.helpers import GOLD, OBS_KEYS, forced_deck, forced_hand_script
+
+pytestmark = pytest.mark.gpu
+
+
+def test_classify_batch_golden():
+    """All 20 000 rows of classify.npz (random 1..8-card subsets) through bg_classify_batch."""
+    import torch
+    from balatro_gym_amd import classify_batch
+    g = np.load(os.path.join(GOLD, "classify.npz"))
+    dev = torch.device("cuda:0")
+    got = classify_batch(torch.from_numpy(g["cards"]).to(dev), torch.from_numpy(g["n"]).to(dev)).cpu().numpy()
+    bad = np.nonzero(got != g["hand_type"])[0]
+    assert bad.size == 0, f"row {bad[0]}: cards {g['cards'][bad[0]][:g['n'][bad[0]]]} got {got[bad[0]]} want {g['hand_type'][bad[0]]}"
+    counts = np.bincount(g["hand_type"], minlength=9)
+    assert (counts[:9] > 0).all()  # every hand type 0..8 occurs in the fixture
+
+
+def test_classify_batch_all_five_card_hands():
+    """Every one of the C(52,5) = 2 598 960 five-card hands in lexicographic order: per-type counts and the CRC32 of the type
+    sequence as the reference produced them (tests/golden/classify.npz all5_*)."""
+    import torch
+    from balatro_gym_amd import classify_batch
+    g = np.load(os.path.join(GOLD, "classify.npz"))
+    combos = np.fromiter((c for combo in combinations(range(52), 5) for c in combo), dtype=np.uint8, count=2598960 * 5).reshape(-1, 5)
+    cards = np.zeros((combos.shape[0], 8), np.uint8)
+    cards[:, :5] = combos
+    dev = torch.device("cuda:0")
+    n = torch.full((cards.shape[0],), 5, dtype=torch.uint8, device=dev)
+    got = classify_batch(torch.from_numpy(cards).to(dev), n).cpu().numpy()
+    assert np.bincount(got, minlength=12).tolist() == g["all5_counts"].tolist()
+    assert zlib.crc32(got.tobytes()) == int(g["all5_crc32"])
+
+
+def _score_cases():
+    cases = json.load(open(os.path.join(GOLD, "score_hand.json")))
+    rec = np.zeros((len(cases), 40), np.int32)
+    for i, c in enumerate(cases):
+        for k, (rank, suit, chips) in enumerate(c["cards"]):
+            rec[i, 3 * k:3 * k + 3] = (rank, suit, chips)
+        rec[i, 24], rec[i, 25], rec[i, 26], rec[i, 27], rec[i, 28] = len(c["cards"]), c["nscoring"], c["hand_type"], c["style"], c["level"]
+        rec[i, 29] = len(c["jokers"])
+        rec[i, 30:30 + len(c["jokers"])] = c["jokers"]
+        rec[i, 35], rec[i, 36], rec[i, 37] = c["hands_left"], c["discards_left"], c["deck_len"]
+        rec[i, 38] = np.uint32(c["gseed"]).astype(np.int32)
+    return cases, rec
+
+
+def test_score_hand_batch_golden():
+    """All 3 000 UnifiedScorer.score_hand cases (joker name lists of 0..5 from all 150 ids, both hand-name styles, scoring
+    subsets, STONE cards, levels 1..15): score, final chips / mult / x_mult bits, money, and the position of the global
+    stream afterwards (the next getrandbits(32) equals the reference's probe, i.e. exactly as many draws were consumed)."""
+    import torch
+    from balatro_gym_amd import score_hand_batch
+    cases, rec = _score_cases()
+    out = score_hand_batch(torch.from_numpy(rec).to("cuda:0")).cpu().numpy()
+    for i, c in enumerate(cases):
+        ctx = f"case {i}: {c} -> {out[i].tolist()}"
+        assert out[i, 0] == c["score"], ctx
+        assert out[i, 1] == c["chips"] and out[i, 2] == c["mult"], ctx
+        assert float(out[i, 3:4].view(np.float64)[0]).hex() == c["x_mult"], ctx
+        assert out[i, 4] == c["money"], ctx
+        assert out[i, 6] == c["probe"], ctx
+    assert len({c["hand_type"] for c in cases}) == 12 and any(c["style"] for c in cases)
+
+
+def test_score_hand_batch_vs_oracle_fresh_cases():
+    """20 000 fresh random cases (denser in jokers and in the hand types of the joker conditions than the fixture) against
+    the CPU oracle's bo_score_hand, incl. the number of words drawn."""
+    import torch
+    from balatro_gym_amd import score_hand_batch
+    from oracle import pyoracle as po
+    r = random.Random(2025)
+    M = 20000
+    rec = np.zeros((M, 40), np.int32)
+    want = []
+    for i in range(M):
+        ncards = r.randint(1, 8)
+        cards = []
+        for _ in range(ncards):
+            rank, suit = r.randint(2, 14), r.randrange(4)
+            chips = 11 if rank == 14 else min(rank, 10)
+            if r.random() < 0.08:
+                rank, suit, chips = 0, 4, chips + 50
+            elif r.random() < 0.2:
+                chips += r.choice([30, 50, 80])
+            cards.append((rank, suit, chips))
+        nsc = ncards if r.random() < 0.6 else r.randint(1, ncards)
+        style, ht, level = r.randrange(2), r.choice([0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 7, 8, 9, 10, 11]), r.choice([1, 1, 2, 7, 15])
+        jokers = r.sample(range(1, 151), r.randint(1, 5)) if r.random() < 0.3 else \
+            r.sample([1, 136, 27, 38, 61, 16, 34, 108, 23, 22, 53, 97, 50, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 131, 132, 133,
+                      134, 135, 48, 128, 122, 72, 140, 31, 39, 40, 41, 101, 124, 26, 33, 104, 147, 118, 119, 116, 117], r.randint(1, 5))
+        hl, dl, deck_len, gseed = r.randint(1, 4), r.randint(0, 3), r.choice([52, 52, 40, 47, 60]), r.randrange(2 ** 32)
+        for k, cd in enumerate(cards):
+            rec[i, 3 * k:3 * k + 3] = cd
+        rec[i, 24:29] = (ncards, nsc, ht, style, level)
+        rec[i, 29] = len(jokers)
+        rec[i, 30:30 + len(jokers)] = jokers
+        rec[i, 35:38] = (hl, dl, deck_len)
+        rec[i, 38] = np.uint32(gseed).astype(np.int32)
+        o = po.score_hand(cards, cards[:nsc], ht, style, level, jokers, hl, dl, deck_len, gseed)
+        want.append((o.score, o.chips, o.mult, np.float64(o.x_mult).view(np.int64), o.money, o.draws))
+    out = score_hand_batch(torch.from_numpy(rec).to("cuda:0")).cpu().numpy()
+    want = np.array(want, dtype=np.int64)
+    bad = np.nonzero((out[:, :6] != want).any(axis=1))[0]
+    assert bad.size == 0, f"case {bad[0]}: {rec[bad[0]].tolist()} got {out[bad[0]].tolist()} want {want[bad[0]].tolist()}"
+
+
+@pytest.mark.parametrize("scorer", [False, True])
+def test_forced_rare_hands_vs_oracle(scorer):
+    """Env-level: decks arranged so that the first play of every episode IS a chosen hand type (bg_inject_deck; a straight
+    flush / four of a kind / flush ... at deck[0..k-1], classified on deck[position]), at antes 1..8 with and
+    without jokers, small / big / boss blinds: reward shaping (hand quality, efficiency, strategy, synergy, the log10 score
+    term), final score and every observation key against the oracle, then 40 more steps of the counter-hash policy with the
+    highlights accumulating."""
+    import torch
+    from balatro_gym_amd import BalatroVecEnv
+    from oracle import pyoracle as po
+    n = 9 * 64
+    seeds = [123_000 + 11 * i for i in range(n)]
+    rr = random.Random(77)
+    hts = [i % 9 for i in range(n)]
+    decks, scripts = [], []
+    for i in range(n):
+        d, k = forced_deck(hts[i], rr)
+        decks.append(d)
+        scripts.append(forced_hand_script(k, rr, blind=[45, 46, 47][(i // 9) % 3]))
+    jokers = [rr.sample(range(1, 151), rr.randint(0, 5)) if i % 4 else [] for i in range(n)] if scorer else [[113, 40, 33][: i % 4] for i in range(n)]
+    antes = [1 + (i // 27) % 8 for i in range(n)]
+    env = BalatroVecEnv(n, seeds, device=0, scorer_jokers=scorer, autoreset=False, max_ante=0)
+    env.inject(jokers=jokers, ante=antes, apply_now=True)
+    env.inject_deck(decks)
+    orc = [po.OracleEnv(s, scorer_jokers=scorer) for s in seeds]
+    for o, js, a, d in zip(orc, jokers, antes, decks):
+        o.set_jokers(js); o.set_ante(a); o.set_deck(d)
+    seen = np.zeros(9, np.int64)
+    T = max(len(s) for s in scripts) + 40
+    for t in range(T):
+        acts = np.array([scripts[i][t] if t < len(scripts[i]) else o.policy_action(0, 31, i, t) for i, o in enumerate(orc)], dtype=np.int32)
+        res = [o.step(int(a)) for o, a in zip(orc, acts)]
+        _, reward, term, _, info = env.step(torch.from_numpy(acts).to(env.device))
+        ctx = f"scorer {scorer} t {t}"
+        wr = np.array([r[1] for r in res])
+        assert np.array_equal(reward.cpu().numpy().view(np.uint64), wr.view(np.uint64)), ctx
+        wt = np.array([r[2] for r in res], dtype=np.uint8)
+        assert np.array_equal(term.cpu().numpy(), wt), ctx
+        assert np.array_equal(info["final_score"].cpu().numpy(), np.array([r[4].final_score for r in res])), ctx
+        wh = np.array([r[4].hand_type for r in res], dtype=np.int8)
+        assert np.array_equal(info["hand_type"].cpu().numpy(), wh), ctx
+        assert np.array_equal(info["error"].cpu().numpy(), np.array([r[4].error for r in res], dtype=np.int32)), ctx
+        wterms = np.array([[r[4].reward_terms[q] for q in range(8)] for r in res])
+        assert np.array_equal(info["reward_terms"].cpu().numpy().view(np.uint64), wterms.view(np.uint64)), ctx
+        got = {k: v.cpu().numpy() for k, v in env.obs.items()}
+        for k in OBS_KEYS:
+            w = np.stack([r[0][k] for r in res])
+            assert np.array_equal(got[k], w), f"{ctx}: obs[{k}]"
+        for i in range(n):
+            if t == len(scripts[i]) - 1 and wh[i] >= 0:
+                assert wh[i] == hts[i], (i, wh[i], hts[i])  # the forced play produced the intended type (boss rejections aside)
+                seen[wh[i]] += 1
+        if wt.any():
+            for i in np.nonzero(wt)[0]:
+                orc[i].reset(); orc[i].set_jokers(jokers[i]); orc[i].set_ante(antes[i])
+            env.reset(mask=torch.from_numpy(wt).to(env.device))
+    env.check()
+    env.close()
+    assert (seen >= 30).all(), seen.tolist()  # every hand type, STRAIGHT_FLUSH included, was played dozens of times

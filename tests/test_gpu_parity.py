@@ -412,20 +412,6 @@ def test_inject_consumables_needs_card_states():
     env.close()
 
 
-def test_lane_per_env_rollout_kernel(monkeypatch):
-    """The first fused kernel (BG_ROLLOUT_V=1, lane = env, lockstep) is kept for A/B comparisons: same bits."""
-    monkeypatch.setenv("BG_ROLLOUT_V", "1")
-    test_fused_rollout_vs_oracle(2, True)
-
-
-def test_barrier_rollout_kernel(monkeypatch):
-    """The barrier-phased kernel (BG_ROLLOUT_V=2: two waves per workgroup alternate between the env phases and phase B) is
-    kept for A/B comparisons with the service-wave kernel: same bits."""
-    monkeypatch.setenv("BG_ROLLOUT_V", "2")
-    test_fused_rollout_vs_oracle(2, True)
-    test_consumables_rollout_vs_oracle(True)
-
-
 def test_wide_workgroup_rollout_kernel(monkeypatch):
     """The service-wave kernel with 256 envs per workgroup (the default from 65 536 envs on: four env waves, two play waves and
     two other waves that share the queues) at a small env count, incl. a last workgroup that is not full: same bits."""

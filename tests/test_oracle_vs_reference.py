@@ -112,6 +112,45 @@ def test_env_lockstep_immolate_cryptid():
                  cards=[(d, [0, 7, 4][d % 3], 0, [0, 4][d % 2]) for d in range(20)] if s % 4 == 0 else None)
 
 
+def test_env_lockstep_forced_rare_hands():
+    """Decks arranged so that the first play IS a chosen hand type (straight flush, four of a kind, flush ... at
+    deck[0..k-1]; classification reads deck[position]), at antes 1..8, small / big / boss blinds, with and without
+    scorer-level jokers: reference and oracle in lockstep through the play and 40 more steps."""
+    from tests.helpers import forced_deck, forced_hand_script
+    rr = random.Random(5)
+    seen = [0] * 9
+    for s in range(9 * 12):
+        ht, scorer = s % 9, bool((s // 9) & 1)
+        seed = 9900 + s
+        r = rh.RefEnv(seed, scorer_jokers=scorer)
+        o = po.OracleEnv(seed, scorer_jokers=scorer)
+        deck, k = forced_deck(ht, rr)
+        jokers = rr.sample(range(1, 151), rr.randint(0, 5)) if scorer else [113, 40, 33][: s % 4]
+        ante = 1 + (s // 18) % 8
+        for e in (r, o):
+            e.set_jokers(jokers); e.set_ante(ante); e.set_deck(deck)
+        script = forced_hand_script(k, rr, blind=[45, 46, 47][(s // 9) % 3])
+        obs_r = r.obs()
+        assert_obs_equal(o.obs(), obs_r, f"forced {s} initial")
+        for t in range(len(script) + 40):
+            a = script[t] if t < len(script) else rh.policy_action(obs_r["action_mask"], int(obs_r["phase"]), 0, 31, s, t)
+            obs_r, rr_, tr, _, ir = r.step(a)
+            obs_o, ro, to, _, io = o.step(a)
+            ctx = f"forced {s} ht {ht} t {t} action {a}"
+            assert_obs_equal(obs_o, obs_r, ctx)
+            assert ro == rr_ and to == tr, f"{ctx}: reward {ro!r} vs {rr_!r}"
+            if "final_score" in ir:
+                assert io.final_score == ir["final_score"] and io.hand_type == int(ir["hand_type"]), ctx
+                for i, kk in enumerate(TERMS):
+                    assert io.reward_terms[i] == float(ir["reward_breakdown"][kk]), f"{ctx}: {kk}"
+                if t == len(script) - 1:
+                    assert io.hand_type == ht, ctx
+                    seen[ht] += 1
+            if tr:
+                break
+    assert min(seen) >= 6, seen
+
+
 def test_reseed_reproduces_first_shuffle():
     """reset(seed=s) rebuilds the streams (balatro_env_2.py:507-509); reset() continues them."""
     r = rh.RefEnv(42)
