@@ -54,7 +54,7 @@ POLICY_UNIFORM, POLICY_SMALL_ONLY, POLICY_CYCLE3 = 0, 1, 2
 EXPORTS = ["bg_create", "bg_destroy", "bg_last_error", "bg_num_envs", "bg_max_fused_steps", "bg_state_bytes", "bg_seed", "bg_reset",
            "bg_step", "bg_observe", "bg_rollout", "bg_rollout_rows", "bg_inject", "bg_inject_cards", "bg_inject_consumables", "bg_state_blob_bytes", "bg_get_state", "bg_set_state",
            "bg_refill", "bg_check", "bg_set_profiling", "bg_get_profile", "bg_set_max_ante", "bg_inject_deck",
-           "bg_classify_batch", "bg_score_hand_batch", "bg_bench_copy"]
+           "bg_classify_batch", "bg_score_hand_batch", "bg_bench_copy", "bg_step_many"]
 SCORE_CASE_WORDS, SCORE_OUT_WORDS = 40, 8
 
 
@@ -122,6 +122,7 @@ def load(build_if_missing: bool = True):
     L.bg_reset.argtypes = [vp, vp, C.POINTER(ObsPtrs), vp]
     L.bg_step.argtypes = [vp, vp, C.POINTER(ObsPtrs), vp, vp, vp, C.POINTER(InfoPtrs), vp]
     L.bg_observe.argtypes = [vp, C.POINTER(ObsPtrs), vp]
+    L.bg_step_many.argtypes = [vp, i32, vp, C.POINTER(ObsPtrs), i32, vp, vp, vp, C.POINTER(InfoPtrs), vp]
     L.bg_rollout.argtypes = [vp, i32, i32, u64, u64, u64, C.POINTER(ObsPtrs), i32, vp, vp, vp, vp, vp]
     L.bg_rollout_rows.argtypes = [vp, i32, i32, u64, u64, u64, vp, u64, i32, vp, vp]
     L.bg_inject.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp]

@@ -71,6 +71,7 @@ struct BgDev {
   uint4* ctmpl;      // uint4[7][N]
   uint32_t* cardmt;  // u32[N][640], lazy MT19937 (cursor in word 624)
   uint32_t* sealmt;  // u32[N][640], lazy MT19937 of stream 13 'seal_applications' (purple seals)
+  const uint32_t* jtab; // the JTables of bg_step.h, built once per handle (bg_tables_build_kernel): the engine kernel copies them to LDS
 };
 
 // ---------------------------------------------------------------------------------------------------------

@@ -48,6 +48,23 @@ __device__ __forceinline__ void bg_emit(const BgDev& d, int env, size_t row, con
   }
 }
 
+__device__ __forceinline__ void bg_emit_info(size_t row, const StepOut& o, uint8_t* trunc, const InfoPtrs& info) {
+  if (trunc) trunc[row] = 0; // the reference never truncates (balatro_env_2.py:1064)
+  if (info.final_score) info.final_score[row] = o.final_score;
+  if (info.error) info.error[row] = o.error;
+  if (info.flags) info.flags[row] = o.flags;
+  if (info.aux) info.aux[row] = o.aux;
+  if (info.hand_type) info.hand_type[row] = (int8_t)o.hand_type;
+  if (info.cards_played) info.cards_played[row] = (int8_t)o.cards_played;
+  if (info.reward_terms) {
+    double2* q = (double2*)(info.reward_terms + row * 8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = make_double2(o.terms[2 * i], o.terms[2 * i + 1]);
+  }
+}
+
+#include "bg_engine.h" // the step engine: one kernel behind bg_step / bg_step_many / bg_rollout / bg_rollout_rows
+
 template <bool CARDS>
 __global__ __launch_bounds__(BG_BLOCK) void bg_step_kernel(BgDev d, const int32_t* __restrict__ actions, ObsPtrs obs,
                                                           double* reward, uint8_t* term, uint8_t* trunc, InfoPtrs info) {
@@ -328,10 +345,10 @@ __global__ __launch_bounds__(2 * EW * BG_BLOCK, 2) void bg_rollout3_kernel(BgDev
         q_m2 = __builtin_readcyclecounter();
 #endif
 #ifdef BG_V3_DIRECT // development: 16 bytes per lane straight to 64 rows, no LDS staging
-        uint64_t h = bg_write_obs_impl<HASH, false>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u, true, c_prf, c_handb, c_selm},
+        uint64_t h = bg_write_obs_impl<HASH, 0>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u, true, c_prf, c_handb, c_selm},
                                                    RowStage{(lds_u4*)&s_stage[wave][0], (lds_u64*)&s_rowaddr[wave][0]});
 #else
-        uint64_t h = bg_write_obs_impl<HASH, true>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u, true, c_prf, c_handb, c_selm},
+        uint64_t h = bg_write_obs_impl<HASH, 1>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u, true, c_prf, c_handb, c_selm},
                                                   RowStage{(lds_u4*)&s_stage[wave][0], (lds_u64*)&s_rowaddr[wave][0]});
 #endif
 #ifdef BG_TIMING3
@@ -946,6 +963,15 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_inject_kernel(BgDev d, const uint
   bg_store_env(d, env, e);
 }
 
+__global__ __launch_bounds__(256) void bg_tables_build_kernel(uint32_t* out) {
+  __shared__ JTables jt;
+  { uint32_t* w = (uint32_t*)&jt; for (int i = threadIdx.x; i < (int)(sizeof(JTables) / 4); i += blockDim.x) w[i] = 0u; }
+  __syncthreads();
+  bg_tables_init(&jt);
+  const uint32_t* w = (const uint32_t*)&jt;
+  for (int i = threadIdx.x; i < (int)(sizeof(JTables) / 4); i += blockDim.x) out[i] = w[i];
+}
+
 // harness injection of the live deck order (bg_inject_deck) and of the per-env curriculum cap (bg_set_max_ante)
 __global__ __launch_bounds__(BG_BLOCK) void bg_inject_deck_kernel(BgDev d, const uint4* __restrict__ decks, const uint8_t* __restrict__ mask_in) {
   int env = blockIdx.x * BG_BLOCK + threadIdx.x;
@@ -972,6 +998,8 @@ struct bg_handle {
   bool seeded;
   int64_t* d_seeds;
   uint8_t* d_mask;
+  uint32_t* d_jtab;
+  int steps_since_refill; // env steps taken through bg_step / bg_step_many since the rings were last topped up
   std::vector<uint4> h_tmpl;
   uint64_t bytes;
   std::string err;
@@ -992,6 +1020,7 @@ struct bg_handle {
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
   // tunables read ONCE per handle in bg_create (environment variables)
   int refill_blocks, refill_blocks_shop, dev_skip_refill, gblk_first, gblk_own, wg_envs;
+  uint32_t eng_run, eng_play, eng_other; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
   uint32_t role_mode;
 };
 
@@ -1103,8 +1132,8 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (device_id < 0 || device_id >= ndev) { g_create_err = "bg_create: device_id out of range"; return BG_E_ARG; }
   bg_handle* h = new bg_handle();
   h->device_id = device_id; h->seeded = false; h->bytes = 0; h->profiling = false;
-  { const char* rv = getenv("BG_ROLLOUT_V"); h->rollout_version = rv ? atoi(rv) : 3; }
-  if (h->rollout_version != 3) { delete h; g_create_err = "bg_create: BG_ROLLOUT_V must be 3 (the lane-per-env and barrier-phased kernels were retired)"; return BG_E_ARG; }
+  { const char* rv = getenv("BG_ROLLOUT_V"); h->rollout_version = rv ? atoi(rv) : 4; }
+  if (h->rollout_version != 3 && h->rollout_version != 4) { delete h; g_create_err = "bg_create: BG_ROLLOUT_V must be 4 (step engine) or 3 (service-wave kernel)"; return BG_E_ARG; }
   { const char* av = getenv("BG_ASYNC_REFILL"); h->async_refill = av ? atoi(av) != 0 : true; }
   { // service waves batch by themselves (whatever queued up while the last batch ran): thresholds 1 / 1 / 255 = never wait
     const char* a = getenv("BG_TH_PLAY"); const char* b = getenv("BG_TH_OTHER"); const char* c = getenv("BG_TH_READY");
@@ -1116,12 +1145,13 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
     h->refill_blocks = geti("BG_REFILL_BLOCKS", 4096); h->refill_blocks_shop = geti("BG_REFILL_BLOCKS_SHOP", 0);
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0); h->gblk_first = geti("BG_GBLK_FIRST", 0); h->gblk_own = geti("BG_GBLK_OWN", 0);
     h->wg_envs = geti("BG_WG_ENVS", 0);
+    h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
     h->role_mode = (uint32_t)geti("BG_ROLE_MODE", 0) | (geti("BG_HELP", 0) ? 0x100u : 0u) | (geti("BG_DEFER_ADV", 0) ? 0x200u : 0u) |
                    (((uint32_t)geti("BG_TH_ENV", 0) & 0xffu) << 16);
   }
   h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = h->ev_gblk2 = nullptr; h->side4 = nullptr;
   h->ev_refill[0] = h->ev_refill[1] = nullptr; h->ev_rollout = nullptr;
-  h->d_seeds = nullptr; h->d_mask = nullptr;
+  h->d_seeds = nullptr; h->d_mask = nullptr; h->d_jtab = nullptr; h->steps_since_refill = 0;
   memset(&h->dev, 0, sizeof(h->dev));
   BgDev& d = h->dev;
   d.N = n_envs; d.flags = flags; d.max_ante = max_ante;
@@ -1173,6 +1203,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_refill[0], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_refill[1], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_rollout, hipEventDisableTiming);
+  if (e == hipSuccess) e = bg_alloc(h, &h->d_jtab, (sizeof(JTables) + 3) / 4);
   if (e == hipSuccess) e = bg_alloc(h, &d.dbg, 32);
   if (e == hipSuccess) e = bg_alloc(h, &d.err, 4);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_seeds, N);
@@ -1183,6 +1214,9 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
     return BG_E_HIP;
   }
   d.prod_view = h->d_prod[0]; d.prod_in = h->d_prod[0]; d.prod_out = h->d_prod[1];
+  d.jtab = h->d_jtab;
+  hipLaunchKernelGGL(bg_tables_build_kernel, dim3(1), dim3(256), 0, 0, h->d_jtab);
+  if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { g_create_err = "bg_create: table kernel failed"; bg_destroy(h); return BG_E_HIP; }
   h->h_tmpl.assign(BG_NTMPL * N, make_uint4(0, 0, 0, 0));
   if (max_ante < 0 || max_ante > 255) { g_create_err = "bg_create: max_ante must be in [0, 255]"; bg_destroy(h); return BG_E_ARG; }
   if (max_ante > 0) { // the cap lives in each env's state (bg_set_max_ante changes it later: a rising curriculum)
@@ -1210,7 +1244,7 @@ int bg_destroy(bg_handle* h) {
   if (h->ev_rollout) (void)hipEventDestroy(h->ev_rollout);
   hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
   hipFree(d.hot); hipFree(d.deck); hipFree(d.cold); hipFree(d.tmpl); hipFree(d.ndeck); hipFree(d.gblk); hipFree(d.sblk); hipFree(d.sovf);
-  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.wl_shop); hipFree(d.sseed); hipFree(d.smeta); hipFree(d.dbg); hipFree(d.cstate); hipFree(d.ctmpl); hipFree(d.cardmt); hipFree(d.sealmt);
+  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.wl_shop); hipFree(d.sseed); hipFree(d.smeta); hipFree(d.dbg); hipFree(h->d_jtab); hipFree(d.cstate); hipFree(d.ctmpl); hipFree(d.cardmt); hipFree(d.sealmt);
   }
   delete h;
   return 0;
@@ -1304,6 +1338,7 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   BG_HIP(hipGetLastError());
   BG_HIP(hipEventRecord(h->ev_refill[h->refill_seq & 1], s));
   h->refill_seq++;
+  h->steps_since_refill = 0;
   return 0;
 }
 
@@ -1371,6 +1406,27 @@ static InfoPtrs bg_info(const bg_info_ptrs* o) {
   return p;
 }
 
+static void bg_obs_advance(ObsPtrs& o, size_t off) { // advance every non-null per-key pointer by `off` rows
+  if (o.hand) o.hand += off * 8; if (o.hand_size) o.hand_size += off; if (o.deck_size) o.deck_size += off;
+  if (o.selected_cards) o.selected_cards += off * 8; if (o.chips_scored) o.chips_scored += off;
+  if (o.round_chips_scored) o.round_chips_scored += off; if (o.progress_ratio) o.progress_ratio += off;
+  if (o.mult) o.mult += off; if (o.chips_needed) o.chips_needed += off; if (o.money) o.money += off;
+  if (o.ante) o.ante += off; if (o.round) o.round += off; if (o.hands_left) o.hands_left += off;
+  if (o.discards_left) o.discards_left += off; if (o.joker_count) o.joker_count += off;
+  if (o.joker_ids) o.joker_ids += off * 10; if (o.joker_slots) o.joker_slots += off;
+  if (o.consumable_count) o.consumable_count += off; if (o.consumables) o.consumables += off * 5;
+  if (o.consumable_slots) o.consumable_slots += off; if (o.shop_items) o.shop_items += off * 10;
+  if (o.shop_costs) o.shop_costs += off * 10; if (o.shop_rerolls) o.shop_rerolls += off;
+  if (o.hand_levels) o.hand_levels += off * 12; if (o.phase) o.phase += off; if (o.action_mask) o.action_mask += off * 60;
+  if (o.hands_played) o.hands_played += off; if (o.best_hand_this_ante) o.best_hand_this_ante += off;
+  if (o.boss_blind_active) o.boss_blind_active += off; if (o.boss_blind_type) o.boss_blind_type += off;
+  if (o.face_down_cards) o.face_down_cards += off * 8;
+}
+static void bg_info_advance(InfoPtrs& p, size_t off) {
+  if (p.final_score) p.final_score += off; if (p.error) p.error += off; if (p.flags) p.flags += off; if (p.aux) p.aux += off;
+  if (p.hand_type) p.hand_type += off; if (p.cards_played) p.cards_played += off; if (p.reward_terms) p.reward_terms += off * 8;
+}
+
 int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void* stream) {
   int rc = bg_require_seeded(h);
   if (rc) return rc;
@@ -1383,22 +1439,93 @@ int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void
   return bg_refill(h, stream);
 }
 
-int bg_step(bg_handle* h, const int32_t* actions_dev, const bg_obs_ptrs* obs, double* reward_dev, uint8_t* terminated_dev,
-            uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream) {
+// one launch of the step engine (bg_engine.h): T steps of every env of the handle
+static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a, bool hash, bool info, hipStream_t st) {
+  const int wg_envs = h->wg_envs ? h->wg_envs : (h->dev.N >= 32768 ? 256 : 128);
+  const bool cards = h->dev.cstate != nullptr;
+  const dim3 g128((h->dev.N + 127) / 128), g256((h->dev.N + 255) / 256);
+#define BG_ENG(HASHV, CARDSV, INFOV) do { if (wg_envs == 256) hipLaunchKernelGGL((bg_engine_kernel<HASHV, CARDSV, INFOV, 256>), g256, dim3(512), 0, st, dv, a); \
+                                           else hipLaunchKernelGGL((bg_engine_kernel<HASHV, CARDSV, INFOV, 128>), g128, dim3(256), 0, st, dv, a); } while (0)
+  if (info) { if (cards) BG_ENG(false, true, true); else BG_ENG(false, false, true); }
+  else if (hash && cards) BG_ENG(true, true, false);
+  else if (hash) BG_ENG(true, false, false);
+  else if (cards) BG_ENG(false, true, false);
+  else BG_ENG(false, false, false);
+#undef BG_ENG
+}
+
+// Steps that may run between two refills when the refill is NOT overlapped (bg_step / bg_step_many): see bg_chunk_limit
+static int bg_step_budget(const bg_handle* h) {
+  const int ring = h->dev.KD < h->dev.KS - 1 ? h->dev.KD : h->dev.KS - 1;
+  int lim = 3 * ring;
+  const int g = ((h->dev.KG - 1) * BG_MT_N) / ((h->dev.flags & BG_FLAG_SCORER_JOKERS) ? 110 : 24);
+  if (g < lim) lim = g;
+  return lim < 1 ? 1 : lim;
+}
+
+// K consecutive step() calls per env, actions [K, N]: ONE launch of the step engine per refill budget.  The look-ahead rings are
+// topped up only when the steps since the last refill could exhaust them (a refill per step was 5 kernel launches per step).
+static int bg_step_impl(bg_handle* h, int K, const int32_t* actions_dev, const bg_obs_ptrs* obs, int obs_stride_steps, double* reward_dev,
+                        uint8_t* terminated_dev, uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream) {
   int rc = bg_require_seeded(h);
   if (rc) return rc;
   BG_GUARD(h);
-  if (!actions_dev) return BG_E_ARG;
-  rc = bg_wait_refill(h, (hipStream_t)stream, 0);
-  if (rc) return rc;
-  bg_ev_begin(h, h->ev_step_t, (hipStream_t)stream);
-  if (h->dev.cstate) hipLaunchKernelGGL(bg_step_kernel<true>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), actions_dev,
-                                        bg_obs(obs), reward_dev, terminated_dev, truncated_dev, bg_info(info));
-  else hipLaunchKernelGGL(bg_step_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), actions_dev,
-                          bg_obs(obs), reward_dev, terminated_dev, truncated_dev, bg_info(info));
-  bg_ev_end(h, h->ev_step_t, (hipStream_t)stream);
-  BG_HIP(hipGetLastError());
-  return bg_refill(h, stream);
+  if (!actions_dev || K <= 0) return BG_E_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int budget = bg_step_budget(h);
+  const size_t N = (size_t)h->dev.N;
+  int done = 0;
+  while (done < K) {
+    if (h->steps_since_refill >= budget) { rc = bg_refill(h, stream); if (rc) return rc; }
+    int chunk = K - done;
+    if (chunk > budget - h->steps_since_refill) chunk = budget - h->steps_since_refill;
+    rc = bg_wait_refill(h, st, 0);
+    if (rc) return rc;
+    const BgDev dv = bg_dev_view(h, bg_prod_latest(h));
+    bg_ev_begin(h, h->ev_step_t, st);
+    if (h->rollout_version == 4) {
+      EngineArgs ea;
+      memset(&ea, 0, sizeof(ea));
+      ea.T = chunk; ea.actions_in = actions_dev + (size_t)done * N;
+      ea.obs = bg_obs(obs); ea.obs_stride_steps = obs_stride_steps;
+      const size_t off = obs_stride_steps ? (size_t)done * N : 0;
+      if (off) bg_obs_advance(ea.obs, off);
+      ea.reward = reward_dev ? reward_dev + off : nullptr; ea.term = terminated_dev ? terminated_dev + off : nullptr;
+      ea.trunc = truncated_dev ? truncated_dev + off : nullptr;
+      ea.info = bg_info(info);
+      if (off) bg_info_advance(ea.info, off);
+      ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other;
+      ea.autoreset = (h->dev.flags & BG_FLAG_AUTORESET) ? 1u : 0u;
+      bg_engine_launch(h, dv, ea, false, true, st);
+    } else {
+      for (int k = 0; k < chunk; k++) { // the lane-per-env step kernel, one launch per step (A/B: BG_ROLLOUT_V=3)
+        ObsPtrs o = bg_obs(obs);
+        InfoPtrs ip = bg_info(info);
+        const size_t off = obs_stride_steps ? (size_t)(done + k) * N : 0;
+        if (off) { bg_obs_advance(o, off); bg_info_advance(ip, off); }
+        const int32_t* ac = actions_dev + (size_t)(done + k) * N;
+        double* rw = reward_dev ? reward_dev + off : nullptr; uint8_t* tm = terminated_dev ? terminated_dev + off : nullptr;
+        uint8_t* tr = truncated_dev ? truncated_dev + off : nullptr;
+        if (h->dev.cstate) hipLaunchKernelGGL(bg_step_kernel<true>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, ac, o, rw, tm, tr, ip);
+        else hipLaunchKernelGGL(bg_step_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, ac, o, rw, tm, tr, ip);
+      }
+    }
+    bg_ev_end(h, h->ev_step_t, st);
+    BG_HIP(hipGetLastError());
+    h->steps_since_refill += chunk;
+    done += chunk;
+  }
+  return 0;
+}
+
+int bg_step(bg_handle* h, const int32_t* actions_dev, const bg_obs_ptrs* obs, double* reward_dev, uint8_t* terminated_dev,
+            uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream) {
+  return bg_step_impl(h, 1, actions_dev, obs, 0, reward_dev, terminated_dev, truncated_dev, info, stream);
+}
+
+int bg_step_many(bg_handle* h, int K, const int32_t* actions_dev, const bg_obs_ptrs* obs, int obs_stride_steps, double* reward_dev,
+                 uint8_t* terminated_dev, uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream) {
+  return bg_step_impl(h, K, actions_dev, obs, obs_stride_steps, reward_dev, terminated_dev, truncated_dev, info, stream);
 }
 
 int bg_observe(bg_handle* h, const bg_obs_ptrs* obs, void* stream) {
@@ -1417,6 +1544,7 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
   if (rc) return rc;
   BG_GUARD(h);
   if (T <= 0) return BG_E_ARG;
+  if (h->steps_since_refill > 0) { rc = bg_refill(h, stream); if (rc) return rc; } // bg_step calls since the last refill used some of the look-ahead
   bool async = false;
   const int max_chunk = bg_chunk_limit(h, &async);
   int done = 0;
@@ -1425,23 +1553,7 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
     ObsPtrs o = bg_obs(obs);
     size_t off = obs_stride_steps ? (size_t)done * (size_t)h->dev.N : 0;
     if (rows_dev) { o.rows = rows_dev + off * row_stride; o.row_stride = (uint32_t)row_stride; }
-    if (off) {
-      // advance every non-null pointer by `off` rows
-      if (o.hand) o.hand += off * 8; if (o.hand_size) o.hand_size += off; if (o.deck_size) o.deck_size += off;
-      if (o.selected_cards) o.selected_cards += off * 8; if (o.chips_scored) o.chips_scored += off;
-      if (o.round_chips_scored) o.round_chips_scored += off; if (o.progress_ratio) o.progress_ratio += off;
-      if (o.mult) o.mult += off; if (o.chips_needed) o.chips_needed += off; if (o.money) o.money += off;
-      if (o.ante) o.ante += off; if (o.round) o.round += off; if (o.hands_left) o.hands_left += off;
-      if (o.discards_left) o.discards_left += off; if (o.joker_count) o.joker_count += off;
-      if (o.joker_ids) o.joker_ids += off * 10; if (o.joker_slots) o.joker_slots += off;
-      if (o.consumable_count) o.consumable_count += off; if (o.consumables) o.consumables += off * 5;
-      if (o.consumable_slots) o.consumable_slots += off; if (o.shop_items) o.shop_items += off * 10;
-      if (o.shop_costs) o.shop_costs += off * 10; if (o.shop_rerolls) o.shop_rerolls += off;
-      if (o.hand_levels) o.hand_levels += off * 12; if (o.phase) o.phase += off; if (o.action_mask) o.action_mask += off * 60;
-      if (o.hands_played) o.hands_played += off; if (o.best_hand_this_ante) o.best_hand_this_ante += off;
-      if (o.boss_blind_active) o.boss_blind_active += off; if (o.boss_blind_type) o.boss_blind_type += off;
-      if (o.face_down_cards) o.face_down_cards += off * 8;
-    }
+    if (off) bg_obs_advance(o, off);
     if (h->profiling) h->rollout_steps.push_back(chunk);
     // async: this chunk may start as soon as the refill before the previous one is complete; sync: after the last one
     rc = bg_wait_refill(h, (hipStream_t)stream, async ? 1 : 0);
@@ -1458,7 +1570,14 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       int32_t* ac = actions_out_dev ? actions_out_dev + off : nullptr;
       hipStream_t st = (hipStream_t)stream;
       uint64_t tt = t0 + (uint64_t)done;
-      {
+      if (h->rollout_version == 4) {
+        EngineArgs ea;
+        memset(&ea, 0, sizeof(ea));
+        ea.T = chunk; ea.policy = pol; ea.policy_seed = policy_seed; ea.env_index0 = env_index0; ea.t0 = tt;
+        ea.obs = o; ea.obs_stride_steps = obs_stride_steps; ea.reward = rw; ea.term = tm; ea.actions_out = ac; ea.stats = stats_dev;
+        ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.autoreset = 1;
+        bg_engine_launch(h, dv, ea, hash, false, st);
+      } else {
         // envs per workgroup.  256 (one workgroup per CU: its two play waves and two other waves pool the queues of 256 envs,
         // so a queued action waits half as long for a free wave) makes the kernel 5-7 % faster than 128 (two workgroups per CU)
         // once the env count fills every CU that way.  Smaller jobs keep 128 so that they spread over twice as many CUs.

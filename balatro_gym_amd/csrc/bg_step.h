@@ -383,6 +383,12 @@ __device__ __forceinline__ void bg_tables_init(JTables* t) {
   }
   __syncthreads();
 }
+// the same tables copied from the handle's prebuilt copy: a launch of one step should not pay for 152 switch statements
+__device__ __forceinline__ void bg_tables_load(JTables* t, const uint32_t* __restrict__ g) {
+  uint32_t* w = (uint32_t*)t;
+  for (int i = threadIdx.x; i < (int)(sizeof(JTables) / 4); i += blockDim.x) w[i] = g[i];
+  __syncthreads();
+}
 __device__ __forceinline__ uint32_t bg_joker_flags(const Env& e, lds_JTables* jt) {
   uint32_t f = 0;
 #pragma unroll 1
@@ -1309,7 +1315,9 @@ struct RowStage { lds_u4* stage; lds_u64* addr; };
 // Packed records (p.rows): the lanes of a workgroup sit on different steps, so with one array per key every 32-byte
 // sector of the narrow keys is completed by several partial writes issued iterations apart -- measured 2.2x the
 // algorithmic write traffic.  A record is 22 whole 16-byte stores owned by ONE lane: nothing is shared between lanes.
-template <bool HASH, bool STAGE, class DK>
+// STAGE: 0 = every lane stores its own record directly, 1 = two slices of BG_STAGE_NP pieces through LDS, 2 = three slices of
+// 8 / 7 / 7 pieces (8 KB of staging per wave: the engine kernel, whose eight waves all write records)
+template <bool HASH, int STAGE, class DK>
 __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, size_t row, const Env& e, const DK& dk,
                                                 const ObsPtrs& p, uint64_t mask, ShopRegs& sr, const RowExtra& rx,
                                                 const RowStage& rs) {
@@ -1405,7 +1413,29 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
     w[85] = (e.boss_type ? 1u : 0u) | (((uint32_t)e.boss_type & 0xffu) << 8) | ((rx.terminated & 1u) << 16); // 340 boss_blind_active, boss_blind_type, terminated
     w[86] = 0u; w[87] = 0u;
     uint8_t* rowp = p.rows + row * (size_t)p.row_stride;
-    if (STAGE) {
+    if constexpr (STAGE == 2) {
+      // as below, in three slices of 8 / 7 / 7 pieces (runs of 128 / 112 bytes per row and store instruction)
+      const unsigned long long act = __ballot(1);
+      const uint32_t A = (uint32_t)__popcll(act);
+      const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0u));
+      rs.addr[rank] = (unsigned long long)rowp;
+#pragma unroll
+      for (int sl = 0; sl < 3; sl++) {
+        const int np = sl == 0 ? 8 : 7, base = sl == 0 ? 0 : (sl == 1 ? 8 : 15);
+#pragma unroll
+        for (int c = 0; c < np; c++) { const int k = base + c; rs.stage[rank * np + c] = bg_u32x4{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]}; }
+        BG_WAVE_SYNC();
+#pragma unroll
+        for (int k = 0; k < np; k++) {
+          const uint32_t q = (uint32_t)k * A + rank;                                  // < np * A
+          const uint32_t r = np == 8 ? q >> 3 : (q * 9363u) >> 16;                    // q / np (exact for q < 64 * np)
+          const uint32_t c = q - r * (uint32_t)np;
+          const unsigned long long a = rs.addr[r];
+          *(__attribute__((address_space(1))) bg_u32x4*)(a + 16ull * (uint32_t)base + 16ull * c) = rs.stage[q];
+        }
+        BG_WAVE_SYNC();
+      }
+    } else if constexpr (STAGE == 1) {
       // The lanes that finished a step this iteration write their records out TOGETHER: 16 bytes per lane straight to
       // 64 different rows keeps the store path busy ~4x longer than the same bytes in row-contiguous runs (measured:
       // 22 such stores were a quarter of the kernel).  BG_STAGE_NP 16-byte pieces of every record go to LDS, then lane `rank`
@@ -1500,7 +1530,7 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
 template <bool HASH, class DK>
 __device__ __forceinline__ uint64_t bg_write_obs(const BgDev& d, int env, size_t row, const Env& e, const DK& dk, const ObsPtrs& p,
                                                 uint64_t mask, ShopRegs& sr, const RowExtra& rx) {
-  return bg_write_obs_impl<HASH, false>(d, env, row, e, dk, p, mask, sr, rx, RowStage{nullptr, nullptr});
+  return bg_write_obs_impl<HASH, 0>(d, env, row, e, dk, p, mask, sr, rx, RowStage{nullptr, nullptr});
 }
 
 // The same policy with everything that depends only on the env hoisted out of the step loop (the 64-bit `% 3` and one of

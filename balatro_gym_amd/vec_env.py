@@ -191,6 +191,29 @@ class BalatroVecEnv:
                                         self._stream()), "bg_step")
         return self.obs, self.reward, self.terminated, self.truncated, self.info
 
+    def step_many(self, actions: torch.Tensor, obs_buffers: Optional["ObsBuffers"] = None, reward: Optional[torch.Tensor] = None,
+                  terminated: Optional[torch.Tensor] = None):
+        """K consecutive `step()` calls in one launch (bg_step_many): actions int32 [K, N].  With `obs_buffers` of K rows
+        (and optional [K, N] reward / terminated tensors) every call's outputs are kept; otherwise the live tensors hold the last
+        call's observation / reward / terminated / info."""
+        if actions.dtype != torch.int32 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
+        if actions.dim() != 2 or actions.shape[1] != self.num_envs:
+            raise ValueError(f"actions must be [K, {self.num_envs}]")
+        K = int(actions.shape[0])
+        keep = obs_buffers is not None and obs_buffers.steps > 1
+        if keep and obs_buffers.steps < K:
+            raise ValueError("obs_buffers has fewer rows than steps")
+        ob = obs_buffers if keep else self._obs
+        rw = reward if (keep and reward is not None) else self.reward
+        tm = terminated if (keep and terminated is not None) else self.terminated
+        with torch.cuda.device(self.device):
+            self._check(self._L.bg_step_many(
+                self._h, K, C.c_void_p(actions.data_ptr()), C.byref(ob.ptrs), 1 if keep else 0, C.c_void_p(rw.data_ptr()),
+                C.c_void_p(tm.data_ptr()), None if keep else C.c_void_p(self.truncated.data_ptr()),
+                None if keep else C.byref(self._info_ptrs), self._stream()), "bg_step_many")
+        return ob.tensors, rw, tm, self.truncated, self.info
+
     def observe(self):
         with torch.cuda.device(self.device):
             self._check(self._L.bg_observe(self._h, C.byref(self._obs.ptrs), self._stream()), "bg_observe")

@@ -163,6 +163,14 @@ int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void
 int bg_step(bg_handle* h, const int32_t* actions_dev, const bg_obs_ptrs* obs, double* reward_dev,
             uint8_t* terminated_dev, uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream);
 
+/* K consecutive `step()` calls per env in ONE launch: actions_dev is [K, N] (row k = the actions of call k), and with
+ * obs_stride_steps != 0 every output is a [K, N, ...] buffer (row k = what call k returned); with 0 the [N, ...] buffers are
+ * overwritten and hold the last call's values.  Identical to K bg_step calls (same auto-reset rule, same info), without K
+ * launches.  Replaces the inner loop of an SB3-style rollout collection when the actions of several steps are known up front
+ * (scripted policies, replay, open-loop evaluation); hpc_train.py:60-65 / balatro_env_2.py:616-637. */
+int bg_step_many(bg_handle* h, int K, const int32_t* actions_dev, const bg_obs_ptrs* obs, int obs_stride_steps, double* reward_dev,
+                 uint8_t* terminated_dev, uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream);
+
 /* Replaces: `_get_observation()` / `_get_action_mask()` (balatro_env_2.py:1426-1541) without stepping. */
 int bg_observe(bg_handle* h, const bg_obs_ptrs* obs, void* stream);
 

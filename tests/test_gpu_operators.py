@@ -28,7 +28,7 @@ def test_classify_batch_golden():
     bad = np.nonzero(got != g["hand_type"])[0]
     assert bad.size == 0, f"row {bad[0]}: cards {g['cards'][bad[0]][:g['n'][bad[0]]]} got {got[bad[0]]} want {g['hand_type'][bad[0]]}"
     counts = np.bincount(g["hand_type"], minlength=9)
-    assert (counts[:9] > 0).all()  # every hand type 0..8 occurs in the fixture
+    assert (counts[:8] > 0).all()  # hand types 0..7 occur among the random subsets (straight flushes: the C(52,5) sweep below)
 
 
 def test_classify_batch_all_five_card_hands():
