@@ -7,11 +7,11 @@ steps tens of thousands of games in lockstep on one GPU; `ShardedBalatroVecEnv` 
 from .constants import Action, Phase  # noqa: F401
 
 __all__ = ["Action", "Phase", "BalatroEnv", "BalatroVecEnv", "BalatroSB3VecEnv", "ShardedBalatroVecEnv", "make_balatro_env",
-           "shard_range", "classify_batch", "score_hand_batch"]
+           "shard_range", "classify_batch", "score_hand_batch", "sim_evaluate_batch", "sim_score_batch"]
 
 
 def __getattr__(name):  # lazy: importing the package must not need torch / the GPU
-    if name in ("BalatroVecEnv", "ObsBuffers", "RowBuffers", "classify_batch", "score_hand_batch"):
+    if name in ("BalatroVecEnv", "ObsBuffers", "RowBuffers", "classify_batch", "score_hand_batch", "sim_evaluate_batch", "sim_score_batch"):
         from . import vec_env
         return getattr(vec_env, name)
     if name in ("BalatroEnv", "make_balatro_env"):

@@ -37,7 +37,8 @@ struct EngineArgs {
   const int32_t* actions_in;   // [T, N] actions (row t * N + env) or null = counter-hash policy on device
   InfoPtrs info;               // bg_step's info arrays (null pointers are skipped)
   bg_rollout_stats* stats;
-  uint32_t th_run, th_play, th_other; // a queue is served once it holds this many items -- or when nothing better is there
+  uint32_t th_run, th_play, th_other; // a queue is served once it holds this many items ...
+  uint32_t th_part;            // ... or, while other waves are busy (their envs will come back soon), this many; anything when no wave is busy
   uint32_t autoreset;          // SAME_STEP auto-reset of terminated envs
 };
 
@@ -66,10 +67,12 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
   __shared__ uint32_t s_q[3][NE];             // rings of env lanes (| action << 16 | VALID)
   __shared__ uint32_t s_tail[3], s_head[3];   // items ever queued / ever claimed per queue
   __shared__ uint32_t s_done;                 // envs that have finished their T steps
+  __shared__ uint32_t s_busy;                 // waves inside a batch
   __shared__ bg_u32x4 s_scratch[NW][BG_BLOCK * 8]; // per wave: record staging (8 KB), and the RNG window of a service batch (6 KB) before it
   __shared__ unsigned long long s_rowaddr[NW][BG_BLOCK];
   __shared__ JTables jt;
   __builtin_amdgcn_s_setprio(3);
+  BG_PROBE_INIT();
   bg_tables_load(&jt, d.jtab);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int env0 = blockIdx.x * NE;
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
   using DeckT = DeckLdsS<NE, CARDS>;
   // ---------------------------------------------------------------- prologue: HBM -> LDS, lane = env
   if (tid < 3) { s_tail[tid] = tid == BG_Q_RUN ? (uint32_t)n_live : 0u; s_head[tid] = 0; }
-  if (tid == 0) s_done = 0;
+  if (tid == 0) { s_done = 0; s_busy = 0; }
   if (tid < NE) {
     const int l = tid, env = env0 + l;
     s_q[BG_Q_PLAY][l] = 0; s_q[BG_Q_OTHER][l] = 0;
@@ -107,7 +110,17 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
   int64_t ssum = 0;
   const uint32_t bmod3 = (uint32_t)(a.env_index0 % 3ull);
   uint32_t polls = 0;
+#ifdef BG_TIMING4
+  unsigned long long q_batches[3] = {0, 0, 0}, q_items[3] = {0, 0, 0}, q_busy[3] = {0, 0, 0}, q_idle = 0, q_fail = 0, q_sec[3][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+  const unsigned long long q_t0 = __builtin_readcyclecounter();
+#define BG_Q(k) do { const unsigned long long _n = __builtin_readcyclecounter(); q_sec[cls][k] += _n - q_mark; q_mark = _n; } while (0)
+#else
+#define BG_Q(k) do {} while (0)
+#endif
   for (;;) {
+#ifdef BG_TIMING4
+    const unsigned long long q_l0 = __builtin_readcyclecounter();
+#endif
     // -- pick a queue: a full batch of runnable envs first (it feeds the others), then a service queue at its threshold, then
     //    whatever there is (work conserving)
     const uint32_t hr = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_head[BG_Q_RUN])), hp = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_head[BG_Q_PLAY])),
@@ -118,23 +131,43 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
     if (nr >= a.th_run) cls = BG_Q_RUN;
     else if (np >= a.th_play) cls = BG_Q_PLAY;
     else if (no >= a.th_other) cls = BG_Q_OTHER;
-    else if (nr) cls = BG_Q_RUN;
-    else if (np >= no && np) cls = BG_Q_PLAY;
-    else if (no) cls = BG_Q_OTHER;
+    else if (nr | np | no) {
+      // nothing is full.  While other waves are inside batches their envs will be back in a moment, so a small batch now only
+      // costs instructions at a low lane count; when no wave is busy nothing will ever arrive: take what there is.
+      const uint32_t busy = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_busy));
+      const uint32_t need = busy ? a.th_part : 1u;
+      if (nr >= need && nr >= np && nr >= no) cls = BG_Q_RUN;
+      else if (np >= need && np >= no) cls = BG_Q_PLAY;
+      else if (no >= need) cls = BG_Q_OTHER;
+      else if (nr >= need) cls = BG_Q_RUN;
+      else if (np >= need) cls = BG_Q_PLAY;
+    }
     if (cls < 0) {
       if (__builtin_amdgcn_readfirstlane(bg_lds_ld(&s_done)) >= (uint32_t)n_live) break; // every env has done its T steps
       __builtin_amdgcn_s_sleep(8);
       if (++polls > BG_SPIN_LIMIT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
+#ifdef BG_TIMING4
+      q_idle += __builtin_readcyclecounter() - q_l0;
+#endif
       continue;
     }
     const uint32_t head = cls == BG_Q_RUN ? hr : (cls == BG_Q_PLAY ? hp : ho), navail = cls == BG_Q_RUN ? nr : (cls == BG_Q_PLAY ? np : no);
     const uint32_t nb = navail > BG_BLOCK ? BG_BLOCK : navail;
     {
       uint32_t got = 0;
-      if (lane == 0) got = atomicCAS(&s_head[cls], head, head + nb) == head ? 1u : 0u; // another wave may be claiming the same items
-      if (__builtin_amdgcn_readfirstlane(got) == 0u) continue;
+      if (lane == 0) { got = atomicCAS(&s_head[cls], head, head + nb) == head ? 1u : 0u; if (got) __hip_atomic_fetch_add(&s_busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+      if (__builtin_amdgcn_readfirstlane(got) == 0u) {
+#ifdef BG_TIMING4
+        q_fail++;
+#endif
+        continue;
+      }
     }
     polls = 0;
+#ifdef BG_TIMING4
+    unsigned long long q_mark = __builtin_readcyclecounter();
+    const unsigned long long q_b0 = q_mark;
+#endif
     if ((uint32_t)lane < nb) {
       uint32_t* slotp = &s_q[cls][(head + (uint32_t)lane) & (NE - 1)];
       uint32_t item = bg_lds_ld(slotp);
@@ -153,6 +186,7 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
         DeckT dk; dk.col = (lds_u32*)&s_deck[0][l];
         const uint32_t t = s_t[l];
         uint64_t mask = s_mask[l];
+        BG_Q(0); // claim + state load / unpack
         StepOut o;
         bg_step_init(o);
         int action;
@@ -186,10 +220,11 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
           if (e.phase == 1 && (e.bflags & BG_BF_SHOP_EXISTS)) { sr.c3 = s_shop[0][l]; sr.c4 = s_shop[1][l]; sr.c5 = s_shop[2][l]; sr.c6 = s_shop[3][l]; sr.valid = true; }
           RngWin w;
           bg_win_init(w, (uint32_t*)&s_scratch[wave][0] + lane, &jt);
-          bg_env_dispatch(d, env, e, w, sr, dk, action, o);
+          { BG_PROBE_BEGIN(); bg_env_dispatch(d, env, e, w, sr, dk, action, o); BG_PROBE(cls == BG_Q_PLAY ? 20 : 21); }
           if (sr.valid) { s_shop[0][l] = sr.c3; s_shop[1][l] = sr.c4; s_shop[2][l] = sr.c5; s_shop[3][l] = sr.c6; }
           heavy = true;
         }
+        BG_Q(1); // policy + guards + cheap action / dispatch
         if (fin) {
           // ---- finish the step: curriculum cap, SAME_STEP auto-reset, mask, observation, outputs, statistics
           if (e.max_ante > 0 && e.ante > e.max_ante) { o.terminated = true; o.flags |= 256; }
@@ -206,9 +241,11 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
           else { handb = s_handb[l]; prf = s_prf[l]; selm = s_selm[l]; }
           if (!sr.valid && e.phase == 1 && (e.bflags & BG_BF_SHOP_EXISTS)) { sr.c3 = s_shop[0][l]; sr.c4 = s_shop[1][l]; sr.c5 = s_shop[2][l]; sr.c6 = s_shop[3][l]; sr.valid = true; }
           mask = bg_action_mask(d, env, e, sr);
+          BG_Q(2); // cap, reset, carried values, mask
           const size_t row = (size_t)env + (a.obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
           const uint64_t h = bg_write_obs_impl<HASH, 2>(d, env, row, e, dk, a.obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u, true, prf, handb, selm},
                                                        RowStage{(lds_u4*)&s_scratch[wave][0], (lds_u64*)&s_rowaddr[wave][0]});
+          BG_Q(3); // record
           if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(a.t0 + t)) + (a.env_index0 + (uint64_t)env);
           if (a.reward) a.reward[row] = o.reward;
           if (a.term) a.term[row] = o.terminated ? 1 : 0;
@@ -226,11 +263,25 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
             const uint32_t slot = __hip_atomic_fetch_add(&s_tail[BG_Q_RUN], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             bg_lds_st(&s_q[BG_Q_RUN][slot & (NE - 1)], (uint32_t)l | BG_ITEM_VALID);
           } else __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          BG_Q(4); // outputs, statistics, state store, requeue
         }
       }
     }
+    if (lane == 0) __hip_atomic_fetch_sub(&s_busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // after the pushes of this batch
+#ifdef BG_TIMING4
+    q_batches[cls]++; q_items[cls] += nb; q_busy[cls] += __builtin_readcyclecounter() - q_b0;
+#endif
   }
+#ifdef BG_TIMING4
+  if (lane == 0 && d.dbg) {
+    atomicAdd(&d.dbg[0], __builtin_readcyclecounter() - q_t0); atomicAdd(&d.dbg[1], 1ull);
+    for (int c = 0; c < 3; c++) { atomicAdd(&d.dbg[2 + 3 * c], q_batches[c]); atomicAdd(&d.dbg[3 + 3 * c], q_items[c]); atomicAdd(&d.dbg[4 + 3 * c], q_busy[c]); }
+    atomicAdd(&d.dbg[11], q_idle); atomicAdd(&d.dbg[12], q_fail);
+    for (int c = 0; c < 3; c++) for (int k = 0; k < 5; k++) atomicAdd(&d.dbg[16 + 5 * c + k], q_sec[c][k]);
+  }
+#endif
   // ---------------------------------------------------------------- epilogue: LDS -> HBM, statistics
+  BG_PROBE_FLUSH(d);
   __syncthreads();
   if (tid < n_live) {
 #pragma unroll

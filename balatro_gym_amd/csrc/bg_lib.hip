@@ -708,7 +708,8 @@ __device__ void bg_mt_twist(const uint32_t* src, uint32_t* dst) {
   }
 }
 
-#include "bg_ops.h" // operator-level batch kernels (classify / score_hand / balatro_sim): need bg_mt_seed, bg_mt_twist
+#include "bg_ops.h" // operator-level batch kernels (classify / score_hand): need bg_mt_seed, bg_mt_twist
+#include "bg_sim.h" // balatro_sim.py evaluator / scorer (operator-level)
 
 // DeterministicRNG(seed) (balatro_env_2.py:84-106) for streams 0 ('deck_shuffle') and 2 ('shop_generation'), plus the
 // per-env global stream seeded G(seed).  Streams are seeded `(master + 1000 * i) % 2**32` (:105).
@@ -1020,7 +1021,7 @@ struct bg_handle {
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
   // tunables read ONCE per handle in bg_create (environment variables)
   int refill_blocks, refill_blocks_shop, dev_skip_refill, gblk_first, gblk_own, wg_envs;
-  uint32_t eng_run, eng_play, eng_other; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
+  uint32_t eng_run, eng_play, eng_other, eng_part; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
   uint32_t role_mode;
 };
 
@@ -1146,6 +1147,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0); h->gblk_first = geti("BG_GBLK_FIRST", 0); h->gblk_own = geti("BG_GBLK_OWN", 0);
     h->wg_envs = geti("BG_WG_ENVS", 0);
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
+    h->eng_part = (uint32_t)geti("BG_ENG_PART", 1);
     h->role_mode = (uint32_t)geti("BG_ROLE_MODE", 0) | (geti("BG_HELP", 0) ? 0x100u : 0u) | (geti("BG_DEFER_ADV", 0) ? 0x200u : 0u) |
                    (((uint32_t)geti("BG_TH_ENV", 0) & 0xffu) << 16);
   }
@@ -1494,7 +1496,7 @@ static int bg_step_impl(bg_handle* h, int K, const int32_t* actions_dev, const b
       ea.trunc = truncated_dev ? truncated_dev + off : nullptr;
       ea.info = bg_info(info);
       if (off) bg_info_advance(ea.info, off);
-      ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other;
+      ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part;
       ea.autoreset = (h->dev.flags & BG_FLAG_AUTORESET) ? 1u : 0u;
       bg_engine_launch(h, dv, ea, false, true, st);
     } else {
@@ -1575,7 +1577,7 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
         memset(&ea, 0, sizeof(ea));
         ea.T = chunk; ea.policy = pol; ea.policy_seed = policy_seed; ea.env_index0 = env_index0; ea.t0 = tt;
         ea.obs = o; ea.obs_stride_steps = obs_stride_steps; ea.reward = rw; ea.term = tm; ea.actions_out = ac; ea.stats = stats_dev;
-        ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.autoreset = 1;
+        ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.autoreset = 1;
         bg_engine_launch(h, dv, ea, hash, false, st);
       } else {
         // envs per workgroup.  256 (one workgroup per CU: its two play waves and two other waves pool the queues of 256 envs,
@@ -1962,6 +1964,47 @@ int bg_score_hand_batch(const int32_t* cases_dev, int64_t* out_dev, int m, void*
   (void)hipFree(scratch);
   if (e != hipSuccess) { g_create_err = std::string("bg_score_hand_batch: ") + hipGetErrorString(e); return BG_E_HIP; }
   if (errw) { g_create_err = "bg_score_hand_batch: a case drew more than two blocks of the global stream"; return BG_E_INTERNAL; }
+  return 0;
+}
+
+// scratch of a batch op that draws from a per-case global stream: two MT19937 blocks per case + the device error word
+static int bg_batch_dev(BgDev& d, int m, uint32_t** scratch_out) {
+  memset(&d, 0, sizeof(d));
+  d.N = m; d.flags = BG_FLAG_SCORER_JOKERS; d.KG = 2; d.KS = 2; d.KD = 1;
+  uint32_t* scratch = nullptr;
+  BG_HIP0(hipMalloc((void**)&scratch, ((size_t)m * 2 * BG_MTS + 4) * sizeof(uint32_t)));
+  d.gblk = scratch; d.err = scratch + (size_t)m * 2 * BG_MTS;
+  *scratch_out = scratch;
+  return 0;
+}
+
+int bg_sim_evaluate_batch(const int32_t* hands_dev, const int32_t* n_dev, const int32_t* flags_dev, int8_t* out_dev, int m, void* stream) {
+  if (!hands_dev || !n_dev || !flags_dev || !out_dev || m < 0) { g_create_err = "bg_sim_evaluate_batch: bad arguments"; return BG_E_ARG; }
+  if (m == 0) return 0;
+  hipLaunchKernelGGL(bg_sim_evaluate_batch_kernel, dim3((m + BG_BLOCK - 1) / BG_BLOCK), dim3(BG_BLOCK), 0, (hipStream_t)stream, hands_dev, n_dev, flags_dev, out_dev, m);
+  BG_HIP0(hipGetLastError());
+  return 0;
+}
+
+int bg_sim_score_batch(const int32_t* cases_dev, int64_t* out_dev, int m, void* stream) {
+  if (!cases_dev || !out_dev || m < 0) { g_create_err = "bg_sim_score_batch: bad arguments"; return BG_E_ARG; }
+  if (m == 0) return 0;
+  hipStream_t s = (hipStream_t)stream;
+  BgDev d;
+  uint32_t* scratch = nullptr;
+  int rc = bg_batch_dev(d, m, &scratch);
+  if (rc) return rc;
+  hipError_t e = hipMemsetAsync(d.err, 0, 4 * sizeof(uint32_t), s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(bg_sim_score_batch_kernel, dim3((m + BG_BLOCK - 1) / BG_BLOCK), dim3(BG_BLOCK), 0, s, d, cases_dev, out_dev);
+    e = hipGetLastError();
+  }
+  uint32_t errw = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&errw, d.err, sizeof(errw), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  (void)hipFree(scratch);
+  if (e != hipSuccess) { g_create_err = std::string("bg_sim_score_batch: ") + hipGetErrorString(e); return BG_E_HIP; }
+  if (errw) { g_create_err = "bg_sim_score_batch: a case drew more than two blocks of the global stream"; return BG_E_INTERNAL; }
   return 0;
 }
 

@@ -1233,7 +1233,7 @@ __device__ __forceinline__ void bg_env_dispatch(const BgDev& d, int env, Env& e,
     else bg_use_consumable(d, env, e, w, dk, action - 10, o); // 10..14
   } else if (e.phase == 1) bg_step_shop(d, env, e, w, sr, action, o);
   else if (e.phase == 2) bg_step_blind<DK::kCards>(d, env, e, w, sr, action, o);
-  if (w.need_inv) { bg_shop_inventory(d, env, e, w, sr); w.need_inv = false; }
+  if (w.need_inv) { BG_PROBE_BEGIN(); bg_shop_inventory(d, env, e, w, sr); w.need_inv = false; BG_PROBE(22); }
 }
 
 // the guards in front of the dispatch (balatro_env_2.py:619-627); returns true when the action must be dispatched

@@ -414,3 +414,37 @@ def score_hand_batch(cases: torch.Tensor) -> torch.Tensor:
     if rc != 0:
         raise nat.NativeError(f"bg_score_hand_batch failed ({rc}): {L.bg_last_error(None).decode()}")
     return out
+
+
+def sim_evaluate_batch(hands: torch.Tensor, n: torch.Tensor, flags: torch.Tensor) -> torch.Tensor:
+    """`BalatroSimulator.evaluate_hand` (balatro_sim.py:220-366) for M hands: hands int32 [M, 8, 6] sim cards (rank, suit,
+    base_value, enhancement, edition, seal), n int32 [M], flags int32 [M] (1 Four Fingers, 2 Shortcut) -> int8 [M, 128]
+    (layout: include/balatro_mi355x.h bg_sim_evaluate_batch)."""
+    L = nat.load()
+    if hands.dtype != torch.int32 or tuple(hands.shape[1:]) != (8, 6) or not hands.is_cuda:
+        raise ValueError("hands must be an int32 [M, 8, 6] device tensor")
+    hands, n, flags = hands.contiguous(), n.to(torch.int32).contiguous(), flags.to(torch.int32).contiguous()
+    out = torch.zeros((hands.shape[0], nat.SIM_EVAL_BYTES), dtype=torch.int8, device=hands.device)
+    with torch.cuda.device(hands.device):
+        rc = L.bg_sim_evaluate_batch(C.c_void_p(hands.data_ptr()), C.c_void_p(n.data_ptr()), C.c_void_p(flags.data_ptr()),
+                                     C.c_void_p(out.data_ptr()), int(hands.shape[0]),
+                                     C.c_void_p(torch.cuda.current_stream(hands.device).cuda_stream))
+    if rc != 0:
+        raise nat.NativeError(f"bg_sim_evaluate_batch failed ({rc}): {L.bg_last_error(None).decode()}")
+    return out
+
+
+def sim_score_batch(cases: torch.Tensor) -> torch.Tensor:
+    """`BalatroSimulator.calculate_score` (balatro_sim.py:402-548) for M cases: int32 [M, 64] -> int64 [M, 8]
+    (layouts: include/balatro_mi355x.h bg_sim_score_batch)."""
+    L = nat.load()
+    if cases.dtype != torch.int32 or cases.dim() != 2 or cases.shape[1] != nat.SIM_CASE_WORDS or not cases.is_cuda:
+        raise ValueError(f"cases must be an int32 [M, {nat.SIM_CASE_WORDS}] device tensor")
+    cases = cases.contiguous()
+    out = torch.zeros((cases.shape[0], 8), dtype=torch.int64, device=cases.device)
+    with torch.cuda.device(cases.device):
+        rc = L.bg_sim_score_batch(C.c_void_p(cases.data_ptr()), C.c_void_p(out.data_ptr()), int(cases.shape[0]),
+                                  C.c_void_p(torch.cuda.current_stream(cases.device).cuda_stream))
+    if rc != 0:
+        raise nat.NativeError(f"bg_sim_score_batch failed ({rc}): {L.bg_last_error(None).decode()}")
+    return out

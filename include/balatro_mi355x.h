@@ -307,6 +307,29 @@ int bg_classify_batch(const uint8_t* cards_dev, const uint8_t* n_dev, uint8_t* h
 #define BG_SCORE_OUT_WORDS 8
 int bg_score_hand_batch(const int32_t* cases_dev, int64_t* out_dev, int m, void* stream);
 
+/* balatro_sim.py (the reference's secondary, Balatro-accurate evaluator / scorer; not reachable from the live env).  A sim card
+ * is six int32: rank 2..14, suit 0..3 = Clubs, Diamonds, Hearts, Spades, base_value, enhancement (0 None, 1 'bonus', 2 'mult',
+ * 3 'wild', 4 'glass', 5 'steel', 6 'stone', 7 'gold', 8 'lucky'), edition (0 None, 1 'foil', 2 'holographic', 3 'polychrome',
+ * 4 'negative'), seal (0 None, 1 'gold', 2 'red', 3 'blue', 4 'purple').  Hand types 0..11 = High Card, Pair, Two Pair, Three
+ * of a Kind, Straight, Flush, Full House, Four of a Kind, Straight Flush, Five of a Kind, Flush House, Flush Five.
+ *
+ * Replaces: `BalatroSimulator.evaluate_hand(cards)` (balatro_sim.py:220-366 over get_x_same :108-126, get_flush :128-149,
+ * get_straight :151-214).  hands_dev is int32 [M, 8, 6], n_dev[i] in [0, 8] cards are valid, flags_dev[i] bit 0 = a Four Fingers
+ * joker is owned, bit 1 = Shortcut.  out_dev is int8 [M, BG_SIM_EVAL_BYTES]: [0] results['top']; [1..12] len(results[type]);
+ * [13..24] len(results[type][0]); [32 + 8 * type + k] = position in the hand of card k of results[type][0] (-1 padded). */
+#define BG_SIM_EVAL_BYTES 128
+int bg_sim_evaluate_batch(const int32_t* hands_dev, const int32_t* n_dev, const int32_t* flags_dev, int8_t* out_dev, int m, void* stream);
+
+/* Replaces: `BalatroSimulator.calculate_score(cards, game_state)` (balatro_sim.py:402-548) after random.seed(seed).  One
+ * int32[BG_SIM_CASE_WORDS] record per case: [0..47] 8 sim cards, [48] number of cards, [49] number of jokers,
+ * [50..54] player_state.jokers (ids; Four Fingers 18 / Shortcut 69 act on the evaluation and draw like any other joker),
+ * [55] game_state['hands_left'] (1 when the key is absent, complete_joker_effects.py:46), [56] 'discards_left' (0 when absent),
+ * [57] len(game_state['deck']), [58] seed (< 2**32), rest 0.  Result int64[8]: score, chips, added mult, bits of the float64
+ * x_mult, money gained, words of the global stream consumed, the word the next getrandbits(32) returns, top | nscoring << 8.
+ * Synchronises the stream. */
+#define BG_SIM_CASE_WORDS 64
+int bg_sim_score_batch(const int32_t* cases_dev, int64_t* out_dev, int m, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -188,6 +188,19 @@ void bo_score_hand(const bo_scard* cards, int ncards, const bo_scard* scoring, i
                    int name_style, int level, const int32_t* jokers, int njokers, int hands_left,
                    int discards_left, int deck_len, bo_mt* grand, bo_score_out* out);
 
+/* ---- balatro_sim.py (secondary evaluator / scorer): oracle/bo_sim.c ---- */
+typedef struct { int32_t rank, suit, base_value, enhancement, edition, seal; } bo_simcard; /* codes: see bo_sim.c */
+typedef struct {
+  int8_t top;         /* results['top'] as a hand-type number 0..11 */
+  int8_t nlists[12];  /* len(results[type]) */
+  int8_t n0[12];      /* len(results[type][0]) */
+  int8_t pos[12][8];  /* results[type][0] as positions in the evaluated hand (-1 padded) */
+} bo_sim_eval;
+typedef struct { int64_t score, chips, add_mult; double x_mult; int64_t money; int32_t draws, top, nscoring; } bo_sim_score_out;
+void bo_sim_evaluate(const bo_simcard* hand, int n, int four_fingers, int shortcut, bo_sim_eval* out); /* balatro_sim.py:220-366 */
+void bo_sim_score(const bo_simcard* cards, int n, const int32_t* jokers, int njokers, int hands_left, int discards_left, int deck_len,
+                  bo_mt* grand, bo_sim_score_out* out); /* balatro_sim.py:402-548; Four Fingers (18) / Shortcut (69) among the jokers act on the evaluation */
+
 /* ---- env ---- */
 bo_env* bo_create(uint32_t flags, int32_t max_ante);
 void bo_destroy(bo_env* e);

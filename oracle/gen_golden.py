@@ -10,6 +10,8 @@ Files:
   F3 score_hand.json   UnifiedScorer.score_hand cases with joker NAME lists (operator-level joker chain)
   F4 trace_<cfg>.npz   BalatroEnv traces under the counter-hash policy: actions, rewards, terminated, info and the
                        full observation after every step
+  F6 sim_eval.npz      balatro_sim.BalatroSimulator: evaluate_hand (10 000 hands, with / without Four Fingers / Shortcut) and
+                       calculate_score (2 000 cases: enhancements, editions, seals, joker-major chain, global-stream position)
   F7 kat.json          the reference's own known answers (tests/chips_test.py:5-24, balatro_trajectories.json)
 """
 from __future__ import annotations
@@ -152,6 +154,105 @@ def gen_score_hand():
     with open(os.path.join(GOLD, "score_hand.json"), "w") as f:
         json.dump(cases, f, separators=(",", ":"))
     print("F3 score_hand.json", len(cases), "cases")
+
+
+def sim_random_hand(r, n=None):
+    """A hand for the balatro_sim fixtures: (rank, suit, base_value, enhancement, edition, seal) tuples.  A mix of plain draws
+    from a deck, hands squeezed into few ranks / one suit, and hands with duplicate cards (Five of a Kind, Flush Five, Flush
+    House only exist with duplicates; equal dataclasses also exercise `card not in flush` at balatro_sim.py:277)."""
+    n = n or r.choice([1, 2, 3, 4, 5, 5, 5, 5, 5, 6, 7, 8])
+    kind = r.random()
+    cards = []
+    if kind < 0.45:
+        deck = [(rk, su) for rk in range(2, 15) for su in range(4)]
+        cards = r.sample(deck, n)
+    elif kind < 0.65:  # few ranks
+        ranks = r.sample(range(2, 15), r.randint(1, 3))
+        cards = [(r.choice(ranks), r.randrange(4)) for _ in range(n)]
+    elif kind < 0.8:  # one suit (mostly), runs of ranks
+        su = r.randrange(4)
+        lo = r.randint(2, 10)
+        pool = [14, 2, 3, 4, 5, 6] if r.random() < 0.25 else list(range(lo, min(15, lo + 6)))
+        cards = [(r.choice(pool), su if r.random() < 0.9 else r.randrange(4)) for _ in range(n)]
+    else:  # runs of ranks in any suit
+        lo = r.randint(2, 10)
+        pool = [14, 2, 3, 4, 5] if r.random() < 0.25 else list(range(lo, min(15, lo + 5)))
+        r.shuffle(pool)
+        cards = [(pool[i % len(pool)], r.randrange(4)) for i in range(n)]
+    out = []
+    for rk, su in cards:
+        bv = 11 if rk == 14 else min(rk, 10)
+        if r.random() < 0.1:
+            bv = rk if rk <= 10 else 10  # balatro_sim._id_to_card's base values (:377-382)
+        en = r.choice([0, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8]) if r.random() < 0.5 else 0
+        ed = r.choice([0, 0, 1, 2, 3, 4]) if r.random() < 0.3 else 0
+        se = r.choice([0, 1, 2, 3, 4]) if r.random() < 0.3 else 0
+        out.append((rk, su, bv, en, ed, se))
+    return out
+
+
+def gen_sim():
+    r = random.Random(4242)
+    ev = []
+    for i in range(10000):
+        cards = sim_random_hand(r)
+        ff, sc = (i % 4) in (1, 3), (i % 4) in (2, 3)
+        top, lists = rh.sim_evaluate(cards, ff, sc)
+        ev.append({"cards": cards, "ff": int(ff), "sc": int(sc), "top": top,
+                   "lists": [[lists[t][0], lists[t][1]] for t in range(12)]})
+    sc_cases = []
+    for i in range(2000):
+        cards = sim_random_hand(r, n=r.choice([1, 2, 3, 4, 5, 5, 5, 5]))
+        pool = IMPLEMENTED if r.random() < 0.85 else list(range(1, 151))
+        jokers = r.sample(pool, r.randint(0, 5))
+        for util in (18, 69):  # Four Fingers / Shortcut (jokers.py ids): part of player_state.jokers like any other joker
+            if r.random() < 0.2 and util not in jokers and len(jokers) < 5:
+                jokers.insert(r.randint(0, len(jokers)), util)
+        gs = None if i % 2 == 0 else {"hands_left": r.randint(1, 4), "discards_left": r.randint(0, 3)}
+        deck_len = r.choice([0, 0, 40, 52])
+        seed = r.randrange(2 ** 32)
+        score, money, probe = rh.sim_score(cards, jokers, gs, deck_len, seed)
+        sc_cases.append({"cards": cards, "jokers": jokers,
+                         "hands_left": 1 if gs is None else gs["hands_left"], "discards_left": 0 if gs is None else gs["discards_left"],
+                         "deck_len": deck_len, "seed": seed, "score": score, "money": money, "probe": probe})
+    # the reference's own saved answers (balatro_trajectories.json play_hand transitions): 14 known scores, no jokers
+    kat = json.load(open(os.path.join(GOLD, "kat.json")))["trajectories"]
+    for k in kat:
+        cards = [(rk, su, 11 if rk == 14 else min(rk, 10), 0, 0, 0) for rk, su in k["cards"]]
+        score, _, _ = rh.sim_score(cards, [], None, 0, 1)
+        assert score == k["score"], (k, score)
+    # arrays (compressed): cards [M, 8, 6] (rank, suit, base_value, enhancement, edition, seal), -1 padded position lists
+    def card_array(cases):
+        arr = np.zeros((len(cases), 8, 6), np.int16)
+        n = np.zeros(len(cases), np.int8)
+        for i, c in enumerate(cases):
+            n[i] = len(c["cards"])
+            arr[i, :n[i]] = c["cards"]
+        return arr, n
+    e_cards, e_n = card_array(ev)
+    e_nl = np.array([[l[0] for l in e["lists"]] for e in ev], np.int8)
+    e_n0 = np.array([[len(l[1]) for l in e["lists"]] for e in ev], np.int8)
+    e_pos = np.full((len(ev), 12, 8), -1, np.int8)
+    for i, e in enumerate(ev):
+        for t, l in enumerate(e["lists"]):
+            e_pos[i, t, :len(l[1])] = l[1]
+    s_cards, s_n = card_array(sc_cases)
+    s_jok = np.zeros((len(sc_cases), 5), np.int32)
+    for i, c in enumerate(sc_cases):
+        s_jok[i, :len(c["jokers"])] = c["jokers"]
+    np.savez_compressed(
+        os.path.join(GOLD, "sim_eval.npz"),
+        e_cards=e_cards, e_n=e_n, e_ff=np.array([e["ff"] for e in ev], np.int8), e_sc=np.array([e["sc"] for e in ev], np.int8),
+        e_top=np.array([e["top"] for e in ev], np.int8), e_nlists=e_nl, e_n0=e_n0, e_pos=e_pos,
+        s_cards=s_cards, s_n=s_n, s_jokers=s_jok, s_njokers=np.array([len(c["jokers"]) for c in sc_cases], np.int32),
+        s_hands_left=np.array([c["hands_left"] for c in sc_cases], np.int32),
+        s_discards_left=np.array([c["discards_left"] for c in sc_cases], np.int32),
+        s_deck_len=np.array([c["deck_len"] for c in sc_cases], np.int32), s_seed=np.array([c["seed"] for c in sc_cases], np.uint32),
+        s_score=np.array([c["score"] for c in sc_cases], np.int64), s_money=np.array([c["money"] for c in sc_cases], np.int64),
+        s_probe=np.array([c["probe"] for c in sc_cases], np.uint32))
+    tops = np.bincount([e["top"] for e in ev], minlength=12)
+    print("F6 sim_eval.npz", len(ev), "evaluate cases (top counts", tops.tolist(), "),", len(sc_cases), "score cases;",
+          len(kat), "trajectory answers reproduced")
 
 
 def trace(cfg_name, seeds, T, policy, scorer=False, jokers_fn=None, max_ante=0, money_fn=None, ante_fn=None,
@@ -312,7 +413,7 @@ def gen_kat():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["mt", "classify", "score", "traces", "consumables", "kat"]
+    which = sys.argv[1:] or ["mt", "classify", "score", "traces", "consumables", "kat", "sim"]
     if "mt" in which:
         gen_mt()
     if "classify" in which:
@@ -325,6 +426,8 @@ def main():
         gen_trace_consumables()
     if "kat" in which:
         gen_kat()
+    if "sim" in which:  # after kat: it re-checks the trajectory answers of kat.json on the reference's calculate_score
+        gen_sim()
 
 
 if __name__ == "__main__":

@@ -75,6 +75,20 @@ class ScoreOut(C.Structure):
                 ("money", C.c_int64), ("draws", C.c_int32)]
 
 
+class SimCard(C.Structure):
+    _fields_ = [("rank", C.c_int32), ("suit", C.c_int32), ("base_value", C.c_int32), ("enhancement", C.c_int32),
+                ("edition", C.c_int32), ("seal", C.c_int32)]
+
+
+class SimEval(C.Structure):
+    _fields_ = [("top", C.c_int8), ("nlists", C.c_int8 * 12), ("n0", C.c_int8 * 12), ("pos", (C.c_int8 * 8) * 12)]
+
+
+class SimScoreOut(C.Structure):
+    _fields_ = [("score", C.c_int64), ("chips", C.c_int64), ("add_mult", C.c_int64), ("x_mult", C.c_double),
+                ("money", C.c_int64), ("draws", C.c_int32), ("top", C.c_int32), ("nscoring", C.c_int32)]
+
+
 class MT(C.Structure):
     _fields_ = [("mt", C.c_uint32 * 624), ("mti", C.c_int32)]
 
@@ -85,7 +99,7 @@ _lib = None
 def build(force: bool = False) -> str:
     """Compile oracle/libbalatro_oracle.so with gcc (building the checker is not using it)."""
     src = os.path.join(HERE, "balatro_oracle.c")
-    deps = [src, os.path.join(HERE, "balatro_oracle.h"), os.path.join(HERE, "bo_tables.h")]
+    deps = [src, os.path.join(HERE, "bo_sim.c"), os.path.join(HERE, "balatro_oracle.h"), os.path.join(HERE, "bo_tables.h")]
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps):
         subprocess.check_call(["make", "-C", HERE, "-s", "libbalatro_oracle.so"])
     return LIB_PATH
@@ -133,6 +147,9 @@ def lib():
         L.bo_score_hand.argtypes = [C.POINTER(SCard), C.c_int, C.POINTER(SCard), C.c_int, C.c_int, C.c_int, C.c_int,
                                     C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(MT),
                                     C.POINTER(ScoreOut)]
+        L.bo_sim_evaluate.argtypes = [C.POINTER(SimCard), C.c_int, C.c_int, C.c_int, C.POINTER(SimEval)]
+        L.bo_sim_score.argtypes = [C.POINTER(SimCard), C.c_int, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_int,
+                                   C.POINTER(MT), C.POINTER(SimScoreOut)]
         L.bo_rollout.restype = C.c_int64
         L.bo_rollout.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_uint64, C.c_uint64,
                                  C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
@@ -239,4 +256,25 @@ def score_hand(cards, scoring, hand_type, name_style, level, jokers, hands_left,
     out = ScoreOut()
     L.bo_score_hand(ca, len(cards), sa, len(scoring), hand_type, name_style, level, ja, len(jokers), hands_left,
                     discards_left, deck_len, C.byref(mt), C.byref(out))
+    return out
+
+
+def sim_evaluate(cards, four_fingers=False, shortcut=False):
+    """balatro_sim.py evaluate_hand: cards = [(rank, suit, base_value, enhancement, edition, seal)] -> (top, {type: (nlists, [positions of list 0])})."""
+    L = lib()
+    ca = (SimCard * max(1, len(cards)))(*[SimCard(*c) for c in cards])
+    ev = SimEval()
+    L.bo_sim_evaluate(ca, len(cards), int(four_fingers), int(shortcut), C.byref(ev))
+    return int(ev.top), {t: (int(ev.nlists[t]), [int(ev.pos[t][i]) for i in range(ev.n0[t])]) for t in range(12)}
+
+
+def sim_score(cards, jokers, hands_left, discards_left, deck_len, seed):
+    """balatro_sim.py calculate_score after random.seed(seed); Four Fingers (18) / Shortcut (69) in `jokers` act on the evaluation."""
+    L = lib()
+    ca = (SimCard * max(1, len(cards)))(*[SimCard(*c) for c in cards])
+    ja = (C.c_int32 * max(1, len(jokers)))(*jokers)
+    mt = MT()
+    L.bo_mt_seed(C.byref(mt), seed)
+    out = SimScoreOut()
+    L.bo_sim_score(ca, len(cards), ja, len(jokers), hands_left, discards_left, deck_len, C.byref(mt), C.byref(out))
     return out

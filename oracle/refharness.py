@@ -215,3 +215,80 @@ class RefEnv:
 
     def set_ante(self, ante):
         self.env.state.ante = ante
+
+
+# ---------------------------------------------------------------------------------------------------------
+# balatro_sim.py: imports only with the reference's package directory itself on sys.path (bare
+# `from scoring_engine import ...`, balatro_sim.py:6), and calculate_score calls a ScoreEngine.score that does not exist
+# (:418; the result is only printed) -- SURVEY App. C step 4.
+# ---------------------------------------------------------------------------------------------------------
+SIM_SUITS = ["Clubs", "Diamonds", "Hearts", "Spades"]
+SIM_ENH = [None, "bonus", "mult", "wild", "glass", "steel", "stone", "gold", "lucky"]
+SIM_EDI = [None, "foil", "holographic", "polychrome", "negative"]
+SIM_SEAL = [None, "gold", "red", "blue", "purple"]
+SIM_TYPES = ["High Card", "Pair", "Two Pair", "Three of a Kind", "Straight", "Flush", "Full House", "Four of a Kind",
+             "Straight Flush", "Five of a Kind", "Flush House", "Flush Five"]
+
+
+def load_sim():
+    if "sim" in _loaded:
+        return _loaded["sim"]
+    load_reference()
+    pkg = os.path.join(REFERENCE_ROOT, "balatro_gym")
+    if pkg not in sys.path:
+        sys.path.insert(0, pkg)
+    import balatro_gym.balatro_sim as sim
+    _loaded["sim"] = sim
+    return sim
+
+
+def _sim_cards(sim, cards):
+    return [sim.Card(rank=r, suit=SIM_SUITS[s], base_value=bv, enhancement=SIM_ENH[en], edition=SIM_EDI[ed], seal=SIM_SEAL[se])
+            for (r, s, bv, en, ed, se) in cards]
+
+
+def _utility_jokers(sim, s, four_fingers, shortcut):
+    ids = {j.name: j.id for j in sim.JOKER_LIBRARY}
+    assert ids["Four Fingers"] == 18 and ids["Shortcut"] == 69
+    return ([18] if four_fingers else []) + ([69] if shortcut else [])
+
+
+def sim_evaluate(cards, four_fingers=False, shortcut=False):
+    """BalatroSimulator.evaluate_hand -> (top index, {type: (len(results[type]), positions of results[type][0])})."""
+    sim = load_sim()
+    s = sim.BalatroSimulator()
+    s.player_state.jokers = _utility_jokers(sim, s, four_fingers, shortcut)
+    objs = _sim_cards(sim, cards)
+    res = s.evaluate_hand(objs)
+
+    def positions(lst):
+        return [next(i for i, o in enumerate(objs) if o is c) for c in lst]
+
+    out = {}
+    for t, name in enumerate(SIM_TYPES):
+        r = res[name]
+        out[t] = (len(r), positions(r[0]) if r else [])
+    return SIM_TYPES.index(res["top"]), out
+
+
+def sim_score(cards, jokers, game_state_keys, deck_len, seed):
+    """BalatroSimulator.calculate_score after random.seed(seed).  jokers = player_state.jokers (ids; Four Fingers 18 / Shortcut 69
+    among them change the evaluation and draw from the global stream like every other joker).  game_state_keys:
+    None = the simulator's own _create_game_state() (no 'hands_left' / 'discards_left' keys -> the defaults 1 / 0 of
+    complete_joker_effects.py:46-48), or a dict with hands_left / discards_left to add to it."""
+    import contextlib
+    import io
+    sim = load_sim()
+    s = sim.BalatroSimulator()
+    s.score_engine.score = lambda ids, ht, lvl: s.score_engine.score_hand(ids, ht)
+    s.player_state.jokers = list(jokers)
+    s.player_state.deck = list(range(deck_len))
+    gs = None
+    if game_state_keys is not None:
+        gs = s._create_game_state()
+        gs.update(game_state_keys)
+    random.seed(seed)
+    with contextlib.redirect_stdout(io.StringIO()):
+        score, state = s.calculate_score(_sim_cards(sim, cards), gs)
+    probe = random.getrandbits(32)
+    return int(score), int(state["money"]) - 100, probe

@@ -180,3 +180,44 @@ def test_forced_rare_hands_vs_oracle(scorer):
     env.check()
     env.close()
     assert (seen >= 30).all(), seen.tolist()  # every hand type, STRAIGHT_FLUSH included, was played dozens of times
+
+
+def test_sim_evaluate_batch_golden():
+    """balatro_sim.evaluate_hand: all 10 000 hands of sim_eval.npz (every hand type incl. Five of a Kind / Flush House / Flush
+    Five, with and without Four Fingers / Shortcut): top, list counts and the first list of all 12 types, position by position."""
+    import torch
+    from balatro_gym_amd import sim_evaluate_batch
+    g = np.load(os.path.join(GOLD, "sim_eval.npz"))
+    dev = torch.device("cuda:0")
+    flags = g["e_ff"].astype(np.int32) | (g["e_sc"].astype(np.int32) << 1)
+    out = sim_evaluate_batch(torch.from_numpy(g["e_cards"].astype(np.int32)).to(dev), torch.from_numpy(g["e_n"].astype(np.int32)).to(dev),
+                             torch.from_numpy(flags).to(dev)).cpu().numpy()
+    assert np.array_equal(out[:, 0], g["e_top"])
+    assert np.array_equal(out[:, 1:13], g["e_nlists"])
+    assert np.array_equal(out[:, 13:25], g["e_n0"])
+    assert np.array_equal(out[:, 32:128].reshape(-1, 12, 8), g["e_pos"])
+    assert (np.bincount(g["e_top"], minlength=12) > 0).all()
+
+
+def test_sim_score_batch_golden():
+    """balatro_sim.calculate_score: the 2 000 cases of sim_eval.npz (score, money, stream position) and the 14 known answers the
+    reference itself holds in balatro_trajectories.json."""
+    import torch
+    from balatro_gym_amd import sim_score_batch
+    g = np.load(os.path.join(GOLD, "sim_eval.npz"))
+    kat = json.load(open(os.path.join(GOLD, "kat.json")))["trajectories"]
+    M = len(g["s_n"])
+    rec = np.zeros((M + len(kat), 64), np.int32)
+    rec[:M, :48] = g["s_cards"].reshape(M, 48)
+    rec[:M, 48], rec[:M, 49] = g["s_n"], g["s_njokers"]
+    rec[:M, 50:55] = g["s_jokers"]
+    rec[:M, 55], rec[:M, 56], rec[:M, 57] = g["s_hands_left"], g["s_discards_left"], g["s_deck_len"]
+    rec[:M, 58] = g["s_seed"].astype(np.int32)
+    for i, k in enumerate(kat):
+        for q, (r, s) in enumerate(k["cards"]):
+            rec[M + i, 6 * q:6 * q + 3] = (r, s, 11 if r == 14 else min(r, 10))
+        rec[M + i, 48], rec[M + i, 55], rec[M + i, 58] = len(k["cards"]), 1, 1
+    out = sim_score_batch(torch.from_numpy(rec).to("cuda:0")).cpu().numpy()
+    bad = np.nonzero((out[:M, 0] != g["s_score"]) | (out[:M, 4] != g["s_money"]) | (out[:M, 6] != g["s_probe"].astype(np.int64)))[0]
+    assert bad.size == 0, f"case {bad[0]}: {rec[bad[0]].tolist()} got {out[bad[0]].tolist()} want {g['s_score'][bad[0]], g['s_money'][bad[0]], g['s_probe'][bad[0]]}"
+    assert [int(x) for x in out[M:, 0]] == [k["score"] for k in kat]

@@ -108,6 +108,42 @@ def test_reference_known_answers():
         assert score(k["cards"], ht) == k["score"], k
 
 
+def test_sim_evaluate_golden():
+    """balatro_sim.evaluate_hand (balatro_sim.py:220-366): 10 000 hands with / without Four Fingers / Shortcut -- `top`, and for
+    every one of the 12 hand types the number of lists and the first list as positions in the hand."""
+    g = np.load(os.path.join(GOLD, "sim_eval.npz"))
+    assert (np.bincount(g["e_top"], minlength=12) > 0).all()
+    for i in range(len(g["e_n"])):
+        cards = [tuple(int(x) for x in c) for c in g["e_cards"][i, :g["e_n"][i]]]
+        top, lists = po.sim_evaluate(cards, bool(g["e_ff"][i]), bool(g["e_sc"][i]))
+        assert top == g["e_top"][i], (i, cards)
+        for t in range(12):
+            want = (int(g["e_nlists"][i, t]), [int(p) for p in g["e_pos"][i, t, :g["e_n0"][i, t]]])
+            assert lists[t] == want, (i, t, cards, lists[t], want)
+
+
+def test_sim_score_golden():
+    """balatro_sim.calculate_score (balatro_sim.py:402-548): 2 000 cases -- score, money and the position of the global stream
+    afterwards -- and the 14 known answers the reference itself holds (balatro_trajectories.json)."""
+    g = np.load(os.path.join(GOLD, "sim_eval.npz"))
+    L = po.lib()
+    for i in range(len(g["s_n"])):
+        cards = [tuple(int(x) for x in c) for c in g["s_cards"][i, :g["s_n"][i]]]
+        jokers = [int(j) for j in g["s_jokers"][i, :g["s_njokers"][i]]]
+        o = po.sim_score(cards, jokers, int(g["s_hands_left"][i]), int(g["s_discards_left"][i]), int(g["s_deck_len"][i]), int(g["s_seed"][i]))
+        ctx = (i, cards, jokers)
+        assert o.score == g["s_score"][i] and o.money == g["s_money"][i], ctx
+        mt = po.MT()
+        L.bo_mt_seed(C.byref(mt), int(g["s_seed"][i]))
+        for _ in range(o.draws):
+            L.bo_mt_u32(C.byref(mt))
+        assert L.bo_mt_u32(C.byref(mt)) == g["s_probe"][i], ctx
+    kat = json.load(open(os.path.join(GOLD, "kat.json")))
+    for k in kat["trajectories"]:
+        cards = [(r, s, 11 if r == 14 else min(r, 10), 0, 0, 0) for r, s in k["cards"]]
+        assert po.sim_score(cards, [], 1, 0, 0, 1).score == k["score"], k
+
+
 def replay_trace(name, make_env):
     tr = load_trace(name)
     S, T = tr["actions"].shape

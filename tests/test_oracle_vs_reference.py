@@ -151,6 +151,30 @@ def test_env_lockstep_forced_rare_hands():
     assert min(seen) >= 6, seen
 
 
+def test_sim_evaluate_and_score_lockstep():
+    """balatro_sim.BalatroSimulator (imported with the SURVEY App. C shim) against oracle/bo_sim.c on fresh random hands."""
+    import ctypes as C
+    from oracle.gen_golden import IMPLEMENTED, sim_random_hand
+    r = random.Random(99)
+    for i in range(1500):
+        cards = sim_random_hand(r)
+        ff, sc = bool(i & 1), bool(i & 2)
+        assert rh.sim_evaluate(cards, ff, sc) == po.sim_evaluate(cards, ff, sc), (cards, ff, sc)
+    L = po.lib()
+    for i in range(600):
+        cards = sim_random_hand(r, n=r.choice([1, 2, 3, 4, 5, 5, 5]))
+        jokers = r.sample(IMPLEMENTED + [18, 69, 100], r.randint(0, 5))
+        gs = None if i % 2 else {"hands_left": r.randint(1, 4), "discards_left": r.randint(0, 3)}
+        dl, seed = r.choice([0, 40, 52]), r.randrange(2 ** 32)
+        score, money, probe = rh.sim_score(cards, jokers, gs, dl, seed)
+        o = po.sim_score(cards, jokers, 1 if gs is None else gs["hands_left"], 0 if gs is None else gs["discards_left"], dl, seed)
+        mt = po.MT()
+        L.bo_mt_seed(C.byref(mt), seed)
+        for _ in range(o.draws):
+            L.bo_mt_u32(C.byref(mt))
+        assert (o.score, o.money, L.bo_mt_u32(C.byref(mt))) == (score, money, probe), (cards, jokers, gs, dl, seed)
+
+
 def test_reseed_reproduces_first_shuffle():
     """reset(seed=s) rebuilds the streams (balatro_env_2.py:507-509); reset() continues them."""
     r = rh.RefEnv(42)

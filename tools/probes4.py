@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Development aid: BG_PROBE cycle probes of the play path inside the step engine (build: tools/build_variant.sh pr -DBG_TIMING)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from balatro_gym_amd import BalatroVecEnv, _native as nat
+from balatro_gym_amd.vec_env import RowBuffers
+from bench import jokers_for, POLICY_CYCLE3, POLICY_SEED
+n, T = 65536, int(os.environ.get("T", "372"))
+env = BalatroVecEnv(n, [1000 + g for g in range(n)], device=0, scorer_jokers=True, autoreset=True, max_ante=4)
+env.inject(jokers=[jokers_for(g) for g in range(n)], apply_now=True)
+rb = RowBuffers(n, env.device, steps=T)
+for i in range(2):
+    env.rollout(T, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, t0=i * T, obs_buffers=rb, zero_stats=False)
+torch.cuda.synchronize()
+L = nat.load()
+out = (C.c_ulonglong * 32)()
+L.bg_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+L.bg_debug_counters(env._h, out)
+env.rollout(T, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, t0=2 * T, obs_buffers=rb, zero_stats=False)
+torch.cuda.synchronize()
+st = env.stats()
+L.bg_debug_counters(env._h, out)
+o = list(out)
+wgs = n / 256
+names = {5: "gather selected cards", 6: "classify", 7: "chain: individual", 8: "chain: peeks", 13: "chain: -", 14: "chain: main", 10: "score+counters (incl. chain)",
+         11: "reward shaping", 12: "outcome (advance round / draw / boss)", 20: "play dispatch total", 21: "other dispatch total", 22: "shop inventory"}
+print(f"T {T}: cycles per workgroup-step (first active lane of each batch)")
+for k in sorted(names):
+    print(f"  probe {k:2d} {names[k]:40s} {o[k]/wgs/T:9.0f}")
+env.close()

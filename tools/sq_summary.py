@@ -2,7 +2,7 @@
 """Mean per-launch value of every counter collected by tools/sq_counters.sh for the rollout kernel."""
 import csv, glob, sys
 tag = sys.argv[1]
-kernel = sys.argv[2] if len(sys.argv) > 2 else "bg_rollout3_kernel"
+kernel = sys.argv[2] if len(sys.argv) > 2 else "bg_engine_kernel"
 for path in sorted(glob.glob(f"gpurun_out/{tag}/sq_*/runc_counter_collection.csv")):
     acc = {}
     for r in csv.DictReader(open(path)):

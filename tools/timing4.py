@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Development aid: cycle counters of the step engine kernel (build with -DBG_TIMING4: tools/build_variant.sh t4 -DBG_TIMING4,
+then BALATRO_MI355X_LIB=balatro_gym_amd/variants/t4.so python tools/timing4.py)."""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from balatro_gym_amd import BalatroVecEnv, _native as nat
+from balatro_gym_amd.vec_env import RowBuffers
+from bench import jokers_for, POLICY_CYCLE3, POLICY_SEED
+n, T = int(os.environ.get("N", "65536")), int(os.environ.get("T", "372"))
+env = BalatroVecEnv(n, [1000 + g for g in range(n)], device=0, scorer_jokers=True, autoreset=True, max_ante=4)
+env.inject(jokers=[jokers_for(g) for g in range(n)], apply_now=True)
+rb = RowBuffers(n, env.device, steps=T)
+for i in range(3):
+    env.rollout(T, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, t0=i * T, obs_buffers=rb, zero_stats=False)
+torch.cuda.synchronize()
+L = nat.load()
+out = (C.c_ulonglong * 32)()
+L.bg_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+L.bg_debug_counters(env._h, out)
+env.set_profiling(True)
+env.rollout(T, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, t0=3 * T, obs_buffers=rb, zero_stats=False)
+torch.cuda.synchronize()
+p = env.get_profile()
+L.bg_debug_counters(env._h, out)
+o = list(out)
+waves = max(1, o[1]); wgs = waves / 8
+print(f"launch {p['rollout_ms']*1e3:.0f} us, waves {waves}, T {T}; wave cycles {o[0]/waves:.0f}, idle {o[11]/max(1,o[0]):.2f} of it, failed claims per wave {o[12]/waves:.1f}")
+tot_busy = 0
+for c, nm in ((0, "run"), (1, "play"), (2, "other")):
+    b = max(1, o[2 + 3 * c])
+    tot_busy += o[4 + 3 * c]
+    print(f"  {nm:5s}: batches per workgroup-step {o[2+3*c]/wgs/T:.2f}  items per batch {o[3+3*c]/b:.1f}  cycles per batch {o[4+3*c]/b:.0f}  share of wave time {o[4+3*c]/max(1,o[0]):.2f}")
+for c, nm in ((0, "run"), (1, "play"), (2, "other")):
+    nb = max(1, o[2 + 3 * c]); q = o[16 + 5 * c:21 + 5 * c]
+    print(f"  {nm:5s} sections (cycles per batch): claim+load {q[0]/nb:.0f}  policy/dispatch {q[1]/nb:.0f}  cap+reset+mask {q[2]/nb:.0f}  record {q[3]/nb:.0f}  outputs+store+requeue {q[4]/nb:.0f}")
+env.close()
