@@ -7,14 +7,26 @@ the whole per-GPU batch (65 536 envs) through the fused rollout path: counter-ha
 SAME_STEP auto-reset, the observation of EVERY step written to HBM.  K steps are timed between barrier +
 torch.cuda.synchronize() on both sides; value = (envs on all ranks x K) / max-over-ranks time.
 
+Before the W warm-up steps the bench runs an UNTIMED internal warm-up of full-depth launches (~0.5 s: clocks, TLBs, the
+look-ahead pipeline in steady state), so a short driver run (`--steps 20 --warmup 5`) measures the same machine state as a
+long one.
+
 Workload = BASELINE.json configs[2] (the config the metric is quoted on, fits one GPU): 65 536 envs per GPU, 5 random
 jokers per env out of the 51 that complete_joker_effects implements (scorer-level joker chain live), Antes 1-4 cap,
 policy: blind 45/46/47 by env index, shop -> 31, otherwise uniform over valid actions.  Envs are independent, so
-multi-GPU is pure sharding with no data-path collective ("weak" scaling: 65 536 envs per GPU).
+multi-GPU is pure sharding with no data-path collective ("weak" scaling: 65 536 envs per GPU); the one exchange of the
+design -- an RCCL all_gather of the CURRENT observation record of every env ([N, 352] bytes per GPU, once per launch) --
+runs on a side stream beside the next launch and is inside the timed region when N > 1 (`gather` in the JSON line).
+
+Beside the headline the line carries `step_path`: the same workload driven through bg_step (one call per step, actions
+from a device tensor: the surface RL code calls, balatro_env_2.py:616-637) and bg_step_many (K steps per call), timed on a
+short sample outside the headline's timed region.
 """
 from __future__ import annotations
 
 import argparse
+import ctypes as C
+import glob
 import json
 import os
 import random
@@ -36,7 +48,6 @@ IMPLEMENTED = [1, 136, 27, 38, 61, 16, 34, 108, 23, 22, 53, 97, 50, 2, 3, 4, 5, 
                131, 132, 133, 134, 135, 48, 128, 122, 72, 140, 31, 39, 40, 41, 101, 124, 26, 33, 104, 147, 118, 119,
                116, 117]
 POLICY_CYCLE3 = 2
-TRAFFIC_FILE = {"rows": "r01_v21_hbm_traffic.json", "keys": None}  # PMC result of the default layout (none measured for per-key arrays at v21)
 POLICY_SEED = 20251001
 MAX_ANTE = 4
 
@@ -47,7 +58,6 @@ def jokers_for(global_env: int):
 
 def cpu_baseline(n_envs: int, steps: int, threads: int):
     """The CPU oracle ("port": plain-C restatement of the reference path) on the host cores, same workload/policy."""
-    import ctypes as C
     from oracle import pyoracle as po
     L = po.lib()
     envs = []
@@ -76,18 +86,54 @@ def cpu_baseline(n_envs: int, steps: int, threads: int):
     return sum(results) / dt, dt
 
 
+def measured_copy_gbps(dev) -> float:
+    """What a plain 16-byte-per-lane streaming copy sustains on this GPU (bg_bench_copy): read + written bytes per second."""
+    import torch
+    from balatro_gym_amd import _native as nat
+    L = nat.load()
+    nbytes = 1 << 30
+    src = torch.empty(nbytes, dtype=torch.uint8, device=dev).random_(0, 256)
+    dst = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    g = C.c_double()
+    with torch.cuda.device(dev):
+        rc = L.bg_bench_copy(C.c_void_p(src.data_ptr()), C.c_void_p(dst.data_ptr()), C.c_uint64(nbytes), 20, C.byref(g),
+                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"bg_bench_copy failed: {L.bg_last_error(None).decode()}")
+    del src, dst
+    return float(g.value)
+
+
+def matching_traffic(kernel: str, n: int, fused: float):
+    """HBM bytes per launch of the dominant kernel from the PMC counters -- ONLY if a committed measurement of THIS launch
+    shape exists (profiles/*_hbm_traffic.json written by tools/hbm_traffic.py from separate rocprofv3 --pmc FETCH_SIZE /
+    WRITE_SIZE passes of this command); otherwise null.  Never a value scaled from another shape."""
+    best = None
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json"))):
+        try:
+            with open(path) as f:
+                j = json.load(f)
+            if j.get("kernel") == kernel and int(j.get("envs", 0)) == n and int(round(j.get("fused_steps_per_launch", 0))) == int(round(fused)):
+                best = (float(j["hbm_bytes_per_launch"]), os.path.basename(path))
+        except Exception:
+            continue
+    return best
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=7440)   # 20 launches of 372 fused steps (~0.13 s on one MI355X)
-    ap.add_argument("--warmup", type=int, default=37200)  # ~0.6 s: clocks and TLBs settle (372 -> 37200: +3 % measured)
+    ap.add_argument("--steps", type=int, default=7440)   # 20 launches of 372 fused steps
+    ap.add_argument("--warmup", type=int, default=744)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--chunk", type=int, default=0, help="fused steps per rollout call (0 = as many as the rings allow)")
     ap.add_argument("--keep-obs", type=int, default=1, help="write every step's observation to a [chunk, N] buffer")
     ap.add_argument("--obs-layout", choices=["rows", "keys"], default="rows",
                     help="rows: one packed 352-byte record per (step, env) (bg_rollout_rows); keys: one array per key")
+    ap.add_argument("--internal-warmup-s", type=float, default=0.5, help="untimed full-depth launches before --warmup")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-obs", action="store_true", help="also RCCL all_gather the last observation per chunk")
+    ap.add_argument("--no-step-path", action="store_true", help="skip the bg_step / bg_step_many sample")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the RCCL all_gather of the current observation out")
     args = ap.parse_args()
 
     import torch
@@ -111,44 +157,68 @@ def main():
     lo, hi = shard_range(total, world, rank)
     assert hi - lo == n
 
-    env = BalatroVecEnv(n, [1000 + g for g in range(lo, hi)], device=local_rank, scorer_jokers=True, autoreset=True,
-                        max_ante=MAX_ANTE)
-    env.inject(jokers=[jokers_for(g) for g in range(lo, hi)], apply_now=True)
+    def make_env():
+        e = BalatroVecEnv(n, [1000 + g for g in range(lo, hi)], device=local_rank, scorer_jokers=True, autoreset=True,
+                          max_ante=MAX_ANTE)
+        e.inject(jokers=[jokers_for(g) for g in range(lo, hi)], apply_now=True)
+        return e
+
+    env = make_env()
     # chunk = steps per bg_rollout call = what the library fuses into one launch (ring depths: bg_create / BG_KG,KS,KD)
     chunk = args.chunk or int(os.environ.get("BG_BENCH_CHUNK", "0")) or min(372, env.max_fused_steps)
     ob = None
     if args.keep_obs and chunk > 1:
         ob = (RowBuffers if args.obs_layout == "rows" else ObsBuffers)(n, dev, steps=chunk)
 
+    # the design's one collective: all_gather of the CURRENT observation record of every env, once per launch, on a side
+    # stream so that it runs beside the next launch (what a central evaluator / logger sees; learners train on their own shard)
+    do_gather = world > 1 and not args.no_gather and isinstance(ob, RowBuffers)
+    gather_stream = torch.cuda.Stream(device=dev) if do_gather else None
+    gathered = torch.empty((world, n, ob.rows.shape[-1]), dtype=torch.uint8, device=dev) if do_gather else None
+    gather_bytes = 0
+
     def run(nsteps, t0):
+        nonlocal gather_bytes
         done = 0
         while done < nsteps:
             c = min(chunk, nsteps - done)
             env.rollout(c, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, env_index0=lo, t0=t0 + done,
                         obs_buffers=ob, zero_stats=False)  # a shorter last call fills the first c rows
-            if args.gather_obs and world > 1:
-                gathered = torch.empty(world * env.obs_flat.numel(), dtype=torch.uint8, device=dev)
-                dist.all_gather_into_tensor(gathered, env.obs_flat)
+            if do_gather:
+                gather_stream.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(gather_stream):
+                    dist.all_gather_into_tensor(gathered.view(-1), ob.rows[c - 1].reshape(-1))
+                gather_bytes += ob.rows[c - 1].numel()
             done += c
+        if do_gather:
+            torch.cuda.current_stream(dev).wait_stream(gather_stream)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    run(args.warmup, 0)
+    # ---- untimed internal warm-up at full depth, then the W warm-up steps of the contract
+    t_w = time.perf_counter()
+    t_off = 0
+    while time.perf_counter() - t_w < args.internal_warmup_s:
+        run(chunk, t_off)
+        torch.cuda.synchronize(dev)
+        t_off += chunk
+    run(args.warmup, t_off)
+    t_off += args.warmup
     env.check()
     env._stats.zero_()
     env.set_profiling(True)
+    gather_bytes = 0
     barrier()
     t_start = time.perf_counter()
-    run(args.steps, args.warmup)
+    run(args.steps, t_off)
     barrier()
     elapsed = time.perf_counter() - t_start
     prof = env.get_profile()
     env.set_profiling(False)
-    env.check()
-    stats = env.stats()
+    stats = env.stats()  # also checks the device error word
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     agg = torch.tensor([stats["steps"], stats["episodes"], stats["plays"]], dtype=torch.int64, device=dev)
@@ -161,23 +231,16 @@ def main():
 
     if rank == 0:
         value = env_steps / elapsed
-        # roofline of the dominant kernel (bg_rollout3_kernel): algorithmic bytes per launch / mean launch duration
+        kernel = "bg_engine_kernel" if os.environ.get("BG_ROLLOUT_V", "4") == "4" else "bg_rollout3_kernel"
+        # roofline of the dominant kernel: algorithmic bytes per launch / mean launch duration (HIP events on the launch stream)
         launches = max(1, prof["rollout_launches"])
         fused = prof["rollout_fused_steps"] / launches           # mean fused steps T per launch
         a_step = OBS_BYTES + IO_BYTES + 2 * STATE_BYTES / max(1.0, fused)
         bytes_per_launch = a_step * n * fused
         mean_launch_s = prof["rollout_ms"] / launches * 1e-3
         achieved = bytes_per_launch / mean_launch_s / 1e9 if mean_launch_s > 0 else 0.0
-        # HBM traffic of that kernel from the PMC counters (rocprofv3, separate FETCH_SIZE / WRITE_SIZE passes of this same
-        # command; the corrected per-env-step figure is committed under profiles/ and scaled to this run's launch shape)
-        traffic = None
-        try:
-            if TRAFFIC_FILE[args.obs_layout] is None:
-                raise FileNotFoundError
-            with open(os.path.join(ROOT, "profiles", TRAFFIC_FILE[args.obs_layout])) as f:
-                traffic = json.load(f)["hbm_bytes_per_env_step"] * n * fused
-        except Exception:
-            pass
+        traffic = matching_traffic(kernel, n, fused) if args.obs_layout == "rows" else None
+        peak_measured = measured_copy_gbps(dev)
         out = {
             "metric": "env-steps/sec at 65536 envs, random policy; achieved HBM GB/s vs peak",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -191,16 +254,63 @@ def main():
                                       if args.obs_layout == "rows" else " as one [T, N] array per key"),
                        "obs_layout": args.obs_layout,
                        "envs_per_gpu": n, "total_envs": total, "fused_steps_per_launch": fused,
+                       "internal_warmup_s": args.internal_warmup_s,
                        "ring_depths": {k: os.environ.get(k, "default") for k in ("BG_KG", "BG_KS", "BG_KD")},
                        "parallelism": f"shard{world} (independent envs, no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "bg_rollout3_kernel" if os.environ.get("BG_ROLLOUT_V", "3") == "3" else "bg_rollout2_kernel", "algorithmic_bytes_per_env_step": a_step,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic[0] if traffic else None,
+                         "traffic_source": traffic[1] if traffic else None,
+                         "peak_measured": peak_measured, "frac_of_measured": achieved / peak_measured if peak_measured else None,
+                         "kernel": kernel, "algorithmic_bytes_per_env_step": a_step,
                          "mean_launch_us": mean_launch_s * 1e6, "launches": launches,
                          "refill_mean_launch_us": prof["refill_ms"] / max(1, prof["refill_launches"]) * 1e3},
             "episodes": int(agg[1].item()), "accepted_plays": int(agg[2].item()),
             "state_bytes_per_gpu": env.state_bytes(),
         }
+        if world > 1:
+            out["gather"] = {"in_timed_region": bool(do_gather), "what": "all_gather_into_tensor of the current 352-byte record of every env, once per launch, side stream",
+                             "bytes_per_gpu_per_launch": (gather_bytes // max(1, launches)) if do_gather else 0}
+    env.close()
+    del ob
+
+    if rank == 0 and world == 1 and not args.no_step_path:
+        # ---- the Gymnasium-surface path: bg_step with actions from a device tensor (recorded from a fused rollout of a twin
+        # handle, so every action is the valid policy action of that state), then the same steps through bg_step_many
+        ks = 200
+        twin = make_env()
+        acts = torch.zeros((ks, n), dtype=torch.int32, device=dev)
+        twin.rollout(ks, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, env_index0=lo, actions=acts)
+        twin_stats = twin.stats()
+        twin.close()
+        res = {}
+        for mode in ("bg_step", "bg_step_many"):
+            e2 = make_env()
+            e2.step(acts[0]); e2.reset(); torch.cuda.synchronize(dev)  # first-call costs out of the way
+            e2.close()
+            e2 = make_env()
+            e2.set_profiling(True)
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            if mode == "bg_step":
+                for k in range(ks):
+                    e2.step(acts[k])
+            else:
+                e2.step_many(acts)
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t0
+            p = e2.get_profile()
+            e2.check()
+            a1 = OBS_BYTES + IO_BYTES + 2 * STATE_BYTES  # one launch per step: the state crosses HBM every step
+            a_k = OBS_BYTES + IO_BYTES + 2 * STATE_BYTES / ks
+            alg = (a1 if mode == "bg_step" else a_k) * n * ks
+            res[mode] = {"value": n * ks / dt, "unit": "env-steps/s", "steps": ks, "ms_per_step": dt / ks * 1e3,
+                         "kernel_ms_per_step": p["step_ms"] / ks, "launches": p["step_launches"],
+                         "roofline_frac": alg / (p["step_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if p["step_ms"] > 0 else None}
+            e2.close()
+        out["step_path"] = {"what": f"{ks} steps of the same workload, actions from a device tensor [K, N], observation as one array per key",
+                            "twin_rollout_plays": twin_stats["plays"], **res}
+
+    if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             threads = os.cpu_count() or 1
             n_cpu, t_cpu = 256 * threads, 3000
@@ -212,7 +322,6 @@ def main():
                                    "sample": f"{n_cpu} envs x {t_cpu} steps of the same workload on the C oracle "
                                              f"(oracle/balatro_oracle.c), {threads} threads, {dt:.1f} s"}
         print(json.dumps(out), flush=True)
-    env.close()
     if world > 1:
         dist.destroy_process_group()
 

@@ -2,7 +2,7 @@
 """Run bench.py with the given extra args / env and print the few numbers an A/B needs on one line."""
 import json, os, subprocess, sys
 args = sys.argv[1:]
-out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py"), "--no-cpu-baseline"] + args,
+out = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "bench.py"), "--no-cpu-baseline", "--no-step-path"] + args,
                      capture_output=True, text=True)
 line = [l for l in out.stdout.splitlines() if l.startswith("{")]
 if not line:
