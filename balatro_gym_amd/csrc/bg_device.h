@@ -307,6 +307,21 @@ __device__ __forceinline__ int bg_card(const BgDev& d, int env, const DeckLds& k
   return (int)((const lds_u8*)k.col)[(idx >> 2) * (BG_RB * 4) + (idx & 3)];
 }
 
+// The first 16 cards of the deck in two registers: every deck index a hand normally holds (the hand is a
+// permutation of deck[0..hand_size)).  Four independent LDS reads up front instead of one dependent read per card looked at.
+struct DeckHead { uint64_t lo, hi; };
+__device__ __forceinline__ DeckHead bg_deck_head(const BgDev& d, int env, const Deck0& k) { return DeckHead{k.lo, k.hi}; }
+template <int S, bool C>
+__device__ __forceinline__ DeckHead bg_deck_head(const BgDev& d, int env, const DeckLdsS<S, C>& k) {
+  const uint32_t a = k.col[0], b = k.col[S], c = k.col[2 * S], e = k.col[3 * S];
+  return DeckHead{((uint64_t)b << 32) | a, ((uint64_t)e << 32) | c};
+}
+template <class DK>
+__device__ __forceinline__ int bg_card_h(const BgDev& d, int env, const DK& k, const DeckHead& h, int idx) {
+  if (idx < 16) return (int)(((idx < 8 ? h.lo : h.hi) >> (8 * (idx & 7))) & 0xffull);
+  return bg_card(d, env, k, idx);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // MT19937 pieces (CPython Modules/_randommodule.c)
 // ---------------------------------------------------------------------------------------------------------
@@ -429,6 +444,21 @@ __device__ __forceinline__ void bg_gpeek12(const BgDev& d, int env, const Env& e
   } else {
 #pragma unroll
     for (int i = 0; i < 12; i++) out[i] = 0u;
+  }
+}
+// the same 12 words UNTEMPERED: nothing here waits for the loads, so they can be issued long before the values are needed
+__device__ __forceinline__ void bg_gpeek12_raw(const BgDev& d, int env, const Env& e, int skip, uint32_t (&out)[12], uint32_t& avail) {
+  int idx = e.g_idx + skip, blk = e.g_cur, need = 1;
+  if (idx >= BG_MT_N) { idx -= BG_MT_N; blk = (blk + 1 == d.KG) ? 0 : blk + 1; need = 2; }
+  if (idx >= BG_MT_N) { idx -= BG_MT_N; blk = (blk + 1 == d.KG) ? 0 : blk + 1; need = 3; }
+  const bool have = e.g_valid >= need;
+  const int in_blk = BG_MT_N - idx; // words before the mirror
+  avail = have ? ((e.g_valid > need || in_blk >= 12) ? 0xfffu : ((1u << in_blk) - 1u)) : 0u;
+  const BgU4* p = (const BgU4*)(bg_gblock(d, env, have ? blk : e.g_cur) + (have ? idx : 0));
+#pragma unroll
+  for (int g = 0; g < 3; g++) {
+    const BgU4 v = p[g];
+    out[4 * g] = v.x; out[4 * g + 1] = v.y; out[4 * g + 2] = v.z; out[4 * g + 3] = v.w;
   }
 }
 // fetch the next `count` words of the global stream into the window (stops at the block end)

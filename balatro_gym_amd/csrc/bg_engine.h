@@ -1,21 +1,25 @@
 // bg_engine.h -- the step engine: ONE kernel behind bg_step, bg_step_many, bg_rollout and bg_rollout_rows.
 //
-// A workgroup owns NE envs (256: one workgroup per CU; 128 for small jobs) whose whole state lives in LDS for the launch
-// (hot chunks, deck, shop inventory, the carried observation values, the step counter).  Its waves are WORKERS, not owners:
-// each pulls a BATCH of up to 64 envs that need the same kind of work from one of three LDS queues and completes one step for
-// every env of the batch -- action, state change, SAME_STEP auto-reset, action mask, observation record, reward / terminated /
-// info, statistics -- then hands the envs on:
-//   run queue    envs whose next step is due: counter-hash policy (or the caller's action), guards (balatro_env_2.py:619-627);
-//                card-select toggles and shop-end are applied on the spot; PLAY_HAND goes to the play queue and every other
-//                action to the other queue (the state is untouched, so queueing costs one LDS word)
+// A workgroup owns 256 envs (one workgroup per CU).  For the length of the launch every env has, in LDS,
+//   * its observation RECORD IMAGE: the 352-byte packed record of include/balatro_mi355x.h (BG_ROW_*), always current;
+//   * hot chunks 3 and 4 (phase / counters / hand / selection order): all a card-select toggle needs;
+//   * its deck (52 card codes), its cached 60-bit action mask and its step counter;
+// the other six hot chunks stay in HBM (the service batches below load and store them; every access to an env's state comes
+// from this CU, whose vector-memory pipeline is in order).  The waves are WORKERS, not owners: each pulls a batch of up to 64
+// envs that need the same kind of work from one of three LDS queues and completes one step for every env of the batch:
+//   run queue    envs whose next step is due: counter-hash policy (or the caller's action) on the cached mask, guards
+//                (balatro_env_2.py:619-627).  A card-select toggle (84 % of a random policy's steps, :1052-1058) or a rejected
+//                action is settled ON THE IMAGE: the selection list in chunk 4, one int64 of selected_cards, the two mask
+//                bytes that depend on "anything selected", reward / action / terminated -- no unpack of the state, no record
+//                build.  Everything else is queued (the state is untouched, so queueing costs one LDS word).
 //   play queue   PLAY_HAND (bg_step_play_hand: classification, joker chain, reward shaping, blind outcome, shop generation)
-//   other queue  DISCARD, blind select / skip, shop buy / reroll / sell, consumables
-// Why: with lane = env for the whole launch (the service-wave kernel before this one) a lane whose action is queued idles
-// until it is served, so an env-wave iteration ran with ~35 of 64 lanes and 1.9 iterations per step, and the service waves
-// ran batches of ~21 / ~6 items; every instruction was paid at a third to a half of the lanes.  Here a blocked env blocks
-// nobody: batches are as full as the queues allow (a wave prefers a full batch of any kind over a partial one), and the wave
-// that steps an env also finishes the step, so there is no hand-back, no polling and no second pass over the env.
-// The per-env step counters drift apart exactly as before (row = env + t * N; envs are independent).
+//   other queue  DISCARD, blind select / skip, shop end / buy / reroll / sell, consumables, the terminal guards
+//                -- full state from HBM + LDS, the step, curriculum cap, SAME_STEP auto-reset, mask, a freshly built image.
+// Every batch ends with the COPY-OUT of its images to their rows: lane <-> 16-byte piece, consecutive lanes = consecutive
+// pieces of a row (whole 352-byte runs per row), trip count proportional to the envs of the batch.
+// Why: the kernels before this one kept lane = env and rebuilt the 88-dword record from the unpacked state on every step
+// (~700 of the ~1100 instructions of a step whose game logic is a dozen), at 35 of 64 lanes; a SIMD's VALU was 50 % busy doing
+// that.  Per-env step counters drift apart as before (row = env + t * N; envs are independent).
 // No workgroup barrier inside the loop; queues and counters are LDS words (one wave's LDS operations execute in program
 // order, so "data, then flag" needs compiler barriers only); every spin is bounded (sticky device error instead of a hang).
 #pragma once
@@ -26,6 +30,9 @@
 #define BG_ITEM_VALID 0x80000000u
 #define BG_SPIN_LIMIT (1u << 24)
 #define BG_DEVERR_SPIN 16u
+#define BG_ENG_NE 256   // envs per workgroup
+#define BG_ENG_NW 8     // waves per workgroup (two per SIMD)
+#define BG_ENG_NSV 4    // of them, how many own an RNG window and may run service batches (waves NW-NSV .. NW-1)
 
 struct EngineArgs {
   int T;                       // steps per env in this launch
@@ -39,6 +46,7 @@ struct EngineArgs {
   bg_rollout_stats* stats;
   uint32_t th_run, th_play, th_other; // a queue is served once it holds this many items ...
   uint32_t th_part;            // ... or, while other waves are busy (their envs will come back soon), this many; anything when no wave is busy
+  uint32_t th_more;            // further cheap steps an env may take inside the batch that has it
   uint32_t autoreset;          // SAME_STEP auto-reset of terminated envs
 };
 
@@ -53,23 +61,23 @@ __device__ __forceinline__ void bg_lds_st(uint32_t* p, uint32_t v) {
 }
 __device__ __forceinline__ void bg_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-// INFO: the launch serves bg_step / bg_step_many (per-step info arrays, actions from the caller); false for the rollouts
-template <bool HASH, bool CARDS, bool INFO, int NE>
-__global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArgs a) {
-  static_assert(NE == 128 || NE == 256, "128 or 256 envs per workgroup");
-  constexpr int NW = NE / 32;                 // waves per workgroup (two per SIMD at NE = 256)
-  __shared__ uint4 s_state[BG_NHOT][NE];
-  __shared__ uint4 s_shop[4][NE];
+struct CopyEnt { uint32_t l, pad; unsigned long long row; }; // one finished env of a batch: its image, its destination row
+
+// INFO: the launch serves bg_step / bg_step_many (per-step info arrays); false for the rollouts
+template <bool HASH, bool CARDS, bool INFO>
+__global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, 2) void bg_engine_kernel(BgDev d, EngineArgs a) {
+  constexpr int NE = BG_ENG_NE, NW = BG_ENG_NW, NSV = BG_ENG_NSV;
+  __shared__ bg_u32x4 s_img[NE][22];          // record images (88 KB)
+  __shared__ uint4 s_c34[2][NE];              // hot chunks 3 and 4
   __shared__ uint32_t s_deck[16][NE];
-  __shared__ unsigned long long s_handb[NE], s_mask[NE];
-  __shared__ float s_prf[NE];
-  __shared__ uint32_t s_selm[NE], s_t[NE], s_prod[NE];
+  __shared__ unsigned long long s_mask[NE];
+  __shared__ uint32_t s_t[NE], s_prod[NE];
   __shared__ uint32_t s_q[3][NE];             // rings of env lanes (| action << 16 | VALID)
   __shared__ uint32_t s_tail[3], s_head[3];   // items ever queued / ever claimed per queue
   __shared__ uint32_t s_done;                 // envs that have finished their T steps
   __shared__ uint32_t s_busy;                 // waves inside a batch
-  __shared__ bg_u32x4 s_scratch[NW][BG_BLOCK * 8]; // per wave: record staging (8 KB), and the RNG window of a service batch (6 KB) before it
-  __shared__ unsigned long long s_rowaddr[NW][BG_BLOCK];
+  __shared__ uint32_t s_win[NSV][BG_WIN][BG_BLOCK]; // RNG windows of the service-capable waves
+  __shared__ CopyEnt s_list[NW][BG_BLOCK];    // copy-out lists
   __shared__ JTables jt;
   __builtin_amdgcn_s_setprio(3);
   BG_PROBE_INIT();
@@ -77,8 +85,10 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int env0 = blockIdx.x * NE;
   const int n_live = d.N - env0 < NE ? d.N - env0 : NE;
+  const bool can_serve = wave >= NW - NSV;
   using DeckT = DeckLdsS<NE, CARDS>;
-  // ---------------------------------------------------------------- prologue: HBM -> LDS, lane = env
+  const size_t N = (size_t)d.N;
+  // ---------------------------------------------------------------- prologue: HBM -> LDS, images built, lane = env
   if (tid < 3) { s_tail[tid] = tid == BG_Q_RUN ? (uint32_t)n_live : 0u; s_head[tid] = 0; }
   if (tid == 0) { s_done = 0; s_busy = 0; }
   if (tid < NE) {
@@ -89,10 +99,11 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
     if (l < n_live) {
       uint4 c[BG_NHOT];
 #pragma unroll
-      for (int k = 0; k < BG_NHOT; k++) { c[k] = d.hot[(size_t)k * d.N + env]; s_state[k][l] = c[k]; }
+      for (int k = 0; k < BG_NHOT; k++) c[k] = d.hot[(size_t)k * N + env];
+      s_c34[0][l] = c[3]; s_c34[1][l] = c[4];
       DeckT dk; dk.col = (lds_u32*)&s_deck[0][l];
 #pragma unroll
-      for (int k = 0; k < BG_NDECK; k++) bg_deck_set(dk, k, d.deck[(size_t)k * d.N + env]);
+      for (int k = 0; k < BG_NDECK; k++) bg_deck_set(dk, k, d.deck[(size_t)k * N + env]);
       const uint32_t prod = d.prod_view ? d.prod_view[env] : 0u;
       s_prod[l] = prod;
       Env e;
@@ -100,8 +111,9 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
       bg_derive_ready(e, prod);
       ShopRegs sr; sr.valid = false;
       const uint64_t mask = bg_action_mask(d, env, e, sr);
-      if (sr.valid) { s_shop[0][l] = sr.c3; s_shop[1][l] = sr.c4; s_shop[2][l] = sr.c5; s_shop[3][l] = sr.c6; }
-      s_mask[l] = mask; s_handb[l] = bg_obs_handb(d, env, e, dk); s_prf[l] = bg_obs_prf(e); s_selm[l] = bg_obs_selm(e);
+      s_mask[l] = mask;
+      const ObsPtrs none{};
+      bg_write_obs_impl<false, 3>(d, env, 0, e, dk, none, mask, sr, RowExtra{0.0, 0, 0u}, RowStage{(lds_u4*)&s_img[l][0], nullptr});
     }
   }
   __syncthreads();
@@ -111,35 +123,32 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
   const uint32_t bmod3 = (uint32_t)(a.env_index0 % 3ull);
   uint32_t polls = 0;
 #ifdef BG_TIMING4
-  unsigned long long q_batches[3] = {0, 0, 0}, q_items[3] = {0, 0, 0}, q_busy[3] = {0, 0, 0}, q_idle = 0, q_fail = 0, q_sec[3][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+  unsigned long long q_batches[3] = {0, 0, 0}, q_items[3] = {0, 0, 0}, q_busy[3] = {0, 0, 0}, q_idle = 0, q_fail = 0, q_copy = 0;
   const unsigned long long q_t0 = __builtin_readcyclecounter();
-#define BG_Q(k) do { const unsigned long long _n = __builtin_readcyclecounter(); q_sec[cls][k] += _n - q_mark; q_mark = _n; } while (0)
-#else
-#define BG_Q(k) do {} while (0)
 #endif
   for (;;) {
 #ifdef BG_TIMING4
     const unsigned long long q_l0 = __builtin_readcyclecounter();
 #endif
-    // -- pick a queue: a full batch of runnable envs first (it feeds the others), then a service queue at its threshold, then
-    //    whatever there is (work conserving)
+    // -- pick a queue
     const uint32_t hr = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_head[BG_Q_RUN])), hp = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_head[BG_Q_PLAY])),
                    ho = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_head[BG_Q_OTHER]));
-    const uint32_t nr = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_tail[BG_Q_RUN])) - hr, np = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_tail[BG_Q_PLAY])) - hp,
-                   no = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_tail[BG_Q_OTHER])) - ho;
+    const uint32_t nr = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_tail[BG_Q_RUN])) - hr;
+    const uint32_t np = can_serve ? __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_tail[BG_Q_PLAY])) - hp : 0u,
+                   no = can_serve ? __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_tail[BG_Q_OTHER])) - ho : 0u;
     int cls = -1;
-    if (nr >= a.th_run) cls = BG_Q_RUN;
-    else if (np >= a.th_play) cls = BG_Q_PLAY;
+    if (np >= a.th_play) cls = BG_Q_PLAY;          // a service-capable wave serves first: the long chains are the critical path
     else if (no >= a.th_other) cls = BG_Q_OTHER;
+    else if (nr >= a.th_run) cls = BG_Q_RUN;
     else if (nr | np | no) {
       // nothing is full.  While other waves are inside batches their envs will be back in a moment, so a small batch now only
       // costs instructions at a low lane count; when no wave is busy nothing will ever arrive: take what there is.
       const uint32_t busy = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_busy));
-      const uint32_t need = busy ? a.th_part : 1u;
-      if (nr >= need && nr >= np && nr >= no) cls = BG_Q_RUN;
+      const uint32_t need = busy ? a.th_part : 1u; // (service queues only: a partial run batch is cheap)
+      if (nr && nr >= np && nr >= no) cls = BG_Q_RUN;
       else if (np >= need && np >= no) cls = BG_Q_PLAY;
       else if (no >= need) cls = BG_Q_OTHER;
-      else if (nr >= need) cls = BG_Q_RUN;
+      else if (nr) cls = BG_Q_RUN;
       else if (np >= need) cls = BG_Q_PLAY;
     }
     if (cls < 0) {
@@ -164,108 +173,224 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
       }
     }
     polls = 0;
-#ifdef BG_TIMING4
-    unsigned long long q_mark = __builtin_readcyclecounter();
-    const unsigned long long q_b0 = q_mark;
+#ifndef BG_NO_SERVICE_PRIO
+    // the service chains are the critical path of every env they hold: they issue ahead of the run batches on their SIMD
+    if (cls == BG_Q_RUN) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
 #endif
+#ifdef BG_TIMING4
+    const unsigned long long q_b0 = __builtin_readcyclecounter();
+#endif
+    // A batch = the step the envs were queued for, then up to th_more further CHEAP steps of the same envs (a toggle is followed
+    // by another toggle five times out of six): the env stays with the wave that has it instead of going through the run queue
+    // -- and its wait for a free wave -- once per step.  A lane leaves the batch when its env has done its T steps or its next
+    // action needs a service batch.
+    bool active = false;           // this lane holds an env
+    int l = 0, env = 0;
+    uint32_t t = 0, item = 0;
     if ((uint32_t)lane < nb) {
       uint32_t* slotp = &s_q[cls][(head + (uint32_t)lane) & (NE - 1)];
-      uint32_t item = bg_lds_ld(slotp);
+      item = bg_lds_ld(slotp);
       uint32_t spin = 0;
       while (!(item & BG_ITEM_VALID) && ++spin < BG_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); item = bg_lds_ld(slotp); }
       bg_lds_st(slotp, 0u);
       if (!(item & BG_ITEM_VALID)) atomicOr(d.err, BG_DEVERR_SPIN);
+      else { active = true; l = (int)(item & 0xffffu); env = env0 + l; t = s_t[l]; }
+    }
+    // one CHEAP step of this lane's env on its image: a card-select toggle, shop end, or an action the guards reject; anything
+    // else is queued for a service batch and the lane gives the env up.  Returns true when a step was completed.
+    auto cheap_step = [&](int& action, double& reward, StepOut& o) __attribute__((always_inline)) -> bool {
+      bool fin = false;
+      uint64_t mask = s_mask[l];
+      lds_u32* img32 = (lds_u32*)&s_img[l][0];
+      lds_u8* img8 = (lds_u8*)&s_img[l][0];
+      const uint4 c3 = s_c34[0][l];
+      const uint32_t ante = bg_b(c3.x, 0), phase = bg_b(c3.x, 2), discards_left = bg_b(c3.y, 0), nsel0 = bg_b(c3.y, 3);
+      if (a.actions_in) action = a.actions_in[(size_t)t * N + env];
       else {
-        const int l = (int)(item & 0xffffu), env = env0 + l;
+        const uint64_t gi = a.env_index0 + (uint64_t)env;
+        Env pe; pe.phase = (int)phase; // the policy only looks at the phase and the mask
+        PolicyLane pl;
+        pl.seed_env = a.policy_seed + 0x9E3779B97F4A7C15ull * (gi + 1);
+        pl.blind = a.policy == 2 ? 45 + (int)((bmod3 + (uint32_t)env % 3u) % 3u) : 45;
+        action = bg_policy_action_fast(pe, mask, a.policy, pl, pl.seed_env + BG_POLICY_PSI * (a.t0 + (uint64_t)t + 1), (lds_JTables*)&jt);
+      }
+      const int64_t chips_scored = (int64_t)(((uint64_t)img32[33] << 32) | img32[32]);
+      const bool valid = action >= 0 && action < 60 && ((mask >> (action & 63)) & 1ull);
+      const bool terminal = ante > 100u || chips_scored > 1000000000ll;   // :619-623, settled by a service batch (it resets the env)
+      if (!terminal && valid && phase == 0u && action >= 2 && action < 10) {
+        // :1052-1058 toggle position `pos` in state.selected_cards (bg_toggle_select on chunk 4)
+        const int pos = action - 2;
+        uint4 c4 = s_c34[1][l];
+        Env te; te.sel = ((uint64_t)c4.w << 32) | c4.z; te.nsel = (int)nsel0;
+        bg_toggle_select(te, pos);
+        c4.z = (uint32_t)te.sel; c4.w = (uint32_t)(te.sel >> 32);
+        s_c34[1][l] = c4;
+        ((lds_u8*)&s_c34[0][l])[7] = (uint8_t)te.nsel;                   // chunk 3, word y, byte 3
+        *(lds_u64*)&img32[2 * pos] = te.nsel > (int)nsel0 ? 1ull : 0ull;  // selected_cards[pos] (int64)
+        if ((te.nsel > 0) != (nsel0 > 0u)) {                             // PLAY_HAND / DISCARD availability (:1436-1441)
+          const uint32_t play = te.nsel > 0 ? 1u : 0u, disc = (te.nsel > 0 && discards_left > 0u) ? 1u : 0u;
+          mask = (mask & ~3ull) | play | ((uint64_t)disc << 1);
+          s_mask[l] = mask;
+          *(__attribute__((address_space(3))) uint16_t*)&img8[BG_ROW_ACTION_MASK] = (uint16_t)(play | (disc << 8));
+        }
+        fin = true;
+      } else if (!terminal && valid && phase == 1u && action == 31 && (int)(int8_t)bg_b(c3.y, 1) <= (int)bg_b(c3.y, 2)) {
+        // :1247-1251 leave the shop; the hand is full (played cards never left it: `_draw_cards` would draw nothing), so all
+        // that changes is the phase, the mask and the shop rows of the observation (shown in SHOP phase only, :1534-1539)
+        const uint32_t nhand = bg_b(c3.y, 2), ncons = bg_b(c3.z, 1);
+        ((lds_u8*)&s_c34[0][l])[2] = 0;                                   // chunk 3, word x, byte 2: phase = PLAY
+        uint64_t m = (((1ull << (nhand < 8u ? nhand : 8u)) - 1ull) << 2) | (((1ull << ncons) - 1ull) << 10);
+        if (nsel0 > 0u) m |= 1ull | (discards_left > 0u ? 2ull : 0ull);
+        mask = m;
+        s_mask[l] = mask;
+#pragma unroll
+        for (int wq = 0; wq < 15; wq++) img32[44 + wq] = __umul24((uint32_t)(mask >> (4 * wq)) & 0xfu, 0x204081u) & 0x01010101u; // action_mask i8[60]
+#pragma unroll
+        for (int wq = 64; wq < 74; wq++) img32[wq] = 0u;                  // shop_items, shop_costs
+        img8[BG_ROW_PHASE] = 0;
+        fin = true;
+      } else if (!terminal && !valid) { reward = -1.0; fin = true; }    // :626-627 'Invalid action': nothing changes
+      else {
+        const int q = (!terminal && phase == 0u && action == 0) ? BG_Q_PLAY : BG_Q_OTHER;
+        const uint32_t slot = __hip_atomic_fetch_add(&s_tail[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        bg_lds_st(&s_q[q][slot & (NE - 1)], (uint32_t)l | (((uint32_t)action & 0x7fffu) << 16) | BG_ITEM_VALID);
+        active = false;                                                   // the env is the service queue's now
+      }
+      if (fin) {
+        *(__attribute__((address_space(3))) double*)&img32[34] = reward;  // BG_ROW_REWARD
+        img32[43] = (uint32_t)action;                                      // BG_ROW_ACTION
+        img8[BG_ROW_TERMINATED] = 0;
+        if constexpr (INFO) { bg_step_init(o); o.reward = reward; o.error = valid ? 0 : 1; }
+      }
+      return fin;
+    };
+    // the outputs of a completed step other than the image, and the env's step counter
+    auto finish = [&](bool cheap, size_t row, int action, double reward, bool terminated, const StepOut& o) __attribute__((always_inline)) {
+      if (cheap && !a.obs.rows) bg_emit_keys_from_image((const lds_u4*)&s_img[l][0], a.obs, row); // per-key arrays of a cheap step
+      if (a.reward) a.reward[row] = reward;
+      if (a.term) a.term[row] = terminated ? 1 : 0;
+      if (a.actions_out) a.actions_out[row] = action;
+      if constexpr (INFO) bg_emit_info(row, o, a.trunc, a.info);
+      if (HASH) ohash ^= bg_hash_image((const lds_u4*)&s_img[l][0]) * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(a.t0 + t)) + (a.env_index0 + (uint64_t)env);
+      n_steps++;
+      rbits ^= (uint64_t)__double_as_longlong(reward) * (2 * (uint64_t)(a.t0 + t) + 1);
+      t++;
+      s_t[l] = t;
+    };
+    // copy-out: the images of the finished envs to their rows, lane <-> piece (whole 352-byte runs per row); then envs that are
+    // through leave (after their images have been READ)
+    auto copy_out = [&](bool fin, size_t row) __attribute__((always_inline)) {
+    if (a.obs.rows) {
+#ifdef BG_TIMING4
+      const unsigned long long q_c0 = __builtin_readcyclecounter();
+#endif
+      const unsigned long long fm = __ballot(fin);
+      const uint32_t A = (uint32_t)__popcll(fm);
+      if (fin) {
+        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+        CopyEnt ce; ce.l = (uint32_t)l; ce.pad = 0; ce.row = (unsigned long long)(a.obs.rows + row * (size_t)a.obs.row_stride);
+        s_list[wave][rank] = ce;
+      }
+      BG_WAVE_SYNC();
+      const uint32_t total = 22u * A;
+      // four pieces per lane and round: the four list reads, then the four image reads, then the four stores are each issued
+      // back to back (one LDS round trip per group instead of two per piece)
+      for (uint32_t q0 = (uint32_t)lane; q0 < total; q0 += 4u * BG_BLOCK) {
+        CopyEnt ce[4];
+        uint32_t cpc[4];
+        bg_u32x4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+          const uint32_t q = q0 + (uint32_t)k * BG_BLOCK;
+          const uint32_t r = (q * 2979u) >> 16;   // q / 22 (exact for q < 64 * 22)
+          cpc[k] = q - 22u * r;
+          ce[k] = s_list[wave][r < BG_BLOCK ? r : 0u];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = s_img[ce[k].l & (NE - 1)][cpc[k]];
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+          if (q0 + (uint32_t)k * BG_BLOCK < total) *(__attribute__((address_space(1))) bg_u32x4*)(ce[k].row + 16ull * cpc[k]) = v[k];
+      }
+      BG_WAVE_SYNC();
+#ifdef BG_TIMING4
+      q_copy += __builtin_readcyclecounter() - q_c0;
+#endif
+    }
+      if (active && t >= (uint32_t)a.T) { __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); active = false; }
+    };
+    // ---------------- the step the batch was claimed for
+    {
+      bool fin = false;
+      size_t row = 0;
+      if (active) {
+        row = (size_t)env + (a.obs_stride_steps ? (size_t)t * N : 0);
+        int action = 0;
+        double reward = 0.0;
+        bool terminated = false;
+        StepOut o;
+        if (cls == BG_Q_RUN) fin = cheap_step(action, reward, o);
+        else {
+          uint64_t mask = s_mask[l];
+        action = a.actions_in ? a.actions_in[(size_t)t * N + env] : (int)((item >> 16) & 0x7fffu);
+        BG_PROBE_BEGIN();
         uint4 c[BG_NHOT];
 #pragma unroll
-        for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][l];
+        for (int k = 0; k < BG_NHOT; k++) if (k != 3 && k != 4) c[k] = d.hot[(size_t)k * N + env];
+        c[3] = s_c34[0][l]; c[4] = s_c34[1][l];
         Env e;
         bg_unpack(c, e);
+        BG_PROBE(23);
         bg_derive_ready(e, s_prod[l]);
         DeckT dk; dk.col = (lds_u32*)&s_deck[0][l];
-        const uint32_t t = s_t[l];
-        uint64_t mask = s_mask[l];
-        BG_Q(0); // claim + state load / unpack
-        StepOut o;
-        bg_step_init(o);
-        int action;
-        bool fin = true;                 // the step completes in this batch (false: queued for a service batch)
-        bool heavy = false;              // handb / prf / selm must be recomputed
         ShopRegs sr; sr.valid = false;
-        if (cls == BG_Q_RUN) {
-          if (a.actions_in) action = a.actions_in[(size_t)t * (size_t)d.N + env];
-          else {
-            PolicyLane pl;
-            const uint64_t gi = a.env_index0 + (uint64_t)env;
-            pl.seed_env = a.policy_seed + 0x9E3779B97F4A7C15ull * (gi + 1);
-            pl.blind = a.policy == 2 ? 45 + (int)((bmod3 + (uint32_t)env % 3u) % 3u) : 45;
-            action = bg_policy_action_fast(e, mask, a.policy, pl, pl.seed_env + BG_POLICY_PSI * (a.t0 + (uint64_t)t + 1), (lds_JTables*)&jt);
-          }
-          if (bg_step_guards(e, mask, action, o)) {
-            if (e.phase == 0 && action >= 2 && action < 10) { bg_toggle_select(e, action - 2); s_selm[l] ^= 1u << (action - 2); }
-            else if (e.phase == 1 && action == 31) {                                            // shop end :1247-1251
-              const int nh0 = e.nhand;
-              e.phase = 0; bg_draw_cards(e);
-              if (e.nhand != nh0) s_handb[l] = bg_obs_handb(d, env, e, dk); // rare: the played cards never left the hand
-            } else {
-              const int q = (e.phase == 0 && action == 0) ? BG_Q_PLAY : BG_Q_OTHER;
-              const uint32_t slot = __hip_atomic_fetch_add(&s_tail[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              bg_lds_st(&s_q[q][slot & (NE - 1)], (uint32_t)l | ((uint32_t)action << 16) | BG_ITEM_VALID);
-              fin = false;
-            }
-          }
-        } else {
-          action = (int)((item >> 16) & 0x7fffu);
-          if (e.phase == 1 && (e.bflags & BG_BF_SHOP_EXISTS)) { sr.c3 = s_shop[0][l]; sr.c4 = s_shop[1][l]; sr.c5 = s_shop[2][l]; sr.c6 = s_shop[3][l]; sr.valid = true; }
-          RngWin w;
-          bg_win_init(w, (uint32_t*)&s_scratch[wave][0] + lane, &jt);
-          { BG_PROBE_BEGIN(); bg_env_dispatch(d, env, e, w, sr, dk, action, o); BG_PROBE(cls == BG_Q_PLAY ? 20 : 21); }
-          if (sr.valid) { s_shop[0][l] = sr.c3; s_shop[1][l] = sr.c4; s_shop[2][l] = sr.c5; s_shop[3][l] = sr.c6; }
-          heavy = true;
-        }
-        BG_Q(1); // policy + guards + cheap action / dispatch
-        if (fin) {
-          // ---- finish the step: curriculum cap, SAME_STEP auto-reset, mask, observation, outputs, statistics
-          if (e.max_ante > 0 && e.ante > e.max_ante) { o.terminated = true; o.flags |= 256; }
-          bool did_reset = false;
-          if (o.terminated && a.autoreset) { bg_env_reset(d, env, e, dk); n_eps++; did_reset = true; if (INFO) o.flags |= BG_INFO_AUTORESET; }
-          else if (o.terminated) n_eps++;
-          // a reset zeroes the env's play counts (and re-applies its card states) in HBM, which another wave's play touches a
-          // few steps later; card-state builds also edit card states / lazy streams in HBM from the service batches: let
-          // those stores land before the env is handed on.  What else is in flight is this wave's previous record write-out.
-          if (CARDS ? (heavy || __ballot(did_reset) != 0ull) : (__ballot(did_reset) != 0ull)) bg_vm_drain();
-          uint64_t handb; float prf; uint32_t selm;
-          if (did_reset) { handb = ~0ull; prf = 0.0f; selm = 0u; }
-          else if (heavy) { handb = bg_obs_handb(d, env, e, dk); prf = bg_obs_prf(e); selm = bg_obs_selm(e); }
-          else { handb = s_handb[l]; prf = s_prf[l]; selm = s_selm[l]; }
-          if (!sr.valid && e.phase == 1 && (e.bflags & BG_BF_SHOP_EXISTS)) { sr.c3 = s_shop[0][l]; sr.c4 = s_shop[1][l]; sr.c5 = s_shop[2][l]; sr.c6 = s_shop[3][l]; sr.valid = true; }
-          mask = bg_action_mask(d, env, e, sr);
-          BG_Q(2); // cap, reset, carried values, mask
-          const size_t row = (size_t)env + (a.obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
-          const uint64_t h = bg_write_obs_impl<HASH, 2>(d, env, row, e, dk, a.obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u, true, prf, handb, selm},
-                                                       RowStage{(lds_u4*)&s_scratch[wave][0], (lds_u64*)&s_rowaddr[wave][0]});
-          BG_Q(3); // record
-          if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(a.t0 + t)) + (a.env_index0 + (uint64_t)env);
-          if (a.reward) a.reward[row] = o.reward;
-          if (a.term) a.term[row] = o.terminated ? 1 : 0;
-          if (a.actions_out) a.actions_out[row] = action;
-          if constexpr (INFO) bg_emit_info(row, o, a.trunc, a.info);
-          n_steps++;
-          rbits ^= (uint64_t)__double_as_longlong(o.reward) * (2 * (uint64_t)(a.t0 + t) + 1);
-          if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
-          // ---- state back to LDS, env back to the run queue (or done)
-          bg_pack(e, c);
+        RngWin w;
+        bg_win_init(w, &s_win[wave - (NW - NSV)][0][lane], &jt);
+        bg_step_init(o);
+        if (bg_step_guards(e, mask, action, o)) bg_env_dispatch(d, env, e, w, sr, dk, action, o);
+        BG_PROBE(cls == BG_Q_PLAY ? 20 : 21);
+        if (e.max_ante > 0 && e.ante > e.max_ante) { o.terminated = true; o.flags |= 256; }
+        if (o.terminated) n_eps++;
+        if (o.terminated && a.autoreset) { bg_env_reset(d, env, e, dk); if (INFO) o.flags |= BG_INFO_AUTORESET; }
+        if constexpr (CARDS) bg_vm_drain(); // card states / lazy streams in HBM are edited from any service wave: let the stores land
+        BG_PROBE(24);
+        mask = bg_action_mask(d, env, e, sr);
+        BG_PROBE(25);
+        bg_write_obs_impl<false, 3>(d, env, row, e, dk, a.obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u}, RowStage{(lds_u4*)&s_img[l][0], nullptr});
+        BG_PROBE(26);
+        bg_pack(e, c);
 #pragma unroll
-          for (int k = 0; k < BG_NHOT; k++) s_state[k][l] = c[k];
-          s_mask[l] = mask; s_handb[l] = handb; s_prf[l] = prf; s_selm[l] = selm; s_t[l] = t + 1;
-          if (t + 1 < (uint32_t)a.T) {
-            const uint32_t slot = __hip_atomic_fetch_add(&s_tail[BG_Q_RUN], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            bg_lds_st(&s_q[BG_Q_RUN][slot & (NE - 1)], (uint32_t)l | BG_ITEM_VALID);
-          } else __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          BG_Q(4); // outputs, statistics, state store, requeue
+        for (int k = 0; k < BG_NHOT; k++) if (k != 3 && k != 4) d.hot[(size_t)k * N + env] = c[k];
+        s_c34[0][l] = c[3]; s_c34[1][l] = c[4];
+        s_mask[l] = mask;
+        BG_PROBE(27);
+        reward = o.reward; terminated = o.terminated;
+        if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
+        fin = true;
         }
+        if (fin) finish(cls == BG_Q_RUN, row, action, reward, terminated, o);
       }
+      copy_out(fin, row);
+    }
+    // ---------------- further cheap steps of the envs this wave still holds
+    // (run batches only: a service wave hands its envs back at once -- service capacity is what the whole workgroup waits for)
+    for (uint32_t sub = 0; cls == BG_Q_RUN && sub < a.th_more && __ballot(active) != 0ull; sub++) {
+      bool fin = false;
+      size_t row = 0;
+      if (active) {
+        row = (size_t)env + (a.obs_stride_steps ? (size_t)t * N : 0);
+        int action = 0;
+        double reward = 0.0;
+        StepOut o;
+        fin = cheap_step(action, reward, o);
+        if (fin) finish(true, row, action, reward, false, o);
+      }
+      copy_out(fin, row);
+    }
+    // ---- hand the remaining envs back to the run queue
+    if (active) {
+      const uint32_t slot = __hip_atomic_fetch_add(&s_tail[BG_Q_RUN], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      bg_lds_st(&s_q[BG_Q_RUN][slot & (NE - 1)], (uint32_t)l | BG_ITEM_VALID);
     }
     if (lane == 0) __hip_atomic_fetch_sub(&s_busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // after the pushes of this batch
 #ifdef BG_TIMING4
@@ -276,16 +401,15 @@ __global__ __launch_bounds__(NE * 2, 2) void bg_engine_kernel(BgDev d, EngineArg
   if (lane == 0 && d.dbg) {
     atomicAdd(&d.dbg[0], __builtin_readcyclecounter() - q_t0); atomicAdd(&d.dbg[1], 1ull);
     for (int c = 0; c < 3; c++) { atomicAdd(&d.dbg[2 + 3 * c], q_batches[c]); atomicAdd(&d.dbg[3 + 3 * c], q_items[c]); atomicAdd(&d.dbg[4 + 3 * c], q_busy[c]); }
-    atomicAdd(&d.dbg[11], q_idle); atomicAdd(&d.dbg[12], q_fail);
-    for (int c = 0; c < 3; c++) for (int k = 0; k < 5; k++) atomicAdd(&d.dbg[16 + 5 * c + k], q_sec[c][k]);
+    atomicAdd(&d.dbg[11], q_idle); atomicAdd(&d.dbg[12], q_fail); atomicAdd(&d.dbg[13], q_copy);
   }
 #endif
-  // ---------------------------------------------------------------- epilogue: LDS -> HBM, statistics
+  // ---------------------------------------------------------------- epilogue: chunks 3 / 4 -> HBM, statistics
   BG_PROBE_FLUSH(d);
   __syncthreads();
   if (tid < n_live) {
-#pragma unroll
-    for (int k = 0; k < BG_NHOT; k++) d.hot[(size_t)k * d.N + env0 + tid] = s_state[k][tid];
+    d.hot[(size_t)3 * N + env0 + tid] = s_c34[0][tid];
+    d.hot[(size_t)4 * N + env0 + tid] = s_c34[1][tid];
   }
   if (a.stats) {
 #pragma unroll

@@ -1021,7 +1021,7 @@ struct bg_handle {
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
   // tunables read ONCE per handle in bg_create (environment variables)
   int refill_blocks, refill_blocks_shop, dev_skip_refill, gblk_first, gblk_own, wg_envs;
-  uint32_t eng_run, eng_play, eng_other, eng_part; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
+  uint32_t eng_run, eng_play, eng_other, eng_part, eng_more; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
   uint32_t role_mode;
 };
 
@@ -1147,7 +1147,7 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0); h->gblk_first = geti("BG_GBLK_FIRST", 0); h->gblk_own = geti("BG_GBLK_OWN", 0);
     h->wg_envs = geti("BG_WG_ENVS", 0);
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
-    h->eng_part = (uint32_t)geti("BG_ENG_PART", 1);
+    h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 3);
     h->role_mode = (uint32_t)geti("BG_ROLE_MODE", 0) | (geti("BG_HELP", 0) ? 0x100u : 0u) | (geti("BG_DEFER_ADV", 0) ? 0x200u : 0u) |
                    (((uint32_t)geti("BG_TH_ENV", 0) & 0xffu) << 16);
   }
@@ -1443,11 +1443,9 @@ int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void
 
 // one launch of the step engine (bg_engine.h): T steps of every env of the handle
 static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a, bool hash, bool info, hipStream_t st) {
-  const int wg_envs = h->wg_envs ? h->wg_envs : (h->dev.N >= 32768 ? 256 : 128);
   const bool cards = h->dev.cstate != nullptr;
-  const dim3 g128((h->dev.N + 127) / 128), g256((h->dev.N + 255) / 256);
-#define BG_ENG(HASHV, CARDSV, INFOV) do { if (wg_envs == 256) hipLaunchKernelGGL((bg_engine_kernel<HASHV, CARDSV, INFOV, 256>), g256, dim3(512), 0, st, dv, a); \
-                                           else hipLaunchKernelGGL((bg_engine_kernel<HASHV, CARDSV, INFOV, 128>), g128, dim3(256), 0, st, dv, a); } while (0)
+  const dim3 g((h->dev.N + BG_ENG_NE - 1) / BG_ENG_NE), b(BG_ENG_NW * BG_BLOCK);
+#define BG_ENG(HASHV, CARDSV, INFOV) hipLaunchKernelGGL((bg_engine_kernel<HASHV, CARDSV, INFOV>), g, b, 0, st, dv, a)
   if (info) { if (cards) BG_ENG(false, true, true); else BG_ENG(false, false, true); }
   else if (hash && cards) BG_ENG(true, true, false);
   else if (hash) BG_ENG(true, false, false);
@@ -1496,7 +1494,7 @@ static int bg_step_impl(bg_handle* h, int K, const int32_t* actions_dev, const b
       ea.trunc = truncated_dev ? truncated_dev + off : nullptr;
       ea.info = bg_info(info);
       if (off) bg_info_advance(ea.info, off);
-      ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part;
+      ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more;
       ea.autoreset = (h->dev.flags & BG_FLAG_AUTORESET) ? 1u : 0u;
       bg_engine_launch(h, dv, ea, false, true, st);
     } else {
@@ -1577,7 +1575,7 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
         memset(&ea, 0, sizeof(ea));
         ea.T = chunk; ea.policy = pol; ea.policy_seed = policy_seed; ea.env_index0 = env_index0; ea.t0 = tt;
         ea.obs = o; ea.obs_stride_steps = obs_stride_steps; ea.reward = rw; ea.term = tm; ea.actions_out = ac; ea.stats = stats_dev;
-        ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.autoreset = 1;
+        ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.autoreset = 1;
         bg_engine_launch(h, dv, ea, hash, false, st);
       } else {
         // envs per workgroup.  256 (one workgroup per CU: its two play waves and two other waves pool the queues of 256 envs,

@@ -448,9 +448,13 @@ struct ChainIn {
   bool all_black;   // GENERAL: every card of context['cards'] is a Spade or a Club (Blackboard)
   int deck_len, style; // GENERAL: len(game_state['deck']), 1 = 'Pair' / 'Three of a Kind' / 'Four of a Kind' names
 };
+// The main phase's 12 candidate words, requested EARLY (bg_step_play_hand issues the loads before it gathers and classifies the
+// cards, so their HBM round trip runs beside ~5k cycles of LDS work instead of after it): valid when `skip` equals the number
+// of words the individual phase turns out to consume.
+struct ChainPeek { uint32_t mw[12]; uint32_t avail; int skip; bool ok; };
 template <bool GENERAL, class DK>
 __device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, RngWin& w, const ChainIn& in, int64_t& chips,
-                                               int64_t& mult, double& x_mult, int& money) {
+                                               int64_t& mult, double& x_mult, int& money, const ChainPeek* pre = nullptr) {
   BG_PROBE_BEGIN();
   // unified_scoring.py:174-209 individual phase.  Totals do not depend on the (card-major, joker-minor) order: chips
   // and mult add up, and every x factor is exactly 2.0.
@@ -514,7 +518,11 @@ __device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, 
   uint32_t avail = 0; // main-phase words the ring already holds
 #pragma unroll
   for (int c = 0; c < 8; c++) { ra[c] = 0x80000000u; if (boff[c] >= 0) ra[c] = bg_gpeek(d, env, e, boff[c]); }
-  bg_gpeek12(d, env, e, consumed, mw, avail);
+  if (pre && pre->ok && pre->skip == consumed) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) mw[i] = bg_temper(pre->mw[i]); // requested raw (the first use of a loaded value is the wait)
+    avail = pre->avail;
+  } else bg_gpeek12(d, env, e, consumed, mw, avail);
 #pragma unroll
   for (int c = 0; c < 8; c++) xexp += (int)((ra[c] >> 31) ^ 1u);
   bg_gskip(d, e, consumed);
@@ -608,17 +616,42 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   uint64_t phist = 0, pcodes = 0, pmask = 0;
   uint32_t scnt = 0;
   int n = 0, chip_sum = 0;
+  // the joker chain's main-phase words sit 2 * n * njokers (+ 2 per 8 Ball draw) words ahead: known before any card is
+  // looked at unless an 8 Ball is owned -- request them now
+  ChainPeek pre; pre.ok = false; pre.skip = 0; pre.avail = 0;
+  if ((d.flags & 1u) && e.njokers > 0) {
+    int npre = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) npre += (i < e.nsel && bg_get8(e.sel, i) < e.nhand) ? 1 : 0;
+    bool ball = false;
+#pragma unroll
+    for (int j = 0; j < 5; j++) ball = ball || (j < e.njokers && bg_get8(e.jokers, j) == 26);
+    if (!ball) {
+      bg_gnorm(d, e);
+      pre.skip = 2 * npre * e.njokers;
+      bg_gpeek12_raw(d, env, e, pre.skip, pre.mw, pre.avail);
+      pre.ok = true;
+    }
+  }
+  // A play that beats the blind generates a shop, whose inventory reads two lines of the next pre-seeded shop stream: touch
+  // them now (two dword loads nobody waits for) so that they come from L2, not from HBM, if the play wins
+  uint32_t touch0 = 0, touch1 = 0;
+  if (e.s_ready > 0) {
+    const uint32_t* nxt = bg_sblock(d, env, (e.s_cur + 1 == d.KS) ? 0 : e.s_cur + 1);
+    touch0 = nxt[0]; touch1 = nxt[BG_SW_A];
+  }
   // card states (CardAdapter.to_scoring_format :287-325): BONUS +30, STONE +50 and no rank / suit, FOIL +50; the seals
   // and the GLASS / LUCKY rolls are settled after the scorer (:703-734)
   uint32_t stone = 0;                      // bit per play index
   uint64_t dhist = 0;                      // rank histogram of the DECK cards played (boss Plant, face synergy)
   uint64_t cst = 0;                        // enh | seal << 4 per play index, one byte each
+  const DeckHead dh = bg_deck_head(d, env, dk); // deck[0..15]: the cards under the hand's indexes AND the classifier's positions
 #pragma unroll 1
   for (int i = 0; i < e.nsel; i++) {
     int pos = bg_get8(e.sel, i);
     if (pos < e.nhand) {
       int ci = bg_get8(e.hand, pos);
-      int code = bg_card(d, env, dk, ci);
+      int code = bg_card_h(d, env, dk, dh, ci);
       int bonus = 0;
       bool is_stone = false;
       if constexpr (DK::kCards) {
@@ -650,7 +683,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
 #pragma unroll 1
   for (uint32_t hm = e.highlighted & 0xffffu; hm; hm &= hm - 1) {
     int p = __ffs((int)hm) - 1;
-    if (nh < 8) hc |= (uint64_t)bg_card(d, env, dk, p) << (8 * nh);
+    if (nh < 8) hc |= (uint64_t)bg_card_h(d, env, dk, dh, p) << (8 * nh);
     nh++;
   }
   int ht = bg_classify(hc, nh < 8 ? nh : 8);
@@ -675,7 +708,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     in.phist = phist; in.pcodes = pcodes; in.scnt = scnt; in.stone = stone; in.n = n; in.ht = ht; in.kings = kings; in.queens = queens;
     in.all_black = false; in.deck_len = 52; in.style = 0;
     int chain_money = 0; // game_state is state.to_dict(): the scorer's money goes nowhere (unified_scoring.py:292-294)
-    bg_joker_chain<false, DK>(d, env, e, w, in, chips, mult, x_mult, chain_money);
+    bg_joker_chain<false, DK>(d, env, e, w, in, chips, mult, x_mult, chain_money, &pre);
   }
   int64_t final_score = (int64_t)((double)(chips * mult) * x_mult); // unified_scoring.py:286
   int retriggers = 0;
@@ -818,6 +851,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   }
   BG_PROBE(12);
   o.reward = r;
+  asm volatile("" ::"v"(touch0), "v"(touch1)); // the touched words are dead: this only keeps the two loads alive
 }
 
 // DISCARD  balatro_env_2.py:962-1050
@@ -1274,10 +1308,11 @@ struct RowExtra { double reward; int32_t action; uint32_t terminated; bool cache
 template <class DK>
 __device__ __forceinline__ uint64_t bg_obs_handb(const BgDev& d, int env, const Env& e, const DK& dk) {
   uint64_t handb = 0;
+  const DeckHead dh = bg_deck_head(d, env, dk);
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     int v = 0xff;
-    if (i < e.nhand) v = bg_card(d, env, dk, bg_get8(e.hand, i));
+    if (i < e.nhand) v = bg_card_h(d, env, dk, dh, bg_get8(e.hand, i));
     handb |= (uint64_t)(v & 0xff) << (8 * i);
   }
   return handb;
@@ -1316,7 +1351,9 @@ struct RowStage { lds_u4* stage; lds_u64* addr; };
 // sector of the narrow keys is completed by several partial writes issued iterations apart -- measured 2.2x the
 // algorithmic write traffic.  A record is 22 whole 16-byte stores owned by ONE lane: nothing is shared between lanes.
 // STAGE: 0 = every lane stores its own record directly, 1 = two slices of BG_STAGE_NP pieces through LDS, 2 = three slices of
-// 8 / 7 / 7 pieces (8 KB of staging per wave: the engine kernel, whose eight waves all write records)
+// 8 / 7 / 7 pieces (8 KB of staging per wave), 3 = the record goes to the env's IMAGE in LDS (rs.stage = its 22 pieces; the
+// step engine copies images out cooperatively and patches them in place on cheap steps) -- and, when p.rows is null, the
+// per-key arrays are written as well
 template <bool HASH, int STAGE, class DK>
 __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, size_t row, const Env& e, const DK& dk,
                                                 const ObsPtrs& p, uint64_t mask, ShopRegs& sr, const RowExtra& rx,
@@ -1385,7 +1422,7 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
   BG_MIX(e.boss_type);
 #undef BG_MIX
   // ---- packed record (offsets: BG_ROW_* in include/balatro_mi355x.h)
-  if (p.rows) {
+  if (p.rows || STAGE == 3) {
     uint32_t w[88];
 #pragma unroll
     for (int i = 0; i < 8; i++) { w[2 * i] = (selm >> i) & 1u; w[2 * i + 1] = 0u; }            //   0 selected_cards i64[8]
@@ -1413,7 +1450,10 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
     w[85] = (e.boss_type ? 1u : 0u) | (((uint32_t)e.boss_type & 0xffu) << 8) | ((rx.terminated & 1u) << 16); // 340 boss_blind_active, boss_blind_type, terminated
     w[86] = 0u; w[87] = 0u;
     uint8_t* rowp = p.rows + row * (size_t)p.row_stride;
-    if constexpr (STAGE == 2) {
+    if constexpr (STAGE == 3) {
+#pragma unroll
+      for (int k = 0; k < 22; k++) rs.stage[k] = bg_u32x4{w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]};
+    } else if constexpr (STAGE == 2) {
       // as below, in three slices of 8 / 7 / 7 pieces (runs of 128 / 112 bytes per row and store instruction)
       const unsigned long long act = __ballot(1);
       const uint32_t A = (uint32_t)__popcll(act);
@@ -1467,7 +1507,7 @@ __device__ __forceinline__ uint64_t bg_write_obs_impl(const BgDev& d, int env, s
 #pragma unroll
       for (int k = 0; k < 22; k++) q[k] = make_uint4(w[4 * k], w[4 * k + 1], w[4 * k + 2], w[4 * k + 3]);
     }
-    return hsh;
+    if (STAGE != 3 || p.rows) return hsh;
   }
   // ---- one array per key
   if (p.hand) ((uint64_t*)p.hand)[row] = handb;
@@ -1531,6 +1571,74 @@ template <bool HASH, class DK>
 __device__ __forceinline__ uint64_t bg_write_obs(const BgDev& d, int env, size_t row, const Env& e, const DK& dk, const ObsPtrs& p,
                                                 uint64_t mask, ShopRegs& sr, const RowExtra& rx) {
   return bg_write_obs_impl<HASH, 0>(d, env, row, e, dk, p, mask, sr, rx, RowStage{nullptr, nullptr});
+}
+
+// ---- record images (LDS): one 352-byte record per env, 22 pieces of 16 bytes, kept current by the step engine
+// per-key arrays of one row from an image (cheap steps of the engine in per-key mode); byte offsets: BG_ROW_*
+__device__ __forceinline__ void bg_emit_keys_from_image(const lds_u4* img, const ObsPtrs& p, size_t row) {
+  const lds_u32* w = (const lds_u32*)img;
+  const lds_u8* b = (const lds_u8*)img;
+  if (p.selected_cards) { ulonglong2* q = (ulonglong2*)(p.selected_cards + row * 8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const bg_u32x4 v = img[i]; q[i] = make_ulonglong2(((unsigned long long)v.y << 32) | v.x, ((unsigned long long)v.w << 32) | v.z); } }
+  if (p.face_down_cards) { ulonglong2* q = (ulonglong2*)(p.face_down_cards + row * 8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const bg_u32x4 v = img[4 + i]; q[i] = make_ulonglong2(((unsigned long long)v.y << 32) | v.x, ((unsigned long long)v.w << 32) | v.z); } }
+  if (p.chips_scored) p.chips_scored[row] = (int64_t)(((uint64_t)w[33] << 32) | w[32]);
+  if (p.round_chips_scored) p.round_chips_scored[row] = (int32_t)w[36];
+  if (p.progress_ratio) p.progress_ratio[row] = __uint_as_float(w[37]);
+  if (p.mult) p.mult[row] = (int32_t)w[38];
+  if (p.chips_needed) p.chips_needed[row] = (int32_t)w[39];
+  if (p.money) p.money[row] = (int32_t)w[40];
+  if (p.hands_played) p.hands_played[row] = (int32_t)w[41];
+  if (p.best_hand_this_ante) p.best_hand_this_ante[row] = (int32_t)w[42];
+  if (p.action_mask) { uint32_t* q = (uint32_t*)(p.action_mask + row * 60);
+#pragma unroll
+    for (int i = 0; i < 15; i++) q[i] = w[44 + i]; }
+  if (p.joker_ids) { uint32_t* q = (uint32_t*)(p.joker_ids + row * 10);
+#pragma unroll
+    for (int i = 0; i < 5; i++) q[i] = w[59 + i]; }
+  if (p.shop_items) { uint32_t* q = (uint32_t*)(p.shop_items + row * 10);
+#pragma unroll
+    for (int i = 0; i < 5; i++) q[i] = w[64 + i]; }
+  if (p.shop_costs) { uint32_t* q = (uint32_t*)(p.shop_costs + row * 10);
+#pragma unroll
+    for (int i = 0; i < 5; i++) q[i] = w[69 + i]; }
+  if (p.consumables) { int16_t* q = p.consumables + row * 5; const uint32_t a = w[74], c = w[75]; q[0] = (int16_t)(a & 0xffffu); q[1] = (int16_t)(a >> 16); q[2] = (int16_t)(c & 0xffffu); q[3] = (int16_t)(c >> 16); q[4] = (int16_t)(w[76] & 0xffffu); }
+  if (p.ante) p.ante[row] = (int16_t)(w[76] >> 16);
+  if (p.shop_rerolls) p.shop_rerolls[row] = (int16_t)(w[77] & 0xffffu);
+  if (p.hand) { int8_t* q = p.hand + row * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) q[i] = (int8_t)b[310 + i]; }
+  if (p.hand_levels) { int8_t* q = p.hand_levels + row * 12;
+#pragma unroll
+    for (int i = 0; i < 12; i++) q[i] = (int8_t)b[318 + i]; }
+  if (p.hand_size) p.hand_size[row] = (int8_t)b[330];
+  if (p.deck_size) p.deck_size[row] = (int8_t)b[331];
+  if (p.round) p.round[row] = (int8_t)b[332];
+  if (p.hands_left) p.hands_left[row] = (int8_t)b[333];
+  if (p.discards_left) p.discards_left[row] = (int8_t)b[334];
+  if (p.joker_count) p.joker_count[row] = (int8_t)b[335];
+  if (p.joker_slots) p.joker_slots[row] = (int8_t)b[336];
+  if (p.consumable_count) p.consumable_count[row] = (int8_t)b[337];
+  if (p.consumable_slots) p.consumable_slots[row] = (int8_t)b[338];
+  if (p.phase) p.phase[row] = (int8_t)b[339];
+  if (p.boss_blind_active) p.boss_blind_active[row] = (int8_t)b[340];
+  if (p.boss_blind_type) p.boss_blind_type[row] = (int8_t)b[341];
+}
+// checksum of one observation: every byte of the image except the step's reward / action / terminated (tests: BG_POLICY_HASH_OBS)
+__device__ __forceinline__ uint64_t bg_hash_image(const lds_u4* img) {
+  uint64_t h = 0x9E3779B97F4A7C15ull;
+#pragma unroll
+  for (int k = 0; k < 22; k++) {
+    bg_u32x4 v = img[k];
+    if (k == 8) { v.z = 0; v.w = 0; }               // reward (bytes 136..143)
+    if (k == 10) v.w = 0;                            // action (172..175)
+    if (k == 21) v.y &= 0xff00ffffu;                 // terminated (342)
+    h ^= ((uint64_t)v.y << 32) | v.x; h *= 0xBF58476D1CE4E5B9ull; h ^= h >> 29;
+    h ^= ((uint64_t)v.w << 32) | v.z; h *= 0x94D049BB133111EBull; h ^= h >> 31;
+  }
+  return h;
 }
 
 // The same policy with everything that depends only on the env hoisted out of the step loop (the 64-bit `% 3` and one of

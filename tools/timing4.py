@@ -31,7 +31,5 @@ for c, nm in ((0, "run"), (1, "play"), (2, "other")):
     b = max(1, o[2 + 3 * c])
     tot_busy += o[4 + 3 * c]
     print(f"  {nm:5s}: batches per workgroup-step {o[2+3*c]/wgs/T:.2f}  items per batch {o[3+3*c]/b:.1f}  cycles per batch {o[4+3*c]/b:.0f}  share of wave time {o[4+3*c]/max(1,o[0]):.2f}")
-for c, nm in ((0, "run"), (1, "play"), (2, "other")):
-    nb = max(1, o[2 + 3 * c]); q = o[16 + 5 * c:21 + 5 * c]
-    print(f"  {nm:5s} sections (cycles per batch): claim+load {q[0]/nb:.0f}  policy/dispatch {q[1]/nb:.0f}  cap+reset+mask {q[2]/nb:.0f}  record {q[3]/nb:.0f}  outputs+store+requeue {q[4]/nb:.0f}")
+print(f"  copy-out: {o[13]/max(1,o[2]+o[5]+o[8]):.0f} cycles per batch, {o[13]/max(1,o[0]):.2f} of wave time")
 env.close()
