@@ -55,7 +55,7 @@ EXPORTS = ["bg_create", "bg_destroy", "bg_last_error", "bg_num_envs", "bg_max_fu
            "bg_step", "bg_observe", "bg_rollout", "bg_rollout_rows", "bg_inject", "bg_inject_cards", "bg_inject_consumables", "bg_state_blob_bytes", "bg_get_state", "bg_set_state",
            "bg_refill", "bg_check", "bg_set_profiling", "bg_get_profile", "bg_set_max_ante", "bg_inject_deck",
            "bg_classify_batch", "bg_score_hand_batch", "bg_bench_copy", "bg_step_many",
-           "bg_sim_evaluate_batch", "bg_sim_score_batch"]
+           "bg_sim_evaluate_batch", "bg_sim_score_batch", "bg_create_ex"]
 SCORE_CASE_WORDS, SCORE_OUT_WORDS = 40, 8
 SIM_EVAL_BYTES, SIM_CASE_WORDS = 128, 64
 
@@ -113,6 +113,7 @@ def load(build_if_missing: bool = True):
             raise NativeError(f"{path} does not export {name}")
     vp, i32, u32, u64, i64 = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_int64
     L.bg_create.argtypes = [i32, i32, u32, i32, C.POINTER(vp)]
+    L.bg_create_ex.argtypes = [i32, i32, u32, i32, i32, C.POINTER(vp)]
     L.bg_destroy.argtypes = [vp]
     L.bg_last_error.restype = C.c_char_p
     L.bg_last_error.argtypes = [vp]

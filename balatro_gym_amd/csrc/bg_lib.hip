@@ -1123,7 +1123,9 @@ int bg_get_profile(bg_handle* h, double* out8) {
   return 0;
 }
 
-int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle** out) {
+int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle** out) { return bg_create_ex(n_envs, device_id, flags, max_ante, 0, out); }
+
+int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fused_steps_hint, bg_handle** out) {
   if (!out || n_envs <= 0) { g_create_err = "bg_create: bad arguments"; return BG_E_ARG; }
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
@@ -1164,8 +1166,17 @@ int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle
   // per global / shop slot and 64 B per deck: ~1 MB (372 fused steps; 64 GB of the 288 at 65 536 envs), ~198 KB (64),
   // ~105 KB (32) or ~60 KB (16).  Ring positions are bytes, so 250 is the deepest ring.
   // (0.66 MB per env at full depth since the shop-stream slots are compact: 43 GB at 65 536 envs, 86 GB at 131 072)
-  const int dg = n_envs <= 131072 ? 137 : (n_envs <= 262144 ? 73 : (n_envs <= 1048576 ? 13 : 8));
-  const int dsd = n_envs <= 131072 ? 248 : (n_envs <= 262144 ? 124 : (n_envs <= 1048576 ? 24 : 12));
+  int dg = n_envs <= 131072 ? 137 : (n_envs <= 262144 ? 73 : (n_envs <= 1048576 ? 13 : 8));
+  int dsd = n_envs <= 131072 ? 248 : (n_envs <= 262144 ? 124 : (n_envs <= 1048576 ? 24 : 12));
+  if (fused_steps_hint > 0) {
+    // the caller says how many steps it will ever fuse into one launch (bg_step users: a handful): rings only as deep as that
+    // needs -- two launches' worth (the refill is overlapped), a deck / shop stream per 3 steps, 110 global words per step
+    const int hint = fused_steps_hint > 372 ? 372 : fused_steps_hint;
+    int ring = 2 * ((hint + 2) / 3); if (ring < 4) ring = 4;
+    int gb = 2 * ((hint * ((flags & BG_FLAG_SCORER_JOKERS) ? 110 : 24) + BG_MT_N - 1) / BG_MT_N) + 1; if (gb < 5) gb = 5;
+    if (ring < dsd) dsd = ring;
+    if (gb < dg) dg = gb;
+  }
   d.KG = kg ? atoi(kg) : dg; d.KS = ks ? atoi(ks) : dsd + 1; d.KD = kd ? atoi(kd) : dsd;
   if (d.KG < 2 || d.KS < 2 || d.KD < 1 || d.KG > 250 || d.KS > 250 || d.KD > 250) { delete h; g_create_err = "bg_create: bad ring depths"; return BG_E_ARG; }
   size_t N = (size_t)n_envs;
@@ -1833,6 +1844,7 @@ int bg_set_state(bg_handle* h, int env_index, const void* blob_host, uint64_t bl
     BG_HIP(hipMemcpy(h->d_prod[1] + env_index, &w, 4, hipMemcpyHostToDevice));
   }
   h->seeded = true;
+  h->steps_since_refill = 1 << 30; // the restored env's look-ahead is as deep as it was when the blob was taken: top up before the next step
   return 0;
 }
 

@@ -94,7 +94,8 @@ class BalatroEnv(_EnvBase):
         self.action_space = _spaces.Discrete(ACTION_SPACE_SIZE)
         self.observation_space = make_observation_space()
         self._vec = BalatroVecEnv(1, None if seed is None else [seed], device=device, scorer_jokers=scorer_jokers,
-                                  autoreset=False, max_ante=max_ante, card_states=card_states)
+                                  autoreset=False, max_ante=max_ante, card_states=card_states,
+                                  fused_steps=16)  # one step per call: shallow look-ahead rings (42 KB instead of 0.66 MB)
         self._action = torch.zeros(1, dtype=torch.int32, device=self._vec.device)
 
     # -- helpers

@@ -104,7 +104,7 @@ class BalatroSB3VecEnv(_SB3VecEnv):
         # make_env_fixed(seed, rank): BalatroEnvFixed(seed=seed + rank) (train_balatro_fixed.py:285-288)
         self.seeds = list(seeds) if seeds is not None else [seed + r for r in range(self.num_envs)]
         self.env = BalatroVecEnv(self.num_envs, self.seeds, device=device, scorer_jokers=scorer_jokers, autoreset=True,
-                                 max_ante=max_ante)
+                                 max_ante=max_ante, fused_steps=32)  # a VecEnv steps once per call: shallow look-ahead rings
         dev = self.env.device
         self.observation_spec = FIXED_SPEC
         self.num_actions = 60
@@ -212,3 +212,43 @@ class BalatroSB3VecEnv(_SB3VecEnv):
     def env_is_wrapped(self, wrapper_class, indices=None):
         n = self.num_envs if indices is None else len(list(indices))
         return [False] * n
+
+
+class CurriculumTracker:
+    """`CurriculumBalatroEnv` (train_balatro_agent.py:126-170), vectorised: one `current_max_ante` per env, raised by
+    `ante_increment` when the env has played at least 100 episodes at its level and `success_threshold` of its last 100
+    episodes ended at an ante >= the cap.  The cap itself lives in the device env (bg_set_max_ante: episodes end with
+    `curriculum_limit_reached` as soon as ante > cap); this class only keeps the per-env episode statistics the rule needs and
+    decides WHEN to raise a cap.  Call `update(done, ante_at_end)` after every step with the finished envs' final antes."""
+
+    def __init__(self, env: BalatroVecEnv, initial_max_ante: int = 3, ante_increment: int = 1, success_threshold: float = 0.8,
+                 window: int = 100):
+        self.env = env
+        n = env.num_envs
+        self.cap = np.full(n, int(initial_max_ante), np.int32)
+        self.inc, self.thr, self.window = int(ante_increment), float(success_threshold), int(window)
+        self.hist = np.zeros((n, self.window), np.int32)   # final antes of the last `window` episodes
+        self.count = np.zeros(n, np.int64)                 # episodes ever finished
+        self.at_level = np.zeros(n, np.int64)              # episodes at the current level (`episodes_at_current_level`)
+        env.set_max_ante(self.cap)
+
+    def update(self, done: np.ndarray, ante_at_end: np.ndarray) -> np.ndarray:
+        """done: bool [N]; ante_at_end: int [N] (state.ante when the episode ended).  Returns the mask of envs whose cap rose."""
+        done = np.asarray(done, bool)
+        idx = np.flatnonzero(done)
+        if idx.size == 0:
+            return np.zeros(len(done), bool)
+        self.hist[idx, self.count[idx] % self.window] = np.asarray(ante_at_end)[idx]
+        self.count[idx] += 1
+        self.at_level[idx] += 1  # the reference counts in reset(); one reset follows every finished episode
+        raised = np.zeros(len(done), bool)
+        for i in idx:  # train_balatro_agent.py:157-166
+            if self.at_level[i] >= self.window:
+                recent = self.hist[i] if self.count[i] >= self.window else self.hist[i, :self.count[i]]
+                if (recent >= self.cap[i]).sum() / float(self.window) >= self.thr:
+                    self.cap[i] += self.inc
+                    self.at_level[i] = 0
+                    raised[i] = True
+        if raised.any():
+            self.env.set_max_ante(self.cap, mask=raised)
+        return raised

@@ -1,10 +1,16 @@
 """Sharding independent envs over the GPUs of a node: one process per GPU (torch.distributed, backend "nccl" = RCCL).
 
 Envs never interact, so the data path has NO collective: rank r owns the contiguous env range shard_range(total, W, r)
-and steps it locally.  The only exchange is the OPTIONAL gather of the observation tensor for a learner that wants all
-shards (`gather_obs`): one all_gather of the flat observation buffer (all 31 keys live in one allocation, so one
-collective moves every key).  On MI355X the 8 GPUs are fully connected by xGMI, so RCCL can move each rank's shard on
-its own link; at 65 536 envs x 330 B the whole observation is 21.6 MB (2.7 MB per GPU).
+and steps it locally.  The one exchange of the design is the gather of the CURRENT observation of every env, for whoever
+needs all shards in one place (a central evaluator, a logger, a learner that does not train shard-locally):
+  * `gather_obs()`      after reset() / step(): one all_gather of the flat per-key observation buffer (all 31 keys live in
+                        one allocation, so one collective moves every key);
+  * `gather_records(r)` after a fused rollout with packed records: one all_gather of a [n, 352] record row (normally the
+                        last row of the launch, `rows[T - 1]`) -- what bench.py times at N > 1.
+The [T, N] record history of a fused rollout is NOT gathered: at 65 536 envs per GPU it is produced at ~1.8 TB/s per GPU,
+more than the ~1.07 TB/s of xGMI a GPU has (7 links x 153 GB/s); learners consume their own shard (data-parallel PPO
+all-reduces gradients, not observations).  On MI355X the 8 GPUs are fully connected by xGMI, so RCCL moves each rank's shard
+on its own link: 65 536 x 352 B = 23 MB per GPU and launch, ~0.15 ms per link, beside a ~4 ms launch.
 """
 from __future__ import annotations
 
@@ -68,6 +74,16 @@ class ShardedBalatroVecEnv:
             self._gathered = torch.empty(self.world * n, dtype=torch.uint8, device=flat.device)
         dist.all_gather_into_tensor(self._gathered, flat.contiguous(), group=self.group)
         return self._gathered.view(self.world, n)
+
+    def gather_records(self, rows: torch.Tensor) -> torch.Tensor:
+        """all_gather of one packed-record row of this shard (uint8 [n, 352], e.g. `RowBuffers.rows[T - 1]`) ->
+        uint8 [world, n, 352].  Shards must have equal sizes (total_envs divisible by the world size)."""
+        if self.total_envs % self.world:
+            raise ValueError("gather_records needs equal shards")
+        rows = rows.contiguous()
+        out = torch.empty((self.world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
+        dist.all_gather_into_tensor(out.view(-1), rows.view(-1), group=self.group)
+        return out
 
     def close(self):
         self.local.close()

@@ -83,7 +83,7 @@ class BalatroVecEnv:
 
     def __init__(self, num_envs: int, seeds: Optional[Sequence[int]] = None, *, device: int | str | torch.device = 0,
                  scorer_jokers: bool = False, autoreset: bool = True, max_ante: int = 0, info_terms: bool = True,
-                 card_states: bool = False):
+                 card_states: bool = False, fused_steps: int = 0):
         if not torch.cuda.is_available():
             raise nat.NativeError("BalatroVecEnv needs a HIP device (torch.cuda.is_available() is False); "
                                   "there is no CPU fallback")
@@ -97,7 +97,9 @@ class BalatroVecEnv:
         flags = ((nat.FLAG_SCORER_JOKERS if scorer_jokers else 0) | (nat.FLAG_AUTORESET if autoreset else 0) |
                  (nat.FLAG_CARD_STATES if card_states else 0))
         self._h = C.c_void_p()
-        rc = self._L.bg_create(self.num_envs, self.device.index or 0, flags, self.max_ante, C.byref(self._h))
+        # fused_steps: the longest rollout / step_many the caller will fuse into one launch (0 = 372-step launches): sizes the RNG
+        # look-ahead rings, i.e. the HBM this handle holds (0.66 MB per env at full depth, ~42 KB per env at 16)
+        rc = self._L.bg_create_ex(self.num_envs, self.device.index or 0, flags, self.max_ante, int(fused_steps), C.byref(self._h))
         if rc != 0:
             raise nat.NativeError(f"bg_create failed ({rc}): {self._L.bg_last_error(None).decode()}")
         n, dev = self.num_envs, self.device

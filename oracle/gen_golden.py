@@ -12,6 +12,7 @@ Files:
                        full observation after every step
   F6 sim_eval.npz      balatro_sim.BalatroSimulator: evaluate_hand (10 000 hands, with / without Four Fingers / Shortcut) and
                        calculate_score (2 000 cases: enhancements, editions, seals, joker-major chain, global-stream position)
+  F8 sb3_fixed.npz     SafeBalatroEnv(BalatroEnvFixed(seed)) (train_balatro_fixed.py) stepped like a VecEnv: fixed space + observations
   F7 kat.json          the reference's own known answers (tests/chips_test.py:5-24, balatro_trajectories.json)
 """
 from __future__ import annotations
@@ -255,6 +256,49 @@ def gen_sim():
           len(kat), "trajectory answers reproduced")
 
 
+def gen_sb3_fixed():
+    """F8 sb3_fixed.npz: the reference's own wrappers -- SafeBalatroEnv(BalatroEnvFixed(seed + rank)) (train_balatro_fixed.py:20-288)
+    -- stepped like an SB3 VecEnv (finished envs are reset in the same step): the fixed observation space (51 keys: dtype /
+    shape), every fixed observation, float32 rewards, dones, the wrapper's info flags and its terminal observations."""
+    S, T, seed0, max_inv, max_steps = 24, 120, 300, 5, 40
+    envs = [rh.RefFixedEnv(seed0 + r, max_inv, max_steps) for r in range(S)]
+    spaces = envs[0].fixed.observation_space.spaces
+    keys = list(spaces)
+    obs = [e.reset() for e in envs]
+    rec = {"seed0": np.int64(seed0), "max_invalid_actions": np.int32(max_inv), "max_episode_steps": np.int32(max_steps),
+           "keys": np.array(keys), "dtypes": np.array([spaces[k].dtype.name for k in keys]),
+           "shapes": np.array([",".join(str(x) for x in spaces[k].shape) for k in keys]),
+           "actions": np.zeros((S, T), np.int32), "rewards": np.zeros((S, T), np.float32), "dones": np.zeros((S, T), np.uint8),
+           "terminated": np.zeros((S, T), np.uint8), "truncated": np.zeros((S, T), np.uint8),
+           "invalid_action_termination": np.zeros((S, T), np.uint8), "max_steps_reached": np.zeros((S, T), np.uint8)}
+    for k in keys:
+        rec["obs0_" + k] = np.stack([o[k] for o in obs])
+        rec["obs_" + k] = np.zeros((S, T) + spaces[k].shape, spaces[k].dtype)
+        rec["term_" + k] = np.zeros((S, T) + spaces[k].shape, spaces[k].dtype)  # terminal observation of a finished episode
+    for t in range(T):
+        for i, e in enumerate(envs):
+            if i % 4 == 0:
+                a = 59  # never valid: SafeBalatroEnv ends the episode after max_invalid_actions of them in a row
+            else:
+                a = rh.policy_action(obs[i]["action_mask"], int(obs[i]["phase"][0]), rh.POLICY_UNIFORM, 77, i, t)
+            o, r, term, trunc, info = e.step(a)
+            rec["actions"][i, t], rec["rewards"][i, t] = a, np.float32(r)
+            rec["terminated"][i, t], rec["truncated"][i, t], rec["dones"][i, t] = term, trunc, term or trunc
+            rec["invalid_action_termination"][i, t] = bool(info.get("invalid_action_termination"))
+            rec["max_steps_reached"][i, t] = bool(info.get("max_steps_reached"))
+            if term or trunc:
+                for k in keys:
+                    rec["term_" + k][i, t] = o[k]
+                o = e.reset()
+            obs[i] = o
+            for k in keys:
+                rec["obs_" + k][i, t] = o[k]
+    np.savez_compressed(os.path.join(GOLD, "sb3_fixed.npz"), **rec)
+    print("F8 sb3_fixed.npz", S, "envs x", T, "steps;", int(rec["dones"].sum()), "episode ends,",
+          int(rec["invalid_action_termination"].sum()), "by invalid actions,", int(rec["max_steps_reached"].sum()), "by the step limit,",
+          int((rec["terminated"] & ~rec["invalid_action_termination"]).sum()), "game overs")
+
+
 def trace(cfg_name, seeds, T, policy, scorer=False, jokers_fn=None, max_ante=0, money_fn=None, ante_fn=None,
           cards_fn=None, levels_fn=None, pseed=7, cons_fn=None):
     S = len(seeds)
@@ -413,7 +457,7 @@ def gen_kat():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["mt", "classify", "score", "traces", "consumables", "kat", "sim"]
+    which = sys.argv[1:] or ["mt", "classify", "score", "traces", "consumables", "kat", "sim", "sb3"]
     if "mt" in which:
         gen_mt()
     if "classify" in which:
@@ -426,6 +470,8 @@ def main():
         gen_trace_consumables()
     if "kat" in which:
         gen_kat()
+    if "sb3" in which:
+        gen_sb3_fixed()
     if "sim" in which:  # after kat: it re-checks the trajectory answers of kat.json on the reference's calculate_score
         gen_sim()
 

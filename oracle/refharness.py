@@ -31,8 +31,12 @@ def reference_available() -> bool:
 
 
 def _install_gymnasium_shim():
+    """Stand-in for the missing `gymnasium` package: space classes that only CARRY what they are given (shape, dtype, bounds,
+    n) -- no arithmetic of the reference lives in gymnasium.  train_balatro_fixed.BalatroEnvFixed reads these
+    attributes to build its fixed observation space, so they are kept faithfully."""
     if "gymnasium" in sys.modules:
         return
+    import numpy as np
     gym = types.ModuleType("gymnasium")
     spaces = types.ModuleType("gymnasium.spaces")
 
@@ -42,20 +46,48 @@ def _install_gymnasium_shim():
         def __init__(self, *a, **k):
             pass
 
-    class _Space:
-        def __init__(self, *a, **k):
-            pass
+    class Wrapper(Env):
+        def __init__(self, env):
+            self.env = env
+            self.action_space = getattr(env, "action_space", None)
+            self.observation_space = getattr(env, "observation_space", None)
 
-    class Discrete(_Space):
+    class Space:
+        def __init__(self, shape=None, dtype=None):
+            self.shape = None if shape is None else tuple(shape)
+            self.dtype = None if dtype is None else np.dtype(dtype)
+
+    class Box(Space):
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            if shape is None:
+                shape = np.shape(low)
+            super().__init__(shape, dtype)
+            self.low = np.broadcast_to(np.asarray(low), self.shape).astype(self.dtype) if np.ndim(low) else np.full(self.shape, low, dtype=self.dtype)
+            self.high = np.broadcast_to(np.asarray(high), self.shape).astype(self.dtype) if np.ndim(high) else np.full(self.shape, high, dtype=self.dtype)
+
+        def sample(self):
+            return np.zeros(self.shape, dtype=self.dtype)
+
+    class Discrete(Space):
         def __init__(self, n, *a, **k):
+            super().__init__((), np.int64)
             self.n = int(n)
 
-    class Dict_(_Space):
+        def sample(self):
+            return 0
+
+    class MultiBinary(Space):
+        def __init__(self, n, *a, **k):
+            super().__init__((int(n),), np.int8)
+            self.n = int(n)
+
+    class Dict_(Space):
         def __init__(self, d=None, **k):
+            super().__init__(None, None)
             self.spaces = dict(d or {}, **k)
 
-    spaces.Discrete, spaces.Box, spaces.MultiBinary, spaces.Dict = Discrete, _Space, _Space, Dict_
-    gym.Env, gym.Wrapper, gym.spaces = Env, type("Wrapper", (Env,), {}), spaces
+    spaces.Space, spaces.Discrete, spaces.Box, spaces.MultiBinary, spaces.Dict = Space, Discrete, Box, MultiBinary, Dict_
+    gym.Env, gym.Wrapper, gym.spaces = Env, Wrapper, spaces
     sys.modules["gymnasium"], sys.modules["gymnasium.spaces"] = gym, spaces
 
 
@@ -292,3 +324,67 @@ def sim_score(cards, jokers, game_state_keys, deck_len, seed):
         score, state = s.calculate_score(_sim_cards(sim, cards), gs)
     probe = random.getrandbits(32)
     return int(score), int(state["money"]) - 100, probe
+
+
+# ---------------------------------------------------------------------------------------------------------
+# train_balatro_fixed.py: BalatroEnvFixed / SafeBalatroEnv, the wrappers every training script puts around the
+# env.  The script imports stable_baselines3 (not installed: import-time only, no arithmetic -> empty stand-ins) and
+# `balatro_gym.envs.balatro_env_2`, a path that does not exist in the tree (the env lives at balatro_gym/balatro_env_2.py):
+# the module is registered under that name as well.
+# ---------------------------------------------------------------------------------------------------------
+def load_fixed_wrappers():
+    if "fixed" in _loaded:
+        return _loaded["fixed"]
+    ref = load_reference()
+    for name, attrs in (("stable_baselines3", ["PPO"]), ("stable_baselines3.common", []),
+                        ("stable_baselines3.common.vec_env", ["SubprocVecEnv", "DummyVecEnv", "VecNormalize"]),
+                        ("stable_baselines3.common.monitor", ["Monitor"]),
+                        ("stable_baselines3.common.callbacks", ["CheckpointCallback", "BaseCallback", "EvalCallback"])):
+        if name not in sys.modules:
+            m = types.ModuleType(name)
+            for a in attrs:
+                setattr(m, a, type(a, (), {"__init__": lambda self, *x, **k: None}))
+            sys.modules[name] = m
+    if "balatro_gym.envs" not in sys.modules:
+        pkg = types.ModuleType("balatro_gym.envs")
+        pkg.__path__ = []
+        sys.modules["balatro_gym.envs"] = pkg
+    sys.modules["balatro_gym.envs.balatro_env_2"] = ref["env2"]
+    if REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        import train_balatro_fixed as tbf
+    _loaded["fixed"] = tbf
+    return tbf
+
+
+class RefFixedEnv:
+    """SafeBalatroEnv(BalatroEnvFixed(seed)) with this harness's per-env global stream (see RefEnv)."""
+
+    def __init__(self, seed: int, max_invalid_actions: int = 50, max_episode_steps: int = 1000):
+        import contextlib
+        import io
+        tbf = load_fixed_wrappers()
+        random.seed(global_seed(seed))
+        with contextlib.redirect_stdout(io.StringIO()):
+            self.fixed = tbf.BalatroEnvFixed(seed=seed)
+            self.env = tbf.SafeBalatroEnv(self.fixed, max_invalid_actions=max_invalid_actions, max_episode_steps=max_episode_steps)
+        self._g = random.getstate()
+
+    def _call(self, fn, *a, **k):
+        import contextlib
+        import io
+        random.setstate(self._g)
+        try:
+            with contextlib.redirect_stdout(io.StringIO()):
+                return fn(*a, **k)
+        finally:
+            self._g = random.getstate()
+
+    def reset(self):
+        return self._call(self.env.reset)[0]
+
+    def step(self, action: int):
+        return self._call(self.env.step, int(action))

@@ -110,6 +110,20 @@ def test_sb3_fixed_observation_space_and_transform():
             assert not fixed[k].any()
 
 
+def test_sb3_fixed_space_matches_reference_fixture():
+    """FIXED_SPEC (the adapter's statement of BalatroEnvFixed's observation space) key by key against the space the reference's
+    own BalatroEnvFixed built (tests/golden/sb3_fixed.npz, generated by oracle/gen_golden.py gen_sb3_fixed from
+    train_balatro_fixed.py:20-124): same 51 keys in the same order, same dtypes, same shapes."""
+    from balatro_gym_amd.sb3_adapter import FIXED_SPEC
+    from tests.helpers import GOLD
+    with np.load(os.path.join(GOLD, "sb3_fixed.npz")) as z:
+        keys, dtypes, shapes = [str(k) for k in z["keys"]], [str(d) for d in z["dtypes"]], [str(x) for x in z["shapes"]]
+    assert list(FIXED_SPEC) == keys
+    for k, dt, sh in zip(keys, dtypes, shapes):
+        want_shape = tuple(int(x) for x in sh.split(",") if x)
+        assert FIXED_SPEC[k][0] == dt and FIXED_SPEC[k][1] == want_shape, (k, FIXED_SPEC[k], dt, want_shape)
+
+
 def test_packed_record_layout_matches_header():
     """The record offsets the Python views use are the BG_ROW_* constants of include/balatro_mi355x.h, every key is
     naturally aligned and no two fields overlap."""

@@ -304,7 +304,7 @@ def test_packed_records_same_content_full_size():
     seeds = [1000 + i for i in range(n)]
     out = []
     for packed in (False, True):
-        env = _vec(n, seeds, autoreset=True)
+        env = _vec(n, seeds, autoreset=True, fused_steps=T)
         ob = (RowBuffers if packed else ObsBuffers)(n, env.device, steps=T)
         env.rollout(T, policy=2 | 0x100, policy_seed=7, obs_buffers=ob)
         env.check()
@@ -421,43 +421,110 @@ def test_wide_workgroup_rollout_kernel(monkeypatch):
     test_immolate_cryptid_rollout_vs_oracle()
 
 
-def test_rollout_properties_full_size():
-    """Size-independent properties at BASELINE.json's N = 65 536: determinism, chunking invariance (one T=48 call ==
-    48 T=1 calls), sharding invariance (two half-size handles with env_index0 offsets == one full handle)."""
+@pytest.mark.parametrize("config", ["configs2_jokers_antes_1_4", "configs4_full_game_curriculum"])
+def test_rollout_properties_full_size(config):
+    """Size-independent properties at BASELINE.json's N = 65 536 on the REAL workloads -- configs[2] (5 random implemented jokers
+    per env, scorer-level joker chain, Antes 1-4 cap, blind 45/46/47 by env index) and the single-GPU share of configs[4] (full
+    game: uniform policy incl. boss blinds and shop buys / rerolls / sells, all 150 joker ids, a per-env curriculum cap that
+    rises 3 -> 8 between launches): determinism, chunking invariance (one T=48 call == 48 T=1 calls), sharding invariance (two
+    half-size handles with env_index0 offsets == one full handle), by statistics + XOR checksums of every reward and every
+    observation record."""
     import torch
+    from oracle.gen_golden import IMPLEMENTED
     n, T = 65536, 48
     seeds = [1000 + i for i in range(n)]
+    full = config.startswith("configs4")
+    policy = (0 if full else 2) | 0x100
+    pool = list(range(1, 151)) if full else IMPLEMENTED
+    jokers = [random.Random(i).sample(pool, 5) for i in range(n)]
+    caps = np.array([3 + (i % 3) for i in range(n)], np.int32)
 
-    def run(count, seeds_, index0, chunks):
-        env = _vec(count, seeds_, autoreset=True)
-        tot = None
+    def run(count, index0, chunks):
+        env = _vec(count, seeds[index0:index0 + count], autoreset=True, scorer_jokers=True, max_ante=3 if full else 4, fused_steps=48)
+        env.inject(jokers=jokers[index0:index0 + count], apply_now=True)
         t0 = 0
         for c in chunks:
-            env.rollout(c, policy=2 | 0x100, policy_seed=7, env_index0=index0, t0=t0, zero_stats=(t0 == 0))
+            if full and t0 == 24:  # the curriculum: caps rise mid-run (CurriculumBalatroEnv.current_max_ante, per env)
+                env.set_max_ante(caps[index0:index0 + count] + 3)
+            env.rollout(c, policy=policy, policy_seed=7, env_index0=index0, t0=t0, zero_stats=(t0 == 0))
             t0 += c
-        env.check()
         st = env.stats()
         final = {k: v.clone() for k, v in env.obs.items()}
         env.close()
         return st, final
 
-    a, fa = run(n, seeds, 0, [T])
-    b, fb = run(n, seeds, 0, [T])
+    a, fa = run(n, 0, [24, 24])
+    b, fb = run(n, 0, [24, 24])
     assert a == b, "rollout is not deterministic"
     assert a["steps"] == n * T and a["episodes"] > 0 and a["plays"] > 0
-    c, fc = run(n, seeds, 0, [1] * T)
+    c, fc = run(n, 0, [1] * T)
     assert a == c, "chunking changed the result"
     for k in OBS_KEYS:
         assert torch.equal(fa[k], fc[k]), k
     h = n // 2
-    s0, f0 = run(h, seeds[:h], 0, [T])
-    s1, f1 = run(h, seeds[h:], h, [T])
+    s0, f0 = run(h, 0, [24, 24])
+    s1, f1 = run(h, h, [24, 24])
     for k in ("steps", "episodes", "plays", "score_sum"):
         assert s0[k] + s1[k] == a[k], k
     assert s0["reward_bits"] ^ s1["reward_bits"] == a["reward_bits"]
     assert s0["obs_hash"] ^ s1["obs_hash"] == a["obs_hash"]
     for k in OBS_KEYS:
         assert torch.equal(torch.cat([f0[k], f1[k]]), fa[k]), k
+
+
+def test_curriculum_caps_vs_oracle():
+    """bg_set_max_ante (CurriculumBalatroEnv.current_max_ante, train_balatro_agent.py:126-152): per-env caps set and RAISED in
+    the middle of a fused rollout, against oracle envs whose caps change at the same steps; a template ante above the cap is
+    refused."""
+    import torch
+    from balatro_gym_amd._native import NativeError
+    from balatro_gym_amd.vec_env import RowBuffers
+    from oracle import pyoracle as po
+    n, T = 192, 90
+    seeds = [61_000 + 3 * i for i in range(n)]
+    caps0 = [1 + i % 3 for i in range(n)]
+    caps1 = [c + 2 for c in caps0]
+    env = _vec(n, seeds, autoreset=True, max_ante=0)
+    env.inject(levels=np.full((n, 12), 15, np.uint8), apply_now=True)  # level-15 hands beat every blind at once: antes rise fast
+    env.observe()
+    env.set_max_ante(caps0)
+    orc = [po.OracleEnv(s, max_ante=c) for s, c in zip(seeds, caps0)]
+
+    def lv(o):
+        for ht in range(12):
+            o.set_hand_level(ht, 15)
+    for o in orc:
+        lv(o)
+    got_r, got_t, want_r, want_t = [], [], [], []
+    limit_hits = 0
+    for part, caps in ((0, caps0), (1, caps1)):
+        if part:
+            env.set_max_ante(caps)
+            for o, c in zip(orc, caps):
+                o.set_max_ante(c)
+        rb = RowBuffers(n, env.device, steps=T)
+        env.rollout(T, policy=1, policy_seed=21, t0=part * T, obs_buffers=rb)
+        got_r.append(rb.reward.contiguous().cpu().numpy()); got_t.append(rb.terminated.cpu().numpy())
+        wr = np.zeros((T, n)); wt = np.zeros((T, n), np.uint8)
+        for t in range(T):
+            for i, o in enumerate(orc):
+                _, r, term, _, info = o.step(o.policy_action(1, 21, i, part * T + t))
+                wr[t, i], wt[t, i] = r, term
+                limit_hits += bool(info.flags & 256)
+                if term:
+                    o.reset(); lv(o)
+        want_r.append(wr); want_t.append(wt)
+        last = {k: rb.tensors[k][T - 1].contiguous().cpu().numpy() for k in OBS_KEYS}
+        for k in OBS_KEYS:
+            assert np.array_equal(last[k], np.stack([o.obs()[k] for o in orc])), (part, k)
+    for part in range(2):
+        assert np.array_equal(got_t[part], want_t[part]), part
+        assert np.array_equal(got_r[part].view(np.uint64), want_r[part].view(np.uint64)), part
+    assert limit_hits > 20, limit_hits  # episodes really ended at their cap
+    env.set_max_ante(4)
+    with pytest.raises(NativeError, match="cap"):
+        env.inject(ante=[5] * n)
+    env.close()
 
 
 def test_single_env_gym_surface():
@@ -512,6 +579,90 @@ def test_save_load_state_roundtrip(cards):
     env.close()
 
 
+def test_state_blob_into_another_handle_vs_oracle(monkeypatch):
+    """save_state / load_state (balatro_env_2.py:1575-1615) as blobs that travel: the state of env 5 of one handle after 60
+    steps is restored into env 2 of ANOTHER handle (other size, other seeds), and that env then continues in lockstep with the
+    oracle env that took the same 60 steps -- every observation key, reward bits, terminated, resets included.  Blobs that do
+    not fit (truncated, another version, other ring depths, a handle without card states) are refused with a message."""
+    import torch
+    from balatro_gym_amd._native import NativeError
+    from oracle import pyoracle as po
+    from oracle.gen_golden import IMPLEMENTED
+    nA, src, K, M = 16, 5, 60, 120
+    seedsA = [41_000 + 3 * i for i in range(nA)]
+    jok = [random.Random(900 + i).sample(IMPLEMENTED, 5) for i in range(nA)]
+    A = _vec(nA, seedsA, scorer_jokers=True, autoreset=False, max_ante=4)
+    A.inject(jokers=jok, apply_now=True)
+    orc = po.OracleEnv(seedsA[src], scorer_jokers=True, max_ante=4)
+    orc.set_jokers(jok[src])
+    for t in range(K):
+        a_src = orc.policy_action(0, 13, src, t)
+        acts = np.full(nA, 59, np.int32)  # the other envs only send an action that is never valid
+        acts[src] = a_src
+        _, _, term, _, _ = A.step(torch.from_numpy(acts).to(A.device))
+        _, _, ot, _, _ = orc.step(a_src)
+        assert bool(term[src].item()) == ot
+        if ot:
+            orc.reset(); orc.set_jokers(jok[src])
+            m = np.zeros(nA, np.uint8); m[src] = 1
+            A.reset(mask=torch.from_numpy(m).to(A.device))
+    blob = A.get_state(src)
+    A.close()
+    nB, dst = 7, 2
+    B = _vec(nB, [77 + i for i in range(nB)], scorer_jokers=True, autoreset=False, max_ante=4)
+    B.set_state(dst, blob)
+    B.observe()
+    want = orc.obs()
+    for k in OBS_KEYS:
+        assert np.array_equal(B.obs[k][dst].cpu().numpy(), want[k]), k
+    for t in range(K, K + M):
+        a_dst = orc.policy_action(0, 13, src, t)
+        acts = np.full(nB, 59, np.int32)
+        acts[dst] = a_dst
+        _, reward, term, _, info = B.step(torch.from_numpy(acts).to(B.device))
+        ob, r, ot, _, oi = orc.step(a_dst)
+        ctx = f"t {t} action {a_dst}"
+        assert np.float64(reward[dst].item()).view(np.uint64) == np.float64(r).view(np.uint64), ctx
+        assert bool(term[dst].item()) == ot and int(info["final_score"][dst].item()) == oi.final_score, ctx
+        for k in OBS_KEYS:
+            assert np.array_equal(B.obs[k][dst].cpu().numpy(), ob[k]), f"{ctx}: {k}"
+        if ot:
+            ob = orc.reset(); orc.set_jokers(jok[src])
+            m = np.zeros(nB, np.uint8); m[dst] = 1
+            B.reset(mask=torch.from_numpy(m).to(B.device))   # the reset template (jokers) travelled in the blob
+            ob = orc.obs()
+            for k in OBS_KEYS:
+                assert np.array_equal(B.obs[k][dst].cpu().numpy(), ob[k]), f"{ctx} reset: {k}"
+    B.check()
+    # blobs that do not fit
+    with pytest.raises(NativeError, match="bytes"):
+        B.set_state(dst, blob[:-16])
+    bad = bytearray(blob); bad[4] ^= 0x7f
+    with pytest.raises(NativeError, match="version"):
+        B.set_state(dst, bytes(bad))
+    bad = bytearray(blob); bad[0] ^= 0xff
+    with pytest.raises(NativeError, match="magic"):
+        B.set_state(dst, bytes(bad))
+    with pytest.raises(NativeError, match="env_index"):
+        B.set_state(nB, blob)
+    B.close()
+    monkeypatch.setenv("BG_KG", "9"); monkeypatch.setenv("BG_KS", "13"); monkeypatch.setenv("BG_KD", "12")
+    C_ = _vec(4, [1, 2, 3, 4], scorer_jokers=True, autoreset=False, max_ante=4)
+    with pytest.raises(NativeError, match="bytes|ring depths"):
+        C_.set_state(0, blob)
+    small = C_.get_state(0)
+    C_.close()
+    monkeypatch.delenv("BG_KG"); monkeypatch.delenv("BG_KS"); monkeypatch.delenv("BG_KD")
+    D_ = _vec(4, [1, 2, 3, 4], scorer_jokers=True, autoreset=False, max_ante=4)
+    with pytest.raises(NativeError, match="bytes|ring depths"):
+        D_.set_state(0, small + bytes(len(blob)))  # long enough, but saved with other ring depths
+    D_.close()
+    E_ = _vec(4, [1, 2, 3, 4], scorer_jokers=True, autoreset=False, max_ante=4, card_states=True)
+    with pytest.raises(NativeError, match="bytes|card states"):
+        E_.set_state(0, blob)
+    E_.close()
+
+
 def test_invalid_actions_and_no_raise():
     """Invalid actions never raise: reward -1.0, state unchanged (balatro_env_2.py:626-627)."""
     import torch
@@ -524,6 +675,47 @@ def test_invalid_actions_and_no_raise():
         for k in OBS_KEYS:
             assert torch.equal(env.obs[k], before[k]), (bad, k)
     env.close()
+
+
+def test_sb3_adapter_vs_reference_wrappers():
+    """BalatroSB3VecEnv against the reference's OWN wrappers: SafeBalatroEnv(BalatroEnvFixed(seed + rank)) stepped like an SB3
+    VecEnv (tests/golden/sb3_fixed.npz, generated from train_balatro_fixed.py:20-288): all 51 keys of every fixed observation,
+    float32 rewards (incl. the -50 of an invalid-action termination), dones, the wrapper's info flags, the terminal
+    observation of every wrapper-made ending, and the first observation of the episode that follows a game over."""
+    from balatro_gym_amd.sb3_adapter import BalatroSB3VecEnv
+    from tests.helpers import GOLD
+    import os
+    with np.load(os.path.join(GOLD, "sb3_fixed.npz")) as z:
+        g = {k: z[k] for k in z.files}
+    keys = [str(k) for k in g["keys"]]
+    S, T = g["actions"].shape
+    venv = BalatroSB3VecEnv(S, seed=int(g["seed0"]), max_invalid_actions=int(g["max_invalid_actions"]),
+                            max_episode_steps=int(g["max_episode_steps"]))
+    obs = venv.reset()
+    for k in keys:
+        assert obs[k].dtype == g["obs0_" + k].dtype and np.array_equal(obs[k], g["obs0_" + k]), k
+    wrapper_ends = game_overs = 0
+    for t in range(T):
+        obs, rew, done, infos = venv.step(g["actions"][:, t])
+        ctx = f"t {t}"
+        assert rew.dtype == np.float32 and np.array_equal(rew.view(np.uint32), g["rewards"][:, t].view(np.uint32)), ctx
+        assert np.array_equal(done, g["dones"][:, t].astype(bool)), ctx
+        for k in keys:
+            assert np.array_equal(obs[k], g["obs_" + k][:, t]), f"{ctx}: obs[{k}]"
+        for i in range(S):
+            assert bool(infos[i].get("invalid_action_termination")) == bool(g["invalid_action_termination"][i, t]), (ctx, i)
+            assert bool(infos[i].get("max_steps_reached")) == bool(g["max_steps_reached"][i, t]), (ctx, i)
+            if done[i]:
+                assert infos[i]["TimeLimit.truncated"] == bool(g["truncated"][i, t] and not g["invalid_action_termination"][i, t]), (ctx, i)
+                if g["invalid_action_termination"][i, t] or (g["truncated"][i, t] and not g["terminated"][i, t]):
+                    wrapper_ends += 1
+                    tob = infos[i]["terminal_observation"]
+                    for k in keys:
+                        assert np.array_equal(tob[k], g["term_" + k][i, t]), f"{ctx} env {i}: terminal_observation[{k}]"
+                else:
+                    game_overs += 1
+    assert wrapper_ends > 100 and game_overs > 10, (wrapper_ends, game_overs)
+    venv.close()
 
 
 def test_sb3_adapter_conventions():

@@ -111,7 +111,8 @@ def test_reference_known_answers():
 def test_sim_evaluate_golden():
     """balatro_sim.evaluate_hand (balatro_sim.py:220-366): 10 000 hands with / without Four Fingers / Shortcut -- `top`, and for
     every one of the 12 hand types the number of lists and the first list as positions in the hand."""
-    g = np.load(os.path.join(GOLD, "sim_eval.npz"))
+    with np.load(os.path.join(GOLD, "sim_eval.npz")) as z:
+        g = {k: z[k] for k in z.files}  # (an NpzFile re-inflates the array on every [] access)
     assert (np.bincount(g["e_top"], minlength=12) > 0).all()
     for i in range(len(g["e_n"])):
         cards = [tuple(int(x) for x in c) for c in g["e_cards"][i, :g["e_n"][i]]]
@@ -125,7 +126,8 @@ def test_sim_evaluate_golden():
 def test_sim_score_golden():
     """balatro_sim.calculate_score (balatro_sim.py:402-548): 2 000 cases -- score, money and the position of the global stream
     afterwards -- and the 14 known answers the reference itself holds (balatro_trajectories.json)."""
-    g = np.load(os.path.join(GOLD, "sim_eval.npz"))
+    with np.load(os.path.join(GOLD, "sim_eval.npz")) as z:
+        g = {k: z[k] for k in z.files}
     L = po.lib()
     for i in range(len(g["s_n"])):
         cards = [tuple(int(x) for x in c) for c in g["s_cards"][i, :g["s_n"][i]]]

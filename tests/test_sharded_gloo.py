@@ -58,6 +58,14 @@ def _worker(rank, world, port, total, q):
     assert (env.lo, env.hi) == shard_range(total, world, rank)
     env.rollout(40, policy=2, policy_seed=3)
     gathered = env.gather_obs()
+    # the packed-record gather (bench.py at N > 1): one [n, 352] row per rank, here the rank's env indexes as a marker
+    rows = torch.zeros((env.hi - env.lo, 352), dtype=torch.uint8)
+    rows[:, 0] = torch.arange(env.lo, env.hi, dtype=torch.uint8)
+    rec = env.gather_records(rows)
+    assert tuple(rec.shape) == (world, env.hi - env.lo, 352)
+    for r in range(world):
+        lo_r, hi_r = shard_range(total, world, r)
+        assert rec[r, :, 0].tolist() == list(range(lo_r, hi_r)) and not rec[r, :, 1:].any()
     q.put((rank, gathered.numpy().copy(), env.local.obs_flat.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
