@@ -46,6 +46,7 @@ struct EngineArgs {
   bg_rollout_stats* stats;
   uint32_t th_run, th_play, th_other; // a queue is served once it holds this many items ...
   uint32_t th_part;            // ... or, while other waves are busy (their envs will come back soon), this many; anything when no wave is busy
+  uint32_t n_serve;            // waves that may run service batches (<= BG_ENG_NSV)
   uint32_t th_more;            // further cheap steps an env may take inside the batch that has it
   uint32_t autoreset;          // SAME_STEP auto-reset of terminated envs
 };
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, 2) void bg_engine_kernel(BgDe
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int env0 = blockIdx.x * NE;
   const int n_live = d.N - env0 < NE ? d.N - env0 : NE;
-  const bool can_serve = wave >= NW - NSV;
+  const bool can_serve = wave >= NW - NSV && wave < NW - NSV + (int)a.n_serve; // (n_serve <= NSV: development knob BG_ENG_NSERVE)
   using DeckT = DeckLdsS<NE, CARDS>;
   const size_t N = (size_t)d.N;
   // ---------------------------------------------------------------- prologue: HBM -> LDS, images built, lane = env

@@ -1021,7 +1021,7 @@ struct bg_handle {
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
   // tunables read ONCE per handle in bg_create (environment variables)
   int refill_blocks, refill_blocks_shop, dev_skip_refill, gblk_first, gblk_own, wg_envs;
-  uint32_t eng_run, eng_play, eng_other, eng_part, eng_more; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
+  uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_nserve; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
   uint32_t role_mode;
 };
 
@@ -1149,7 +1149,8 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0); h->gblk_first = geti("BG_GBLK_FIRST", 0); h->gblk_own = geti("BG_GBLK_OWN", 0);
     h->wg_envs = geti("BG_WG_ENVS", 0);
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
-    h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 3);
+    h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_nserve = (uint32_t)geti("BG_ENG_NSERVE", BG_ENG_NSV);
+    if (h->eng_nserve < 1 || h->eng_nserve > BG_ENG_NSV) h->eng_nserve = BG_ENG_NSV;
     h->role_mode = (uint32_t)geti("BG_ROLE_MODE", 0) | (geti("BG_HELP", 0) ? 0x100u : 0u) | (geti("BG_DEFER_ADV", 0) ? 0x200u : 0u) |
                    (((uint32_t)geti("BG_TH_ENV", 0) & 0xffu) << 16);
   }
@@ -1505,7 +1506,7 @@ static int bg_step_impl(bg_handle* h, int K, const int32_t* actions_dev, const b
       ea.trunc = truncated_dev ? truncated_dev + off : nullptr;
       ea.info = bg_info(info);
       if (off) bg_info_advance(ea.info, off);
-      ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more;
+      ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.n_serve = h->eng_nserve;
       ea.autoreset = (h->dev.flags & BG_FLAG_AUTORESET) ? 1u : 0u;
       bg_engine_launch(h, dv, ea, false, true, st);
     } else {
@@ -1586,7 +1587,7 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
         memset(&ea, 0, sizeof(ea));
         ea.T = chunk; ea.policy = pol; ea.policy_seed = policy_seed; ea.env_index0 = env_index0; ea.t0 = tt;
         ea.obs = o; ea.obs_stride_steps = obs_stride_steps; ea.reward = rw; ea.term = tm; ea.actions_out = ac; ea.stats = stats_dev;
-        ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.autoreset = 1;
+        ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.n_serve = h->eng_nserve; ea.autoreset = 1;
         bg_engine_launch(h, dv, ea, hash, false, st);
       } else {
         // envs per workgroup.  256 (one workgroup per CU: its two play waves and two other waves pool the queues of 256 envs,
