@@ -31,8 +31,17 @@
 #define BG_SPIN_LIMIT (1u << 24)
 #define BG_DEVERR_SPIN 16u
 #define BG_ENG_NE 256   // envs per workgroup
-#define BG_ENG_NW 8     // waves per workgroup (two per SIMD)
-#define BG_ENG_NSV 4    // of them, how many own an RNG window and may run service batches (waves NW-NSV .. NW-1)
+// Waves per workgroup.  SEVEN, not eight: a wave of this kernel needs 256 VGPRs, so eight fill the register file of all four SIMDs and
+// nothing can be placed beside the workgroup -- the RNG refill of the previous launch (~1 ms of one-wave workgroups) then waits for
+// the engine to retire and the next launch waits for the refill.  With seven, one SIMD per CU keeps 256 free registers (and the
+// workgroup leaves ~5 KB of LDS), the dispatcher places the refill's one-wave workgroups there (multi-wave workgroups do NOT fit:
+// tools/micro/corun.hip), and the refill runs beside the engine: +8.5 % env-steps/s measured on one box although the kernel itself
+// is slower with seven waves and a busy neighbour (3.86 -> 4.30 ms per 372-step launch; -DBG_ENG_NW=8 is the old shape).
+#ifndef BG_ENG_NW
+#define BG_ENG_NW 7
+#endif
+#define BG_ENG_NSV 4    // of them, how many own an RNG window and may run service batches
+#define BG_ENG_SMASK_DEFAULT (((1u << BG_ENG_NSV) - 1u) << (BG_ENG_NW - BG_ENG_NSV)) // which: the last NSV waves (BG_ENG_SMASK)
 
 struct EngineArgs {
   int T;                       // steps per env in this launch
@@ -46,7 +55,7 @@ struct EngineArgs {
   bg_rollout_stats* stats;
   uint32_t th_run, th_play, th_other; // a queue is served once it holds this many items ...
   uint32_t th_part;            // ... or, while other waves are busy (their envs will come back soon), this many; anything when no wave is busy
-  uint32_t n_serve;            // waves that may run service batches (<= BG_ENG_NSV)
+  uint32_t serve_mask;         // bit w: wave w owns an RNG window and may run service batches (<= BG_ENG_NSV bits)
   uint32_t th_more;            // further cheap steps an env may take inside the batch that has it
   uint32_t autoreset;          // SAME_STEP auto-reset of terminated envs
 };
@@ -86,7 +95,8 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, 2) void bg_engine_kernel(BgDe
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int env0 = blockIdx.x * NE;
   const int n_live = d.N - env0 < NE ? d.N - env0 : NE;
-  const bool can_serve = wave >= NW - NSV && wave < NW - NSV + (int)a.n_serve; // (n_serve <= NSV: development knob BG_ENG_NSERVE)
+  const bool can_serve = ((a.serve_mask >> wave) & 1u) != 0;
+  const int serve_idx = __popc(a.serve_mask & ((1u << wave) - 1u)); // which RNG window
   using DeckT = DeckLdsS<NE, CARDS>;
   const size_t N = (size_t)d.N;
   // ---------------------------------------------------------------- prologue: HBM -> LDS, images built, lane = env
@@ -346,7 +356,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, 2) void bg_engine_kernel(BgDe
         DeckT dk; dk.col = (lds_u32*)&s_deck[0][l];
         ShopRegs sr; sr.valid = false;
         RngWin w;
-        bg_win_init(w, &s_win[wave - (NW - NSV)][0][lane], &jt);
+        bg_win_init(w, &s_win[serve_idx][0][lane], &jt);
         bg_step_init(o);
         if (bg_step_guards(e, mask, action, o)) bg_env_dispatch(d, env, e, w, sr, dk, action, o);
         BG_PROBE(cls == BG_Q_PLAY ? 20 : 21);

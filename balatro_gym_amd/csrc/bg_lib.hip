@@ -543,132 +543,151 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_observe_kernel(BgDev d, ObsPtrs o
 // mt[i] again, and gets it from a SECOND run of the pass-1 recurrence in lockstep (two independent chains = ILP) --
 // recomputing 623 steps is far cheaper than writing 2.5 KB per stream and reading it back.  The only memory traffic
 // is the final state: 156 16-byte stores.
-// init_genrand(19650218), the key-independent state init_by_array starts from: a compile-time table read with scalar
-// loads (the index is the loop counter, uniform over the wave) instead of a third multiply chain per step
+// init_genrand(19650218), the key-independent state init_by_array starts from: a compile-time table read with SCALAR loads (the
+// index is the loop counter, uniform over the wave) instead of a third multiply chain per step -- sixteen entries per load
+// (`s_load_dwordx16`), the next block requested before the current one is used: with one dword per step each of the 1 870 steps
+// waited ~200 cycles for its own scalar load and the seeding of a shop stream was latency bound on the constant cache (0.58 ms
+// per refill for 1.1 M streams against a VALU bound of ~0.15).
+struct alignas(64) BgG16 { uint32_t v[16]; };
 struct BgGenrandTab {
-  uint32_t g[BG_MT_N];
-  constexpr BgGenrandTab() : g{} {
+  BgG16 blk[BG_MT_N / 16];
+  constexpr BgGenrandTab() : blk{} {
     uint32_t x = 19650218u;
-    g[0] = x;
-    for (int i = 1; i < BG_MT_N; i++) { x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i; g[i] = x; }
+    blk[0].v[0] = x;
+    for (int i = 1; i < BG_MT_N; i++) { x = 1812433253u * (x ^ (x >> 30)) + (uint32_t)i; blk[i / 16].v[i % 16] = x; }
   }
 };
+static_assert(BG_MT_N % 16 == 0, "624 = 39 blocks of 16");
 static constexpr BgGenrandTab BG_GENRAND{};
 
-__device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) {
+// SLOT = false: the whole seeded state (156 16-byte stores); true: a shop-stream ring slot -- only words 0..131 and 396..527 of the
+// state are kept (BG_SW_*), plus the seed
+template <bool SLOT>
+__device__ __forceinline__ void bg_mt_seed_impl(uint32_t* __restrict__ p, uint32_t key) {
+  constexpr int NB = BG_MT_N / 16;
   uint4* p4 = (uint4*)p;
-  uint32_t a = BG_GENRAND.g[0], a1 = 0; // a: pass-1 recurrence
-#pragma unroll 4
-  for (int i = 1; i < BG_MT_N; i++) {
-    a = (BG_GENRAND.g[i] ^ ((a ^ (a >> 30)) * 1664525u)) + key;
-    if (i == 1) a1 = a;
+  uint32_t a = BG_GENRAND.blk[0].v[0], a1 = 0; // a: pass-1 recurrence
+  {
+    BgG16 cur = BG_GENRAND.blk[0];
+#pragma unroll 1
+    for (int b = 0; b < NB; b++) {
+      const BgG16 nxt = BG_GENRAND.blk[b + 1 < NB ? b + 1 : NB - 1];
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (b > 0 || c >= 1) {
+          a = (cur.v[c] ^ ((a ^ (a >> 30)) * 1664525u)) + key;
+          if (b == 0 && c == 1) a1 = a;
+        }
+      }
+      cur = nxt;
+    }
   }
   // wrap: mt[0] = mt[623]; 624th iteration of pass 1 at i = 1
   const uint32_t a1w = (a1 ^ ((a ^ (a >> 30)) * 1664525u)) + key;
   // pass 2: i = 2..623 (then the wrapped step at i = 1), beside a rerun of pass 1 that supplies mt[i]
-  a = BG_GENRAND.g[0];
-  a = (BG_GENRAND.g[1] ^ ((a ^ (a >> 30)) * 1664525u)) + key; // pass-1 mt[1] (before the wrap)
+  a = BG_GENRAND.blk[0].v[0];
+  a = (BG_GENRAND.blk[0].v[1] ^ ((a ^ (a >> 30)) * 1664525u)) + key; // pass-1 mt[1] (before the wrap)
   uint32_t bprev = a1w, w2 = 0, w3 = 0;
-#pragma unroll 2
-  for (int q = 0; q < BG_MT_N / 4; q++) {
-    uint32_t v[4] = {0, 0, 0, 0};
+  {
+    BgG16 cur = BG_GENRAND.blk[0];
+#pragma unroll 1
+    for (int b = 0; b < NB; b++) {
+      const BgG16 nxt = BG_GENRAND.blk[b + 1 < NB ? b + 1 : NB - 1];
+      uint32_t v[16];
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int i = 4 * q + c;
-      if (i >= 2) {
-        a = (BG_GENRAND.g[i] ^ ((a ^ (a >> 30)) * 1664525u)) + key;
-        bprev = (a ^ ((bprev ^ (bprev >> 30)) * 1566083941u)) - (uint32_t)i;
-        v[c] = bprev;
+      for (int c = 0; c < 16; c++) {
+        v[c] = 0;
+        if (b > 0 || c >= 2) {
+          a = (cur.v[c] ^ ((a ^ (a >> 30)) * 1664525u)) + key;
+          bprev = (a ^ ((bprev ^ (bprev >> 30)) * 1566083941u)) - (uint32_t)(16 * b + c);
+          v[c] = bprev;
+        }
       }
+      if (b == 0) { w2 = v[2]; w3 = v[3]; }
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int q = 4 * b + k; // 16-byte group of the state
+        const uint4 val = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        if (q == 0) continue;
+        if (!SLOT) p4[q] = val;
+        else if (q < BG_SW_A / 4) p4[q] = val;
+        else if (q >= BG_SW_F / 4 && q < BG_SW_F / 4 + BG_SW_A / 4) p4[q - (BG_SW_F - BG_SW_A) / 4] = val;
+      }
+      cur = nxt;
     }
-    if (q == 0) { w2 = v[2]; w3 = v[3]; }
-    else p4[q] = make_uint4(v[0], v[1], v[2], v[3]);
   }
   const uint32_t w1 = (a1w ^ ((bprev ^ (bprev >> 30)) * 1566083941u)) - 1u; // mt[0] = mt[623], wrapped step at i = 1
   p4[0] = make_uint4(0x80000000u, w1, w2, w3);
+  if (SLOT) p[BG_SW_SEED] = key;
 }
-
-// The same seeding for a shop-stream ring slot: only words 0..131 and 396..527 of the state are kept (BG_SW_*), plus the seed.
-__device__ void bg_mt_seed_slot(uint32_t* __restrict__ p, uint32_t key) {
-  uint4* p4 = (uint4*)p;
-  uint32_t a = BG_GENRAND.g[0], a1 = 0;
-#pragma unroll 4
-  for (int i = 1; i < BG_MT_N; i++) {
-    a = (BG_GENRAND.g[i] ^ ((a ^ (a >> 30)) * 1664525u)) + key;
-    if (i == 1) a1 = a;
-  }
-  const uint32_t a1w = (a1 ^ ((a ^ (a >> 30)) * 1664525u)) + key;
-  a = BG_GENRAND.g[0];
-  a = (BG_GENRAND.g[1] ^ ((a ^ (a >> 30)) * 1664525u)) + key;
-  uint32_t bprev = a1w, w2 = 0, w3 = 0;
-#pragma unroll 2
-  for (int q = 0; q < BG_MT_N / 4; q++) {
-    uint32_t v[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const int i = 4 * q + c;
-      if (i >= 2) {
-        a = (BG_GENRAND.g[i] ^ ((a ^ (a >> 30)) * 1664525u)) + key;
-        bprev = (a ^ ((bprev ^ (bprev >> 30)) * 1566083941u)) - (uint32_t)i;
-        v[c] = bprev;
-      }
-    }
-    if (q == 0) { w2 = v[2]; w3 = v[3]; }
-    else if (q < BG_SW_A / 4) p4[q] = make_uint4(v[0], v[1], v[2], v[3]);
-    else if (q >= BG_SW_F / 4 && q < BG_SW_F / 4 + BG_SW_A / 4) p4[q - (BG_SW_F - BG_SW_A) / 4] = make_uint4(v[0], v[1], v[2], v[3]);
-  }
-  const uint32_t w1 = (a1w ^ ((bprev ^ (bprev >> 30)) * 1566083941u)) - 1u;
-  p4[0] = make_uint4(0x80000000u, w1, w2, w3);
-  p[BG_SW_SEED] = key;
-}
+__device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) { bg_mt_seed_impl<false>(p, key); }
+__device__ void bg_mt_seed_slot(uint32_t* __restrict__ p, uint32_t key) { bg_mt_seed_impl<true>(p, key); }
 
 // ---------------------------------------------------------------------------------------------------------
 // Lazy MT19937 for the streams only the refill kernels read (deck shuffles, shop seeds).  genrand_uint32() regenerates
 // all 624 words when the block is exhausted; computing word k of the next block just before it is read gives the same
 // sequence (new[k] = old[k+397 mod 624 (already new for k >= 227)] ^ twist(old[k], old[k+1]); k = 623 pairs with the
 // new word 0) and never needs the 624-word pass.  State: [new words 0..c) | old words c..624), cursor c in word 624.
-// A window = the next 4*G aligned words from the cursor's 16-byte group on: 2*(G+1) independent 16-byte loads, one
-// wait, the new (untempered) words and the old ones go to LDS [word][lane]; commit writes back exactly the words that
-// were consumed (whole 16-byte groups, untouched words keep their old value).
-// 4*G < 227, so no operand of a window is produced inside the same window.
-template <int G>
-__device__ __forceinline__ void bg_lazy_window(const uint32_t* S, uint32_t c, lds_u32* win, lds_u32* old) {
-  const uint4* S4 = (const uint4*)S;
-  const uint32_t q0 = c >> 2;
-  uint32_t f0 = q0 + 99u; if (f0 >= 156u) f0 -= 156u; // group of word (4*q0 + 396) mod 624
-  uint32_t A[4 * G + 4], F[4 * G + 4];
-#pragma unroll
-  for (int g = 0; g <= G; g++) {
-    uint32_t q = q0 + (uint32_t)g; if (q >= 156u) q -= 156u;
-    uint4 v = S4[q];
-    A[4 * g] = v.x; A[4 * g + 1] = v.y; A[4 * g + 2] = v.z; A[4 * g + 3] = v.w;
-  }
-#pragma unroll
-  for (int g = 0; g <= G; g++) {
-    uint32_t q = f0 + (uint32_t)g; if (q >= 156u) q -= 156u;
-    uint4 v = S4[q];
-    F[4 * g] = v.x; F[4 * g + 1] = v.y; F[4 * g + 2] = v.z; F[4 * g + 3] = v.w;
-  }
-#pragma unroll
-  for (int i = 0; i < 4 * G; i++) { win[i * BG_BLOCK] = bg_twist(A[i], A[i + 1], F[i + 1]); old[i * BG_BLOCK] = A[i]; }
-}
-// write back the `used` words consumed from the cursor on (aligned coordinates [c & 3, (c & 3) + used)); returns the new cursor
-template <int G>
-__device__ __forceinline__ uint32_t bg_lazy_commit(uint32_t* S, uint32_t c, uint32_t used, lds_u32* win, lds_u32* old) {
+// The stream is read BG_LAZY_U 16-byte groups (16 words) per iteration, every lane on its own stream: the groups of the iteration,
+// the one behind them (word k+1 of the last word) and the groups holding words k+397 live in registers, the groups of the NEXT
+// iteration are requested before the current ones are used (beside the step engine a load takes microseconds), and a group is
+// written back as soon as the lane has consumed its words (consumed words new, the others as loaded).  Nothing goes through LDS,
+// so the refill kernels fit beside the step engine (which leaves one SIMD's registers and ~5 KB of LDS per CU free).
+// No operand is produced less than 227 words before it is read, the look-ahead is 36 words.
+// take(y): consumes one untempered word, returns true while the lane wants another.  Returns the new cursor.  Every lane of
+// the wave must call this (lanes with active == false touch no memory); the loop runs until the last lane has had enough.
+__device__ __forceinline__ uint32_t bg_q156(uint32_t q) { return q >= 156u ? q - 156u : q; }
+#ifndef BG_LAZY_U
+#define BG_LAZY_U 4 // 16-byte groups per iteration of bg_lazy_stream
+#endif
+#ifndef BG_REFILL_WAVE_PRIO
+#define BG_REFILL_WAVE_PRIO 0 // s_setprio of the deck / seed-ring / block waves (the shop seeding stays at 0, the step engine runs at 3)
+#endif
+template <class F>
+__device__ __forceinline__ uint32_t bg_lazy_stream(uint32_t* S, uint32_t c, bool active, F&& take) {
+  constexpr int U = BG_LAZY_U;
   uint4* S4 = (uint4*)S;
-  const uint32_t q0 = c >> 2, off = c & 3u, end = off + used;
-#pragma unroll 4
-  for (int g = 0; g < G; g++) {
-    if ((uint32_t)(4 * g) < end) {
-      uint32_t o[4];
+  uint32_t q = c >> 2, off = c & 3u, fq = bg_q156(q + 99u); // fq: group of word (4*q + 396) mod 624
+  uint4 a[U + 1], f[U + 1]; // groups q .. q+U and fq .. fq+U
 #pragma unroll
-      for (int k = 0; k < 4; k++) { const uint32_t i = (uint32_t)(4 * g + k); o[k] = (i >= off && i < end) ? win[i * BG_BLOCK] : old[i * BG_BLOCK]; }
-      uint32_t q = q0 + (uint32_t)g; if (q >= 156u) q -= 156u;
-      S4[q] = make_uint4(o[0], o[1], o[2], o[3]);
-    }
+  for (int g = 0; g <= U; g++) { a[g] = make_uint4(0, 0, 0, 0); f[g] = a[g]; }
+  if (active) {
+#pragma unroll
+    for (int g = 0; g <= U; g++) { a[g] = S4[bg_q156(q + (uint32_t)g)]; f[g] = S4[bg_q156(fq + (uint32_t)g)]; }
   }
-  uint32_t nc = c + used; if (nc >= (uint32_t)BG_MT_N) nc -= (uint32_t)BG_MT_N;
-  return nc;
+#pragma unroll 1
+  while (__ballot(active) != 0ull) {
+    uint4 an[U], fn[U]; // the U groups behind them: requested now, used by the next iteration
+#pragma unroll
+    for (int g = 0; g < U; g++) { an[g] = a[0]; fn[g] = a[0]; }
+    if (active) {
+#pragma unroll
+      for (int g = 0; g < U; g++) { an[g] = S4[bg_q156(q + (uint32_t)(U + 1 + g))]; fn[g] = S4[bg_q156(fq + (uint32_t)(U + 1 + g))]; }
+    }
+    bool more = active;
+#pragma unroll
+    for (int g = 0; g < U; g++) {
+      const uint4 a0 = a[g], f0 = f[g];
+      const uint32_t n0 = bg_twist(a0.x, a0.y, f0.y), n1 = bg_twist(a0.y, a0.z, f0.z), n2 = bg_twist(a0.z, a0.w, f0.w), n3 = bg_twist(a0.w, a[g + 1].x, f[g + 1].x);
+      const uint32_t goff = g == 0 ? off : 0u;
+      uint4 o = a0;
+      uint32_t used = 0;
+      if (more && goff == 0u) { o.x = n0; used++; more = take(n0); }
+      if (more && goff <= 1u) { o.y = n1; used++; more = take(n1); }
+      if (more && goff <= 2u) { o.z = n2; used++; more = take(n2); }
+      if (more) { o.w = n3; used++; more = take(n3); }
+      if (used) {
+        const uint32_t qg = bg_q156(q + (uint32_t)g);
+        S4[qg] = o;
+        if (!more) { c = 4u * qg + goff + used; if (c >= (uint32_t)BG_MT_N) c -= (uint32_t)BG_MT_N; active = false; }
+      }
+    }
+    q = bg_q156(q + (uint32_t)U); fq = bg_q156(fq + (uint32_t)U); off = 0u;
+    a[0] = a[U]; f[0] = f[U];
+#pragma unroll
+    for (int g = 0; g < U; g++) { a[g + 1] = an[g]; f[g + 1] = fn[g]; }
+  }
+  return c;
 }
 
 #define BG_MTB 16 // words per batch of the block twist
@@ -773,6 +792,8 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_
 //   * shops : `shop_seed = rng.get_int('shop_generation', 0, 2**31 - 1)` (:1389), `random.Random(shop_seed)` (shop.py:96)
 //   * gblk  : next 624-word block(s) of the per-env global stream
 // ---------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_zero_kernel(BgDev d) { if (threadIdx.x < 4) d.wl_count[threadIdx.x] = 0; }
+
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
   int env = blockIdx.x * BG_BLOCK + threadIdx.x;
   if (env >= d.N) return;
@@ -817,99 +838,102 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
   if (g_valid > 0 && g_valid < d.KG) { uint32_t i = atomicAdd(&d.wl_count[2], 1u); d.wl[2 * N + i] = (uint32_t)env; }
 }
 
-// 16-byte groups per lazy window of the deck stream: >= 37 words, a shuffle reads ~70 (two or three windows).  Sized so
-// that the kernel needs <= 168 VGPRs: its waves must fit on SIMDs that already hold a rollout wave (~336 of the 512
-// registers) -- with a 256-register build the kernel only ran in the gaps between rollout launches (7x longer).
-#ifndef BG_DECK_G
-#define BG_DECK_G 10
-#endif
+// One lane per env that is short of pre-shuffled decks; rounds of one shuffle each until every lane of the wave has its ring
+// full (~1.7 decks per env and 372-step launch).  The deck under construction is the kernel's only LDS (52 bytes per lane:
+// random.shuffle indexes it with a per-lane j): 3.3 KB per wave, which fits beside a step-engine workgroup.
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
+  __builtin_amdgcn_s_setprio(BG_REFILL_WAVE_PRIO);
   __shared__ uint8_t sdeck[52][BG_BLOCK];
-  __shared__ uint32_t rwin[4 * BG_DECK_G][BG_BLOCK], rold[4 * BG_DECK_G][BG_BLOCK];
   size_t N = d.N;
-  int tid = threadIdx.x;
-  uint32_t count = d.wl_count[0];
-  for (uint32_t item = blockIdx.x * BG_BLOCK + tid; item < count; item += gridDim.x * BG_BLOCK) {
-    int env = (int)d.wl[item];
-    uint32_t w5 = ((const uint32_t*)&d.hot[(size_t)5 * N + env])[3];
-    uint32_t prod = d.prod_out[env];
-    int d_head = bg_b(w5, 2), d_cons = bg_b(w5, 3);
-    int d_ready = (int)((prod - (uint32_t)d_cons) & 0xffu);
-    int made = 0;
+  const int tid = threadIdx.x;
+  const uint32_t count = d.wl_count[0];
+  for (uint32_t base = blockIdx.x * BG_BLOCK; base < count; base += gridDim.x * BG_BLOCK) {
+    const bool valid = base + tid < count;
+    const int env = valid ? (int)d.wl[base + tid] : 0;
+    uint32_t prod = 0, cur = 0;
+    int d_head = 0, d_ready = d.KD, made = 0;
     uint32_t* mt = bg_deckmt(d, env);
-    uint32_t cur = mt[BG_MT_N] & 0x3ffu;
-    lds_u32* win = (lds_u32*)&rwin[0][tid];
-    lds_u32* old = (lds_u32*)&rold[0][tid];
-    while (d_ready < d.KD) {
-      int p = 0;
-      for (int s = 0; s < 4; s++) for (int r = 0; r < 13; r++) sdeck[p++][tid] = (uint8_t)(r * 4 + s); // :519-522
-      int i = 51; // random.shuffle: for i = 51..1: j = _randbelow(i + 1), swap
-#pragma unroll 1
-      while (i >= 1) {
-        bg_lazy_window<BG_DECK_G>(mt, cur, win, old);
-        const uint32_t off = cur & 3u, cap = 4u * BG_DECK_G - off;
-        uint32_t used = 0;
-        while (i >= 1 && used < cap) {
-          const int k = 32 - __clz((uint32_t)(i + 1));
-          const uint32_t j = bg_temper(win[(off + used) * BG_BLOCK]) >> (32 - k);
-          used++;
-          if (j <= (uint32_t)i) {
-            uint8_t a = sdeck[i][tid], b = sdeck[j][tid];
-            sdeck[i][tid] = b; sdeck[j][tid] = a;
-            i--;
-          }
-        }
-        cur = bg_lazy_commit<BG_DECK_G>(mt, cur, used, win, old);
-      }
-      int slot = (d_head + d_ready) % d.KD;
-#pragma unroll
-      for (int k = 0; k < BG_NDECK; k++) {
-        uint32_t wv[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int b = 0; b < 16; b++) { int i2 = k * 16 + b; if (i2 < 52) wv[b >> 2] |= (uint32_t)sdeck[i2][tid] << (8 * (b & 3)); }
-        d.ndeck[((size_t)slot * BG_NDECK + k) * N + env] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-      }
-      d_ready++; made++;
+    if (valid) {
+      const uint32_t w5 = ((const uint32_t*)&d.hot[(size_t)5 * N + env])[3];
+      prod = d.prod_out[env];
+      d_head = bg_b(w5, 2);
+      d_ready = (int)((prod - (uint32_t)bg_b(w5, 3)) & 0xffu);
+      cur = mt[BG_MT_N] & 0x3ffu;
     }
-    mt[BG_MT_N] = cur | BG_LAZY_SEEDED;
-    ((uint8_t*)&d.prod_out[env])[0] = (uint8_t)((prod + (uint32_t)made) & 0xffu); // byte store: the block kernel may run concurrently
+    bool need = valid && d_ready < d.KD;
+#pragma unroll 1
+    while (__ballot(need) != 0ull) {
+      if (need) { int p = 0; for (int s = 0; s < 4; s++) for (int r = 0; r < 13; r++) sdeck[p++][tid] = (uint8_t)(r * 4 + s); } // :519-522
+      int i = 51; // random.shuffle: for i = 51..1: j = _randbelow(i + 1), swap
+      cur = bg_lazy_stream(mt, cur, need, [&](uint32_t y) {
+        const int k = 32 - __clz((uint32_t)(i + 1));
+        const uint32_t j = bg_temper(y) >> (32 - k);
+        if (j <= (uint32_t)i) {
+          const uint8_t a = sdeck[i][tid], b = sdeck[j][tid];
+          sdeck[i][tid] = b; sdeck[j][tid] = a;
+          i--;
+        }
+        return i >= 1;
+      });
+      if (need) {
+        const int slot = (d_head + d_ready) % d.KD;
+#pragma unroll
+        for (int k = 0; k < BG_NDECK; k++) {
+          uint32_t wv[4] = {0, 0, 0, 0};
+#pragma unroll
+          for (int b = 0; b < 16; b++) { int i2 = k * 16 + b; if (i2 < 52) wv[b >> 2] |= (uint32_t)sdeck[i2][tid] << (8 * (b & 3)); }
+          d.ndeck[((size_t)slot * BG_NDECK + k) * N + env] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+        }
+        d_ready++; made++;
+        need = d_ready < d.KD;
+      }
+    }
+    if (valid) {
+      mt[BG_MT_N] = cur | BG_LAZY_SEEDED;
+      ((uint8_t*)&d.prod_out[env])[0] = (uint8_t)((prod + (uint32_t)made) & 0xffu); // byte store: the block kernel may run concurrently
+    }
   }
 }
 
 // top up the per-env ring of pre-drawn shop seeds: `rng.get_int('shop_generation', 0, 2**31 - 1)` (:1389) in stream order
-#define BG_SEED_G 16 // one lazy window of the shop_generation stream per refill: >= 61 words, ~30 accepted seeds
+// (_randbelow(2**31): k = 32 bits, accept r < 2**31)
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_seedring_kernel(BgDev d) {
-  __shared__ uint32_t rwin[4 * BG_SEED_G][BG_BLOCK], rold[4 * BG_SEED_G][BG_BLOCK];
+  __builtin_amdgcn_s_setprio(BG_REFILL_WAVE_PRIO);
   size_t N = d.N;
-  uint32_t count = d.wl_count[1];
-  lds_u32* win = (lds_u32*)&rwin[0][threadIdx.x];
-  lds_u32* old = (lds_u32*)&rold[0][threadIdx.x];
-  for (uint32_t item = blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
-    int env = (int)d.wl[N + item];
-    uint32_t sm = d.smeta[env];
-    int head = (int)(sm & 0xffu), cnt = (int)((sm >> 8) & 0xffu);
+  const uint32_t count = d.wl_count[1];
+  for (uint32_t base = blockIdx.x * BG_BLOCK; base < count; base += gridDim.x * BG_BLOCK) {
+    const bool valid = base + threadIdx.x < count;
+    const int env = valid ? (int)d.wl[N + base + threadIdx.x] : 0;
     uint32_t* mt = bg_shopgenmt(d, env);
-    uint32_t cur = mt[BG_MT_N] & 0x3ffu;
-#pragma unroll 1
-    while (cnt < BG_SSEED) { // one or two windows in steady state
-      bg_lazy_window<BG_SEED_G>(mt, cur, win, old);
-      const uint32_t off = cur & 3u, cap = 4u * BG_SEED_G - off;
-      uint32_t used = 0;
-      while (cnt < BG_SSEED && used < cap) { // _randbelow(2**31): k = 32 bits, accept r < 2**31
-        const uint32_t r = bg_temper(win[(off + used) * BG_BLOCK]);
-        used++;
-        if (r < 2147483648u) { d.sseed[(size_t)env * BG_SSEED + ((head + cnt) & (BG_SSEED - 1))] = r; cnt++; }
-      }
-      cur = bg_lazy_commit<BG_SEED_G>(mt, cur, used, win, old);
+    int head = 0, cnt = BG_SSEED;
+    uint32_t cur = 0;
+    if (valid) {
+      const uint32_t sm = d.smeta[env];
+      head = (int)(sm & 0xffu); cnt = (int)((sm >> 8) & 0xffu);
+      cur = mt[BG_MT_N] & 0x3ffu;
     }
-    mt[BG_MT_N] = cur | BG_LAZY_SEEDED;
-    d.smeta[env] = (uint32_t)head | ((uint32_t)cnt << 8);
+    const bool need = valid && cnt < BG_SSEED;
+    cur = bg_lazy_stream(mt, cur, need, [&](uint32_t y) {
+      const uint32_t r = bg_temper(y);
+      if (r < 2147483648u) { d.sseed[(size_t)env * BG_SSEED + ((head + cnt) & (BG_SSEED - 1))] = r; cnt++; }
+      return cnt < BG_SSEED;
+    });
+    if (need) {
+      mt[BG_MT_N] = cur | BG_LAZY_SEEDED;
+      d.smeta[env] = (uint32_t)head | ((uint32_t)cnt << 8);
+    }
   }
 }
 
 // `random.Random(shop_seed)` (shop.py:96): one stream per lane, pure ALU + 156 stores.  The slot holds the SEEDED state;
 // the consumer regenerates the few words a shop visit reads (bg_sprefetch), so no block twist is ever run for a shop.
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop_kernel(BgDev d) {
+#ifdef BG_SHOP_VGPR128
+  asm volatile("v_mov_b32 v127, 0" ::: "v127"); // development: at most 2 of these waves on the SIMD the step engine leaves free
+#endif
+#ifdef BG_SHOP_VGPR200
+  asm volatile("v_mov_b32 v199, 0" ::: "v199");
+#endif
   uint32_t count = d.wl_count[3];
   for (uint32_t item = blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
     uint32_t es = d.wl_shop[2 * (size_t)item], seed = d.wl_shop[2 * (size_t)item + 1];
@@ -917,32 +941,66 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop_kernel(BgDev d) {
   }
 }
 
+// Next 624-word block(s) of the per-env global stream, ONE WAVE PER ENV: lane l holds words l, l + 64, ... of the block (ten
+// registers), so the block is read and written as ten 256-byte rows (a lane per env read 16 bytes of 64 different blocks per
+// instruction), word k+1 and word k+397 / k-227 come from other lanes (`__shfl`), and a block that is twisted again stays in
+// registers.  Row r only needs NEW rows r-4 / r-3, so the rows go in order; word 623 pairs with the new word 0.
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_gblk_kernel(BgDev d) {
-  size_t N = d.N;
-  uint32_t count = d.wl_count[2];
-  for (uint32_t item = blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
-    int env = (int)d.wl[2 * N + item];
-    uint32_t w6 = ((const uint32_t*)&d.hot[(size_t)6 * N + env])[3];
-    uint32_t prod = d.prod_out[env];
-    int g_cur = bg_b(w6, 2), g_cons = bg_b(w6, 3);
+  __builtin_amdgcn_s_setprio(BG_REFILL_WAVE_PRIO);
+  const size_t N = d.N;
+  const uint32_t count = d.wl_count[2];
+  const int l = threadIdx.x;
+  constexpr int NR = (BG_MT_N + 63) / 64; // 10 rows, the last one 48 words
+  for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+    const int env = (int)d.wl[2 * N + item];
+    const uint32_t w6 = ((const uint32_t*)&d.hot[(size_t)6 * N + env])[3];
+    const uint32_t prod = d.prod_out[env];
+    const int g_cur = bg_b(w6, 2), g_cons = bg_b(w6, 3);
     int g_valid = (int)(((prod >> 16) - (uint32_t)g_cons) & 0xffu);
-    int made = 0;
-    while (g_valid > 0 && g_valid < d.KG) {
-      int last = (g_cur + g_valid - 1) % d.KG;
-      int nxt = last + 1 == d.KG ? 0 : last + 1;
-      bg_mt_twist(bg_gblock(d, env, last), bg_gblock(d, env, nxt));
-      { // the 16 spare words behind a block mirror the head of its successor: a 16-word read never has to change blocks
-        const uint4* h4 = (const uint4*)bg_gblock(d, env, nxt);
-        uint4* t4 = (uint4*)(bg_gblock(d, env, last) + BG_MT_N);
-        uint4 v0 = h4[0], v1 = h4[1], v2 = h4[2], v3 = h4[3];
-        t4[0] = v0; t4[1] = v1; t4[2] = v2; t4[3] = v3;
-      }
-      g_valid++; made++;
+    if (g_valid <= 0 || g_valid >= d.KG) continue;
+    int last = (g_cur + g_valid - 1) % d.KG, made = 0;
+    uint32_t o[NR + 1];
+    {
+      const uint32_t* src = bg_gblock(d, env, last);
+#pragma unroll
+      for (int r = 0; r < NR; r++) o[r] = (64 * r + l < BG_MT_N) ? src[64 * r + l] : 0u;
+      o[NR] = 0u;
     }
-    if (made) {
-      uint32_t g = ((prod >> 16) + (uint32_t)made) & 0xffu;
-      // only this lane touches byte 2 of this env's word during a refill; bytes 0/1 may be updated concurrently by the
-      // deck kernel of the SAME refill only if kernels overlapped -- they run back to back on one stream
+#pragma unroll 1
+    while (g_valid < d.KG) {
+      const int nxt = last + 1 == d.KG ? 0 : last + 1;
+      uint32_t* dst = bg_gblock(d, env, nxt);
+      uint32_t n[NR];
+#pragma unroll
+      for (int r = 0; r < NR; r++) {
+        const int k = 64 * r + l;
+        // word k+1: lane l+1 of this row, lane 0 of the next one for l = 63
+        const uint32_t up_same = __shfl(o[r], (l + 1) & 63), up_next = __shfl(o[r + 1], 0);
+        uint32_t up = l == 63 ? up_next : up_same;
+        if (r == NR - 1) { const uint32_t new0 = __shfl(n[0], 0); if (k == BG_MT_N - 1) up = new0; } // kk == 623 pairs with the NEW word 0
+        // word k+397 (old, k < 227): 64 (r+6) + l + 13;  word k-227 (new, k >= 227): 64 (r-4) + l + 29
+        uint32_t far = 0u;
+        if (64 * r < BG_MT_N - BG_MT_M) { // some lane of this row has k < 227
+          const uint32_t a = r + 6 < NR ? __shfl(o[r + 6], (l + 13) & 63) : 0u, b2 = r + 7 < NR ? __shfl(o[r + 7], (l + 13) & 63) : 0u;
+          far = l + 13 < 64 ? a : b2;
+        }
+        if (64 * r + 63 >= BG_MT_N - BG_MT_M) { // some lane has k >= 227
+          const uint32_t a = r >= 4 ? __shfl(n[r >= 4 ? r - 4 : 0], (l + 29) & 63) : 0u, b2 = r >= 3 ? __shfl(n[r >= 3 ? r - 3 : 0], (l + 29) & 63) : 0u;
+          const uint32_t fn = l + 29 < 64 ? a : b2;
+          if (k >= BG_MT_N - BG_MT_M) far = fn;
+        }
+        n[r] = bg_twist(o[r], up, far);
+        if (k < BG_MT_N) dst[k] = n[r];
+      }
+      // the 16 spare words behind a block mirror the head of its successor: a 16-word read never has to change blocks
+      if (l < 16) bg_gblock(d, env, last)[BG_MT_N + l] = n[0];
+#pragma unroll
+      for (int r = 0; r < NR; r++) o[r] = n[r];
+      last = nxt; g_valid++; made++;
+    }
+    if (made && l == 0) {
+      const uint32_t g = ((prod >> 16) + (uint32_t)made) & 0xffu;
+      // only this wave touches byte 2 of this env's word during a refill; bytes 0 / 1 belong to the scan / deck kernels
       ((uint8_t*)&d.prod_out[env])[2] = (uint8_t)g;
     }
   }
@@ -1021,7 +1079,7 @@ struct bg_handle {
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
   // tunables read ONCE per handle in bg_create (environment variables)
   int refill_blocks, refill_blocks_shop, dev_skip_refill, gblk_first, gblk_own, wg_envs;
-  uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_nserve; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
+  uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_smask; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
   uint32_t role_mode;
 };
 
@@ -1093,6 +1151,9 @@ int bg_debug_counters(bg_handle* h, unsigned long long* out16) {
   return 0;
 }
 
+// development aid: choose which refill kernels run (bit set = skipped; tools/refill_alone.py)
+int bg_debug_set_skip(bg_handle* h, int skip) { if (!h) return BG_E_ARG; h->dev_skip_refill = skip; return 0; }
+
 // development aid: the four work-list lengths of the most recent refill (decks, seed rings, global blocks, shop streams)
 int bg_debug_worklists(bg_handle* h, unsigned int* out4) {
   if (!h || !out4) return BG_E_ARG;
@@ -1149,8 +1210,8 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0); h->gblk_first = geti("BG_GBLK_FIRST", 0); h->gblk_own = geti("BG_GBLK_OWN", 0);
     h->wg_envs = geti("BG_WG_ENVS", 0);
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
-    h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_nserve = (uint32_t)geti("BG_ENG_NSERVE", BG_ENG_NSV);
-    if (h->eng_nserve < 1 || h->eng_nserve > BG_ENG_NSV) h->eng_nserve = BG_ENG_NSV;
+    h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT);
+    if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
     h->role_mode = (uint32_t)geti("BG_ROLE_MODE", 0) | (geti("BG_HELP", 0) ? 0x100u : 0u) | (geti("BG_DEFER_ADV", 0) ? 0x200u : 0u) |
                    (((uint32_t)geti("BG_TH_ENV", 0) & 0xffu) << 16);
   }
@@ -1206,7 +1267,13 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
   if (e == hipSuccess) e = bg_alloc(h, &d.smeta, N);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_prod[0], N);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_prod[1], N);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side, hipStreamNonBlocking);
+  // The refill runs BESIDE the next step-engine launch, in the registers of the one SIMD per CU and the ~5 KB of LDS the engine
+  // leaves free.  The shop seeding (1.1 M ALU-bound waves' worth per launch) goes on a stream of the LOWEST priority: its waves
+  // would otherwise take every free register before the few, latency-bound deck / seed-ring / block waves are placed
+  int prio_least = 0, prio_greatest = 0;
+  if (e == hipSuccess) e = hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest);
+  { const char* pv = getenv("BG_REFILL_PRIO"); if (pv && atoi(pv) == 0) prio_least = 0; } // development: 0 = default priority
+  if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->side, hipStreamNonBlocking, prio_least);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side2, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side3, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_scan, hipEventDisableTiming);
@@ -1313,7 +1380,9 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   d.prod_out = h->d_prod[h->refill_seq & 1];
   d.prod_view = nullptr;
   bg_ev_begin(h, h->ev_refill_t, s);
-  BG_HIP(hipMemsetAsync(d.wl_count, 0, 4 * sizeof(uint32_t), s));
+  // a one-wave kernel, not hipMemsetAsync: the runtime's fill kernel has multi-wave workgroups, which the dispatcher cannot place
+  // beside a resident step-engine workgroup (only one SIMD per CU has free registers) -- the whole refill would wait for the engine
+  hipLaunchKernelGGL(bg_refill_zero_kernel, dim3(1), dim3(BG_BLOCK), 0, s, d);
   hipLaunchKernelGGL(bg_refill_scan_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, d);
   // The rollout kernel leaves no registers for a co-resident wave, so the refill runs in the gaps rollout workgroups leave
   // when they retire: wide grids
@@ -1506,7 +1575,7 @@ static int bg_step_impl(bg_handle* h, int K, const int32_t* actions_dev, const b
       ea.trunc = truncated_dev ? truncated_dev + off : nullptr;
       ea.info = bg_info(info);
       if (off) bg_info_advance(ea.info, off);
-      ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.n_serve = h->eng_nserve;
+      ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.serve_mask = h->eng_smask;
       ea.autoreset = (h->dev.flags & BG_FLAG_AUTORESET) ? 1u : 0u;
       bg_engine_launch(h, dv, ea, false, true, st);
     } else {
@@ -1587,7 +1656,7 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
         memset(&ea, 0, sizeof(ea));
         ea.T = chunk; ea.policy = pol; ea.policy_seed = policy_seed; ea.env_index0 = env_index0; ea.t0 = tt;
         ea.obs = o; ea.obs_stride_steps = obs_stride_steps; ea.reward = rw; ea.term = tm; ea.actions_out = ac; ea.stats = stats_dev;
-        ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.n_serve = h->eng_nserve; ea.autoreset = 1;
+        ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.serve_mask = h->eng_smask; ea.autoreset = 1;
         bg_engine_launch(h, dv, ea, hash, false, st);
       } else {
         // envs per workgroup.  256 (one workgroup per CU: its two play waves and two other waves pool the queues of 256 envs,
