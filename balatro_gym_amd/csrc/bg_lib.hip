@@ -2014,37 +2014,73 @@ int bg_bench_copy(const void* src_dev, void* dst_dev, uint64_t bytes, int iters,
   return 0;
 }
 
-int bg_classify_batch(const uint8_t* cards_dev, const uint8_t* n_dev, uint8_t* hand_type_dev, int64_t m, void* stream) {
-  if (!cards_dev || !n_dev || !hand_type_dev || m < 0 || ((uintptr_t)cards_dev & 7)) { g_create_err = "bg_classify_batch: bad arguments (cards_dev must be 8-byte aligned)"; return BG_E_ARG; }
+// kernel-only time of a batch op (the A/B of the two lane mappings): events on the caller's stream around the launch
+struct BgOpTimer {
+  hipEvent_t a = nullptr, b = nullptr;
+  bool on = false;
+  int begin(float* out, hipStream_t s) { on = out != nullptr; if (!on) return 0; BG_HIP0(hipEventCreate(&a)); BG_HIP0(hipEventCreate(&b)); BG_HIP0(hipEventRecord(a, s)); return 0; }
+  void mark(hipStream_t s) { if (on) (void)hipEventRecord(b, s); }
+  int end(float* out) { if (!on) return 0; BG_HIP0(hipEventSynchronize(b)); BG_HIP0(hipEventElapsedTime(out, a, b)); (void)hipEventDestroy(a); (void)hipEventDestroy(b); return 0; }
+};
+
+int bg_classify_batch_ex(const uint8_t* cards_dev, const uint8_t* n_dev, uint8_t* hand_type_dev, int64_t m, int lanes_per_case,
+                         float* kernel_ms_out, void* stream) {
+  if (!cards_dev || !n_dev || !hand_type_dev || m < 0 || ((uintptr_t)cards_dev & 7) || (lanes_per_case != 1 && lanes_per_case != 8)) {
+    g_create_err = "bg_classify_batch: bad arguments (cards_dev must be 8-byte aligned, lanes_per_case 1 or 8)"; return BG_E_ARG;
+  }
+  if (kernel_ms_out) *kernel_ms_out = 0.f;
   if (m == 0) return 0;
-  hipLaunchKernelGGL(bg_classify_batch_kernel, dim3((unsigned)((m + BG_BLOCK - 1) / BG_BLOCK)), dim3(BG_BLOCK), 0, (hipStream_t)stream,
-                     cards_dev, n_dev, hand_type_dev, (long long)m);
+  hipStream_t s = (hipStream_t)stream;
+  BgOpTimer tm;
+  int rc = tm.begin(kernel_ms_out, s);
+  if (rc) return rc;
+  if (lanes_per_case == 1)
+    hipLaunchKernelGGL(bg_classify_batch_kernel, dim3((unsigned)((m + BG_BLOCK - 1) / BG_BLOCK)), dim3(BG_BLOCK), 0, s, cards_dev, n_dev, hand_type_dev, (long long)m);
+  else
+    hipLaunchKernelGGL(bg_classify_batch_l8_kernel, dim3((unsigned)((m * 8 + BG_BLOCK - 1) / BG_BLOCK)), dim3(BG_BLOCK), 0, s, cards_dev, n_dev, hand_type_dev, (long long)m);
+  tm.mark(s);
   BG_HIP0(hipGetLastError());
-  return 0;
+  return tm.end(kernel_ms_out);
+}
+int bg_classify_batch(const uint8_t* cards_dev, const uint8_t* n_dev, uint8_t* hand_type_dev, int64_t m, void* stream) {
+  return bg_classify_batch_ex(cards_dev, n_dev, hand_type_dev, m, 1, nullptr, stream);
 }
 
-int bg_score_hand_batch(const int32_t* cases_dev, int64_t* out_dev, int m, void* stream) {
-  if (!cases_dev || !out_dev || m < 0) { g_create_err = "bg_score_hand_batch: bad arguments"; return BG_E_ARG; }
+static int bg_batch_dev(BgDev& d, int m, uint32_t** scratch_out);
+
+int bg_score_hand_batch_ex(const int32_t* cases_dev, int64_t* out_dev, int m, int lanes_per_case, float* kernel_ms_out, void* stream) {
+  if (!cases_dev || !out_dev || m < 0 || (lanes_per_case != 1 && lanes_per_case != 8)) { g_create_err = "bg_score_hand_batch: bad arguments (lanes_per_case 1 or 8)"; return BG_E_ARG; }
+  if (kernel_ms_out) *kernel_ms_out = 0.f;
   if (m == 0) return 0;
   hipStream_t s = (hipStream_t)stream;
   BgDev d;
-  memset(&d, 0, sizeof(d));
-  d.N = m; d.flags = BG_FLAG_SCORER_JOKERS; d.KG = 2; d.KS = 2; d.KD = 1;
   uint32_t* scratch = nullptr; // two MT19937 blocks per case + the error word
-  BG_HIP0(hipMalloc((void**)&scratch, ((size_t)m * 2 * BG_MTS + 4) * sizeof(uint32_t)));
-  d.gblk = scratch; d.err = scratch + (size_t)m * 2 * BG_MTS;
+  int rc = bg_batch_dev(d, m, &scratch);
+  if (rc) return rc;
+  BgOpTimer tm;
   hipError_t e = hipMemsetAsync(d.err, 0, 4 * sizeof(uint32_t), s);
   if (e == hipSuccess) {
-    hipLaunchKernelGGL(bg_score_hand_batch_kernel, dim3((m + BG_BLOCK - 1) / BG_BLOCK), dim3(BG_BLOCK), 0, s, d, cases_dev, out_dev);
+    hipLaunchKernelGGL(bg_score_seed_kernel, dim3((m + BG_BLOCK - 1) / BG_BLOCK), dim3(BG_BLOCK), 0, s, d, cases_dev); // random.seed(gseed) per case
+    rc = tm.begin(kernel_ms_out, s);
+    if (lanes_per_case == 1)
+      hipLaunchKernelGGL(bg_score_hand_batch_kernel, dim3((m + BG_BLOCK - 1) / BG_BLOCK), dim3(BG_BLOCK), 0, s, d, cases_dev, out_dev);
+    else
+      hipLaunchKernelGGL(bg_score_hand_batch_l8_kernel, dim3((m + BG_BLOCK / 8 - 1) / (BG_BLOCK / 8)), dim3(BG_BLOCK), 0, s, d, cases_dev, out_dev);
+    tm.mark(s);
     e = hipGetLastError();
   }
   uint32_t errw = 0;
   if (e == hipSuccess) e = hipMemcpyAsync(&errw, d.err, sizeof(errw), hipMemcpyDeviceToHost, s);
   if (e == hipSuccess) e = hipStreamSynchronize(s);
+  if (e == hipSuccess && rc == 0) rc = tm.end(kernel_ms_out);
   (void)hipFree(scratch);
   if (e != hipSuccess) { g_create_err = std::string("bg_score_hand_batch: ") + hipGetErrorString(e); return BG_E_HIP; }
+  if (rc) return rc;
   if (errw) { g_create_err = "bg_score_hand_batch: a case drew more than two blocks of the global stream"; return BG_E_INTERNAL; }
   return 0;
+}
+int bg_score_hand_batch(const int32_t* cases_dev, int64_t* out_dev, int m, void* stream) {
+  return bg_score_hand_batch_ex(cases_dev, out_dev, m, 1, nullptr, stream);
 }
 
 // scratch of a batch op that draws from a per-case global stream: two MT19937 blocks per case + the device error word

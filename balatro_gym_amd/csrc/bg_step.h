@@ -452,83 +452,41 @@ struct ChainIn {
 // cards, so their HBM round trip runs beside ~5k cycles of LDS work instead of after it): valid when `skip` equals the number
 // of words the individual phase turns out to consume.
 struct ChainPeek { uint32_t mw[12]; uint32_t avail; int skip; bool ok; };
+// One joker's share of the individual phase: matching cards = sum of the histogram nibbles selected by the rank mask, or the
+// suit's count; (chips, mult) = count x the descriptor's constants; x2 per matching card for Triboulet.  sp = the descriptor's
+// "special" field (1 = 8 Ball, 2 = Bloodstone: settled card by card from the RNG words).
+struct ChainJ { int ic, im, xexp; uint32_t sp; };
+__device__ __forceinline__ ChainJ bg_chain_joker(uint64_t dsc, uint64_t jr, uint64_t phist, uint32_t scnt) {
+  ChainJ r;
+  r.sp = (uint32_t)(dsc >> 20) & 3u;
+  uint64_t x = phist & jr;
+  uint32_t y = (uint32_t)(x & 0x0f0f0f0f0f0f0f0full) + (uint32_t)((x >> 4) & 0x0f0f0f0f0f0f0f0full) +
+               (uint32_t)((x & 0x0f0f0f0f0f0f0f0full) >> 32) + (uint32_t)(((x >> 4) & 0x0f0f0f0f0f0f0f0full) >> 32);
+  y += y >> 16;
+  int cnt = (int)((y + (y >> 8)) & 0xffu);
+  uint32_t suit1 = (uint32_t)(dsc >> 16) & 7u;
+  if (suit1) cnt = (int)((scnt >> (4 * (suit1 - 1))) & 0xfu);
+  if (r.sp == 2u) cnt = 0; // Bloodstone is settled card by card
+  r.ic = cnt * (int)((dsc >> 24) & 0xffu); r.im = cnt * (int)((dsc >> 32) & 0xffu);
+  r.xexp = ((dsc >> 22) & 1u) ? cnt : 0;
+  return r;
+}
+// Bloodstone on a Heart: x2 iff the pair's random() < 0.5.  Pair (c, jb) sits 2*(c*nj + jb) words ahead of the cursor, plus 2
+// for every extra 8-Ball draw that precedes it in card-major order (`eights` = played 8s among cards 0..c-1).  -1: no word to read.
+__device__ __forceinline__ int bg_chain_blood_off(int c, int code, bool st, int n, int nj, int jb, int j8, bool blood, int eights) {
+  const int rk = (code >> 2) + 2;
+  return (blood && c < n && !st && (code & 3) == 2) ? 2 * (c * nj + jb) + 2 * (eights + ((j8 >= 0 && j8 < jb && !st && rk == 8) ? 1 : 0)) : -1;
+}
+
+// unified_scoring.py:216-244 main phase, joker order; one randint(0, 23) per joker (mw = the 12 tempered words that follow the
+// individual phase's draws, avail = which of them the ring holds).
 template <bool GENERAL, class DK>
-__device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, RngWin& w, const ChainIn& in, int64_t& chips,
-                                               int64_t& mult, double& x_mult, int& money, const ChainPeek* pre = nullptr) {
+__device__ __forceinline__ void bg_chain_main(const BgDev& d, int env, Env& e, RngWin& w, const ChainIn& in, const uint32_t (&dms)[5],
+                                              const uint32_t (&mw)[12], uint32_t avail, int64_t& chips, int64_t& mult, double& x_mult) {
   BG_PROBE_BEGIN();
-  // unified_scoring.py:174-209 individual phase.  Totals do not depend on the (card-major, joker-minor) order: chips
-  // and mult add up, and every x factor is exactly 2.0.
   const int nj = e.njokers, n = in.n, ht = in.ht;
-  const uint64_t phist = in.phist, pcodes = in.pcodes;
-  const uint32_t scnt = in.scnt, stone = in.stone;
+  const uint32_t scnt = in.scnt;
   const int kings = in.kings, queens = in.queens;
-  int ic = 0, im = 0, xexp = 0, j8 = -1, jb = -1;
-  // all table reads first (independent LDS reads), then straight-line arithmetic per joker slot
-  uint64_t jds[5], jrs[5];
-  uint32_t dms[5];
-#pragma unroll
-  for (int j = 0; j < 5; j++) {
-    int id = j < nj ? (int)((e.jokers >> (8 * j)) & 0xff) : 0;
-    jds[j] = w.jt->jd[id]; jrs[j] = w.jt->jr[id]; dms[j] = w.jt->jm[id];
-  }
-#pragma unroll
-  for (int j = 0; j < 5; j++) {
-    uint64_t dsc = jds[j];
-    uint32_t sp = (uint32_t)(dsc >> 20) & 3u;
-    if (sp == 1u) j8 = j;
-    if (sp == 2u) jb = j;
-    // matching cards = sum of the histogram nibbles selected by the rank mask, or the suit's count
-    uint64_t x = phist & jrs[j];
-    uint32_t y = (uint32_t)(x & 0x0f0f0f0f0f0f0f0full) + (uint32_t)((x >> 4) & 0x0f0f0f0f0f0f0f0full) +
-                 (uint32_t)((x & 0x0f0f0f0f0f0f0f0full) >> 32) + (uint32_t)(((x >> 4) & 0x0f0f0f0f0f0f0f0full) >> 32);
-    y += y >> 16;
-    int cnt = (int)((y + (y >> 8)) & 0xffu);
-    uint32_t suit1 = (uint32_t)(dsc >> 16) & 7u;
-    if (suit1) cnt = (int)((scnt >> (4 * (suit1 - 1))) & 0xfu);
-    if (sp == 2u) cnt = 0; // Bloodstone is settled card by card below
-    ic += cnt * (int)((dsc >> 24) & 0xffu); im += cnt * (int)((dsc >> 32) & 0xffu);
-    if constexpr (GENERAL) if (j < nj && (int)((e.jokers >> (8 * j)) & 0xff) == 116) money += (int)((scnt >> 4) & 0xfu); // Rough Gem: $1 per Diamond (:160)
-    if ((dsc >> 22) & 1u) xexp += cnt;
-  }
-  BG_PROBE(7);
-  bg_gnorm(d, e);
-  int n8 = j8 >= 0 ? (int)((phist >> 32) & 0xf) : 0; // 8 Ball: one extra random() per played 8 (:167)
-  int consumed = 2 * n * nj + 2 * n8;
-  // Every RNG word the chain looks at is requested in ONE batch of independent loads: Bloodstone's two words per played
-  // Heart, and the 12 words that follow the individual phase's `consumed` (eagerly drawn, never looked at) words, where
-  // the main phase's randint draws will fall (5 accepted among 12 words fails once in ~3000 plays: then the loop).
-  const bool blood = jb >= 0 && ((scnt >> 8) & 0xfu);
-  int boff[8];
-  {
-    // Bloodstone on a Heart: x2 iff the pair's random() < 0.5.  Pair (c, jb) sits 2*(c*nj + jb) words ahead, plus 2
-    // for every extra 8-Ball draw that precedes it in card-major order.
-    int eights = 0;
-#pragma unroll
-    for (int c = 0; c < 8; c++) {
-      int code = (int)((pcodes >> (8 * c)) & 0xff);
-      int rk = (code >> 2) + 2;
-      const bool st = (stone >> c) & 1u; // a STONE card has no rank and no suit for the jokers
-      boff[c] = (blood && c < n && !st && (code & 3) == 2) ? 2 * (c * nj + jb) + 2 * (eights + ((j8 >= 0 && j8 < jb && !st && rk == 8) ? 1 : 0)) : -1;
-      if (c < n && j8 >= 0 && !st && rk == 8) eights++;
-    }
-  }
-  // random() < 0.5 for random() = ((a >> 5) * 2**26 + (b >> 6)) / 2**53 is decided by the top bit of the FIRST word
-  // alone ((a >> 5) < 2**26), so one word per Heart is read and no float arithmetic is needed.
-  uint32_t ra[8], mw[12];
-  uint32_t avail = 0; // main-phase words the ring already holds
-#pragma unroll
-  for (int c = 0; c < 8; c++) { ra[c] = 0x80000000u; if (boff[c] >= 0) ra[c] = bg_gpeek(d, env, e, boff[c]); }
-  if (pre && pre->ok && pre->skip == consumed) {
-#pragma unroll
-    for (int i = 0; i < 12; i++) mw[i] = bg_temper(pre->mw[i]); // requested raw (the first use of a loaded value is the wait)
-    avail = pre->avail;
-  } else bg_gpeek12(d, env, e, consumed, mw, avail);
-#pragma unroll
-  for (int c = 0; c < 8; c++) xexp += (int)((ra[c] >> 31) ^ 1u);
-  bg_gskip(d, e, consumed);
-  chips += ic; mult += im;
-  x_mult *= (double)(1ull << xexp);
-  // :216-244 main phase, joker order; one randint(0, 23) per joker
   // bit 4 = 'Stone': complete_joker_effects.py:98-114 compare suit STRINGS, so a STONE card is a fifth kind of suit for
   // Blackboard / Seeing Double / Flower Pot (and no suit at all for the four suit jokers)
   uint32_t suits = ((scnt & 0xfu) ? 1u : 0u) | ((scnt & 0xf0u) ? 2u : 0u) | ((scnt & 0xf00u) ? 4u : 0u) | ((scnt & 0xf000u) ? 8u : 0u) |
@@ -602,6 +560,71 @@ __device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, 
     }
   }
   BG_PROBE(14);
+}
+
+template <bool GENERAL, class DK>
+__device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, RngWin& w, const ChainIn& in, int64_t& chips,
+                                               int64_t& mult, double& x_mult, int& money, const ChainPeek* pre = nullptr) {
+  BG_PROBE_BEGIN();
+  // unified_scoring.py:174-209 individual phase.  Totals do not depend on the (card-major, joker-minor) order: chips
+  // and mult add up, and every x factor is exactly 2.0.
+  const int nj = e.njokers, n = in.n;
+  const uint64_t phist = in.phist, pcodes = in.pcodes;
+  const uint32_t scnt = in.scnt, stone = in.stone;
+  int ic = 0, im = 0, xexp = 0, j8 = -1, jb = -1;
+  // all table reads first (independent LDS reads), then straight-line arithmetic per joker slot
+  uint64_t jds[5], jrs[5];
+  uint32_t dms[5];
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    int id = j < nj ? (int)((e.jokers >> (8 * j)) & 0xff) : 0;
+    jds[j] = w.jt->jd[id]; jrs[j] = w.jt->jr[id]; dms[j] = w.jt->jm[id];
+  }
+#pragma unroll
+  for (int j = 0; j < 5; j++) {
+    const ChainJ cj = bg_chain_joker(jds[j], jrs[j], phist, scnt);
+    if (cj.sp == 1u) j8 = j;
+    if (cj.sp == 2u) jb = j;
+    ic += cj.ic; im += cj.im; xexp += cj.xexp;
+    if constexpr (GENERAL) if (j < nj && (int)((e.jokers >> (8 * j)) & 0xff) == 116) money += (int)((scnt >> 4) & 0xfu); // Rough Gem: $1 per Diamond (:160)
+  }
+  BG_PROBE(7);
+  bg_gnorm(d, e);
+  int n8 = j8 >= 0 ? (int)((phist >> 32) & 0xf) : 0; // 8 Ball: one extra random() per played 8 (:167)
+  int consumed = 2 * n * nj + 2 * n8;
+  // Every RNG word the chain looks at is requested in ONE batch of independent loads: Bloodstone's two words per played
+  // Heart, and the 12 words that follow the individual phase's `consumed` (eagerly drawn, never looked at) words, where
+  // the main phase's randint draws will fall (5 accepted among 12 words fails once in ~3000 plays: then the loop).
+  const bool blood = jb >= 0 && ((scnt >> 8) & 0xfu);
+  int boff[8];
+  {
+    int eights = 0;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+      int code = (int)((pcodes >> (8 * c)) & 0xff);
+      int rk = (code >> 2) + 2;
+      const bool st = (stone >> c) & 1u; // a STONE card has no rank and no suit for the jokers
+      boff[c] = bg_chain_blood_off(c, code, st, n, nj, jb, j8, blood, eights);
+      if (c < n && j8 >= 0 && !st && rk == 8) eights++;
+    }
+  }
+  // random() < 0.5 for random() = ((a >> 5) * 2**26 + (b >> 6)) / 2**53 is decided by the top bit of the FIRST word
+  // alone ((a >> 5) < 2**26), so one word per Heart is read and no float arithmetic is needed.
+  uint32_t ra[8], mw[12];
+  uint32_t avail = 0; // main-phase words the ring already holds
+#pragma unroll
+  for (int c = 0; c < 8; c++) { ra[c] = 0x80000000u; if (boff[c] >= 0) ra[c] = bg_gpeek(d, env, e, boff[c]); }
+  if (pre && pre->ok && pre->skip == consumed) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) mw[i] = bg_temper(pre->mw[i]); // requested raw (the first use of a loaded value is the wait)
+    avail = pre->avail;
+  } else bg_gpeek12(d, env, e, consumed, mw, avail);
+#pragma unroll
+  for (int c = 0; c < 8; c++) xexp += (int)((ra[c] >> 31) ^ 1u);
+  bg_gskip(d, e, consumed);
+  chips += ic; mult += im;
+  x_mult *= (double)(1ull << xexp);
+  bg_chain_main<GENERAL, DK>(d, env, e, w, in, dms, mw, avail, chips, mult, x_mult);
 }
 
 // ---------------------------------------------------------------------------------------------------------

@@ -385,37 +385,43 @@ class BalatroVecEnv:
 
 
 # ---------------------------------------------------------------------- operator-level entry points
-def classify_batch(cards: torch.Tensor, n: torch.Tensor) -> torch.Tensor:
+def classify_batch(cards: torch.Tensor, n: torch.Tensor, lanes_per_case: int = 1, timing: bool = False):
     """`BalatroGame._classify_hand` (balatro_game.py:40-93) for M hands at once: cards uint8 [M, 8] card codes
-    (rank-2)*4+suit, n uint8 [M] valid cards per row -> uint8 [M] HandType values.  Device tensors in, device tensor out."""
+    (rank-2)*4+suit, n uint8 [M] valid cards per row -> uint8 [M] HandType values.  Device tensors in, device tensor out.
+    lanes_per_case: 1 (lane = hand) or 8 (lane = card, shuffle reductions inside 8-lane groups); identical results.
+    timing=True returns (out, kernel milliseconds)."""
     L = nat.load()
     if cards.dtype != torch.uint8 or n.dtype != torch.uint8 or cards.dim() != 2 or cards.shape[1] != 8 or not cards.is_cuda:
         raise ValueError("cards must be a uint8 [M, 8] device tensor, n a uint8 [M] device tensor")
     cards, n = cards.contiguous(), n.contiguous()
     out = torch.empty(cards.shape[0], dtype=torch.uint8, device=cards.device)
+    ms = C.c_float(0.0)
     with torch.cuda.device(cards.device):
-        rc = L.bg_classify_batch(C.c_void_p(cards.data_ptr()), C.c_void_p(n.data_ptr()), C.c_void_p(out.data_ptr()),
-                                 C.c_int64(cards.shape[0]), C.c_void_p(torch.cuda.current_stream(cards.device).cuda_stream))
+        rc = L.bg_classify_batch_ex(C.c_void_p(cards.data_ptr()), C.c_void_p(n.data_ptr()), C.c_void_p(out.data_ptr()),
+                                    C.c_int64(cards.shape[0]), int(lanes_per_case), C.byref(ms) if timing else None,
+                                    C.c_void_p(torch.cuda.current_stream(cards.device).cuda_stream))
     if rc != 0:
         raise nat.NativeError(f"bg_classify_batch failed ({rc}): {L.bg_last_error(None).decode()}")
-    return out
+    return (out, float(ms.value)) if timing else out
 
 
-def score_hand_batch(cases: torch.Tensor) -> torch.Tensor:
+def score_hand_batch(cases: torch.Tensor, lanes_per_case: int = 1, timing: bool = False):
     """`UnifiedScorer.score_hand` (unified_scoring.py:111-299) with joker NAMES for M cases at once: cases int32
     [M, 40] (layout: include/balatro_mi355x.h bg_score_hand_batch) -> int64 [M, 8] (score, chips, mult, x_mult bits, money,
-    global-stream words consumed, next getrandbits(32), 0)."""
+    global-stream words consumed, next getrandbits(32), 0).  lanes_per_case / timing as in classify_batch."""
     L = nat.load()
     if cases.dtype != torch.int32 or cases.dim() != 2 or cases.shape[1] != nat.SCORE_CASE_WORDS or not cases.is_cuda:
         raise ValueError(f"cases must be an int32 [M, {nat.SCORE_CASE_WORDS}] device tensor")
     cases = cases.contiguous()
     out = torch.zeros((cases.shape[0], nat.SCORE_OUT_WORDS), dtype=torch.int64, device=cases.device)
+    ms = C.c_float(0.0)
     with torch.cuda.device(cases.device):
-        rc = L.bg_score_hand_batch(C.c_void_p(cases.data_ptr()), C.c_void_p(out.data_ptr()), int(cases.shape[0]),
-                                   C.c_void_p(torch.cuda.current_stream(cases.device).cuda_stream))
+        rc = L.bg_score_hand_batch_ex(C.c_void_p(cases.data_ptr()), C.c_void_p(out.data_ptr()), int(cases.shape[0]),
+                                      int(lanes_per_case), C.byref(ms) if timing else None,
+                                      C.c_void_p(torch.cuda.current_stream(cases.device).cuda_stream))
     if rc != 0:
         raise nat.NativeError(f"bg_score_hand_batch failed ({rc}): {L.bg_last_error(None).decode()}")
-    return out
+    return (out, float(ms.value)) if timing else out
 
 
 def sim_evaluate_batch(hands: torch.Tensor, n: torch.Tensor, flags: torch.Tensor) -> torch.Tensor:

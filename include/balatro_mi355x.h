@@ -297,6 +297,11 @@ int bg_check(bg_handle* h, void* stream);
 /* Replaces: `BalatroGame._classify_hand(cards)` (balatro_game.py:40-93).  cards_dev is [M, 8] card codes (rank-2)*4+suit
  * (8-byte aligned), n_dev[i] in [0, 8] of them are valid; hand_type_dev[i] = HandType value 0..8 (scoring_engine.py:12-24). */
 int bg_classify_batch(const uint8_t* cards_dev, const uint8_t* n_dev, uint8_t* hand_type_dev, int64_t m, void* stream);
+/* The same with the lane mapping chosen by the caller: lanes_per_case = 1 (lane = hand, the default above) or 8 (lane = card, the
+ * counts and sets by `__shfl_xor` inside 8-lane groups -- the mapping SURVEY 7.6 asks to benchmark beside the first).  Results are
+ * identical.  kernel_ms_out (may be NULL): time of the kernel alone, HIP events on `stream`; non-NULL synchronises the stream. */
+int bg_classify_batch_ex(const uint8_t* cards_dev, const uint8_t* n_dev, uint8_t* hand_type_dev, int64_t m, int lanes_per_case,
+                         float* kernel_ms_out, void* stream);
 
 /* Replaces: `UnifiedScorer.score_hand(ctx)` (unified_scoring.py:111-299) called with game_state['jokers'] = joker NAMES (as
  * unified_scoring.py:313-351 does) after random.seed(gseed).  One int32[BG_SCORE_CASE_WORDS] record per case:
@@ -311,6 +316,10 @@ int bg_classify_batch(const uint8_t* cards_dev, const uint8_t* n_dev, uint8_t* h
 #define BG_SCORE_CASE_WORDS 40
 #define BG_SCORE_OUT_WORDS 8
 int bg_score_hand_batch(const int32_t* cases_dev, int64_t* out_dev, int m, void* stream);
+/* The same with lanes_per_case = 1 or 8 (8: lane = card while the hand is gathered, lane = joker for the per-card joker phase whose
+ * totals are shuffle reductions, lane = card for Bloodstone's RNG words; the order-dependent main phase runs on every lane).
+ * kernel_ms_out (may be NULL): time of the scoring kernel alone (the per-case random.seed() runs in a kernel of its own before it). */
+int bg_score_hand_batch_ex(const int32_t* cases_dev, int64_t* out_dev, int m, int lanes_per_case, float* kernel_ms_out, void* stream);
 
 /* balatro_sim.py (the reference's secondary, Balatro-accurate evaluator / scorer; not reachable from the live env).  A sim card
  * is six int32: rank 2..14, suit 0..3 = Clubs, Diamonds, Hearts, Spades, base_value, enhancement (0 None, 1 'bonus', 2 'mult',

@@ -18,20 +18,25 @@ from tests.helpers import GOLD, OBS_KEYS, forced_deck, forced_hand_script
 pytestmark = pytest.mark.gpu
 
 
-def test_classify_batch_golden():
-    """All 20 000 rows of classify.npz (random 1..8-card subsets) through bg_classify_batch."""
+LANES = pytest.mark.parametrize("lanes", [1, 8], ids=["lane_per_case", "8_lanes_per_case"])
+
+
+@LANES
+def test_classify_batch_golden(lanes):
+    """All 20 000 rows of classify.npz (random 1..8-card subsets) through bg_classify_batch, in both lane mappings."""
     import torch
     from balatro_gym_amd import classify_batch
     g = np.load(os.path.join(GOLD, "classify.npz"))
     dev = torch.device("cuda:0")
-    got = classify_batch(torch.from_numpy(g["cards"]).to(dev), torch.from_numpy(g["n"]).to(dev)).cpu().numpy()
+    got = classify_batch(torch.from_numpy(g["cards"]).to(dev), torch.from_numpy(g["n"]).to(dev), lanes_per_case=lanes).cpu().numpy()
     bad = np.nonzero(got != g["hand_type"])[0]
     assert bad.size == 0, f"row {bad[0]}: cards {g['cards'][bad[0]][:g['n'][bad[0]]]} got {got[bad[0]]} want {g['hand_type'][bad[0]]}"
     counts = np.bincount(g["hand_type"], minlength=9)
     assert (counts[:8] > 0).all()  # hand types 0..7 occur among the random subsets (straight flushes: the C(52,5) sweep below)
 
 
-def test_classify_batch_all_five_card_hands():
+@LANES
+def test_classify_batch_all_five_card_hands(lanes):
     """Every one of the C(52,5) = 2 598 960 five-card hands in lexicographic order: per-type counts and the CRC32 of the type
     sequence as the reference produced them (tests/golden/classify.npz all5_*)."""
     import torch
@@ -42,7 +47,7 @@ def test_classify_batch_all_five_card_hands():
     cards[:, :5] = combos
     dev = torch.device("cuda:0")
     n = torch.full((cards.shape[0],), 5, dtype=torch.uint8, device=dev)
-    got = classify_batch(torch.from_numpy(cards).to(dev), n).cpu().numpy()
+    got = classify_batch(torch.from_numpy(cards).to(dev), n, lanes_per_case=lanes).cpu().numpy()
     assert np.bincount(got, minlength=12).tolist() == g["all5_counts"].tolist()
     assert zlib.crc32(got.tobytes()) == int(g["all5_crc32"])
 
@@ -61,14 +66,15 @@ def _score_cases():
     return cases, rec
 
 
-def test_score_hand_batch_golden():
+@LANES
+def test_score_hand_batch_golden(lanes):
     """All 3 000 UnifiedScorer.score_hand cases (joker name lists of 0..5 from all 150 ids, both hand-name styles, scoring
     subsets, STONE cards, levels 1..15): score, final chips / mult / x_mult bits, money, and the position of the global
     stream afterwards (the next getrandbits(32) equals the reference's probe, i.e. exactly as many draws were consumed)."""
     import torch
     from balatro_gym_amd import score_hand_batch
     cases, rec = _score_cases()
-    out = score_hand_batch(torch.from_numpy(rec).to("cuda:0")).cpu().numpy()
+    out = score_hand_batch(torch.from_numpy(rec).to("cuda:0"), lanes_per_case=lanes).cpu().numpy()
     for i, c in enumerate(cases):
         ctx = f"case {i}: {c} -> {out[i].tolist()}"
         assert out[i, 0] == c["score"], ctx
@@ -115,10 +121,11 @@ def test_score_hand_batch_vs_oracle_fresh_cases():
         rec[i, 38] = np.uint32(gseed).astype(np.int32)
         o = po.score_hand(cards, cards[:nsc], ht, style, level, jokers, hl, dl, deck_len, gseed)
         want.append((o.score, o.chips, o.mult, np.float64(o.x_mult).view(np.int64), o.money, o.draws))
-    out = score_hand_batch(torch.from_numpy(rec).to("cuda:0")).cpu().numpy()
     want = np.array(want, dtype=np.int64)
-    bad = np.nonzero((out[:, :6] != want).any(axis=1))[0]
-    assert bad.size == 0, f"case {bad[0]}: {rec[bad[0]].tolist()} got {out[bad[0]].tolist()} want {want[bad[0]].tolist()}"
+    for lanes in (1, 8):  # lane = case, and 8 lanes per case (shuffle reductions)
+        out = score_hand_batch(torch.from_numpy(rec).to("cuda:0"), lanes_per_case=lanes).cpu().numpy()
+        bad = np.nonzero((out[:, :6] != want).any(axis=1))[0]
+        assert bad.size == 0, f"lanes {lanes} case {bad[0]}: {rec[bad[0]].tolist()} got {out[bad[0]].tolist()} want {want[bad[0]].tolist()}"
 
 
 @pytest.mark.parametrize("scorer", [False, True])
