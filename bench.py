@@ -104,6 +104,9 @@ def measured_copy_gbps(dev) -> float:
     return float(g.value)
 
 
+KERNEL_BUILD = "7 waves x 256 envs per workgroup"   # tools/hbm_traffic.py stamps the measurements it writes with the same string
+
+
 def matching_traffic(kernel: str, n: int, fused: float):
     """HBM bytes per launch of the dominant kernel from the PMC counters -- ONLY if a committed measurement of THIS launch
     shape exists (profiles/*_hbm_traffic.json written by tools/hbm_traffic.py from separate rocprofv3 --pmc FETCH_SIZE /
@@ -113,7 +116,7 @@ def matching_traffic(kernel: str, n: int, fused: float):
         try:
             with open(path) as f:
                 j = json.load(f)
-            if j.get("kernel") == kernel and int(j.get("envs", 0)) == n and int(round(j.get("fused_steps_per_launch", 0))) == int(round(fused)):
+            if j.get("kernel") == kernel and j.get("kernel_build") == KERNEL_BUILD and int(j.get("envs", 0)) == n and int(round(j.get("fused_steps_per_launch", 0))) == int(round(fused)):
                 best = (float(j["hbm_bytes_per_launch"]), os.path.basename(path))
         except Exception:
             continue
@@ -202,9 +205,9 @@ def main():
     t_w = time.perf_counter()
     t_off = 0
     while time.perf_counter() - t_w < args.internal_warmup_s:
-        run(chunk, t_off)
+        run(8 * chunk, t_off)  # eight launches back to back, as in the timed region (the refill of one runs beside the next)
         torch.cuda.synchronize(dev)
-        t_off += chunk
+        t_off += 8 * chunk
     run(args.warmup, t_off)
     t_off += args.warmup
     env.check()
@@ -263,7 +266,10 @@ def main():
                          "peak_measured": peak_measured, "frac_of_measured": achieved / peak_measured if peak_measured else None,
                          "kernel": kernel, "algorithmic_bytes_per_env_step": a_step,
                          "mean_launch_us": mean_launch_s * 1e6, "launches": launches,
-                         "refill_mean_launch_us": prof["refill_ms"] / max(1, prof["refill_launches"]) * 1e3},
+                         "refill_mean_launch_us": prof["refill_ms"] / max(1, prof["refill_launches"]) * 1e3,
+                         "refill": "RNG look-ahead refill of launch i runs BESIDE launch i+1 (one SIMD per CU is left to it): its time is inside mean_launch_us, not between launches",
+                         # the same fraction for the whole job (everything between the two synchronisations, per GPU)
+                         "end_to_end_gbps": value * a_step / world / 1e9, "end_to_end_frac": value * a_step / world / 1e9 / HBM_PEAK_GBPS},
             "episodes": int(agg[1].item()), "accepted_plays": int(agg[2].item()),
             "state_bytes_per_gpu": env.state_bytes(),
         }
