@@ -54,7 +54,7 @@ POLICY_UNIFORM, POLICY_SMALL_ONLY, POLICY_CYCLE3 = 0, 1, 2
 EXPORTS = ["bg_create", "bg_destroy", "bg_last_error", "bg_num_envs", "bg_max_fused_steps", "bg_state_bytes", "bg_seed", "bg_reset",
            "bg_step", "bg_observe", "bg_rollout", "bg_rollout_rows", "bg_inject", "bg_inject_cards", "bg_inject_consumables", "bg_state_blob_bytes", "bg_get_state", "bg_set_state",
            "bg_refill", "bg_check", "bg_set_profiling", "bg_get_profile", "bg_set_max_ante", "bg_inject_deck",
-           "bg_classify_batch", "bg_score_hand_batch", "bg_classify_batch_ex", "bg_score_hand_batch_ex", "bg_bench_copy", "bg_step_many",
+           "bg_classify_batch", "bg_score_hand_batch", "bg_classify_batch_ex", "bg_score_hand_batch_ex", "bg_bench_copy", "bg_bench_fill", "bg_step_many",
            "bg_sim_evaluate_batch", "bg_sim_score_batch", "bg_create_ex"]
 SCORE_CASE_WORDS, SCORE_OUT_WORDS = 40, 8
 SIM_EVAL_BYTES, SIM_CASE_WORDS = 128, 64
@@ -148,5 +148,6 @@ def load(build_if_missing: bool = True):
     L.bg_sim_evaluate_batch.argtypes = [vp, vp, vp, vp, i32, vp]
     L.bg_sim_score_batch.argtypes = [vp, vp, i32, vp]
     L.bg_bench_copy.argtypes = [vp, vp, u64, i32, C.POINTER(C.c_double), vp]
+    L.bg_bench_fill.argtypes = [vp, u64, i32, C.POINTER(C.c_double), vp]
     _lib = L
     return L

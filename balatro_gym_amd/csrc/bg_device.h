@@ -293,7 +293,7 @@ __device__ __forceinline__ int bg_card(const BgDev& d, int env, const Deck0& k, 
   const uint8_t* p = (const uint8_t*)&d.deck[(size_t)(idx >> 4) * d.N + env];
   return p[idx & 15];
 }
-// workgroup decks with the row stride as a parameter (bg_rollout3_kernel: 128 or 256 envs per workgroup)
+// workgroup decks with the row stride as a parameter (bg_engine_kernel: 256 envs per workgroup)
 template <int S, bool C> struct DeckLdsS { lds_u32* col; static constexpr bool kCards = C; };
 template <int S, bool C>
 __device__ __forceinline__ void bg_deck_set(DeckLdsS<S, C>& dk, int k, uint4 c) {

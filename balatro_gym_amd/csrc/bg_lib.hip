@@ -1,12 +1,11 @@
 // bg_lib.hip -- kernels + C ABI of libbalatro_mi355x.so (gfx950 / CDNA4 only; see include/balatro_mi355x.h).
 //
 // Kernels (one lane = one env, env index fastest in every array => every wave access is one coalesced request):
-//   bg_step_kernel     one lockstep step() of all envs + observation / mask / reward / info
-//   bg_rollout3_kernel T fused steps with the counter-hash policy on device (env waves + dedicated service waves)
+//   bg_engine_kernel   (bg_engine.h) THE step path: bg_step / bg_step_many / bg_rollout / bg_rollout_rows
 //   bg_reset_kernel    masked reset() + observation
 //   bg_observe_kernel  observation only
 //   bg_seed_kernel     DeterministicRNG(seed): CPython init_by_array for streams 0, 2 and the per-env global stream
-//   bg_refill_kernel   RNG look-ahead: pre-shuffled decks, pre-seeded shop streams, next global-stream blocks
+//   bg_refill_*_kernel RNG look-ahead: pre-shuffled decks, pre-seeded shop streams, next global-stream blocks (beside the engine)
 //   bg_inject_kernel   harness injection into live state
 // There is no CPU path: every entry point needs the HIP device bg_create() opened.
 #include "../../include/balatro_mi355x.h"
@@ -30,24 +29,6 @@ static_assert(sizeof(InfoPtrs) == sizeof(bg_info_ptrs), "InfoPtrs must mirror bg
 // ---------------------------------------------------------------------------------------------------------
 // step / rollout / reset / observe
 // ---------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void bg_emit(const BgDev& d, int env, size_t row, const StepOut& o, double* reward,
-                                        uint8_t* term, uint8_t* trunc, const InfoPtrs& info) {
-  if (reward) reward[row] = o.reward;
-  if (term) term[row] = o.terminated ? 1 : 0;
-  if (trunc) trunc[row] = 0; // the reference never truncates (balatro_env_2.py:1064)
-  if (info.final_score) info.final_score[row] = o.final_score;
-  if (info.error) info.error[row] = o.error;
-  if (info.flags) info.flags[row] = o.flags;
-  if (info.aux) info.aux[row] = o.aux;
-  if (info.hand_type) info.hand_type[row] = (int8_t)o.hand_type;
-  if (info.cards_played) info.cards_played[row] = (int8_t)o.cards_played;
-  if (info.reward_terms) {
-    double2* q = (double2*)(info.reward_terms + row * 8);
-#pragma unroll
-    for (int i = 0; i < 4; i++) q[i] = make_double2(o.terms[2 * i], o.terms[2 * i + 1]);
-  }
-}
-
 __device__ __forceinline__ void bg_emit_info(size_t row, const StepOut& o, uint8_t* trunc, const InfoPtrs& info) {
   if (trunc) trunc[row] = 0; // the reference never truncates (balatro_env_2.py:1064)
   if (info.final_score) info.final_score[row] = o.final_score;
@@ -64,450 +45,6 @@ __device__ __forceinline__ void bg_emit_info(size_t row, const StepOut& o, uint8
 }
 
 #include "bg_engine.h" // the step engine: one kernel behind bg_step / bg_step_many / bg_rollout / bg_rollout_rows
-
-template <bool CARDS>
-__global__ __launch_bounds__(BG_BLOCK) void bg_step_kernel(BgDev d, const int32_t* __restrict__ actions, ObsPtrs obs,
-                                                          double* reward, uint8_t* term, uint8_t* trunc, InfoPtrs info) {
-  using DeckT = typename std::conditional<CARDS, Deck0C, Deck0>::type;
-  __shared__ uint32_t win[BG_WIN][BG_BLOCK];
-  __shared__ JTables jt;
-  bg_tables_init(&jt);
-  int env = blockIdx.x * BG_BLOCK + threadIdx.x;
-  if (env >= d.N) return;
-  RngWin w;
-  bg_win_init(w, &win[0][threadIdx.x], &jt);
-  Env e;
-  bg_load_env(d, env, e);
-  DeckT dk; static_cast<Deck0&>(dk) = bg_load_deck0(d, env);
-  ShopRegs sr; sr.valid = false;
-  StepOut o;
-  uint64_t mask = bg_action_mask(d, env, e, sr);
-  bg_env_step(d, env, e, w, sr, dk, mask, actions[env], o);
-  if (o.terminated && (d.flags & BG_FLAG_AUTORESET)) { bg_env_reset(d, env, e, dk); o.flags |= BG_INFO_AUTORESET; }
-  bg_store_env(d, env, e);
-  mask = bg_action_mask(d, env, e, sr);
-  bg_write_obs<false>(d, env, (size_t)env, e, dk, obs, mask, sr, RowExtra{0.0, 0, 0u});
-  bg_emit(d, env, (size_t)env, o, reward, term, trunc, info);
-}
-
-struct OutLds { double reward; int64_t final_score; int32_t misc; int32_t flags; uint64_t handb; float prf; uint32_t selm; }; // misc: hand_type+1 | terminated<<8 | has_shop<<9; handb / prf: bg_obs_handb / bg_obs_prf / bg_obs_selm of the state after the action
-
-// ---------------------------------------------------------------------------------------------------------
-// Fused rollout with DEDICATED SERVICE WAVES (BG_ROLLOUT_V=3).
-//
-// bg_rollout2_kernel runs one wave per SIMD (341 registers) and its waves alternate between the env phases (A / C) and
-// the heavy phase B behind workgroup barriers: nothing overlaps a wave's dependent chains.  Here a workgroup is FOUR
-// waves: waves 0-1 are env waves (lane = env, 128 envs, phases A and C only), wave 2 serves the queued PLAY_HAND items
-// and wave 3 every other queued action.  The two roles sit in disjoint branches, so the register allocation is the
-// larger of the two instead of their union (<= 256: two waves per SIMD, 8 per CU), and there is NO workgroup barrier in
-// the loop: queues, completion flags and the starvation hint are LDS words with workgroup-scope acquire / release.
-//   env lane:     pack state -> s_state, s_out.misc = 0, release, slot = tail[cls]++, s_items[cls][slot & 127] = item | VALID
-//   service wave: n = tail - head; when n >= threshold (or the env waves run dry) take min(n, 64) items: wait for VALID,
-//                 clear the slot, step the env from / to LDS, s_out = result, release, s_out.misc |= DONE
-//   env lane:     polls its own s_out.misc (acquire) at the top of phase C, as before
-// A lane has at most one item in flight, so the 128-entry rings never overflow.  The service waves leave when both env
-// waves have finished.  Every spin loop sleeps and gives up after BG_SPIN_LIMIT polls (sticky device error instead of a
-// hung GPU).
-// ---------------------------------------------------------------------------------------------------------
-#define BG_ITEM_VALID 0x80000000u
-#define BG_ACT_ADVANCE 62 // internal work item: second half of a won PLAY_HAND (valid actions are < 60)
-#define BG_SPIN_LIMIT (1u << 24)
-#define BG_DEVERR_SPIN 16u
-// LDS words shared between waves.  One wave's LDS instructions execute in program order, so "data, then flag" on the
-// producer side and "flag, then data" on the consumer side need no hardware fence -- only the compiler must keep the order
-// (relaxed workgroup-scope atomics + a compiler barrier).  Acquire / release atomics would also wait for the wave's global
-// stores (s_waitcnt vmcnt(0)): for an env wave that is the whole record write-out of the iteration before.
-__device__ __forceinline__ uint32_t bg_lds_load(uint32_t* p) {
-  uint32_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-  asm volatile("" ::: "memory");
-  return v;
-}
-__device__ __forceinline__ void bg_lds_store(uint32_t* p, uint32_t v) {
-  asm volatile("" ::: "memory");
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-}
-__device__ __forceinline__ void bg_wait_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); } // this wave's global stores have landed
-
-// EW = env waves per workgroup (2: 128 envs, two workgroups per CU; 4: 256 envs, ONE workgroup per CU whose two play waves and
-// two other waves share the queues of all 256 envs) -- as many service waves as env waves, half of them per class
-template <bool HASH, bool CARDS, int EW>
-__global__ __launch_bounds__(2 * EW * BG_BLOCK, 2) void bg_rollout3_kernel(BgDev d, int T, int policy, uint64_t policy_seed,
-                                                                   uint64_t env_index0, uint64_t t0, ObsPtrs obs,
-                                                                   int obs_stride_steps, double* reward, uint8_t* term,
-                                                                   int32_t* actions_out, bg_rollout_stats* stats,
-                                                                   uint32_t th_play, uint32_t th_other, uint32_t th_ready, uint32_t role_mode) {
-  static_assert(EW == 2 || EW == 4, "2 or 4 env waves per workgroup");
-  constexpr int NE = EW * BG_BLOCK;        // envs per workgroup
-  __shared__ uint4 s_state[BG_NHOT][NE];
-  __shared__ uint4 s_shop[4][NE];
-  __shared__ OutLds s_out[NE];
-  __shared__ uint32_t s_items[2][NE];      // rings: 0 = PLAY_HAND, 1 = every other deferred action
-  __shared__ uint32_t s_tail[2];           // items ever queued per class (env lanes, atomic)
-  __shared__ uint32_t s_head[2];           // items ever taken per class (service waves; atomic when they help each other)
-  __shared__ uint32_t s_ready[EW];         // runnable lanes of each env wave (starvation hint for the service waves)
-  __shared__ uint32_t s_done;              // env waves that have finished
-  __shared__ uint32_t s_prod[NE];
-  __shared__ uint32_t s_deck[16][NE];
-  __shared__ uint32_t win[EW][BG_WIN][BG_BLOCK];                // RNG windows of the service waves
-  __shared__ bg_u32x4 s_stage[EW][BG_BLOCK * BG_STAGE_NP];      // record staging of the env waves
-  __shared__ unsigned long long s_rowaddr[EW][BG_BLOCK];
-  __shared__ JTables jt;
-#ifdef BG_TIMING3
-  __shared__ unsigned long long s_prof[EW][2];
-  if (threadIdx.x < 2 * EW) s_prof[threadIdx.x >> 1][threadIdx.x & 1] = 0;
-#endif
-  __builtin_amdgcn_s_setprio(3);
-  bg_tables_init(&jt);
-  const int tid = threadIdx.x;
-  // Role of a wave.  The dispatcher spreads the four waves of a workgroup over the four SIMDs of the CU in order, so with
-  // fixed roles both workgroups of a CU would put their env waves (the continuously busy ones) on SIMD 0 and 1 and the
-  // mostly-waiting service waves on SIMD 2 and 3.  role_mode != 0 swaps the roles in every other workgroup: each SIMD
-  // then carries one env wave and one service wave.  (1: odd blockIdx, 2: second half of the grid, 3: hardware wave slot)
-  bool swap_roles = false;
-  if (EW != 2) { /* one workgroup per CU: nothing to alternate */ }
-  else if ((role_mode & 0xffu) == 1u) swap_roles = (blockIdx.x & 1u) != 0u;
-  else if ((role_mode & 0xffu) == 2u) swap_roles = blockIdx.x >= (gridDim.x + 1u) / 2u;
-  else if ((role_mode & 0xffu) == 3u) {
-    __shared__ uint32_t s_slot;
-    if (tid == 0) s_slot = (__builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | ((4 - 1) << 11))) & 1u; // WAVE_ID bit 0 of wave 0
-    __syncthreads();
-    swap_roles = s_slot != 0u;
-  }
-  const int wave = (tid >> 6) ^ (swap_roles ? 2 : 0);
-  const int local = ((wave & (EW - 1)) << 6) | (tid & 63); // env lane index (env waves) -- service lanes use `lane`
-  const int env = blockIdx.x * NE + local;
-  const bool is_env = wave < EW;
-#ifdef BG_PRIO_SERVICE // development: service waves issue ahead of the env wave they share a SIMD with
-  if (is_env) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(3);
-#endif
-  const bool live = is_env && env < d.N;
-  using DeckT = DeckLdsS<NE, CARDS>;
-  if (is_env) s_prod[local] = (live && d.prod_view) ? d.prod_view[env] : 0u;
-  if (tid < 2) { s_tail[tid] = 0; s_head[tid] = 0; }
-  if (tid < EW) s_ready[tid] = BG_BLOCK;
-  if (tid == 0) s_done = 0;
-  if (is_env) {
-    s_items[0][local] = 0; s_items[1][local] = 0;
-    OutLds z; z.reward = 0.0; z.final_score = 0; z.misc = 0; z.flags = 0; z.handb = 0; z.prf = 0.0f; z.selm = 0;
-    s_out[local] = z;
-  }
-  __syncthreads();
-  if (is_env) {
-    // =========================================== env waves: phases A and C ===========================================
-    uint64_t n_steps = 0, n_eps = 0, n_plays = 0, rbits = 0, ohash = 0;
-    int64_t ssum = 0;
-    Env e;
-    DeckT dk;
-    uint64_t mask = 0;
-    dk.col = (lds_u32*)&s_deck[0][local];
-    if (live) {
-      bg_load_env(d, env, e);
-#pragma unroll
-      for (int k = 0; k < BG_NDECK; k++) bg_deck_set(dk, k, d.deck[(size_t)k * d.N + env]);
-      ShopRegs sr; sr.valid = false;
-      mask = bg_action_mask(d, env, e, sr);
-      if (sr.valid) { s_shop[0][local] = sr.c3; s_shop[1][local] = sr.c4; s_shop[2][local] = sr.c5; s_shop[3][local] = sr.c6; }
-    }
-#ifdef BG_DECK_PRELOAD // development: measured -4 % (16 registers held across the whole loop cost more than the round trip)
-    // The ring's NEXT deck sits in registers before the reset that consumes it: a reset then costs no HBM round trip (some lane
-    // of a wave resets in every other iteration, and the four dependent loads were ~2.5 k of its cycles).  Slots the view calls
-    // ready were written by a refill that is complete; the refill running beside this kernel only touches the others.
-    uint4 nd[BG_NDECK];
-    bool nd_ok = live && e.d_ready > 0;
-#pragma unroll
-    for (int q = 0; q < BG_NDECK; q++) nd[q] = nd_ok ? d.ndeck[((size_t)e.d_head * BG_NDECK + q) * d.N + env] : make_uint4(0, 0, 0, 0);
-#endif
-    // observation values that only the heavy actions (and a reset) change: carried, not recomputed every step
-    uint64_t c_handb = live ? bg_obs_handb(d, env, e, dk) : 0ull;
-    float c_prf = live ? bg_obs_prf(e) : 0.0f;
-    uint32_t c_selm = live ? bg_obs_selm(e) : 0u;
-    int t = 0;
-    bool blocked = false;
-    int action = 0;
-    StepOut o;
-    bg_step_init(o);
-    const PolicyLane pl = bg_policy_lane(policy, policy_seed, env_index0 + (uint64_t)env);
-    uint64_t px = pl.seed_env + BG_POLICY_PSI * (t0 + 1); // the hash input of the lane's next step
-    uint32_t idle_polls = 0;
-#ifdef BG_TIMING3
-    unsigned long long q_iter = 0, q_idle = 0, q_a = 0, q_c = 0, q_lanes = 0, q_s1 = 0, q_s2 = 0, q_s3 = 0, q_s4 = 0;
-    const unsigned long long q_t0 = __builtin_readcyclecounter();
-#endif
-    const uint32_t th_env = (role_mode >> 16) & 0xffu; // 0 = off: an iteration starts however few lanes can take part
-    uint32_t gather_polls = 0;
-    for (;;) {
-      if (th_env) {
-        // An iteration costs the wave the same whether 20 or 64 lanes take part.  Wait (a little) until enough lanes can: those
-        // that can step plus those a service wave has finished.  The service waves do not depend on this wave, so no deadlock.
-        const bool pending = live && (blocked ? (bg_lds_load((uint32_t*)&s_out[local].misc) & 0x400u) != 0u : t < T);
-        const uint32_t can = (uint32_t)__popcll(__ballot(pending)), open_ = (uint32_t)__popcll(__ballot(live && (blocked || t < T)));
-        if (can < (th_env < open_ ? th_env : open_) && gather_polls < 256u) { gather_polls++; __builtin_amdgcn_s_sleep(4); continue; }
-        gather_polls = 0;
-      }
-#ifdef BG_TIMING3
-      const unsigned long long q_c0 = __builtin_readcyclecounter();
-#endif
-      // ---------------- phase A: policy, guards, cheap actions inline, everything else queued
-      bool fin = false;
-      if (live && !blocked && t < T) {
-        bg_step_init(o);
-#ifdef BG_TIMING3
-        const unsigned long long q_a0 = __builtin_readcyclecounter();
-#endif
-        action = bg_policy_action_fast(e, mask, policy, pl, px, (lds_JTables*)&jt);
-#ifdef BG_TIMING3
-        const unsigned long long q_a1 = __builtin_readcyclecounter();
-#endif
-        bool deferred = false;
-        if (bg_step_guards(e, mask, action, o)) {
-          if (e.phase == 0 && action >= 2 && action < 10) { bg_toggle_select(e, action - 2); c_selm ^= 1u << (action - 2); }
-          else if (e.phase == 1 && action == 31) {                                                // shop end :1247-1251
-            const int nh0 = e.nhand;
-            e.phase = 0; bg_draw_cards(e);
-            if (e.nhand != nh0) c_handb = bg_obs_handb(d, env, e, dk); // rare: the played cards never left the hand
-          }
-          else deferred = true;
-        }
-#ifdef BG_TIMING3
-        const unsigned long long q_a2 = __builtin_readcyclecounter();
-        if ((tid & 63) == __builtin_ctzll(__ballot(1))) { atomicAdd(&s_prof[wave][0], q_a1 - q_a0); atomicAdd(&s_prof[wave][1], q_a2 - q_a1); }
-#endif
-        if (deferred) {
-          const int cls = (e.phase == 0 && action == 0) ? 0 : 1;
-          uint4 c[BG_NHOT];
-          bg_pack(e, c);
-#pragma unroll
-          for (int k = 0; k < BG_NHOT; k++) s_state[k][local] = c[k];
-          bg_lds_store((uint32_t*)&s_out[local].misc, 0u); // not processed yet
-          const uint32_t slot = __hip_atomic_fetch_add(&s_tail[cls], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          bg_lds_store(&s_items[cls][slot & (NE - 1)], (uint32_t)local | ((uint32_t)action << 16) | BG_ITEM_VALID);
-          blocked = true;
-        } else fin = true;
-      }
-      {
-        const bool runnable_next = live && !blocked && (t + (fin ? 1 : 0)) < T;
-        const unsigned long long bal = __ballot(runnable_next);
-        if ((tid & 63) == 0) bg_lds_store(&s_ready[wave], (uint32_t)__popcll(bal));
-      }
-#ifdef BG_TIMING3
-      const unsigned long long q_c1 = __builtin_readcyclecounter();
-#endif
-      // ---------------- phase C: finish the step of every lane that took one (inline in A, or served by a service wave)
-      if (blocked && (bg_lds_load((uint32_t*)&s_out[local].misc) & 0x400u)) {
-        uint4 c[BG_NHOT];
-#pragma unroll
-        for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][local];
-        bg_unpack(c, e);
-        bg_derive_ready(e, s_prod[local]);
-        OutLds ol = s_out[local];
-        o.reward = ol.reward; o.final_score = ol.final_score; o.flags = ol.flags;
-        o.hand_type = (ol.misc & 0xff) - 1; o.terminated = (ol.misc & 0x100) != 0; o.error = ol.misc >> 16;
-        c_handb = ol.handb; c_prf = ol.prf; c_selm = ol.selm;
-        blocked = false;
-        fin = true;
-      }
-#ifdef BG_TIMING3
-      const unsigned long long q_m0 = __builtin_readcyclecounter();
-      unsigned long long q_m1 = q_m0, q_m2 = q_m0, q_m3 = q_m0;
-#endif
-      if (fin) {
-        if (e.max_ante > 0 && e.ante > e.max_ante) { o.terminated = true; o.flags |= 256; }
-#ifdef BG_DECK_PRELOAD // development: measured -4 % (16 registers held across the whole loop cost more than the round trip)
-        if (o.terminated) { // SAME_STEP auto-reset
-          bg_env_reset(d, env, e, dk, nd_ok ? nd : (const uint4*)nullptr); n_eps++; c_handb = ~0ull; c_prf = 0.0f; c_selm = 0u;
-        }
-#else
-        if (o.terminated) { bg_env_reset(d, env, e, dk); n_eps++; c_handb = ~0ull; c_prf = 0.0f; c_selm = 0u; } // SAME_STEP auto-reset: empty hand, no chips
-#endif
-        // a reset zeroes the env's play counts (and re-applies its card states) in HBM, which a service wave touches a few
-        // steps later: let those stores land first.  What is still in flight here is the record write-out of the iteration
-        // BEFORE (a whole phase A old), so this wait is short -- unlike one right after the write-out
-#ifndef BG_NO_RESET_WAIT // development: measure what the wait costs
-        if (__ballot(o.terminated) != 0ull) bg_wait_vm();
-#endif
-#ifdef BG_DECK_PRELOAD
-        if (o.terminated) { // after the wait: these loads are for the NEXT reset and must not be waited for now
-          nd_ok = e.d_ready > 0;
-#pragma unroll
-          for (int q = 0; q < BG_NDECK; q++) if (nd_ok) nd[q] = d.ndeck[((size_t)e.d_head * BG_NDECK + q) * d.N + env];
-        }
-#endif
-        ShopRegs sr; sr.valid = false;
-        if (e.phase == 1 && (e.bflags & BG_BF_SHOP_EXISTS)) {
-          sr.c3 = s_shop[0][local]; sr.c4 = s_shop[1][local]; sr.c5 = s_shop[2][local]; sr.c6 = s_shop[3][local]; sr.valid = true;
-        }
-#ifdef BG_TIMING3
-        q_m1 = __builtin_readcyclecounter();
-#endif
-        mask = bg_action_mask(d, env, e, sr);
-        size_t row = (size_t)env + (obs_stride_steps ? (size_t)t * (size_t)d.N : 0);
-#ifdef BG_TIMING3
-        q_m2 = __builtin_readcyclecounter();
-#endif
-#ifdef BG_V3_DIRECT // development: 16 bytes per lane straight to 64 rows, no LDS staging
-        uint64_t h = bg_write_obs_impl<HASH, 0>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u, true, c_prf, c_handb, c_selm},
-                                                   RowStage{(lds_u4*)&s_stage[wave][0], (lds_u64*)&s_rowaddr[wave][0]});
-#else
-        uint64_t h = bg_write_obs_impl<HASH, 1>(d, env, row, e, dk, obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u, true, c_prf, c_handb, c_selm},
-                                                  RowStage{(lds_u4*)&s_stage[wave][0], (lds_u64*)&s_rowaddr[wave][0]});
-#endif
-#ifdef BG_TIMING3
-        q_m3 = __builtin_readcyclecounter();
-#endif
-        if (HASH) ohash ^= h * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(t0 + t)) + (env_index0 + (uint64_t)env);
-        if (reward) reward[row] = o.reward;
-        if (term) term[row] = o.terminated ? 1 : 0;
-        if (actions_out) actions_out[row] = action;
-        n_steps++;
-        rbits ^= (uint64_t)__double_as_longlong(o.reward) * (2 * (uint64_t)(t0 + t) + 1);
-        if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
-        t++; px += BG_POLICY_PSI;
-      }
-#ifdef BG_TIMING3
-      { const unsigned long long q_c2 = __builtin_readcyclecounter(); q_a += q_c1 - q_c0; q_c += q_c2 - q_c1; q_iter++;
-        q_s1 += q_m0 - q_c1; q_s2 += q_m1 - q_m0; q_s3 += q_m2 - q_m1; q_s4 += q_m3 - q_m2;
-        q_lanes += (unsigned long long)__popcll(__ballot(fin)); if (__ballot(fin) == 0ull) q_idle++; }
-#endif
-      if (__ballot(live && (blocked || t < T)) == 0ull) break;              // this wave has done its T steps
-      if (__ballot(fin) == 0ull) {                                           // every live lane is waiting for a service wave
-        __builtin_amdgcn_s_sleep(8);
-        if (++idle_polls > BG_SPIN_LIMIT) { if ((tid & 63) == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
-      } else idle_polls = 0;
-    }
-#ifdef BG_TIMING3
-    if ((tid & 63) == 0 && d.dbg) {
-      atomicAdd(&d.dbg[0], __builtin_readcyclecounter() - q_t0); atomicAdd(&d.dbg[1], q_iter); atomicAdd(&d.dbg[2], q_idle);
-      atomicAdd(&d.dbg[3], q_a); atomicAdd(&d.dbg[4], q_c); atomicAdd(&d.dbg[11], 1ull); atomicAdd(&d.dbg[12], q_lanes);
-      atomicAdd(&d.dbg[20], s_prof[wave][0]); atomicAdd(&d.dbg[21], s_prof[wave][1]); atomicAdd(&d.dbg[16], q_s1); atomicAdd(&d.dbg[17], q_s2); atomicAdd(&d.dbg[18], q_s3); atomicAdd(&d.dbg[19], q_s4);
-    }
-#endif
-    if ((tid & 63) == 0) {
-      bg_lds_store(&s_ready[wave], 0u);
-      __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    if (live) bg_store_env(d, env, e);
-    if (stats) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) {
-        n_steps += __shfl_down(n_steps, off); n_eps += __shfl_down(n_eps, off); n_plays += __shfl_down(n_plays, off);
-        ssum += __shfl_down(ssum, off); rbits ^= __shfl_down(rbits, off); ohash ^= __shfl_down(ohash, off);
-      }
-      if ((tid & 63) == 0) {
-        atomicAdd((unsigned long long*)&stats->steps, (unsigned long long)n_steps);
-        atomicAdd((unsigned long long*)&stats->episodes, (unsigned long long)n_eps);
-        atomicAdd((unsigned long long*)&stats->plays, (unsigned long long)n_plays);
-        atomicAdd((unsigned long long*)&stats->score_sum, (unsigned long long)ssum);
-        atomicXor((unsigned long long*)&stats->reward_bits, (unsigned long long)rbits);
-        atomicXor((unsigned long long*)&stats->obs_hash, (unsigned long long)ohash);
-      }
-    }
-  } else {
-    // =========================================== service waves: phase B ===========================================
-    const int own = (wave - EW) & 1;     // class this wave serves first
-    const int wslot = wave - EW;          // its RNG window
-    const int lane = tid & (BG_BLOCK - 1);
-    const uint32_t th = own == 0 ? th_play : th_other;
-    const bool help = (role_mode & 0x100u) != 0u; // an idle service wave also takes the other wave's queue
-    const bool defer_adv = (role_mode & 0x200u) != 0u; // won plays leave _advance_round + shop generation to the other queue
-    uint32_t polls = 0;
-#ifdef BG_TIMING3
-    unsigned long long q_batches = 0, q_items = 0, q_busy = 0;
-    const unsigned long long q_t0 = __builtin_readcyclecounter();
-#endif
-    for (;;) {
-      int cls = own;
-      uint32_t head = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_head[cls]));
-      uint32_t n = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_tail[cls])) - head;
-      uint32_t ready = 0;
-#pragma unroll
-      for (int q = 0; q < EW; q++) ready += __builtin_amdgcn_readfirstlane(bg_lds_load(&s_ready[q]));
-      if (n != 0u && n < th && ready >= th_ready) n = 0u; // batching thresholds (1 / 1 / 255 by default: never)
-      if (n == 0u && help) {
-        cls = own ^ 1;
-        head = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_head[cls]));
-        n = __builtin_amdgcn_readfirstlane(bg_lds_load(&s_tail[cls])) - head;
-      }
-      if (n == 0u) {
-        if (__builtin_amdgcn_readfirstlane(bg_lds_load(&s_done)) >= (uint32_t)EW) break; // all env waves are through: every item was served
-        __builtin_amdgcn_s_sleep(16);
-        if (++polls > BG_SPIN_LIMIT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
-        continue;
-      }
-      {
-        const uint32_t want = n > BG_BLOCK ? BG_BLOCK : n;
-        uint32_t got = 0;
-        if (lane == 0) got = atomicCAS(&s_head[cls], head, head + want) == head ? 1u : 0u; // the other wave may be claiming the same items
-        if (__builtin_amdgcn_readfirstlane(got) == 0u) continue;
-      }
-      polls = 0;
-      const uint32_t nb = n > BG_BLOCK ? BG_BLOCK : n;
-#ifdef BG_TIMING3
-      const unsigned long long q_b0 = __builtin_readcyclecounter();
-#endif
-      if ((uint32_t)lane < nb) {
-        uint32_t* slotp = &s_items[cls][(head + (uint32_t)lane) & (NE - 1)];
-        uint32_t item = bg_lds_load(slotp);
-        uint32_t spin = 0;
-        while (!(item & BG_ITEM_VALID) && ++spin < BG_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); item = bg_lds_load(slotp); }
-        bg_lds_store(slotp, 0u);
-        if (item & BG_ITEM_VALID) {
-          const int l = (int)(item & 0xffffu), a = (int)((item >> 16) & 0x7fffu);
-          const int benv = blockIdx.x * NE + l;
-          uint4 c[BG_NHOT];
-#pragma unroll
-          for (int k = 0; k < BG_NHOT; k++) c[k] = s_state[k][l];
-          Env be;
-          bg_unpack(c, be);
-          bg_derive_ready(be, s_prod[l]);
-          DeckT bdk; bdk.col = (lds_u32*)&s_deck[0][l];
-          ShopRegs bsr; bsr.valid = false;
-          RngWin w;
-          bg_win_init(w, &win[wslot][0][lane], &jt);
-          w.defer_adv = defer_adv;
-          if (a == BG_ACT_ADVANCE) {
-            // second half of a won play: _advance_round (+ the shop it generates); s_out already holds the play's result
-            bg_advance_round<CARDS>(d, benv, be, w, bsr);
-            if (w.need_inv) { bg_shop_inventory(d, benv, be, w, bsr); w.need_inv = false; }
-            bg_pack(be, c);
-#pragma unroll
-            for (int k = 0; k < BG_NHOT; k++) s_state[k][l] = c[k];
-            if (bsr.valid) { s_shop[0][l] = bsr.c3; s_shop[1][l] = bsr.c4; s_shop[2][l] = bsr.c5; s_shop[3][l] = bsr.c6; }
-            s_out[l].handb = bg_obs_handb(d, benv, be, bdk); s_out[l].prf = bg_obs_prf(be); s_out[l].selm = bg_obs_selm(be);
-            const uint32_t misc = bg_lds_load((uint32_t*)&s_out[l].misc) | (bsr.valid ? 0x200u : 0u);
-            bg_wait_vm();
-            bg_lds_store((uint32_t*)&s_out[l].misc, misc | 0x400u);
-          } else {
-            StepOut bo;
-            bg_step_init(bo);
-            bg_env_dispatch(d, benv, be, w, bsr, bdk, a, bo);
-            bg_pack(be, c);
-#pragma unroll
-            for (int k = 0; k < BG_NHOT; k++) s_state[k][l] = c[k];
-            if (bsr.valid) { s_shop[0][l] = bsr.c3; s_shop[1][l] = bsr.c4; s_shop[2][l] = bsr.c5; s_shop[3][l] = bsr.c6; }
-            const int32_t misc = (bo.hand_type + 1) | (bo.terminated ? 0x100 : 0) | (bsr.valid ? 0x200 : 0) | (bo.error << 16);
-            s_out[l].reward = bo.reward; s_out[l].final_score = bo.final_score; s_out[l].flags = bo.flags & ~BG_FLAG_DEFER_ADV;
-            s_out[l].handb = bg_obs_handb(d, benv, be, bdk); s_out[l].prf = bg_obs_prf(be); s_out[l].selm = bg_obs_selm(be);
-            bg_wait_vm(); // shop inventory / play counts / card states written to HBM are read by the OTHER service wave later
-            if (bo.flags & BG_FLAG_DEFER_ADV) { // hand the env on to the other queue; DONE is set by whoever runs the second half
-              bg_lds_store((uint32_t*)&s_out[l].misc, (uint32_t)misc);
-              const uint32_t slot2 = __hip_atomic_fetch_add(&s_tail[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              bg_lds_store(&s_items[1][slot2 & (NE - 1)], (uint32_t)l | ((uint32_t)BG_ACT_ADVANCE << 16) | BG_ITEM_VALID);
-            } else bg_lds_store((uint32_t*)&s_out[l].misc, (uint32_t)misc | 0x400u);
-          }
-        } else atomicOr(d.err, BG_DEVERR_SPIN);
-      }
-#ifdef BG_TIMING3
-      q_busy += __builtin_readcyclecounter() - q_b0; q_batches++; q_items += nb;
-#endif
-    }
-#ifdef BG_TIMING3
-    if (lane == 0 && d.dbg) {
-      atomicAdd(&d.dbg[5 + 3 * own], q_batches); atomicAdd(&d.dbg[6 + 3 * own], q_items); atomicAdd(&d.dbg[7 + 3 * own], q_busy);
-      atomicAdd(&d.dbg[13 + own], __builtin_readcyclecounter() - q_t0);
-    }
-#endif
-  }
-}
 
 template <bool CARDS>
 __global__ __launch_bounds__(BG_BLOCK) void bg_reset_kernel(BgDev d, const uint8_t* __restrict__ mask_in, ObsPtrs obs) {
@@ -1064,11 +601,9 @@ struct bg_handle {
   std::string err;
   // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
   bool profiling;
-  int rollout_version; // 3 = service-wave kernel (BG_ROLLOUT_V)
   // refill pipeline: double-buffered producer counters, a side stream and per-parity completion events
   uint32_t* d_prod[2];
   long refill_seq;       // refills launched so far; refill #i writes d_prod[i & 1]
-  uint32_t th_play, th_other, th_ready; // service-wave batching thresholds (BG_TH_PLAY / _OTHER / _READY)
   bool async_refill;     // BG_ASYNC_REFILL (default on): bg_rollout overlaps refill #i with rollout chunk i+1
   hipStream_t side, side2, side3; // side: overlapped refills; side2/3: the deck and block kernels of one refill run beside the shop kernel
   hipEvent_t ev_scan, ev_deck, ev_gblk, ev_gblk2;
@@ -1078,9 +613,8 @@ struct bg_handle {
   std::vector<hipEvent_t> ev_rollout_t, ev_refill_t, ev_step_t; // start/stop pairs
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
   // tunables read ONCE per handle in bg_create (environment variables)
-  int refill_blocks, refill_blocks_shop, dev_skip_refill, gblk_first, gblk_own, wg_envs;
+  int refill_blocks, refill_blocks_shop, dev_skip_refill, gblk_first, gblk_own;
   uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_smask; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
-  uint32_t role_mode;
 };
 
 static std::string g_create_err;
@@ -1196,24 +730,14 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
   if (device_id < 0 || device_id >= ndev) { g_create_err = "bg_create: device_id out of range"; return BG_E_ARG; }
   bg_handle* h = new bg_handle();
   h->device_id = device_id; h->seeded = false; h->bytes = 0; h->profiling = false;
-  { const char* rv = getenv("BG_ROLLOUT_V"); h->rollout_version = rv ? atoi(rv) : 4; }
-  if (h->rollout_version != 3 && h->rollout_version != 4) { delete h; g_create_err = "bg_create: BG_ROLLOUT_V must be 4 (step engine) or 3 (service-wave kernel)"; return BG_E_ARG; }
   { const char* av = getenv("BG_ASYNC_REFILL"); h->async_refill = av ? atoi(av) != 0 : true; }
-  { // service waves batch by themselves (whatever queued up while the last batch ran): thresholds 1 / 1 / 255 = never wait
-    const char* a = getenv("BG_TH_PLAY"); const char* b = getenv("BG_TH_OTHER"); const char* c = getenv("BG_TH_READY");
-    h->th_play = a ? (uint32_t)atoi(a) : 1u; h->th_other = b ? (uint32_t)atoi(b) : 1u; h->th_ready = c ? (uint32_t)atoi(c) : 255u;
-    if (h->th_play < 1) h->th_play = 1; if (h->th_other < 1) h->th_other = 1; if (h->th_ready < 1) h->th_ready = 1;
-  }
   { // every tunable is read here, once per handle (a process may A/B two handles with different settings)
     auto geti = [](const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; };
     h->refill_blocks = geti("BG_REFILL_BLOCKS", 4096); h->refill_blocks_shop = geti("BG_REFILL_BLOCKS_SHOP", 0);
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0); h->gblk_first = geti("BG_GBLK_FIRST", 0); h->gblk_own = geti("BG_GBLK_OWN", 0);
-    h->wg_envs = geti("BG_WG_ENVS", 0);
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
     h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT);
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
-    h->role_mode = (uint32_t)geti("BG_ROLE_MODE", 0) | (geti("BG_HELP", 0) ? 0x100u : 0u) | (geti("BG_DEFER_ADV", 0) ? 0x200u : 0u) |
-                   (((uint32_t)geti("BG_TH_ENV", 0) & 0xffu) << 16);
   }
   h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = h->ev_gblk2 = nullptr; h->side4 = nullptr;
   h->ev_refill[0] = h->ev_refill[1] = nullptr; h->ev_rollout = nullptr;
@@ -1564,7 +1088,7 @@ static int bg_step_impl(bg_handle* h, int K, const int32_t* actions_dev, const b
     if (rc) return rc;
     const BgDev dv = bg_dev_view(h, bg_prod_latest(h));
     bg_ev_begin(h, h->ev_step_t, st);
-    if (h->rollout_version == 4) {
+    {
       EngineArgs ea;
       memset(&ea, 0, sizeof(ea));
       ea.T = chunk; ea.actions_in = actions_dev + (size_t)done * N;
@@ -1578,18 +1102,6 @@ static int bg_step_impl(bg_handle* h, int K, const int32_t* actions_dev, const b
       ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.serve_mask = h->eng_smask;
       ea.autoreset = (h->dev.flags & BG_FLAG_AUTORESET) ? 1u : 0u;
       bg_engine_launch(h, dv, ea, false, true, st);
-    } else {
-      for (int k = 0; k < chunk; k++) { // the lane-per-env step kernel, one launch per step (A/B: BG_ROLLOUT_V=3)
-        ObsPtrs o = bg_obs(obs);
-        InfoPtrs ip = bg_info(info);
-        const size_t off = obs_stride_steps ? (size_t)(done + k) * N : 0;
-        if (off) { bg_obs_advance(o, off); bg_info_advance(ip, off); }
-        const int32_t* ac = actions_dev + (size_t)(done + k) * N;
-        double* rw = reward_dev ? reward_dev + off : nullptr; uint8_t* tm = terminated_dev ? terminated_dev + off : nullptr;
-        uint8_t* tr = truncated_dev ? truncated_dev + off : nullptr;
-        if (h->dev.cstate) hipLaunchKernelGGL(bg_step_kernel<true>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, ac, o, rw, tm, tr, ip);
-        else hipLaunchKernelGGL(bg_step_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, ac, o, rw, tm, tr, ip);
-      }
     }
     bg_ev_end(h, h->ev_step_t, st);
     BG_HIP(hipGetLastError());
@@ -1651,28 +1163,13 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       int32_t* ac = actions_out_dev ? actions_out_dev + off : nullptr;
       hipStream_t st = (hipStream_t)stream;
       uint64_t tt = t0 + (uint64_t)done;
-      if (h->rollout_version == 4) {
+      {
         EngineArgs ea;
         memset(&ea, 0, sizeof(ea));
         ea.T = chunk; ea.policy = pol; ea.policy_seed = policy_seed; ea.env_index0 = env_index0; ea.t0 = tt;
         ea.obs = o; ea.obs_stride_steps = obs_stride_steps; ea.reward = rw; ea.term = tm; ea.actions_out = ac; ea.stats = stats_dev;
         ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.serve_mask = h->eng_smask; ea.autoreset = 1;
         bg_engine_launch(h, dv, ea, hash, false, st);
-      } else {
-        // envs per workgroup.  256 (one workgroup per CU: its two play waves and two other waves pool the queues of 256 envs,
-        // so a queued action waits half as long for a free wave) makes the kernel 5-7 % faster than 128 (two workgroups per CU)
-        // once the env count fills every CU that way.  Smaller jobs keep 128 so that they spread over twice as many CUs.
-        const int wg_envs = h->wg_envs ? h->wg_envs : (h->dev.N >= 65536 ? 256 : 128);
-        dim3 g2((h->dev.N + 2 * BG_BLOCK - 1) / (2 * BG_BLOCK)), g4((h->dev.N + 4 * BG_BLOCK - 1) / (4 * BG_BLOCK));
-        const uint32_t thp = h->th_play, tho = h->th_other, thr = h->th_ready, role_mode = h->role_mode;
-#define BG_LAUNCH_R3(HASHV, CARDSV) do { if (wg_envs == 256) hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV, 4>), g4, dim3(8 * BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, \
-                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr, role_mode); \
-  else hipLaunchKernelGGL((bg_rollout3_kernel<HASHV, CARDSV, 2>), g2, dim3(4 * BG_BLOCK), 0, st, dv, chunk, pol, policy_seed, \
-                                                   env_index0, tt, o, obs_stride_steps, rw, tm, ac, stats_dev, thp, tho, thr, role_mode); } while (0)
-        const bool cards = h->dev.cstate != nullptr;
-        if (hash && cards) BG_LAUNCH_R3(true, true); else if (hash) BG_LAUNCH_R3(true, false);
-        else if (cards) BG_LAUNCH_R3(false, true); else BG_LAUNCH_R3(false, false);
-#undef BG_LAUNCH_R3
       }
     }
     bg_ev_end(h, h->ev_rollout_t, (hipStream_t)stream);
@@ -2011,6 +1508,34 @@ int bg_bench_copy(const void* src_dev, void* dst_dev, uint64_t bytes, int iters,
   BG_HIP0(hipEventElapsedTime(&ms, a, b));
   (void)hipEventDestroy(a); (void)hipEventDestroy(b);
   *gbps_out = ms > 0 ? 2.0 * (double)(n16 * 16) * iters / (ms * 1e-3) / 1e9 : 0.0; // bytes read + bytes written
+  return 0;
+}
+
+// write-only twin: the step engine's traffic is ~80 % stores (the record of every step), so the store bandwidth is its real ceiling
+__global__ __launch_bounds__(256) void bg_stream_fill_kernel(uint4* __restrict__ dst, size_t n16, uint32_t seed) {
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n16; i += stride) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) if (i + (size_t)k * 256 < n16) dst[i + (size_t)k * 256] = make_uint4(seed, (uint32_t)i, (uint32_t)k, seed ^ (uint32_t)i);
+  }
+}
+int bg_bench_fill(void* dst_dev, uint64_t bytes, int iters, double* gbps_out, void* stream) {
+  if (!dst_dev || !gbps_out || bytes < 16 || iters < 1 || ((uintptr_t)dst_dev & 15)) { g_create_err = "bg_bench_fill: bad arguments"; return BG_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n16 = bytes / 16;
+  const unsigned grid = 256 * 16;
+  hipEvent_t a, b;
+  BG_HIP0(hipEventCreate(&a)); BG_HIP0(hipEventCreate(&b));
+  hipLaunchKernelGGL(bg_stream_fill_kernel, dim3(grid), dim3(256), 0, s, (uint4*)dst_dev, n16, 0u); // warm-up
+  BG_HIP0(hipEventRecord(a, s));
+  for (int i = 0; i < iters; i++) hipLaunchKernelGGL(bg_stream_fill_kernel, dim3(grid), dim3(256), 0, s, (uint4*)dst_dev, n16, (uint32_t)i + 1u);
+  BG_HIP0(hipEventRecord(b, s));
+  BG_HIP0(hipGetLastError());
+  BG_HIP0(hipEventSynchronize(b));
+  float ms = 0;
+  BG_HIP0(hipEventElapsedTime(&ms, a, b));
+  (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+  *gbps_out = ms > 0 ? (double)(n16 * 16) * iters / (ms * 1e-3) / 1e9 : 0.0; // bytes written
   return 0;
 }
 

@@ -42,6 +42,7 @@ ENVS_PER_GPU = 65536
 OBS_BYTES, IO_BYTES, STATE_BYTES = 330, 10, 192  # A_step(T) = 340 + 384 / T bytes per env-step
 # (the packed-record layout writes 352 bytes per env-step, 12 of them padding / the action and terminated flag; the
 #  roofline keeps SURVEY's 340 algorithmic bytes)
+OBS_ROW_WRITE_BYTES = OBS_BYTES + IO_BYTES        # algorithmic bytes WRITTEN per env-step (the state adds 192 / T)
 HBM_PEAK_GBPS = 8000.0                           # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec peak)
 
 IMPLEMENTED = [1, 136, 27, 38, 61, 16, 34, 108, 23, 22, 53, 97, 50, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15,
@@ -86,8 +87,9 @@ def cpu_baseline(n_envs: int, steps: int, threads: int):
     return sum(results) / dt, dt
 
 
-def measured_copy_gbps(dev) -> float:
-    """What a plain 16-byte-per-lane streaming copy sustains on this GPU (bg_bench_copy): read + written bytes per second."""
+def measured_copy_gbps(dev):
+    """What a plain 16-byte-per-lane streaming copy sustains on this GPU (bg_bench_copy: read + written bytes per second), and what a
+    plain 16-byte-per-lane FILL sustains (bg_bench_fill: written bytes per second) -- the step engine's traffic is ~80 % stores."""
     import torch
     from balatro_gym_amd import _native as nat
     L = nat.load()
@@ -100,8 +102,14 @@ def measured_copy_gbps(dev) -> float:
                              C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc != 0:
         raise RuntimeError(f"bg_bench_copy failed: {L.bg_last_error(None).decode()}")
+    gw = C.c_double()
+    with torch.cuda.device(dev):
+        rc = L.bg_bench_fill(C.c_void_p(dst.data_ptr()), C.c_uint64(nbytes), 20, C.byref(gw),
+                             C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError(f"bg_bench_fill failed: {L.bg_last_error(None).decode()}")
     del src, dst
-    return float(g.value)
+    return float(g.value), float(gw.value)
 
 
 KERNEL_BUILD = "7 waves x 256 envs per workgroup"   # tools/hbm_traffic.py stamps the measurements it writes with the same string
@@ -234,7 +242,7 @@ def main():
 
     if rank == 0:
         value = env_steps / elapsed
-        kernel = "bg_engine_kernel" if os.environ.get("BG_ROLLOUT_V", "4") == "4" else "bg_rollout3_kernel"
+        kernel = "bg_engine_kernel"
         # roofline of the dominant kernel: algorithmic bytes per launch / mean launch duration (HIP events on the launch stream)
         launches = max(1, prof["rollout_launches"])
         fused = prof["rollout_fused_steps"] / launches           # mean fused steps T per launch
@@ -243,7 +251,8 @@ def main():
         mean_launch_s = prof["rollout_ms"] / launches * 1e-3
         achieved = bytes_per_launch / mean_launch_s / 1e9 if mean_launch_s > 0 else 0.0
         traffic = matching_traffic(kernel, n, fused) if args.obs_layout == "rows" else None
-        peak_measured = measured_copy_gbps(dev)
+        peak_measured, peak_write = measured_copy_gbps(dev)
+        write_gbps = (OBS_ROW_WRITE_BYTES + STATE_BYTES / max(1.0, fused)) * n * fused / mean_launch_s / 1e9 if mean_launch_s > 0 else 0.0
         out = {
             "metric": "env-steps/sec at 65536 envs, random policy; achieved HBM GB/s vs peak",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -264,6 +273,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
                          "peak_measured": peak_measured, "frac_of_measured": achieved / peak_measured if peak_measured else None,
+                         # stores only: the records + the state written back, against a plain fill kernel on this GPU
+                         "write_gbps": write_gbps, "peak_measured_write": peak_write, "write_frac_of_measured": write_gbps / peak_write if peak_write else None,
                          "kernel": kernel, "algorithmic_bytes_per_env_step": a_step,
                          "mean_launch_us": mean_launch_s * 1e6, "launches": launches,
                          "refill_mean_launch_us": prof["refill_ms"] / max(1, prof["refill_launches"]) * 1e3,

@@ -286,6 +286,9 @@ int bg_get_profile(bg_handle* h, double* out8);
  * 16-byte aligned device buffers) repeated `iters` times; *gbps_out = (bytes read + bytes written) / time.  SURVEY 8(d): the
  * roofline fraction is quoted against the nominal 8 TB/s AND against what a copy kernel reaches on the same GPU. */
 int bg_bench_copy(const void* src_dev, void* dst_dev, uint64_t bytes, int iters, double* gbps_out, void* stream);
+/* The write-only twin (bench.py `roofline.peak_measured_write`): a plain fill of `bytes` (16 B per lane), *gbps_out = bytes written /
+ * time.  The step path's algorithmic traffic is ~80 % stores (every step's record), so this is the ceiling that applies to it. */
+int bg_bench_fill(void* dst_dev, uint64_t bytes, int iters, double* gbps_out, void* stream);
 
 /* Check the sticky device error word (synchronises the stream). */
 int bg_check(bg_handle* h, void* stream);

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Instruction count per source line of one kernel (development tool): hipcc -g -save-temps, parse .loc."""
 import collections, re, subprocess, sys, os, tempfile
-kern = sys.argv[1] if len(sys.argv) > 1 else "_Z18bg_rollout2_kernelILb0E"
+kern = sys.argv[1] if len(sys.argv) > 1 else "_Z16bg_engine_kernelILb0ELb0ELb0E"
 top = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 d = tempfile.mkdtemp()
 subprocess.check_call(["hipcc", "-O3", "-g", "--offload-arch=gfx950", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",

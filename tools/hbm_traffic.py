@@ -7,7 +7,7 @@ usage: hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collection.c
 import csv, json, sys
 
 
-KERNELS = ("bg_engine_kernel", "bg_rollout3_kernel")  # the fused step kernels, in order of preference
+KERNELS = ("bg_engine_kernel",)  # the step engine
 KERNEL_BUILD = "7 waves x 256 envs per workgroup"  # bench.py only uses a measurement of the kernel shape it runs (KERNEL_BUILD there)
 
 
