@@ -52,6 +52,11 @@ if __name__ == "__main__":
         run(8192, 384, 2, True, False, 987002, 4)
         print("BIG STRESS OK")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "long":  # several launches: the refill of one runs beside the next, rings wrap
+        run(2048, 1500, 2, True, False, 987005, 4)
+        run(1024, 1200, 0, True, True, 987006, 8)
+        print("LONG STRESS OK")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "consumables":
         run(4096, 400, 0, True, True, 987003, 8, cons_on=True)
         run(4096, 400, 0, False, True, 987004, 0, cons_on=True)
