@@ -134,7 +134,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, 2) void bg_engine_kernel(BgDe
   const uint32_t bmod3 = (uint32_t)(a.env_index0 % 3ull);
   uint32_t polls = 0;
 #ifdef BG_TIMING4
-  unsigned long long q_batches[3] = {0, 0, 0}, q_items[3] = {0, 0, 0}, q_busy[3] = {0, 0, 0}, q_idle = 0, q_fail = 0, q_copy = 0;
+  unsigned long long q_batches[3] = {0, 0, 0}, q_items[3] = {0, 0, 0}, q_busy[3] = {0, 0, 0}, q_idle = 0, q_fail = 0, q_copy = 0, q_claim = 0, q_failt = 0;
   const unsigned long long q_t0 = __builtin_readcyclecounter();
 #endif
   for (;;) {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, 2) void bg_engine_kernel(BgDe
       if (lane == 0) { got = atomicCAS(&s_head[cls], head, head + nb) == head ? 1u : 0u; if (got) __hip_atomic_fetch_add(&s_busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
       if (__builtin_amdgcn_readfirstlane(got) == 0u) {
 #ifdef BG_TIMING4
-        q_fail++;
+        q_fail++; q_failt += __builtin_readcyclecounter() - q_l0;
 #endif
         continue;
       }
@@ -190,6 +190,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, 2) void bg_engine_kernel(BgDe
 #endif
 #ifdef BG_TIMING4
     const unsigned long long q_b0 = __builtin_readcyclecounter();
+    q_claim += q_b0 - q_l0;
 #endif
     // A batch = the step the envs were queued for, then up to th_more further CHEAP steps of the same envs (a toggle is followed
     // by another toggle five times out of six): the env stays with the wave that has it instead of going through the run queue
@@ -412,7 +413,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, 2) void bg_engine_kernel(BgDe
   if (lane == 0 && d.dbg) {
     atomicAdd(&d.dbg[0], __builtin_readcyclecounter() - q_t0); atomicAdd(&d.dbg[1], 1ull);
     for (int c = 0; c < 3; c++) { atomicAdd(&d.dbg[2 + 3 * c], q_batches[c]); atomicAdd(&d.dbg[3 + 3 * c], q_items[c]); atomicAdd(&d.dbg[4 + 3 * c], q_busy[c]); }
-    atomicAdd(&d.dbg[11], q_idle); atomicAdd(&d.dbg[12], q_fail); atomicAdd(&d.dbg[13], q_copy);
+    atomicAdd(&d.dbg[11], q_idle); atomicAdd(&d.dbg[12], q_fail); atomicAdd(&d.dbg[13], q_copy); atomicAdd(&d.dbg[14], q_claim); atomicAdd(&d.dbg[15], q_failt);
   }
 #endif
   // ---------------------------------------------------------------- epilogue: chunks 3 / 4 -> HBM, statistics

@@ -31,5 +31,6 @@ for c, nm in ((0, "run"), (1, "play"), (2, "other")):
     b = max(1, o[2 + 3 * c])
     tot_busy += o[4 + 3 * c]
     print(f"  {nm:5s}: batches per workgroup-step {o[2+3*c]/wgs/T:.2f}  items per batch {o[3+3*c]/b:.1f}  cycles per batch {o[4+3*c]/b:.0f}  share of wave time {o[4+3*c]/max(1,o[0]):.2f}")
+print(f"  claims: successful {o[14]/max(1,o[0]):.3f} of wave time ({o[14]/max(1,o[2]+o[5]+o[8]):.0f} cycles each), failed {o[15]/max(1,o[0]):.3f} ({o[15]/max(1,o[12]):.0f} cycles each)")
 print(f"  copy-out: {o[13]/max(1,o[2]+o[5]+o[8]):.0f} cycles per batch, {o[13]/max(1,o[0]):.2f} of wave time")
 env.close()
