@@ -595,7 +595,7 @@ struct bg_handle {
   int64_t* d_seeds;
   uint8_t* d_mask;
   uint32_t* d_jtab;
-  int steps_since_refill; // env steps taken through bg_step / bg_step_many since the rings were last topped up
+  int steps_since_refill; // env steps launched (bg_step, bg_step_many, rollouts) since the last refill was LAUNCHED
   std::vector<uint4> h_tmpl;
   uint64_t bytes;
   std::string err;
@@ -1137,9 +1137,18 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
   if (rc) return rc;
   BG_GUARD(h);
   if (T <= 0) return BG_E_ARG;
-  if (h->steps_since_refill > 0) { rc = bg_refill(h, stream); if (rc) return rc; } // bg_step calls since the last refill used some of the look-ahead
   bool async = false;
   const int max_chunk = bg_chunk_limit(h, &async);
+  // Refills are LAZY: the rings are topped up when the steps launched since the last refill (h->steps_since_refill = u) plus the
+  // chunk about to run would exceed what one refill guarantees -- B = max_chunk steps' worth of every ring (half the rings when the
+  // refill is overlapped, all of them otherwise) -- not after every launch: a caller that fuses 20 steps per launch pays for a
+  // refill every 18 launches instead of one per launch (it was 160 us exposed behind every 380 us launch).
+  //   overlapped: the refill R is queued on the side stream when the chunk STARTS, ordered after everything the stream has done
+  //     so far, and runs beside the chunk; the chunk reads the producer counters of the refill BEFORE R, against which it has
+  //     consumed u + chunk <= 2 B steps (u <= B is the invariant: after a chunk u is either u + chunk <= B or chunk).
+  //   synchronous: R runs on the stream before the chunk.
+  // bg_step / bg_step_many budget against the whole ring, so they may leave u > B: then one synchronous refill first.
+  if (async && h->steps_since_refill > max_chunk) { rc = bg_refill(h, stream); if (rc) return rc; }
   int done = 0;
   while (done < T) {
     int chunk = T - done < max_chunk ? T - done : max_chunk;
@@ -1148,11 +1157,22 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
     if (rows_dev) { o.rows = rows_dev + off * row_stride; o.row_stride = (uint32_t)row_stride; }
     if (off) bg_obs_advance(o, off);
     if (h->profiling) h->rollout_steps.push_back(chunk);
-    // async: this chunk may start as soon as the refill before the previous one is complete; sync: after the last one
-    rc = bg_wait_refill(h, (hipStream_t)stream, async ? 1 : 0);
+    const bool need = h->steps_since_refill + chunk > max_chunk;
+    rc = bg_wait_refill(h, (hipStream_t)stream, 0); // the latest refill launched so far: the one whose producer counters this chunk reads
     if (rc) return rc;
-    const uint32_t* view = (async && h->refill_seq >= 2) ? h->d_prod[h->refill_seq & 1] : bg_prod_latest(h);
-    if (async && h->refill_seq < 2) { rc = bg_wait_refill(h, (hipStream_t)stream, 0); if (rc) return rc; }
+    const uint32_t* view = bg_prod_latest(h);
+    if (need && async) { // R beside this chunk: after everything on the stream so far (the previous launches) and after the latest refill
+      BG_HIP(hipEventRecord(h->ev_rollout, (hipStream_t)stream));
+      BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));
+      rc = bg_wait_refill(h, h->side, 0);
+      if (rc) return rc;
+      rc = bg_refill_on(h, h->side); // (sets steps_since_refill = 0)
+      if (rc) return rc;
+    } else if (need) {
+      rc = bg_refill(h, stream);
+      if (rc) return rc;
+      view = bg_prod_latest(h);
+    }
     bg_ev_begin(h, h->ev_rollout_t, (hipStream_t)stream); // after the waits: the events bracket the kernel, not the stream's wait for the refill
     BgDev dv = bg_dev_view(h, view);
     {
@@ -1163,25 +1183,16 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       int32_t* ac = actions_out_dev ? actions_out_dev + off : nullptr;
       hipStream_t st = (hipStream_t)stream;
       uint64_t tt = t0 + (uint64_t)done;
-      {
-        EngineArgs ea;
-        memset(&ea, 0, sizeof(ea));
-        ea.T = chunk; ea.policy = pol; ea.policy_seed = policy_seed; ea.env_index0 = env_index0; ea.t0 = tt;
-        ea.obs = o; ea.obs_stride_steps = obs_stride_steps; ea.reward = rw; ea.term = tm; ea.actions_out = ac; ea.stats = stats_dev;
-        ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.serve_mask = h->eng_smask; ea.autoreset = 1;
-        bg_engine_launch(h, dv, ea, hash, false, st);
-      }
+      EngineArgs ea;
+      memset(&ea, 0, sizeof(ea));
+      ea.T = chunk; ea.policy = pol; ea.policy_seed = policy_seed; ea.env_index0 = env_index0; ea.t0 = tt;
+      ea.obs = o; ea.obs_stride_steps = obs_stride_steps; ea.reward = rw; ea.term = tm; ea.actions_out = ac; ea.stats = stats_dev;
+      ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.serve_mask = h->eng_smask; ea.autoreset = 1;
+      bg_engine_launch(h, dv, ea, hash, false, st);
     }
     bg_ev_end(h, h->ev_rollout_t, (hipStream_t)stream);
     BG_HIP(hipGetLastError());
-    if (async) { // refill on the side stream, ordered after this chunk and after the previous refill
-      BG_HIP(hipEventRecord(h->ev_rollout, (hipStream_t)stream));
-      BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));
-      rc = bg_wait_refill(h, h->side, 0);
-      if (rc) return rc;
-      rc = bg_refill_on(h, h->side);
-    } else rc = bg_refill(h, stream);
-    if (rc) return rc;
+    h->steps_since_refill += chunk;
     done += chunk;
   }
   return 0;
