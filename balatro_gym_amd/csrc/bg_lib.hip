@@ -606,14 +606,13 @@ struct bg_handle {
   long refill_seq;       // refills launched so far; refill #i writes d_prod[i & 1]
   bool async_refill;     // BG_ASYNC_REFILL (default on): bg_rollout overlaps refill #i with rollout chunk i+1
   hipStream_t side, side2, side3; // side: overlapped refills; side2/3: the deck and block kernels of one refill run beside the shop kernel
-  hipEvent_t ev_scan, ev_deck, ev_gblk, ev_gblk2;
-  hipStream_t side4;     // the global-block kernel of a refill when it runs beside the seed-ring kernel instead of behind it
+  hipEvent_t ev_scan, ev_deck, ev_gblk;
   hipEvent_t ev_refill[2];
   hipEvent_t ev_rollout;
   std::vector<hipEvent_t> ev_rollout_t, ev_refill_t, ev_step_t; // start/stop pairs
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
   // tunables read ONCE per handle in bg_create (environment variables)
-  int refill_blocks, refill_blocks_shop, dev_skip_refill, gblk_first, gblk_own;
+  int refill_blocks, refill_blocks_shop, dev_skip_refill;
   uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_smask; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
 };
 
@@ -734,12 +733,12 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
   { // every tunable is read here, once per handle (a process may A/B two handles with different settings)
     auto geti = [](const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; };
     h->refill_blocks = geti("BG_REFILL_BLOCKS", 4096); h->refill_blocks_shop = geti("BG_REFILL_BLOCKS_SHOP", 0);
-    h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0); h->gblk_first = geti("BG_GBLK_FIRST", 0); h->gblk_own = geti("BG_GBLK_OWN", 0);
+    h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0);
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
     h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT);
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
   }
-  h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = h->ev_gblk2 = nullptr; h->side4 = nullptr;
+  h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
   h->ev_refill[0] = h->ev_refill[1] = nullptr; h->ev_rollout = nullptr;
   h->d_seeds = nullptr; h->d_mask = nullptr; h->d_jtab = nullptr; h->steps_since_refill = 0;
   memset(&h->dev, 0, sizeof(h->dev));
@@ -803,8 +802,6 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_scan, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_deck, hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_gblk, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_gblk2, hipEventDisableTiming);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&h->side4, hipStreamNonBlocking);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_refill[0], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_refill[1], hipEventDisableTiming);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_rollout, hipEventDisableTiming);
@@ -843,8 +840,6 @@ int bg_destroy(bg_handle* h) {
   if (h->ev_scan) (void)hipEventDestroy(h->ev_scan);
   if (h->ev_deck) (void)hipEventDestroy(h->ev_deck);
   if (h->ev_gblk) (void)hipEventDestroy(h->ev_gblk);
-  if (h->ev_gblk2) (void)hipEventDestroy(h->ev_gblk2);
-  if (h->side4) (void)hipStreamDestroy(h->side4);
   for (int i = 0; i < 2; i++) if (h->ev_refill[i]) (void)hipEventDestroy(h->ev_refill[i]);
   if (h->ev_rollout) (void)hipEventDestroy(h->ev_rollout);
   hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
@@ -908,35 +903,19 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   // beside a resident step-engine workgroup (only one SIMD per CU has free registers) -- the whole refill would wait for the engine
   hipLaunchKernelGGL(bg_refill_zero_kernel, dim3(1), dim3(BG_BLOCK), 0, s, d);
   hipLaunchKernelGGL(bg_refill_scan_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, d);
-  // The rollout kernel leaves no registers for a co-resident wave, so the refill runs in the gaps rollout workgroups leave
-  // when they retire: wide grids
-  // grid-stride over the compacted work lists: kernels of dependent chains want several waves per SIMD however few envs there are
+  // Grids of ONE-WAVE workgroups, grid-stride over the compacted work lists: they are placed beside the resident step-engine
+  // workgroups (bg_engine.h: one SIMD per CU and ~5 KB of LDS are left to them) or, with nothing else running, several per SIMD.
   const int dense = h->refill_blocks;
-  // the three kinds of work are independent once the lists exist: run them side by side (each is a few hundred
-  // latency-bound waves), join before the completion event
+  // the three kinds of work are independent once the lists exist: side by side on three streams, joined before the completion event
   BG_HIP(hipEventRecord(h->ev_scan, s));
   BG_HIP(hipStreamWaitEvent(h->side2, h->ev_scan, 0));
   BG_HIP(hipStreamWaitEvent(h->side3, h->ev_scan, 0));
   const int skip = h->dev_skip_refill; // development: contention experiments only (breaks the rings)
   const int dense_shop = h->refill_blocks_shop > 0 ? h->refill_blocks_shop : dense;
-  if (!(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d);
+  if (!(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d);            // ALU-bound, lowest-priority stream
   if (!(skip & 2)) hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side2, d);
-  // side3: seed ring, then global blocks.  The global-block kernel would fit beside the rollout (114 VGPRs, no LDS) and
-  // queued first it is done early instead of ~100 us after the rollout -- but its HBM traffic beside the rollout costs the
-  // rollout more than the shorter gap saves (BG_GBLK_FIRST=1: -2..3 % measured), so it stays behind the seed-ring kernel.
-  const int gblk_first = h->gblk_first;
-  if (gblk_first && !(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
   if (!(skip & 4)) hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
-  // development: the global blocks side by side with the seed ring on a stream of their own (BG_GBLK_OWN=1: no change measured)
-  const int gblk_own = h->gblk_own;
-  if (!gblk_first && !(skip & 8)) {
-    if (gblk_own) {
-      BG_HIP(hipStreamWaitEvent(h->side4, h->ev_scan, 0));
-      hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side4, d);
-      BG_HIP(hipEventRecord(h->ev_gblk2, h->side4));
-      BG_HIP(hipStreamWaitEvent(s, h->ev_gblk2, 0));
-    } else hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
-  }
+  if (!(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
   BG_HIP(hipEventRecord(h->ev_deck, h->side2));
   BG_HIP(hipEventRecord(h->ev_gblk, h->side3));
   BG_HIP(hipStreamWaitEvent(s, h->ev_deck, 0));

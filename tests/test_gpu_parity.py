@@ -412,13 +412,13 @@ def test_inject_consumables_needs_card_states():
     env.close()
 
 
-def test_wide_workgroup_rollout_kernel(monkeypatch):
-    """The service-wave kernel with 256 envs per workgroup (the default from 65 536 envs on: four env waves, two play waves and
-    two other waves that share the queues) at a small env count, incl. a last workgroup that is not full: same bits."""
-    monkeypatch.setenv("BG_WG_ENVS", "256")
-    test_fused_rollout_vs_oracle(2, True)
+def test_service_wave_masks(monkeypatch):
+    """The step engine with other waves made service-capable (BG_ENG_SMASK: waves 0, 1, 2 and 5 instead of 3..6) and with three
+    instead of four of them: which waves own the RNG windows must not change a bit."""
+    for mask in ("39", "112"):
+        monkeypatch.setenv("BG_ENG_SMASK", mask)
+        test_fused_rollout_vs_oracle(2, True)
     test_consumables_rollout_vs_oracle(True)
-    test_immolate_cryptid_rollout_vs_oracle()
 
 
 @pytest.mark.parametrize("config", ["configs2_jokers_antes_1_4", "configs4_full_game_curriculum"])
