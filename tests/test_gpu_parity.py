@@ -263,6 +263,44 @@ def test_fused_rollout_shallow_rings(monkeypatch, rings, async_refill):
     test_fused_rollout_vs_oracle(2, True)
 
 
+@pytest.mark.parametrize("rings,async_refill", [("default", "1"), ("8,13,12", "1"), ("8,13,12", "0")])
+def test_many_short_launches_vs_oracle(monkeypatch, rings, async_refill):
+    """The same 120 steps as MANY short launches (7, 1, 20, 13, ... fused steps per bg_rollout_rows call): the look-ahead rings are
+    topped up lazily -- only when the steps launched since the last refill could exhaust them, by a refill that runs beside the
+    launch that needs it -- so most launches run without one.  Every record byte against the oracle, with deep and shallow rings."""
+    from balatro_gym_amd.vec_env import RowBuffers
+    from oracle.gen_golden import IMPLEMENTED
+    if rings != "default":
+        kg, ks, kd = rings.split(",")
+        monkeypatch.setenv("BG_KG", kg); monkeypatch.setenv("BG_KS", ks); monkeypatch.setenv("BG_KD", kd)
+    monkeypatch.setenv("BG_ASYNC_REFILL", async_refill)
+    n, T = 300, 120
+    seeds = [91_000 + 7 * i for i in range(n)]
+    jokers = [random.Random(3000 + i).sample(IMPLEMENTED, 5) for i in range(n)]
+    env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4)
+    env.inject(jokers=jokers, apply_now=True)
+    rb = RowBuffers(n, env.device, steps=T)
+    sizes, done, k = [7, 1, 20, 13, 2, 30, 5, 17, 25], 0, 0
+    while done < T:
+        c = min(sizes[k % len(sizes)], T - done)
+        part = RowBuffers.__new__(RowBuffers)  # a window of c rows of the same byte tensor
+        part.n, part.steps, part.rows = n, c, rb.rows[done:done + c]
+        env.rollout(c, policy=2, policy_seed=31, env_index0=9, t0=done, obs_buffers=part, zero_stats=(done == 0))
+        done += c; k += 1
+    env.check()
+    got_stats = env.stats()
+    wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, T, 2, 31, True, 4, jokers, env_index0=9, t0=0)
+    assert np.array_equal(rb.action.cpu().numpy(), wa)
+    assert np.array_equal(rb.terminated.cpu().numpy(), wt)
+    assert np.array_equal(rb.reward.contiguous().cpu().numpy().view(np.uint64), wr.view(np.uint64))
+    for k in OBS_KEYS:
+        g = rb.tensors[k].contiguous().cpu().numpy()
+        assert np.array_equal(g, wobs[k]), f"record key {k} differs"
+    for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
+        assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
+    env.close()
+
+
 @pytest.mark.parametrize("policy,scorer,n", [(0, False, 256), (2, True, 256), (2, True, 200), (0, True, 77)])
 def test_packed_record_rollout_vs_oracle(policy, scorer, n):
     """bg_rollout_rows: one 352-byte record per (step, env); every key, the reward, the action and the terminated flag
