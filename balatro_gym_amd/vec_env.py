@@ -113,6 +113,9 @@ class BalatroVecEnv:
             self._info_ptrs = nat.InfoPtrs(**{k: (self.info[k].data_ptr() if k in self.info else None)
                                               for k in nat.INFO_KEYS})
             self._stats = torch.zeros(6, dtype=torch.int64, device=dev)
+        # the constant arguments of bg_step, converted once
+        self._step_args = (C.byref(self._obs.ptrs), C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.terminated.data_ptr()),
+                           C.c_void_p(self.truncated.data_ptr()), C.byref(self._info_ptrs))
         self.seed(seeds)
         self.reset()
 
@@ -186,12 +189,14 @@ class BalatroVecEnv:
         """One lockstep `step(action)` (balatro_env_2.py:616).  actions: int32 [N] on this device."""
         if actions.dtype != torch.int32 or actions.device != self.device or not actions.is_contiguous():
             actions = actions.to(device=self.device, dtype=torch.int32).contiguous()
-        with torch.cuda.device(self.device):
-            self._check(self._L.bg_step(self._h, C.c_void_p(actions.data_ptr()), C.byref(self._obs.ptrs),
-                                        C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.terminated.data_ptr()),
-                                        C.c_void_p(self.truncated.data_ptr()), C.byref(self._info_ptrs),
-                                        self._stream()), "bg_step")
-        return self.obs, self.reward, self.terminated, self.truncated, self.info
+        # (no torch.cuda.device() context: every entry point of the library switches to the handle's device itself, and a step is
+        #  short enough for two extra hipSetDevice calls and seven ctypes conversions to show)
+        a = self._step_args
+        rc = self._L.bg_step(self._h, actions.data_ptr(), a[0], a[1], a[2], a[3], a[4],
+                             torch.cuda.current_stream(self.device).cuda_stream)
+        if rc != 0:
+            self._check(rc, "bg_step")
+        return self._obs.tensors, self.reward, self.terminated, self.truncated, self.info
 
     def step_many(self, actions: torch.Tensor, obs_buffers: Optional["ObsBuffers"] = None, reward: Optional[torch.Tensor] = None,
                   terminated: Optional[torch.Tensor] = None):
