@@ -322,7 +322,11 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, 2) void bg_engine_kernel(BgDe
         for (int k = 0; k < 4; k++) v[k] = s_img[ce[k].l & (NE - 1)][cpc[k]];
 #pragma unroll
         for (int k = 0; k < 4; k++)
-          if (q0 + (uint32_t)k * BG_BLOCK < total) *(__attribute__((address_space(1))) bg_u32x4*)(ce[k].row + 16ull * cpc[k]) = v[k];
+          // NON-TEMPORAL stores: the records are a write-once stream (2 TB/s) nothing on the GPU reads back; written through the L2
+          // as ordinary stores they evicted the env state, the RNG rings and the shop streams every service step reads, and every
+          // such read became a trip to HBM (+15 % env-steps/s with the `nt` bit, same box)
+          if (q0 + (uint32_t)k * BG_BLOCK < total)
+            __builtin_nontemporal_store(v[k], (__attribute__((address_space(1))) bg_u32x4*)(ce[k].row + 16ull * cpc[k]));
       }
       BG_WAVE_SYNC();
 #ifdef BG_TIMING4
