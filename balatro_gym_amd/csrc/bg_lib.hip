@@ -500,7 +500,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_gblk_kernel(BgDev d) {
     {
       const uint32_t* src = bg_gblock(d, env, last);
 #pragma unroll
-      for (int r = 0; r < NR; r++) o[r] = (64 * r + l < BG_MT_N) ? src[64 * r + l] : 0u;
+      for (int r = 0; r < NR; r++) o[r] = (64 * r + l < BG_MT_N) ? __builtin_nontemporal_load(&src[64 * r + l]) : 0u; // read once
       o[NR] = 0u;
     }
 #pragma unroll 1
@@ -527,7 +527,9 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_gblk_kernel(BgDev d) {
           if (k >= BG_MT_N - BG_MT_M) far = fn;
         }
         n[r] = bg_twist(o[r], up, far);
-        if (k < BG_MT_N) dst[k] = n[r];
+        // non-temporal: whole 256-byte rows (full lines, nothing for the L2 to combine) that are read a launch later -- kept out of the
+        // L2 the step engine beside this kernel is working from
+        if (k < BG_MT_N) __builtin_nontemporal_store(n[r], &dst[k]);
       }
       // the 16 spare words behind a block mirror the head of its successor: a 16-word read never has to change blocks
       if (l < 16) bg_gblock(d, env, last)[BG_MT_N + l] = n[0];
