@@ -53,9 +53,13 @@ class RowBuffers:
     same byte tensor (`tensors[key]`, `reward`, `action`, `terminated`); `.contiguous()` gives the dense per-key array.
     """
 
-    def __init__(self, n: int, device: torch.device, steps: int = 1):
+    def __init__(self, n: int, device: torch.device, steps: int = 1, row_stride: int = 0):
+        """row_stride: bytes from one record to the next (a multiple of 16, >= 352; 0 = 352, densely packed)."""
         self.n, self.steps = n, steps
-        self.rows = torch.zeros((steps, n, nat.ROW_BYTES), dtype=torch.uint8, device=device)
+        self.row_stride = int(row_stride) or nat.ROW_BYTES
+        if self.row_stride < nat.ROW_BYTES or self.row_stride % 16:
+            raise ValueError("row_stride must be a multiple of 16 and >= the 352-byte record")
+        self.rows = torch.zeros((steps, n, self.row_stride), dtype=torch.uint8, device=device)
         self.tensors: Dict[str, torch.Tensor] = {}
         for k in nat.OBS_KEYS:
             dt, shape = nat.OBS_SPEC[k]
@@ -244,7 +248,7 @@ class BalatroVecEnv:
             with torch.cuda.device(self.device):
                 self._check(self._L.bg_rollout_rows(
                     self._h, int(steps), int(policy), C.c_uint64(policy_seed), C.c_uint64(env_index0), C.c_uint64(t0),
-                    C.c_void_p(obs_buffers.rows.data_ptr()), C.c_uint64(nat.ROW_BYTES), 1 if obs_buffers.steps > 1 else 0,
+                    C.c_void_p(obs_buffers.rows.data_ptr()), C.c_uint64(getattr(obs_buffers, "row_stride", nat.ROW_BYTES)), 1 if obs_buffers.steps > 1 else 0,
                     C.c_void_p(self._stats.data_ptr()), self._stream()), "bg_rollout_rows")
             return self._stats
         ob = obs_buffers or self._obs

@@ -142,6 +142,7 @@ def main():
     ap.add_argument("--obs-layout", choices=["rows", "keys"], default="rows",
                     help="rows: one packed 352-byte record per (step, env) (bg_rollout_rows); keys: one array per key")
     ap.add_argument("--internal-warmup-s", type=float, default=0.5, help="untimed full-depth launches before --warmup")
+    ap.add_argument("--row-stride", type=int, default=0, help="bytes between packed records (0 = 352, dense)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-path", action="store_true", help="skip the bg_step / bg_step_many sample")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the RCCL all_gather of the current observation out")
@@ -179,7 +180,7 @@ def main():
     chunk = args.chunk or int(os.environ.get("BG_BENCH_CHUNK", "0")) or min(372, env.max_fused_steps)
     ob = None
     if args.keep_obs and chunk > 1:
-        ob = (RowBuffers if args.obs_layout == "rows" else ObsBuffers)(n, dev, steps=chunk)
+        ob = RowBuffers(n, dev, steps=chunk, row_stride=args.row_stride) if args.obs_layout == "rows" else ObsBuffers(n, dev, steps=chunk)
 
     # the design's one collective: all_gather of the CURRENT observation record of every env, once per launch, on a side
     # stream so that it runs beside the next launch (what a central evaluator / logger sees; learners train on their own shard)

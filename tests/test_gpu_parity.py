@@ -301,6 +301,26 @@ def test_many_short_launches_vs_oracle(monkeypatch, rings, async_refill):
     env.close()
 
 
+def test_packed_records_padded_stride():
+    """bg_rollout_rows with a record stride of 384 bytes (line-aligned records): the same 352 bytes per record as the dense
+    layout, the 32 bytes behind each record untouched."""
+    import torch
+    from balatro_gym_amd.vec_env import RowBuffers
+    n, T = 300, 40
+    seeds = [5_000 + i for i in range(n)]
+    outs = []
+    for stride in (0, 384):
+        env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4)
+        rb = RowBuffers(n, env.device, steps=T, row_stride=stride)
+        rb.rows.fill_(0xAB)
+        env.rollout(T, policy=2, policy_seed=5, obs_buffers=rb)
+        env.check()
+        outs.append(rb.rows.cpu().numpy())
+        env.close()
+    assert outs[1].shape[-1] == 384 and np.array_equal(outs[0], outs[1][:, :, :352])
+    assert (outs[1][:, :, 352:] == 0xAB).all()
+
+
 @pytest.mark.parametrize("policy,scorer,n", [(0, False, 256), (2, True, 256), (2, True, 200), (0, True, 77)])
 def test_packed_record_rollout_vs_oracle(policy, scorer, n):
     """bg_rollout_rows: one 352-byte record per (step, env); every key, the reward, the action and the terminated flag
