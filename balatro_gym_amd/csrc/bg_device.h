@@ -48,7 +48,7 @@ struct BgDev {
   uint4* tmpl;
   uint4* ndeck;
   uint32_t* gblk;
-  uint32_t* sblk;     // [N][KS][288] compact seeded shop streams (BG_SW_*)
+  uint32_t* sblk;     // [N][KS][BG_SLOT_WORDS] compact seeded shop streams (BG_SW_*)
   uint32_t* sovf;     // [N][640] full seeded state of a shop stream that was read beyond its slot (rare)
   uint32_t* deckmt;
   uint32_t* shopgenmt;
@@ -202,14 +202,19 @@ __device__ __forceinline__ int bg_level(const Env& e, int ht) { return (int)((e.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t* bg_gblock(const BgDev& d, int env, int slot) { return d.gblk + ((size_t)env * d.KG + slot) * BG_MTS; }
 // A shop-stream ring slot keeps only the part of the seeded state S a visit reads: word k of the first output block needs
-// S[k], S[k+1] and S[k+397] (k < 227), and a visit reads ~10 words per inventory -- so words 0..131 and 396..527 (k <= 130:
-// a dozen inventories) plus the seed, 1.1 KB instead of 2.5 KB.  The refill's shop kernel is bound by these writes.  A visit
-// that reads further re-seeds the FULL state into the env's overflow block once (bg_shop_overflow) and carries on there.
-#define BG_SW_A 132                // words 0..131 of S
-#define BG_SW_F (BG_MT_M - 1)      // 396: first word of the far window (396..527)
+// S[k], S[k+1] and S[k+397] (k < 227), and an inventory reads ~13 words -- so words 0..BG_SW_A-1 and 396..396+BG_SW_A-1 plus the
+// seed.  BG_SW_A = 68 (k <= 66: four or five inventories, i.e. a visit with three or four rerolls) makes a slot 576 bytes instead
+// of the state's 2.5 KB: the refill's shop kernel, the ring's footprint (KS x 576 B per env) and what the refill pushes through
+// the L2 beside the step engine all scale with it (132 words per window = 1 152 B was round 1's choice).  A visit that reads
+// further re-seeds the FULL state into the env's overflow block once (bg_shop_overflow) and carries on there.
+#ifndef BG_SW_A
+#define BG_SW_A 68                 // words 0..BG_SW_A-1 of S (a multiple of 4, >= 28: bg_swin_fill0 reads 7 groups of each window)
+#endif
+#define BG_SW_F (BG_MT_M - 1)      // 396: first word of the far window
 #define BG_SW_SEED (2 * BG_SW_A)   // slot word holding the seed
-#define BG_SLOT_WORDS 288          // 264 + seed, padded to 9 x 128 B
-#define BG_S_FASTMAX 130           // largest k whose operands all sit in the slot
+#define BG_SLOT_WORDS ((2 * BG_SW_A + 1 + 7) / 8 * 8) // both windows + the seed, rounded up to 32 bytes
+#define BG_S_FASTMAX (BG_SW_A - 2) // largest k whose operands all sit in the slot
+static_assert(BG_SW_A % 4 == 0 && BG_SW_A >= 28 && BG_SW_A <= 132, "shop slot window");
 #define BG_BF_SHOP_OVF 4           // bflags: the current shop stream lives in the overflow block (full state)
 __device__ __forceinline__ uint32_t* bg_sblock(const BgDev& d, int env, int slot) { return d.sblk + ((size_t)env * d.KS + slot) * BG_SLOT_WORDS; }
 __device__ __forceinline__ uint32_t* bg_sovf(const BgDev& d, int env) { return d.sovf + (size_t)env * BG_MTS; }
@@ -542,7 +547,7 @@ __device__ __forceinline__ void bg_swin_fill(lds_u32* lds, const uint32_t* S, bo
 __device__ __forceinline__ void bg_sprefetch(const BgDev& d, int env, Env& e, RngWin& w, int count) {
   bool full;
   const uint32_t* S = bg_sbase(d, env, e, full);
-  // stay where every operand is a stored seeded word: k <= 130 in the slot, k < 227 in the full state
+  // stay where every operand is a stored seeded word: k <= BG_S_FASTMAX in the slot, k < 227 in the full state
   int len = (full ? (BG_MT_N - BG_MT_M) : (BG_S_FASTMAX + 1)) - e.s_idx;
   if (len > count) len = count;
   if (len > 24) len = 24;

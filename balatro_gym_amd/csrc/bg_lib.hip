@@ -1339,7 +1339,7 @@ uint64_t bg_state_blob_bytes(const bg_handle* h) {
   return b;
 }
 #define BG_BLOB_MAGIC 0x42474d58u
-#define BG_BLOB_VERSION 4u // 4: the curriculum cap in the hot state, card-state flag in the header; 3: compact shop-stream slots + overflow block; 2: stream 13 ('seal_applications') joins the card-state slices, consumables in the reset template
+#define BG_BLOB_VERSION 5u // 5: 576-byte shop-stream slots; 4: the curriculum cap in the hot state, card-state flag in the header; 3: compact shop-stream slots + overflow block; 2: stream 13 ('seal_applications') joins the card-state slices, consumables in the reset template
 // what is wrong with a blob handed to bg_set_state (or with the buffer handed to bg_get_state), as text
 static int bg_blob_args(bg_handle* h, const char* fn, int env_index, const void* blob, uint64_t blob_bytes) {
   if (!h) return BG_E_ARG;
