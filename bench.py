@@ -146,6 +146,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-path", action="store_true", help="skip the bg_step / bg_step_many sample")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the RCCL all_gather of the current observation out")
+    ap.add_argument("--force-gather", action="store_true", help="N = 1: run the gather path anyway (a one-rank RCCL group; exercises the N > 1 code on a one-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -157,8 +158,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
+    use_dist = world > 1 or args.force_gather
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=world)
@@ -184,9 +187,10 @@ def main():
 
     # the design's one collective: all_gather of the CURRENT observation record of every env, once per launch, on a side
     # stream so that it runs beside the next launch (what a central evaluator / logger sees; learners train on their own shard)
-    do_gather = world > 1 and not args.no_gather and isinstance(ob, RowBuffers)
+    do_gather = use_dist and not args.no_gather and isinstance(ob, RowBuffers)
     gather_stream = torch.cuda.Stream(device=dev) if do_gather else None
-    gathered = torch.empty((world, n, ob.rows.shape[-1]), dtype=torch.uint8, device=dev) if do_gather else None
+    staging = torch.empty((n, 352), dtype=torch.uint8, device=dev) if do_gather else None
+    gathered = torch.empty((world, n, 352), dtype=torch.uint8, device=dev) if do_gather else None
     gather_bytes = 0
 
     def run(nsteps, t0):
@@ -197,10 +201,15 @@ def main():
             env.rollout(c, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, env_index0=lo, t0=t0 + done,
                         obs_buffers=ob, zero_stats=False)  # a shorter last call fills the first c rows
             if do_gather:
-                gather_stream.wait_stream(torch.cuda.current_stream(dev))
+                # the launch's last record row -> a staging copy (23 MB, on the launch stream), gathered from there on the side stream
+                # beside the NEXT launch, which is free to overwrite the rows; the staging copy waits for the previous gather
+                cur = torch.cuda.current_stream(dev)
+                cur.wait_stream(gather_stream)
+                staging.copy_(ob.rows[c - 1][:, :staging.shape[1]])
+                gather_stream.wait_stream(cur)
                 with torch.cuda.stream(gather_stream):
-                    dist.all_gather_into_tensor(gathered.view(-1), ob.rows[c - 1].reshape(-1))
-                gather_bytes += ob.rows[c - 1].numel()
+                    dist.all_gather_into_tensor(gathered.view(-1), staging.view(-1))
+                gather_bytes += staging.numel()
             done += c
         if do_gather:
             torch.cuda.current_stream(dev).wait_stream(gather_stream)
@@ -285,7 +294,7 @@ def main():
             "episodes": int(agg[1].item()), "accepted_plays": int(agg[2].item()),
             "state_bytes_per_gpu": env.state_bytes(),
         }
-        if world > 1:
+        if use_dist:
             out["gather"] = {"in_timed_region": bool(do_gather), "what": "all_gather_into_tensor of the current 352-byte record of every env, once per launch, side stream",
                              "bytes_per_gpu_per_launch": (gather_bytes // max(1, launches)) if do_gather else 0}
     env.close()
@@ -339,8 +348,14 @@ def main():
             out["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": threads, "kind": "port",
                                    "sample": f"{n_cpu} envs x {t_cpu} steps of the same workload on the C oracle "
                                              f"(oracle/balatro_oracle.c), {threads} threads, {dt:.1f} s"}
+        # RCCL prints a version banner through C stdio on rank 0; flush it first so that the JSON line is the LAST line of stdout
+        try:
+            C.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
