@@ -189,27 +189,36 @@ def main():
     # stream so that it runs beside the next launch (what a central evaluator / logger sees; learners train on their own shard)
     do_gather = use_dist and not args.no_gather and isinstance(ob, RowBuffers)
     gather_stream = torch.cuda.Stream(device=dev) if do_gather else None
-    staging = torch.empty((n, 352), dtype=torch.uint8, device=dev) if do_gather else None
+    # N > 1: the launch's last record row of every shard is gathered (RCCL all_gather) on a side stream beside the NEXT launch.  Two
+    # record buffers alternate, so the next launch never writes what the gather is still reading; a buffer is reused only after the
+    # gather that read it (two launches earlier) has completed.  (RCCL's workgroups are multi-wave: they cannot be placed beside
+    # a resident step-engine workgroup, so the gather really runs in the tail of the launch it is queued behind.)
     gathered = torch.empty((world, n, 352), dtype=torch.uint8, device=dev) if do_gather else None
+    bufs = [ob, RowBuffers(n, dev, steps=chunk, row_stride=args.row_stride)] if do_gather else [ob]
+    gather_done = [None] * len(bufs)
+    launch_no = 0
     gather_bytes = 0
 
     def run(nsteps, t0):
-        nonlocal gather_bytes
+        nonlocal gather_bytes, launch_no
         done = 0
         while done < nsteps:
             c = min(chunk, nsteps - done)
+            b = launch_no % len(bufs)
+            cur = torch.cuda.current_stream(dev)
+            if gather_done[b] is not None:
+                cur.wait_event(gather_done[b])
             env.rollout(c, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, env_index0=lo, t0=t0 + done,
-                        obs_buffers=ob, zero_stats=False)  # a shorter last call fills the first c rows
+                        obs_buffers=bufs[b], zero_stats=False)  # a shorter last call fills the first c rows
             if do_gather:
-                # the launch's last record row -> a staging copy (23 MB, on the launch stream), gathered from there on the side stream
-                # beside the NEXT launch, which is free to overwrite the rows; the staging copy waits for the previous gather
-                cur = torch.cuda.current_stream(dev)
-                cur.wait_stream(gather_stream)
-                staging.copy_(ob.rows[c - 1][:, :staging.shape[1]])
                 gather_stream.wait_stream(cur)
                 with torch.cuda.stream(gather_stream):
-                    dist.all_gather_into_tensor(gathered.view(-1), staging.view(-1))
-                gather_bytes += staging.numel()
+                    dist.all_gather_into_tensor(gathered.view(-1), bufs[b].rows[c - 1][:, :352].reshape(-1))
+                    ev = torch.cuda.Event()
+                    ev.record(gather_stream)
+                gather_done[b] = ev
+                gather_bytes += n * 352
+            launch_no += 1
             done += c
         if do_gather:
             torch.cuda.current_stream(dev).wait_stream(gather_stream)
@@ -298,7 +307,7 @@ def main():
             out["gather"] = {"in_timed_region": bool(do_gather), "what": "all_gather_into_tensor of the current 352-byte record of every env, once per launch, side stream",
                              "bytes_per_gpu_per_launch": (gather_bytes // max(1, launches)) if do_gather else 0}
     env.close()
-    del ob
+    del ob, bufs
 
     if rank == 0 and world == 1 and not args.no_step_path:
         # ---- the Gymnasium-surface path: bg_step with actions from a device tensor (recorded from a fused rollout of a twin
