@@ -40,6 +40,9 @@
 #ifndef BG_ENG_NW
 #define BG_ENG_NW 7
 #endif
+#ifndef BG_ENG_OCC
+#define BG_ENG_OCC 2     // waves per SIMD the register budget is set for (2 = 256 VGPRs; 3 = 168: measured, spills)
+#endif
 #define BG_ENG_NSV 4    // of them, how many own an RNG window and may run service batches
 #define BG_ENG_SMASK_DEFAULT (((1u << BG_ENG_NSV) - 1u) << (BG_ENG_NW - BG_ENG_NSV)) // which: the last NSV waves (BG_ENG_SMASK)
 
@@ -75,7 +78,7 @@ struct CopyEnt { uint32_t l, pad; unsigned long long row; }; // one finished env
 
 // INFO: the launch serves bg_step / bg_step_many (per-step info arrays); false for the rollouts
 template <bool HASH, bool CARDS, bool INFO>
-__global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, 2) void bg_engine_kernel(BgDev d, EngineArgs a) {
+__global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_kernel(BgDev d, EngineArgs a) {
   constexpr int NE = BG_ENG_NE, NW = BG_ENG_NW, NSV = BG_ENG_NSV;
   __shared__ bg_u32x4 s_img[NE][22];          // record images (88 KB)
   __shared__ uint4 s_c34[2][NE];              // hot chunks 3 and 4
