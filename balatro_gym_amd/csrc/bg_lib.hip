@@ -606,6 +606,7 @@ struct bg_handle {
   // refill pipeline: double-buffered producer counters, a side stream and per-parity completion events
   uint32_t* d_prod[2];
   long refill_seq;       // refills launched so far; refill #i writes d_prod[i & 1]
+  long view_min;         // index of the last SYNCHRONOUS refill: no launch may read producer counters older than its
   bool async_refill;     // BG_ASYNC_REFILL (default on): bg_rollout overlaps refill #i with rollout chunk i+1
   hipStream_t side, side2, side3; // side: overlapped refills; side2/3: the deck and block kernels of one refill run beside the shop kernel
   hipEvent_t ev_scan, ev_deck, ev_gblk;
@@ -740,7 +741,7 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT);
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
   }
-  h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
+  h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->view_min = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
   h->ev_refill[0] = h->ev_refill[1] = nullptr; h->ev_rollout = nullptr;
   h->d_seeds = nullptr; h->d_mask = nullptr; h->d_jtab = nullptr; h->steps_since_refill = 0;
   memset(&h->dev, 0, sizeof(h->dev));
@@ -937,7 +938,9 @@ int bg_refill(bg_handle* h, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   int rc = bg_wait_refill(h, s, 0); // the previous refill may still be running on the side stream
   if (rc) return rc;
-  return bg_refill_on(h, s);
+  rc = bg_refill_on(h, s);
+  h->view_min = h->refill_seq - 1;
+  return rc;
 }
 
 int bg_check(bg_handle* h, void* stream) {
@@ -1139,9 +1142,6 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
     if (off) bg_obs_advance(o, off);
     if (h->profiling) h->rollout_steps.push_back(chunk);
     const bool need = h->steps_since_refill + chunk > max_chunk;
-    rc = bg_wait_refill(h, (hipStream_t)stream, 0); // the latest refill launched so far: the one whose producer counters this chunk reads
-    if (rc) return rc;
-    const uint32_t* view = bg_prod_latest(h);
     if (need && async) { // R beside this chunk: after everything on the stream so far (the previous launches) and after the latest refill
       BG_HIP(hipEventRecord(h->ev_rollout, (hipStream_t)stream));
       BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));
@@ -1152,8 +1152,15 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
     } else if (need) {
       rc = bg_refill(h, stream);
       if (rc) return rc;
-      view = bg_prod_latest(h);
     }
+    // Which producer counters the chunk reads.  Overlapped: those of the refill BEFORE the latest one -- the latest may still be
+    // running (beside this chunk, or beside an earlier short one), and against the one before it this chunk has consumed at most
+    // (steps between the two refills <= B) + u + chunk <= 2 B.  Never one older than the last SYNCHRONOUS refill (bg_reset, bg_step,
+    // ...: the steps before those are not bounded by B).  Synchronous: the latest.
+    long vi = h->refill_seq - 1;
+    if (async && vi - 1 >= h->view_min) vi--;
+    if (vi >= 0) BG_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_refill[vi & 1], 0));
+    const uint32_t* view = vi >= 0 ? h->d_prod[vi & 1] : bg_prod_latest(h);
     bg_ev_begin(h, h->ev_rollout_t, (hipStream_t)stream); // after the waits: the events bracket the kernel, not the stream's wait for the refill
     BgDev dv = bg_dev_view(h, view);
     {
