@@ -112,7 +112,7 @@ def measured_copy_gbps(dev):
     return float(g.value), float(gw.value)
 
 
-KERNEL_BUILD = "7 waves x 256 envs per workgroup, nt record stores"   # tools/hbm_traffic.py stamps the measurements it writes with the same string
+KERNEL_BUILD = "7 worker waves (6 / 4 for short launches) x 256 envs per workgroup, nt record stores"   # tools/hbm_traffic.py stamps the measurements it writes with the same string
 
 
 def matching_traffic(kernel: str, n: int, fused: float):

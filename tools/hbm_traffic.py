@@ -8,7 +8,7 @@ import csv, json, sys
 
 
 KERNELS = ("bg_engine_kernel",)  # the step engine
-KERNEL_BUILD = "7 waves x 256 envs per workgroup, nt record stores"  # bench.py only uses a measurement of the kernel shape it runs (KERNEL_BUILD there)
+KERNEL_BUILD = "7 worker waves (6 / 4 for short launches) x 256 envs per workgroup, nt record stores"  # bench.py only uses a measurement of the kernel shape it runs (KERNEL_BUILD there)
 
 
 def mean_counter(path, counter):
