@@ -291,6 +291,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
+                         # the bytes the HBM really moved per second during a launch (PMC traffic / launch time), when known
+                         "traffic_gbps": traffic[0] / mean_launch_s / 1e9 if (traffic and mean_launch_s > 0) else None,
+                         "traffic_frac_of_measured": traffic[0] / mean_launch_s / 1e9 / peak_measured if (traffic and mean_launch_s > 0 and peak_measured) else None,
                          "peak_measured": peak_measured, "frac_of_measured": achieved / peak_measured if peak_measured else None,
                          # stores only: the records + the state written back, against a plain fill kernel on this GPU
                          "write_gbps": write_gbps, "peak_measured_write": peak_write, "write_frac_of_measured": write_gbps / peak_write if peak_write else None,
