@@ -204,20 +204,25 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_score_hand_batch_l8_kernel(BgDev 
     const ChainJ cj = bg_chain_joker(w.jt->jd[id], w.jt->jr[id], in.phist, in.scnt);
     const int ic = bg_g8_sum<int>(cj.ic), im = bg_g8_sum<int>(cj.im);
     int xexp = bg_g8_sum<int>(cj.xexp);
-    const int j8 = bg_g8_max(cj.sp == 1u ? g : -1), jb = bg_g8_max(cj.sp == 2u ? g : -1);
+    const uint32_t m8 = bg_g8_or(cj.sp == 1u ? 1u << g : 0u), mb = bg_g8_or(cj.sp == 2u ? 1u << g : 0u); // slots with an 8 Ball / a Bloodstone
     money += bg_g8_sum<int>(id == 116 ? (int)((in.scnt >> 4) & 0xfu) : 0);             // Rough Gem: $1 per Diamond (:160)
     uint32_t dms[5];
 #pragma unroll
     for (int j = 0; j < 5; j++) dms[j] = w.jt->jm[j < nj ? (int)((e.jokers >> (8 * j)) & 0xff) : 0];
     bg_gnorm(d, e);
-    const int n8 = j8 >= 0 ? (int)((in.phist >> 32) & 0xf) : 0;                         // 8 Ball: one extra random() per played 8 (:167)
-    const int consumed = 2 * nsc * nj + 2 * n8;
-    // ---- lane = card: Bloodstone's word of this card
-    const bool blood = jb >= 0 && ((in.scnt >> 8) & 0xfu);
-    const uint32_t eightmask = bg_g8_or((sc && !st && rank == 8 && j8 >= 0) ? 1u << g : 0u);
-    const int boff = bg_chain_blood_off(g, code, st, nsc, nj, jb, j8, blood, __popc(eightmask & ((1u << g) - 1u)));
-    const uint32_t ra = boff >= 0 ? bg_gpeek(d, ci, e, boff) : 0x80000000u;
-    xexp += bg_g8_sum<int>((int)((ra >> 31) ^ 1u));
+    const int nb8 = __popc(m8);
+    const int n8 = nb8 ? (int)((in.phist >> 32) & 0xf) : 0;                             // 8 Ball: one extra random() per played 8 and 8 Ball (:167)
+    const int consumed = 2 * nsc * nj + 2 * n8 * nb8;
+    // ---- lane = card: the word of this card for every Bloodstone owned (uniform over the group: the shuffles stay converged)
+    const uint32_t eightmask = bg_g8_or((sc && !st && rank == 8 && nb8) ? 1u << g : 0u);
+    uint32_t mm = ((in.scnt >> 8) & 0xfu) ? mb : 0u;
+    while (mm) {
+      const int jb = __ffs((int)mm) - 1;
+      mm &= mm - 1u;
+      const int boff = bg_chain_blood_off(g, code, st, nsc, nj, jb, m8, nb8, true, __popc(eightmask & ((1u << g) - 1u)));
+      const uint32_t ra = boff >= 0 ? bg_gpeek(d, ci, e, boff) : 0x80000000u;
+      xexp += bg_g8_sum<int>((int)((ra >> 31) ^ 1u));
+    }
     uint32_t mw[12], avail = 0;
     bg_gpeek12(d, ci, e, consumed, mw, avail); // the same three 16-byte loads on all eight lanes (one request)
     bg_gskip(d, e, consumed);

@@ -472,10 +472,12 @@ __device__ __forceinline__ ChainJ bg_chain_joker(uint64_t dsc, uint64_t jr, uint
   return r;
 }
 // Bloodstone on a Heart: x2 iff the pair's random() < 0.5.  Pair (c, jb) sits 2*(c*nj + jb) words ahead of the cursor, plus 2
-// for every extra 8-Ball draw that precedes it in card-major order (`eights` = played 8s among cards 0..c-1).  -1: no word to read.
-__device__ __forceinline__ int bg_chain_blood_off(int c, int code, bool st, int n, int nj, int jb, int j8, bool blood, int eights) {
+// for every extra 8-Ball draw that precedes it in card-major, joker-minor order: `eights` played 8s among cards 0..c-1 times the
+// nb8 8-Ball jokers owned, plus -- when card c is an 8 itself -- the 8 Balls in the slots before jb (m8 = bit per 8-Ball slot).  An id
+// can be owned more than once (Ankh copies a joker), so both kinds are SETS of slots.  -1: no word to read.
+__device__ __forceinline__ int bg_chain_blood_off(int c, int code, bool st, int n, int nj, int jb, uint32_t m8, int nb8, bool blood, int eights) {
   const int rk = (code >> 2) + 2;
-  return (blood && c < n && !st && (code & 3) == 2) ? 2 * (c * nj + jb) + 2 * (eights + ((j8 >= 0 && j8 < jb && !st && rk == 8) ? 1 : 0)) : -1;
+  return (blood && c < n && !st && (code & 3) == 2) ? 2 * (c * nj + jb) + 2 * (eights * nb8 + ((!st && rk == 8) ? __popc(m8 & ((1u << jb) - 1u)) : 0)) : -1;
 }
 
 // unified_scoring.py:216-244 main phase, joker order; one randint(0, 23) per joker (mw = the 12 tempered words that follow the
@@ -571,7 +573,8 @@ __device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, 
   const int nj = e.njokers, n = in.n;
   const uint64_t phist = in.phist, pcodes = in.pcodes;
   const uint32_t scnt = in.scnt, stone = in.stone;
-  int ic = 0, im = 0, xexp = 0, j8 = -1, jb = -1;
+  int ic = 0, im = 0, xexp = 0;
+  uint32_t m8 = 0, mb = 0; // slots holding an 8 Ball / a Bloodstone (an id may be owned twice: Ankh)
   // all table reads first (independent LDS reads), then straight-line arithmetic per joker slot
   uint64_t jds[5], jrs[5];
   uint32_t dms[5];
@@ -583,44 +586,50 @@ __device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, 
 #pragma unroll
   for (int j = 0; j < 5; j++) {
     const ChainJ cj = bg_chain_joker(jds[j], jrs[j], phist, scnt);
-    if (cj.sp == 1u) j8 = j;
-    if (cj.sp == 2u) jb = j;
+    if (cj.sp == 1u) m8 |= 1u << j;
+    if (cj.sp == 2u) mb |= 1u << j;
     ic += cj.ic; im += cj.im; xexp += cj.xexp;
     if constexpr (GENERAL) if (j < nj && (int)((e.jokers >> (8 * j)) & 0xff) == 116) money += (int)((scnt >> 4) & 0xfu); // Rough Gem: $1 per Diamond (:160)
   }
   BG_PROBE(7);
   bg_gnorm(d, e);
-  int n8 = j8 >= 0 ? (int)((phist >> 32) & 0xf) : 0; // 8 Ball: one extra random() per played 8 (:167)
-  int consumed = 2 * n * nj + 2 * n8;
-  // Every RNG word the chain looks at is requested in ONE batch of independent loads: Bloodstone's two words per played
-  // Heart, and the 12 words that follow the individual phase's `consumed` (eagerly drawn, never looked at) words, where
-  // the main phase's randint draws will fall (5 accepted among 12 words fails once in ~3000 plays: then the loop).
-  const bool blood = jb >= 0 && ((scnt >> 8) & 0xfu);
-  int boff[8];
-  {
+  const int nb8 = __popc(m8);
+  const int n8 = nb8 ? (int)((phist >> 32) & 0xf) : 0; // 8 Ball: one extra random() per played 8 and per 8 Ball owned (:167)
+  int consumed = 2 * n * nj + 2 * n8 * nb8;
+  // Every RNG word the chain looks at is requested in ONE batch of independent loads per Bloodstone owned (one, practically
+  // always): its word per played Heart, and the 12 words that follow the individual phase's `consumed` (eagerly drawn, never
+  // looked at) words, where the main phase's randint draws will fall (5 accepted among 12 words fails once in ~3000 plays: then
+  // the loop).
+  // random() < 0.5 for random() = ((a >> 5) * 2**26 + (b >> 6)) / 2**53 is decided by the top bit of the FIRST word
+  // alone ((a >> 5) < 2**26), so one word per Heart is read and no float arithmetic is needed.
+  uint32_t mw[12];
+  uint32_t avail = 0; // main-phase words the ring already holds
+  uint32_t mm = ((scnt >> 8) & 0xfu) ? mb : 0u; // Bloodstones with a Heart to look at
+#pragma unroll 1
+  while (mm) {
+    const int jb = __ffs((int)mm) - 1;
+    mm &= mm - 1u;
+    int boff[8];
     int eights = 0;
 #pragma unroll
     for (int c = 0; c < 8; c++) {
       int code = (int)((pcodes >> (8 * c)) & 0xff);
       int rk = (code >> 2) + 2;
       const bool st = (stone >> c) & 1u; // a STONE card has no rank and no suit for the jokers
-      boff[c] = bg_chain_blood_off(c, code, st, n, nj, jb, j8, blood, eights);
-      if (c < n && j8 >= 0 && !st && rk == 8) eights++;
+      boff[c] = bg_chain_blood_off(c, code, st, n, nj, jb, m8, nb8, true, eights);
+      if (c < n && nb8 && !st && rk == 8) eights++;
     }
-  }
-  // random() < 0.5 for random() = ((a >> 5) * 2**26 + (b >> 6)) / 2**53 is decided by the top bit of the FIRST word
-  // alone ((a >> 5) < 2**26), so one word per Heart is read and no float arithmetic is needed.
-  uint32_t ra[8], mw[12];
-  uint32_t avail = 0; // main-phase words the ring already holds
+    uint32_t ra[8];
 #pragma unroll
-  for (int c = 0; c < 8; c++) { ra[c] = 0x80000000u; if (boff[c] >= 0) ra[c] = bg_gpeek(d, env, e, boff[c]); }
+    for (int c = 0; c < 8; c++) { ra[c] = 0x80000000u; if (boff[c] >= 0) ra[c] = bg_gpeek(d, env, e, boff[c]); }
+#pragma unroll
+    for (int c = 0; c < 8; c++) xexp += (int)((ra[c] >> 31) ^ 1u);
+  }
   if (pre && pre->ok && pre->skip == consumed) {
 #pragma unroll
     for (int i = 0; i < 12; i++) mw[i] = bg_temper(pre->mw[i]); // requested raw (the first use of a loaded value is the wait)
     avail = pre->avail;
   } else bg_gpeek12(d, env, e, consumed, mw, avail);
-#pragma unroll
-  for (int c = 0; c < 8; c++) xexp += (int)((ra[c] >> 31) ^ 1u);
   bg_gskip(d, e, consumed);
   chips += ic; mult += im;
   x_mult *= (double)(1ull << xexp);

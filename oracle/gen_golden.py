@@ -8,6 +8,7 @@ Files:
   F1 mt_streams.json   CPython random.Random known answers + shuffled decks from DeterministicRNG stream 0
   F2 classify.npz      random 1..8-card subsets -> BalatroGame._classify_hand; checksum over all C(52,5) hands
   F3 score_hand.json   UnifiedScorer.score_hand cases with joker NAME lists (operator-level joker chain)
+  F3b score_hand_dups.json  the same with REPEATED jokers (Ankh's copies): several Bloodstones / 8 Balls drawing per card
   F4 trace_<cfg>.npz   BalatroEnv traces under the counter-hash policy: actions, rewards, terminated, info and the
                        full observation after every step
   F6 sim_eval.npz      balatro_sim.BalatroSimulator: evaluate_hand (10 000 hands, with / without Four Fingers / Shortcut) and
@@ -101,6 +102,51 @@ def gen_classify():
     np.savez_compressed(os.path.join(GOLD, "classify.npz"), cards=cards, n=n, hand_type=ht,
                         all5_counts=counts, all5_crc32=np.uint32(zlib.crc32(bytes(types))))
     print("F2 classify.npz", N, "subsets; all5 counts", counts.tolist())
+
+
+def gen_score_hand_dups():
+    """F3b score_hand_dups.json: joker name lists WITH repeats (Ankh copies a joker: `state.jokers` then holds an id twice), dense in the
+    jokers that draw per card -- several Bloodstones, several 8 Balls, Triboulet, Rough Gem -- on hands full of Hearts and 8s."""
+    ref = rh.load_reference()
+    us, se, cje = ref["us"], ref["se"], ref["cje"]
+    names = {j.id: j.name for j in ref["jokers"].JOKER_LIBRARY}
+    ENV_NAMES = ["High Card", "One Pair", "Two Pair", "Three Kind", "Straight", "Flush", "Full House", "Four Kind",
+                 "Straight Flush", "Five Kind", "Flush House", "Flush Five"]
+    SUITS = ["Clubs", "Diamonds", "Hearts", "Spades", "Stone"]
+    pool = [117, 117, 26, 26, 147, 116, 1, 31, 3, 27, 72, 119]
+    r = random.Random(177)
+    cases = []
+    for i in range(1000):
+        ncards = r.randint(1, 8)
+        cards = []
+        for _ in range(ncards):
+            rank, suit = r.choice([8, 8, 8, 2, 12, 13, 14, 5]), r.choice([2, 2, 2, 0, 1, 3])
+            chips = 11 if rank == 14 else min(rank, 10)
+            if r.random() < 0.06:
+                rank, suit, chips = 0, 4, chips + 50
+            cards.append([rank, suit, chips])
+        nscoring = ncards if r.random() < 0.7 else r.randint(1, ncards)
+        ht, level = r.randrange(9), 1
+        jokers = [r.choice(pool) for _ in range(r.randint(2, 5))]
+        hands_left, discards_left, deck_len, gseed = r.randint(1, 4), r.randint(0, 3), 52, r.randrange(2 ** 32)
+        engine = se.ScoreEngine()
+        engine.set_hand_level(se.HandType(ht), level)
+        scorer = us.UnifiedScorer(engine, cje.CompleteJokerEffects())
+        objs = [type("Card", (), {"rank": c[0], "suit": SUITS[c[1]], "chip_value": (lambda v=c[2]: v)}) for c in cards]
+        ctx = us.ScoringContext(cards=objs, scoring_cards=objs[:nscoring], hand_type=se.HandType(ht), hand_type_name=ENV_NAMES[ht],
+                                game_state={"jokers": [names[j] for j in jokers], "hands_left": hands_left,
+                                            "discards_left": discards_left, "deck": [0] * deck_len, "money": 0})
+        random.seed(gseed)
+        score, bd = scorer.score_hand(ctx)
+        probe = random.getrandbits(32)
+        cases.append({"cards": cards, "nscoring": nscoring, "style": 0, "hand_type": ht, "level": level,
+                      "jokers": jokers, "hands_left": hands_left, "discards_left": discards_left,
+                      "deck_len": deck_len, "gseed": gseed, "score": int(score), "chips": int(bd["final_chips"]),
+                      "mult": int(bd["final_mult"]), "x_mult": float(bd["final_x_mult"]).hex(),
+                      "money": int(bd["money_gained"]), "probe": probe})
+    with open(os.path.join(GOLD, "score_hand_dups.json"), "w") as f:
+        json.dump(cases, f, separators=(",", ":"))
+    print("F3b score_hand_dups.json", len(cases), "cases,", sum(len(set(c["jokers"])) < len(c["jokers"]) for c in cases), "with a repeated joker")
 
 
 def gen_score_hand():
@@ -464,6 +510,8 @@ def main():
         gen_classify()
     if "score" in which:
         gen_score_hand()
+    if "score" in which or "score_dups" in which:
+        gen_score_hand_dups()
     if "traces" in which:
         gen_traces()
     if "consumables" in which:

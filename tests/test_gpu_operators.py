@@ -52,8 +52,8 @@ def test_classify_batch_all_five_card_hands(lanes):
     assert zlib.crc32(got.tobytes()) == int(g["all5_crc32"])
 
 
-def _score_cases():
-    cases = json.load(open(os.path.join(GOLD, "score_hand.json")))
+def _score_cases(fixture="score_hand.json"):
+    cases = json.load(open(os.path.join(GOLD, fixture)))
     rec = np.zeros((len(cases), 40), np.int32)
     for i, c in enumerate(cases):
         for k, (rank, suit, chips) in enumerate(c["cards"]):
@@ -64,6 +64,22 @@ def _score_cases():
         rec[i, 35], rec[i, 36], rec[i, 37] = c["hands_left"], c["discards_left"], c["deck_len"]
         rec[i, 38] = np.uint32(c["gseed"]).astype(np.int32)
     return cases, rec
+
+
+@LANES
+def test_score_hand_batch_repeated_jokers(lanes):
+    """1 000 reference cases whose joker lists hold an id more than once (Ankh's copies): two or three Bloodstones and 8 Balls each
+    draw per card, so their RNG words sit at offsets that depend on every other copy."""
+    import torch
+    from balatro_gym_amd import score_hand_batch
+    cases, rec = _score_cases("score_hand_dups.json")
+    out = score_hand_batch(torch.from_numpy(rec).to("cuda:0"), lanes_per_case=lanes).cpu().numpy()
+    for i, c in enumerate(cases):
+        ctx = f"case {i}: {c} -> {out[i].tolist()}"
+        assert out[i, 0] == c["score"] and out[i, 1] == c["chips"] and out[i, 2] == c["mult"], ctx
+        assert float(out[i, 3:4].view(np.float64)[0]).hex() == c["x_mult"], ctx
+        assert out[i, 4] == c["money"] and out[i, 6] == c["probe"], ctx
+    assert sum(len(set(c["jokers"])) < len(c["jokers"]) for c in cases) > 300
 
 
 @LANES
@@ -108,7 +124,8 @@ def test_score_hand_batch_vs_oracle_fresh_cases():
             cards.append((rank, suit, chips))
         nsc = ncards if r.random() < 0.6 else r.randint(1, ncards)
         style, ht, level = r.randrange(2), r.choice([0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 7, 7, 8, 9, 10, 11]), r.choice([1, 1, 2, 7, 15])
-        jokers = r.sample(range(1, 151), r.randint(1, 5)) if r.random() < 0.3 else \
+        jokers = [r.choice([117, 26, 147, 116, 1, 31, 27]) for _ in range(r.randint(2, 5))] if r.random() < 0.15 else \
+            r.sample(range(1, 151), r.randint(1, 5)) if r.random() < 0.3 else \
             r.sample([1, 136, 27, 38, 61, 16, 34, 108, 23, 22, 53, 97, 50, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 131, 132, 133,
                       134, 135, 48, 128, 122, 72, 140, 31, 39, 40, 41, 101, 124, 26, 33, 104, 147, 118, 119, 116, 117], r.randint(1, 5))
         hl, dl, deck_len, gseed = r.randint(1, 4), r.randint(0, 3), r.choice([52, 52, 40, 47, 60]), r.randrange(2 ** 32)

@@ -263,6 +263,32 @@ def test_fused_rollout_shallow_rings(monkeypatch, rings, async_refill):
     test_fused_rollout_vs_oracle(2, True)
 
 
+def test_repeated_jokers_rollout_vs_oracle():
+    """Envs that own a joker id more than once (what Ankh's copy leaves in `state.jokers`): two or three Bloodstones / 8 Balls /
+    Triboulets per env.  Every copy draws per played card, so the chain's RNG offsets depend on all of them."""
+    from balatro_gym_amd.vec_env import RowBuffers
+    n, T = 256, 160
+    seeds = [61_000 + 13 * i for i in range(n)]
+    pool = [117, 117, 26, 26, 147, 116, 31, 1]
+    jokers = [[random.Random(8000 + i).choice(pool) for _ in range(2 + i % 4)] for i in range(n)]
+    env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4)
+    env.inject(jokers=jokers, apply_now=True)
+    rb = RowBuffers(n, env.device, steps=T)
+    env.rollout(T, policy=2, policy_seed=77, obs_buffers=rb)
+    env.check()
+    got_stats = env.stats()
+    wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, T, 2, 77, True, 4, jokers)
+    assert np.array_equal(rb.action.cpu().numpy(), wa)
+    assert np.array_equal(rb.terminated.cpu().numpy(), wt)
+    assert np.array_equal(rb.reward.contiguous().cpu().numpy().view(np.uint64), wr.view(np.uint64))
+    for k in OBS_KEYS:
+        assert np.array_equal(rb.tensors[k].contiguous().cpu().numpy(), wobs[k]), f"record key {k} differs"
+    for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
+        assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
+    assert got_stats["plays"] > 2000
+    env.close()
+
+
 @pytest.mark.parametrize("rings,async_refill", [("default", "1"), ("8,13,12", "1"), ("8,13,12", "0")])
 def test_many_short_launches_vs_oracle(monkeypatch, rings, async_refill):
     """The same 120 steps as MANY short launches (7, 1, 20, 13, ... fused steps per bg_rollout_rows call): the look-ahead rings are

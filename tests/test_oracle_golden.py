@@ -66,8 +66,11 @@ def test_classify_all_five_card_hands():
     assert zlib.crc32(bytes(types)) == int(g["all5_crc32"])
 
 
-def test_score_hand_golden():
-    cases = json.load(open(os.path.join(GOLD, "score_hand.json")))
+@pytest.mark.parametrize("fixture", ["score_hand.json", "score_hand_dups.json"])
+def test_score_hand_golden(fixture):
+    """UnifiedScorer.score_hand cases generated from the reference; `_dups`: joker lists with repeats (Ankh), several Bloodstones /
+    8 Balls drawing per card."""
+    cases = json.load(open(os.path.join(GOLD, fixture)))
     L = po.lib()
     for i, c in enumerate(cases):
         cards = [tuple(x) for x in c["cards"]]

@@ -13,6 +13,7 @@ from bench import IMPLEMENTED
 POOL = list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68))
 
 def run(n, T, policy, scorer, cards_on, seed0, max_ante, cons_on=False):
+    seed0 += int(os.environ.get("SEED_OFFSET", "0"))  # other games than the fixed set
     seeds = [seed0 + 11 * i for i in range(n)]
     jokers = [random.Random(seed0 + i).sample(IMPLEMENTED if i % 2 else list(range(1, 151)), i % 6) for i in range(n)] if scorer else None
     cards = None
