@@ -58,6 +58,14 @@ if __name__ == "__main__":
         run(1024, 1200, 0, True, True, 987006, 8)
         print("LONG STRESS OK")
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "wide":  # configurations drawn from a seed (argv[2]): flags, policy, caps, sizes
+        rr = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+        for k in range(int(sys.argv[3]) if len(sys.argv) > 3 else 6):
+            cards_on = rr.random() < 0.5
+            run(rr.randint(200, 1500), rr.randint(100, 450), rr.choice([0, 0, 1, 2]), rr.random() < 0.7, cards_on,
+                rr.randrange(10 ** 6, 10 ** 9), rr.choice([0, 2, 4, 6, 8]), cons_on=cards_on and rr.random() < 0.6)
+        print("WIDE STRESS OK")
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "consumables":
         run(4096, 400, 0, True, True, 987003, 8, cons_on=True)
         run(4096, 400, 0, False, True, 987004, 0, cons_on=True)
