@@ -17,6 +17,9 @@ from tests.helpers import GOLD, OBS_KEYS, forced_deck, forced_hand_script
 
 pytestmark = pytest.mark.gpu
 
+# BG_TEST_SEED_OFFSET=<k> moves every oracle-compared test below to other games (a soak runs the suite under several offsets)
+SEED_OFFSET = int(os.environ.get("BG_TEST_SEED_OFFSET", "0"))
+
 
 LANES = pytest.mark.parametrize("lanes", [1, 8], ids=["lane_per_case", "8_lanes_per_case"])
 
@@ -156,7 +159,7 @@ def test_forced_rare_hands_vs_oracle(scorer):
     from balatro_gym_amd import BalatroVecEnv
     from oracle import pyoracle as po
     n = 9 * 64
-    seeds = [123_000 + 11 * i for i in range(n)]
+    seeds = [123_000 + SEED_OFFSET + 11 * i for i in range(n)]
     rr = random.Random(77)
     hts = [i % 9 for i in range(n)]
     decks, scripts = [], []

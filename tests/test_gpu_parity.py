@@ -3,6 +3,7 @@
 libbalatro_mi355x.so), against (1) the committed golden traces generated from the Python reference and (2) the CPU
 oracle on fresh seeds.  Integer / byte / index results and float64 rewards must be BIT-exact (tolerance 0).
 """
+import os
 import random
 
 import numpy as np
@@ -11,6 +12,9 @@ import pytest
 from tests.helpers import OBS_KEYS, load_trace, trace_injection
 
 pytestmark = pytest.mark.gpu
+
+# BG_TEST_SEED_OFFSET=<k> moves every oracle-compared test below to other games (a soak runs the suite under several offsets)
+SEED_OFFSET = int(os.environ.get("BG_TEST_SEED_OFFSET", "0"))
 
 GPU_TRACES = ["c1_small_only", "c2_cycle3", "c3_jokers", "c5_uniform", "c5_uniform_rich", "cards_levels", "consumables",
               "consumables_scorer"]
@@ -99,7 +103,7 @@ def test_step_vs_oracle_fresh_seeds(policy, scorer):
     from oracle import pyoracle as po
     from oracle.gen_golden import IMPLEMENTED
     n, T = 512, 250
-    seeds = [910_000 + 7 * i for i in range(n)]
+    seeds = [910_000 + SEED_OFFSET + 7 * i for i in range(n)]
     jokers = [random.Random(i).sample(IMPLEMENTED if i % 2 else list(range(1, 151)), i % 6) for i in range(n)] if scorer else None
     max_ante = 4 if scorer else 0
     env = _vec(n, seeds, scorer_jokers=scorer, autoreset=False, max_ante=max_ante)
@@ -142,7 +146,7 @@ def test_shop_stream_beyond_slot_vs_oracle():
     on there, through the two- and three-level regeneration of words beyond 227.  Every step against the oracle."""
     import torch
     n, T = 96, 260
-    seeds = [77_000 + 3 * i for i in range(n)]
+    seeds = [77_000 + SEED_OFFSET + 3 * i for i in range(n)]
     env = _vec(n, seeds, autoreset=False)
     env.inject(money=[10_000_000] * n, apply_now=True)
     env.observe()
@@ -227,7 +231,7 @@ def test_fused_rollout_vs_oracle(policy, scorer):
     from balatro_gym_amd.vec_env import ObsBuffers
     from oracle.gen_golden import IMPLEMENTED
     n, T = 256, 96
-    seeds = [55_000 + 3 * i for i in range(n)]
+    seeds = [55_000 + SEED_OFFSET + 3 * i for i in range(n)]
     jokers = [random.Random(1000 + i).sample(IMPLEMENTED, 5) for i in range(n)] if scorer else None
     max_ante = 4 if scorer else 0
     env = _vec(n, seeds, scorer_jokers=scorer, autoreset=True, max_ante=max_ante)
@@ -268,7 +272,7 @@ def test_repeated_jokers_rollout_vs_oracle():
     Triboulets per env.  Every copy draws per played card, so the chain's RNG offsets depend on all of them."""
     from balatro_gym_amd.vec_env import RowBuffers
     n, T = 256, 160
-    seeds = [61_000 + 13 * i for i in range(n)]
+    seeds = [61_000 + SEED_OFFSET + 13 * i for i in range(n)]
     pool = [117, 117, 26, 26, 147, 116, 31, 1]
     jokers = [[random.Random(8000 + i).choice(pool) for _ in range(2 + i % 4)] for i in range(n)]
     env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4)
@@ -301,7 +305,7 @@ def test_many_short_launches_vs_oracle(monkeypatch, rings, async_refill):
         monkeypatch.setenv("BG_KG", kg); monkeypatch.setenv("BG_KS", ks); monkeypatch.setenv("BG_KD", kd)
     monkeypatch.setenv("BG_ASYNC_REFILL", async_refill)
     n, T = 300, 120
-    seeds = [91_000 + 7 * i for i in range(n)]
+    seeds = [91_000 + SEED_OFFSET + 7 * i for i in range(n)]
     jokers = [random.Random(3000 + i).sample(IMPLEMENTED, 5) for i in range(n)]
     env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4)
     env.inject(jokers=jokers, apply_now=True)
@@ -333,7 +337,7 @@ def test_packed_records_padded_stride():
     import torch
     from balatro_gym_amd.vec_env import RowBuffers
     n, T = 300, 40
-    seeds = [5_000 + i for i in range(n)]
+    seeds = [5_000 + SEED_OFFSET + i for i in range(n)]
     outs = []
     for stride in (0, 384):
         env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4)
@@ -355,7 +359,7 @@ def test_packed_record_rollout_vs_oracle(policy, scorer, n):
     from balatro_gym_amd.vec_env import RowBuffers
     from oracle.gen_golden import IMPLEMENTED
     T = 96
-    seeds = [77_000 + 5 * i for i in range(n)]
+    seeds = [77_000 + SEED_OFFSET + 5 * i for i in range(n)]
     jokers = [random.Random(2000 + i).sample(IMPLEMENTED, 5) for i in range(n)] if scorer else None
     max_ante = 4 if scorer else 0
     env = _vec(n, seeds, scorer_jokers=scorer, autoreset=True, max_ante=max_ante)
@@ -385,7 +389,7 @@ def test_packed_records_same_content_full_size():
     import torch
     from balatro_gym_amd.vec_env import ObsBuffers, RowBuffers
     n, T = 65536, 24
-    seeds = [1000 + i for i in range(n)]
+    seeds = [1000 + SEED_OFFSET + i for i in range(n)]
     out = []
     for packed in (False, True):
         env = _vec(n, seeds, autoreset=True, fused_steps=T)
@@ -405,7 +409,7 @@ def test_card_states_rollout_vs_oracle():
     from balatro_gym_amd.vec_env import RowBuffers
     from oracle.gen_golden import IMPLEMENTED
     n, T = 200, 128
-    seeds = [91_000 + 7 * i for i in range(n)]
+    seeds = [91_000 + SEED_OFFSET + 7 * i for i in range(n)]
     jokers = [random.Random(3000 + i).sample(IMPLEMENTED, 5) for i in range(n)]
     cards = []
     for i in range(n):
@@ -458,7 +462,7 @@ def test_consumables_rollout_vs_oracle(scorer):
     """Tarot / spectral / planet consumables (every one of the 52 ids, two per episode) plus purple / blue seals through the
     fused rollout with packed records: every record byte against the oracle, resets included."""
     n, T = 256, 160
-    seeds = [93_000 + 5 * i for i in range(n)]
+    seeds = [93_000 + SEED_OFFSET + 5 * i for i in range(n)]
     pool = list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68))
     jokers = [random.Random(5000 + i).sample(list(range(1, 151)), i % 6) for i in range(n)]
     cons = [[pool[i % len(pool)], random.Random(6000 + i).choice(pool)][: 2 - (i % 9 == 0)] for i in range(n)]
@@ -474,7 +478,7 @@ def test_immolate_cryptid_rollout_vs_oracle():
     Immolate removes five sampled cards from the live deck list -- every later deck index, the hand's included, names another
     card, The Pillar's marks move along -- and Cryptid appends copies that only deck_size and Blue Joker ever see."""
     n, T = 192, 200
-    seeds = [95_000 + 7 * i for i in range(n)]
+    seeds = [95_000 + SEED_OFFSET + 7 * i for i in range(n)]
     jokers = [[53, 1, 16][: 1 + i % 3] for i in range(n)]  # Blue Joker: +2 chips per card in the deck
     cons = [[[59, 65], [65, 59], [59, 1], [65, 1], [59, 59], [1, 59]][i % 6] for i in range(n)]
     cards = [[(d, [0, 7, 4][d % 3], 0, [0, 4][d % 2]) for d in range(20)] if i % 3 == 0 else [] for i in range(n)]
@@ -516,7 +520,7 @@ def test_rollout_properties_full_size(config):
     import torch
     from oracle.gen_golden import IMPLEMENTED
     n, T = 65536, 48
-    seeds = [1000 + i for i in range(n)]
+    seeds = [1000 + SEED_OFFSET + i for i in range(n)]
     full = config.startswith("configs4")
     policy = (0 if full else 2) | 0x100
     pool = list(range(1, 151)) if full else IMPLEMENTED
@@ -565,7 +569,7 @@ def test_curriculum_caps_vs_oracle():
     from balatro_gym_amd.vec_env import RowBuffers
     from oracle import pyoracle as po
     n, T = 192, 90
-    seeds = [61_000 + 3 * i for i in range(n)]
+    seeds = [61_000 + SEED_OFFSET + 3 * i for i in range(n)]
     caps0 = [1 + i % 3 for i in range(n)]
     caps1 = [c + 2 for c in caps0]
     env = _vec(n, seeds, autoreset=True, max_ante=0)
