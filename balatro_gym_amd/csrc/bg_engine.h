@@ -94,6 +94,10 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   __shared__ CopyEnt s_list[NW][BG_BLOCK];    // copy-out lists
   __shared__ JTables jt;
   __builtin_amdgcn_s_setprio(3);
+#ifdef BG_TIMING4
+  const unsigned long long q_w0 = wall_clock64();   // 100 MHz, the same clock on every CU
+  const unsigned long long q_k0 = __builtin_readcyclecounter();
+#endif
   BG_PROBE_INIT();
   bg_tables_load(&jt, d.jtab);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -143,7 +147,8 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   const uint32_t bmod3 = (uint32_t)(a.env_index0 % 3ull);
   uint32_t polls = 0;
 #ifdef BG_TIMING4
-  unsigned long long q_batches[3] = {0, 0, 0}, q_items[3] = {0, 0, 0}, q_busy[3] = {0, 0, 0}, q_idle = 0, q_fail = 0, q_copy = 0, q_claim = 0, q_failt = 0;
+  if (tid == 0 && d.dbg) { atomicAdd(&d.dbg[16], __builtin_readcyclecounter() - q_k0); atomicMax(&d.dbg[20], ~q_w0); }
+  unsigned long long q_batches[3] = {0, 0, 0}, q_items[3] = {0, 0, 0}, q_busy[3] = {0, 0, 0}, q_idle = 0, q_fail = 0, q_copy = 0, q_claim = 0, q_failt = 0, q_item = 0, q_cheap = 0, q_fin = 0, q_push = 0;
   const unsigned long long q_t0 = __builtin_readcyclecounter();
 #endif
   for (;;) {
@@ -217,6 +222,10 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       if (!(item & BG_ITEM_VALID)) atomicOr(d.err, BG_DEVERR_SPIN);
       else { active = true; l = (int)(item & 0xffffu); env = env0 + l; t = s_t[l]; }
     }
+#ifdef BG_TIMING4
+    const unsigned long long q_i1 = __builtin_readcyclecounter();
+    if (cls == BG_Q_RUN) q_item += q_i1 - q_b0;
+#endif
     // one CHEAP step of this lane's env on its image: a card-select toggle, shop end, or an action the guards reject; anything
     // else is queued for a service batch and the lane gives the env up.  Returns true when a step was completed.
     auto cheap_step = [&](int& action, double& reward, StepOut& o) __attribute__((always_inline)) -> bool {
@@ -342,7 +351,18 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       q_copy += __builtin_readcyclecounter() - q_c0;
 #endif
     }
+#ifdef BG_TIMING4
+      if (active && t >= (uint32_t)a.T) {
+        const uint32_t dn = __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u; active = false;
+        if (d.dbg) {  // when half / 15 of 16 / all of the workgroup's envs were through (100 MHz ticks since the kernel started here)
+          if (dn == (uint32_t)n_live / 2u) atomicAdd(&d.dbg[24], wall_clock64() - q_w0);
+          if (dn == (uint32_t)n_live - (uint32_t)n_live / 16u) atomicAdd(&d.dbg[25], wall_clock64() - q_w0);
+          if (dn == (uint32_t)n_live) { atomicAdd(&d.dbg[22], wall_clock64() - q_w0); atomicMax(&d.dbg[21], wall_clock64()); atomicMax(&d.dbg[23], wall_clock64() - q_w0); }
+        }
+      }
+#else
       if (active && t >= (uint32_t)a.T) { __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); active = false; }
+#endif
     };
     // ---------------- the step the batch was claimed for
     {
@@ -393,10 +413,20 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
         if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
         fin = true;
         }
+#ifdef BG_TIMING4
+        const unsigned long long q_f0 = __builtin_readcyclecounter();
+        if (cls == BG_Q_RUN) q_cheap += q_f0 - q_i1;
+#endif
         if (fin) finish(cls == BG_Q_RUN, row, action, reward, terminated, o);
+#ifdef BG_TIMING4
+        if (cls == BG_Q_RUN) q_fin += __builtin_readcyclecounter() - q_f0;
+#endif
       }
       copy_out(fin, row);
     }
+#ifdef BG_TIMING4
+    const unsigned long long q_p0 = __builtin_readcyclecounter();
+#endif
     // ---------------- further cheap steps of the envs this wave still holds
     // (run batches only: a service wave hands its envs back at once -- service capacity is what the whole workgroup waits for)
     for (uint32_t sub = 0; cls == BG_Q_RUN && sub < a.th_more && __ballot(active) != 0ull; sub++) {
@@ -420,6 +450,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     if (lane == 0) __hip_atomic_fetch_sub(&s_busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // after the pushes of this batch
 #ifdef BG_TIMING4
     q_batches[cls]++; q_items[cls] += nb; q_busy[cls] += __builtin_readcyclecounter() - q_b0;
+    if (cls == BG_Q_RUN) q_push += __builtin_readcyclecounter() - q_p0;
 #endif
   }
 #ifdef BG_TIMING4
@@ -427,6 +458,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     atomicAdd(&d.dbg[0], __builtin_readcyclecounter() - q_t0); atomicAdd(&d.dbg[1], 1ull);
     for (int c = 0; c < 3; c++) { atomicAdd(&d.dbg[2 + 3 * c], q_batches[c]); atomicAdd(&d.dbg[3 + 3 * c], q_items[c]); atomicAdd(&d.dbg[4 + 3 * c], q_busy[c]); }
     atomicAdd(&d.dbg[11], q_idle); atomicAdd(&d.dbg[12], q_fail); atomicAdd(&d.dbg[13], q_copy); atomicAdd(&d.dbg[14], q_claim); atomicAdd(&d.dbg[15], q_failt);
+    atomicAdd(&d.dbg[26], q_item); atomicAdd(&d.dbg[27], q_cheap); atomicAdd(&d.dbg[28], q_fin); atomicAdd(&d.dbg[29], q_push);
   }
 #endif
   // ---------------------------------------------------------------- epilogue: chunks 3 / 4 -> HBM, statistics

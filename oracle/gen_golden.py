@@ -11,6 +11,7 @@ Files:
   F3b score_hand_dups.json  the same with REPEATED jokers (Ankh's copies): several Bloodstones / 8 Balls drawing per card
   F4 trace_<cfg>.npz   BalatroEnv traces under the counter-hash policy: actions, rewards, terminated, info and the
                        full observation after every step
+  F5 trace_boss_forced[_scorer].npz  every BossBlindType forced as the first boss blind of 24 seeds (the seed picks it), boss-only policy
   F6 sim_eval.npz      balatro_sim.BalatroSimulator: evaluate_hand (10 000 hands, with / without Four Fingers / Shortcut) and
                        calculate_score (2 000 cases: enhancements, editions, seals, joker-major chain, global-stream position)
   F8 sb3_fixed.npz     SafeBalatroEnv(BalatroEnvFixed(seed)) (train_balatro_fixed.py) stepped like a VecEnv: fixed space + observations
@@ -345,8 +346,55 @@ def gen_sb3_fixed():
           int((rec["terminated"] & ~rec["invalid_action_termination"]).sum()), "game overs")
 
 
+REWARD_TERMS = ["progress", "milestone", "score", "hand_quality", "efficiency", "synergy", "strategy", "ante_bonus"]
+BREAKDOWN_INT = ["base_chips", "base_mult", "card_chips", "joker_chips", "joker_mult", "final_chips", "final_mult", "money_gained"]
+BREAKDOWN_F64 = ["joker_x_mult", "final_x_mult"]
+POLICY_SCRIPTED = 255   # the actions of the trace come from the generator (boss_policy below), not from a policy the build re-derives
+
+
+def error_code(info, action):
+    """The reference's info dict -> the numeric code of include/balatro_mi355x.h (BG_ERR_*).  Every message the traces meet must be
+    known: an unknown one stops the generator."""
+    if info.get("raised"):
+        return 11
+    if info.get("terminated") == "max_ante_reached":
+        return 9
+    if info.get("terminated") == "max_score_reached":
+        return 10
+    msg = info.get("error")
+    if msg is None:
+        return 0
+    if msg == "Invalid action":
+        return 1
+    if msg == "Must play exactly 5 cards":
+        return 2
+    if msg.startswith("Cannot play "):
+        return 3
+    if msg.startswith("Can only play "):
+        return 4
+    if msg.startswith("Must play at least "):
+        return 5
+    if msg == "Insufficient chips for reroll":
+        return 6
+    if msg == "Joker slots full":
+        return 7
+    if 10 <= action <= 14:
+        return 8   # balatro_env_2.py:1166-1169 the consumable reported no success
+    raise RuntimeError(f"unmapped reference error message {msg!r} (action {action})")
+
+
+def boss_policy(obs, pseed, si, t):
+    """F5: always take the boss blind, leave the shop at once, otherwise uniform over the valid actions."""
+    phase = int(obs["phase"])
+    if phase == 2:
+        return 47
+    if phase == 1:
+        return 31
+    return rh.policy_action(obs["action_mask"], phase, rh.POLICY_UNIFORM, pseed, si, t)
+
+
 def trace(cfg_name, seeds, T, policy, scorer=False, jokers_fn=None, max_ante=0, money_fn=None, ante_fn=None,
-          cards_fn=None, levels_fn=None, pseed=7, cons_fn=None):
+          cards_fn=None, levels_fn=None, pseed=7, cons_fn=None, policy_fn=None):
     S = len(seeds)
     rec = {
         "seeds": np.array(seeds, dtype=np.int64), "policy": np.int32(policy), "policy_seed": np.uint64(pseed),
@@ -358,7 +406,14 @@ def trace(cfg_name, seeds, T, policy, scorer=False, jokers_fn=None, max_ante=0, 
         "inj_money": np.full(S, -1, np.int64), "inj_ante": np.full(S, -1, np.int32),
         "inj_cards": np.zeros((S, 52, 3), np.uint8), "inj_levels": np.zeros((S, 12), np.uint8),
         "inj_cons": np.zeros((S, 2), np.int32), "inj_ncons": np.zeros(S, np.int32),
+        # the rest of the info dict (balatro_env_2.py:894-925, :1283-1288): exact error code + message, play details, boss name
+        "error_code": np.zeros((S, T), np.uint8), "error_msg": np.full((S, T), "", dtype="U48"),
+        "cards_played": np.zeros((S, T), np.int8), "beat_blind": np.zeros((S, T), np.uint8), "failed": np.zeros((S, T), np.uint8),
+        "reward_terms": np.zeros((S, T, 8), np.float64), "breakdown_int": np.zeros((S, T, len(BREAKDOWN_INT)), np.int64),
+        "breakdown_f64": np.zeros((S, T, len(BREAKDOWN_F64)), np.float64), "boss_blind": np.full((S, T), "", dtype="U16"),
     }
+    if policy_fn is not None:
+        rec["policy"] = np.int32(POLICY_SCRIPTED)
     obs_rec = None
     for si, seed in enumerate(seeds):
         env = rh.RefEnv(seed, scorer_jokers=scorer, max_ante=max_ante)
@@ -403,9 +458,19 @@ def trace(cfg_name, seeds, T, policy, scorer=False, jokers_fn=None, max_ante=0, 
         for k in OBS_KEYS:
             obs0[k][si] = obs[k]
         for t in range(T):
-            a = rh.policy_action(obs["action_mask"], int(obs["phase"]), policy, pseed, si, t)
+            a = policy_fn(obs, pseed, si, t) if policy_fn else rh.policy_action(obs["action_mask"], int(obs["phase"]), policy, pseed, si, t)
             obs, r, term, _, info = env.step(a)
             rec["actions"][si, t] = a
+            rec["error_code"][si, t] = error_code(info, a)
+            rec["error_msg"][si, t] = info.get("error", "") if not info.get("raised") else ""
+            rec["boss_blind"][si, t] = info.get("boss_blind", "")
+            if "final_score" in info:
+                rec["cards_played"][si, t] = info["cards_played"]
+                rec["beat_blind"][si, t] = bool(info.get("beat_blind"))
+                rec["failed"][si, t] = bool(info.get("failed"))
+                rec["reward_terms"][si, t] = [info["reward_breakdown"][k] for k in REWARD_TERMS]
+                rec["breakdown_int"][si, t] = [int(info["score_breakdown"][k]) for k in BREAKDOWN_INT]
+                rec["breakdown_f64"][si, t] = [float(info["score_breakdown"][k]) for k in BREAKDOWN_F64]
             rec["rewards"][si, t] = r
             rec["terminated"][si, t] = term
             if "final_score" in info:
@@ -425,7 +490,8 @@ def trace(cfg_name, seeds, T, policy, scorer=False, jokers_fn=None, max_ante=0, 
     np.savez_compressed(path, **rec)
     plays = int((rec["hand_type"] >= 0).sum())
     print(f"F4 trace_{cfg_name}.npz seeds={S} T={T} plays={plays} episodes={int(rec['terminated'].sum())} "
-          f"size={os.path.getsize(path) / 1024:.0f} KiB")
+          f"errors by code={np.bincount(rec['error_code'].ravel(), minlength=12).tolist()} size={os.path.getsize(path) / 1024:.0f} KiB")
+    return rec
 
 
 def gen_traces():
@@ -473,6 +539,43 @@ def gen_trace_consumables():
               money_fn=lambda i: [None, 3, 15, 200][i % 4])
 
 
+def gen_boss():
+    """F5: every one of the 28 BossBlindTypes FORCED as the first boss blind of its seeds.  select_boss_blind
+    (boss_blinds.py:522-532) is random.choice(list(BossBlindType)) on the env's global stream, so the type of the first boss is a function
+    of the env seed: the seeds are searched (harness convention G(seed) = seed + 16000), the reference runs UNPATCHED.  Policy: always the
+    boss blind (47), leave the shop at once, otherwise uniform -- later boss blinds of a trace are free-running.  Two traces: the live env
+    (inert jokers) and scorer-level joker names with jokers / antes / hand levels injected.  The generator asserts the coverage the
+    tests rely on: >= 20 accepted plays under every type, >= 1 rejection by every restrictive type (Psychic / Eye / Mouth / Verdant)."""
+    per_type = 24
+    for scorer in (False, True):
+        seeds, want = [], []
+        cand = 20000 if scorer else 10000
+        found = {b: 0 for b in range(1, 29)}
+        while min(found.values()) < per_type:
+            b = 1 + random.Random(rh.global_seed(cand))._randbelow(28)
+            if found[b] < per_type:
+                found[b] += 1
+                seeds.append(cand)
+                want.append(b)
+            cand += 1
+        order = sorted(range(len(seeds)), key=lambda i: (want[i], seeds[i]))
+        seeds, want = [seeds[i] for i in order], [want[i] for i in order]
+        kw = dict(scorer=True, max_ante=20, jokers_fn=lambda i: random.Random(2100 + i).sample(list(range(1, 151)), i % 6),
+                  ante_fn=lambda i: [1, 1, 2, 3, 5, 8][i % 6],
+                  levels_fn=lambda i: [(ht, random.Random(2300 + i * 13 + ht).randint(1, 9)) for ht in range(9)] if i % 2 else []) if scorer else {}
+        rec = trace("boss_forced_scorer" if scorer else "boss_forced", seeds, 72, rh.POLICY_UNIFORM, policy_fn=boss_policy, pseed=11, **kw)
+        # coverage: the boss type in force when a step was taken = boss_blind_type of the PREVIOUS observation
+        prev = np.concatenate([rec["obs0_boss_blind_type"][:, None], rec["obs_boss_blind_type"][:, :-1]], axis=1).astype(int)
+        prev[:, 1:][rec["terminated"][:, :-1] != 0] = 0   # a reset precedes the next step
+        assert [int(b) for b in rec["obs_boss_blind_type"][:, 0]] == want, "the first boss blind of every seed is the forced one"
+        plays = np.bincount(prev[rec["hand_type"] >= 0], minlength=29)
+        rejected = {c: np.bincount(prev[rec["error_code"] == c], minlength=29) for c in (2, 3, 4, 5)}
+        print("   accepted plays under boss types 1..28:", plays[1:].tolist())
+        print("   rejections: Psychic", int(rejected[2][7]), "Eye", int(rejected[3][12]), "Mouth", int(rejected[4][13]), "Verdant", int(rejected[5][25]))
+        assert plays[1:].min() >= 20, plays
+        assert rejected[2][7] and rejected[3][12] and rejected[4][13] and rejected[5][25]
+
+
 def gen_kat():
     """The reference's own known answers, as data."""
     kat = {"chips_test": [
@@ -503,7 +606,7 @@ def gen_kat():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    which = sys.argv[1:] or ["mt", "classify", "score", "traces", "consumables", "kat", "sim", "sb3"]
+    which = sys.argv[1:] or ["mt", "classify", "score", "traces", "consumables", "boss", "kat", "sim", "sb3"]
     if "mt" in which:
         gen_mt()
     if "classify" in which:
@@ -516,6 +619,8 @@ def main():
         gen_traces()
     if "consumables" in which:
         gen_trace_consumables()
+    if "boss" in which:
+        gen_boss()
     if "kat" in which:
         gen_kat()
     if "sb3" in which:

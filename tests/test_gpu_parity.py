@@ -17,7 +17,7 @@ pytestmark = pytest.mark.gpu
 SEED_OFFSET = int(os.environ.get("BG_TEST_SEED_OFFSET", "0"))
 
 GPU_TRACES = ["c1_small_only", "c2_cycle3", "c3_jokers", "c5_uniform", "c5_uniform_rich", "cards_levels", "consumables",
-              "consumables_scorer"]
+              "consumables_scorer", "boss_forced", "boss_forced_scorer"]
 TERMS = 8
 
 
@@ -78,8 +78,11 @@ def test_golden_trace(name):
         assert np.array_equal(info["final_score"].cpu().numpy(), tr["final_score"][:, t]), ctx
         assert np.array_equal(info["hand_type"].cpu().numpy(), tr["hand_type"][:, t]), ctx
         err = info["error"].cpu().numpy()
-        assert np.array_equal((err != 0) & (err < 9), tr["error"][:, t].astype(bool) & (err < 9)), ctx
-        assert np.array_equal(err == 11, tr["error"][:, t] == 2), ctx  # steps where the reference raised
+        assert np.array_equal(err, tr["error_code"][:, t].astype(np.int32)), f"{ctx}: error codes {err} vs {tr['error_code'][:, t]}"  # the exact BG_ERR_* (11: the reference raised)
+        assert np.array_equal(info["cards_played"].cpu().numpy(), tr["cards_played"][:, t]), ctx
+        fl = info["flags"].cpu().numpy()
+        assert np.array_equal((fl & 1) != 0, tr["beat_blind"][:, t] != 0) and np.array_equal((fl & 2) != 0, tr["failed"][:, t] != 0), ctx
+        assert np.array_equal(info["reward_terms"].cpu().numpy().view(np.uint64), tr["reward_terms"][:, t].view(np.uint64)), ctx
         _assert_obs(_obs_np(env), {k: tr["obs_" + k][:, t] for k in OBS_KEYS}, ctx)
         if tm.any():
             env.reset(mask=torch.from_numpy(tm).to(env.device))  # un-seeded reset() + reset template

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from oracle import pyoracle as po
-from tests.helpers import GOLD, OBS_KEYS, TRACES, assert_obs_equal, load_trace, trace_injection
+from tests.helpers import BG_INFO_BEAT_BLIND, BG_INFO_FAILED, GOLD, OBS_KEYS, POLICY_SCRIPTED, TRACES, assert_obs_equal, load_trace, trace_injection
 
 
 def test_mt_known_answers():
@@ -175,19 +175,39 @@ def replay_trace(name, make_env):
         assert_obs_equal(env.obs(), {k: tr["obs0_" + k][si] for k in OBS_KEYS}, f"{name} seed {seed} initial")
         for t in range(T):
             a = int(tr["actions"][si, t])
-            assert env.policy_action(int(tr["policy"]), int(tr["policy_seed"]), si, t) == a
+            if int(tr["policy"]) != POLICY_SCRIPTED:
+                assert env.policy_action(int(tr["policy"]), int(tr["policy_seed"]), si, t) == a
             obs, r, term, _, info = env.step(a)
             ctx = f"{name} seed {seed} t {t} action {a}"
             assert r == tr["rewards"][si, t], f"{ctx}: reward {r!r} vs {tr['rewards'][si, t]!r}"
             assert term == bool(tr["terminated"][si, t]), ctx
             assert info.final_score == tr["final_score"][si, t], ctx
             assert info.hand_type == tr["hand_type"][si, t], ctx
-            assert (info.error != 0) == bool(tr["error"][si, t]) or info.error in (9, 10), ctx
-            assert (info.error == 11) == (tr["error"][si, t] == 2), ctx  # the reference raised (consumables.py:246,381,496,506)
+            assert info.error == tr["error_code"][si, t], f"{ctx}: error {info.error} vs {tr['error_code'][si, t]} ({tr['error_msg'][si, t]!r})"
+            assert info.cards_played == tr["cards_played"][si, t], ctx
+            assert bool(info.flags & BG_INFO_BEAT_BLIND) == bool(tr["beat_blind"][si, t]) and bool(info.flags & BG_INFO_FAILED) == bool(tr["failed"][si, t]), ctx
+            assert [float(x).hex() for x in info.reward_terms] == [float(x).hex() for x in tr["reward_terms"][si, t]], ctx
             assert_obs_equal(obs, {k: tr["obs_" + k][si, t] for k in OBS_KEYS}, ctx)
             if term:
                 env.reset()
                 inject()
+
+
+def test_forced_boss_coverage():
+    """F5: each of the 28 BossBlindTypes is the FIRST boss blind of 24 seeds in both traces (boss_blinds.py:522-532 draws it from the env's
+    global stream: the seed picks it), >= 20 accepted plays under every type, every restrictive type rejects at least once
+    (can_play_hand, boss_blinds.py:380-407)."""
+    for name in ("boss_forced", "boss_forced_scorer"):
+        tr = load_trace(name)
+        first = tr["obs_boss_blind_type"][:, 0].astype(int)
+        assert np.bincount(first, minlength=29)[1:].tolist() == [24] * 28, name
+        prev = np.concatenate([tr["obs0_boss_blind_type"][:, None], tr["obs_boss_blind_type"][:, :-1]], axis=1).astype(int)
+        prev[:, 1:][tr["terminated"][:, :-1] != 0] = 0
+        plays = np.bincount(prev[tr["hand_type"] >= 0], minlength=29)
+        assert plays[1:].min() >= 20, (name, plays)
+        for code, boss in ((2, 7), (3, 12), (4, 13), (5, 25)):
+            assert ((tr["error_code"] == code) & (prev == boss)).sum() >= 1, (name, code)
+            assert ((tr["error_code"] == code) & (prev != boss)).sum() == 0, (name, code)
 
 
 @pytest.mark.parametrize("name", TRACES)

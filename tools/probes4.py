@@ -9,15 +9,16 @@ from bench import jokers_for, POLICY_CYCLE3, POLICY_SEED
 n, T = 65536, int(os.environ.get("T", "372"))
 env = BalatroVecEnv(n, [1000 + g for g in range(n)], device=0, scorer_jokers=True, autoreset=True, max_ante=4)
 env.inject(jokers=[jokers_for(g) for g in range(n)], apply_now=True)
-rb = RowBuffers(n, env.device, steps=T)
+WARM = int(os.environ.get("WARM", str(T)))
+rb = RowBuffers(n, env.device, steps=max(T, WARM))
 for i in range(2):
-    env.rollout(T, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, t0=i * T, obs_buffers=rb, zero_stats=False)
+    env.rollout(WARM, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, t0=i * WARM, obs_buffers=rb, zero_stats=False)
 torch.cuda.synchronize()
 L = nat.load()
 out = (C.c_ulonglong * 32)()
 L.bg_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 L.bg_debug_counters(env._h, out)
-env.rollout(T, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, t0=2 * T, obs_buffers=rb, zero_stats=False)
+env.rollout(T, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, t0=2 * WARM, obs_buffers=rb, zero_stats=False)
 torch.cuda.synchronize()
 st = env.stats()
 L.bg_debug_counters(env._h, out)
