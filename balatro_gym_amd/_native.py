@@ -56,6 +56,10 @@ EXPORTS = ["bg_create", "bg_destroy", "bg_last_error", "bg_num_envs", "bg_max_fu
            "bg_refill", "bg_check", "bg_set_profiling", "bg_get_profile", "bg_set_max_ante", "bg_inject_deck",
            "bg_classify_batch", "bg_score_hand_batch", "bg_classify_batch_ex", "bg_score_hand_batch_ex", "bg_bench_copy", "bg_bench_fill", "bg_step_many",
            "bg_sim_evaluate_batch", "bg_sim_score_batch", "bg_create_ex"]
+# state-blob geometry (csrc/bg_device.h; tests/test_cabi_and_host.py checks these against the header): 16-byte chunks per env of the
+# hot / deck / cold / template arrays, words per stored MT19937 block, words per shop-stream ring slot and where its seed sits
+BLOB_NHOT, BLOB_NDECK, BLOB_NCOLD, BLOB_NTMPL, BLOB_NCST, BLOB_MTS, BLOB_SSEED = 8, 4, 7, 2, 7, 640, 128
+SHOP_SLOT_WORDS, SHOP_SLOT_SEED_WORD = 144, 136
 SCORE_CASE_WORDS, SCORE_OUT_WORDS = 40, 8
 SIM_EVAL_BYTES, SIM_CASE_WORDS = 128, 64
 
@@ -84,6 +88,30 @@ def lib_path() -> str:
     # BALATRO_MI355X_LIB points at an installed / experimental build of the same C ABI (still the HIP library: there is
     # no other implementation to fall back to)
     return os.environ.get("BALATRO_MI355X_LIB") or _build.LIB
+
+
+def device_code_signature(path: str | None = None) -> str:
+    """sha256 (first 16 hex digits) of the `.hip_fatbin` section of the library: identifies the DEVICE code that runs.  bench.py
+    only quotes a committed PMC traffic measurement (profiles/*_hbm_traffic.json) taken on exactly this device code."""
+    import hashlib
+    import struct
+    path = path or lib_path()
+    with open(path, "rb") as f:
+        data = f.read()
+    if data[:4] != b"\x7fELF" or data[4] != 2:
+        return "not-elf64"
+    shoff, = struct.unpack_from("<Q", data, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", data, 0x3A)
+    def sh(i):
+        name, _type, _flags, _addr, off, size = struct.unpack_from("<IIQQQQ", data, shoff + i * shentsize)
+        return name, off, size
+    _, stroff, strsize = sh(shstrndx)
+    for i in range(shnum):
+        name, off, size = sh(i)
+        end = data.index(b"\0", stroff + name)
+        if data[stroff + name:end] == b".hip_fatbin":
+            return hashlib.sha256(data[off:off + size]).hexdigest()[:16]
+    return "no-fatbin"
 
 
 def load(build_if_missing: bool = True):

@@ -30,7 +30,7 @@
 #define BG_ITEM_VALID 0x80000000u
 #define BG_SPIN_LIMIT (1u << 24)
 #define BG_DEVERR_SPIN 16u
-#define BG_ENG_NE 256   // envs per workgroup
+#define BG_ENG_NE 256   // envs per workgroup (an item holds the env's lane in 8 bits)
 // Waves per workgroup.  SEVEN, not eight: a wave of this kernel needs 256 VGPRs, so eight fill the register file of all four SIMDs and
 // nothing can be placed beside the workgroup -- the RNG refill of the previous launch (~1 ms of one-wave workgroups) then waits for
 // the engine to retire and the next launch waits for the refill.  With seven, one SIMD per CU keeps 256 free registers (and the
@@ -86,10 +86,14 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   __shared__ uint32_t s_deck[16][NE];
   __shared__ unsigned long long s_mask[NE];
   __shared__ uint32_t s_t[NE], s_prod[NE];
-  __shared__ uint32_t s_q[3][NE];             // rings of env lanes (| action << 16 | VALID)
-  __shared__ uint32_t s_tail[3], s_head[3];   // items ever queued / ever claimed per queue
-  __shared__ uint32_t s_done;                 // envs that have finished their T steps
-  __shared__ uint32_t s_busy;                 // waves inside a batch
+  __shared__ uint32_t s_q[3][NE];             // rings of items: env lane | generation of the ring position << 8 | action << 16 | VALID
+  // queue control words, 32 bytes: [0..2] items ever queued per queue, [3] envs that have finished their T steps,
+  // [4..6] items ever claimed per queue, [7] waves inside a batch -- a wave reads all eight with two 16-byte LDS loads
+  __shared__ __attribute__((aligned(16))) uint32_t s_ctl[8];
+  uint32_t* const s_tail = &s_ctl[0];
+  uint32_t* const s_head = &s_ctl[4];
+#define s_done s_ctl[3]
+#define s_busy s_ctl[7]
   __shared__ uint32_t s_win[NSV][BG_WIN][BG_BLOCK]; // RNG windows of the service-capable waves
   __shared__ CopyEnt s_list[NW][BG_BLOCK];    // copy-out lists
   __shared__ JTables jt;
@@ -155,12 +159,14 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
 #ifdef BG_TIMING4
     const unsigned long long q_l0 = __builtin_readcyclecounter();
 #endif
-    // -- pick a queue
-    const uint32_t hr = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_head[BG_Q_RUN])), hp = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_head[BG_Q_PLAY])),
-                   ho = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_head[BG_Q_OTHER]));
-    const uint32_t nr = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_tail[BG_Q_RUN])) - hr;
-    const uint32_t np = can_serve ? __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_tail[BG_Q_PLAY])) - hp : 0u,
-                   no = can_serve ? __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_tail[BG_Q_OTHER])) - ho : 0u;
+    // -- pick a queue: the eight control words with two 16-byte loads (one LDS round trip; each word is written atomically by its
+    // owner, so a torn pair of words is no worse than two separate loads)
+    asm volatile("" ::: "memory");
+    const bg_u32x4 ct = *(volatile __attribute__((address_space(3))) bg_u32x4*)&s_ctl[0], ch = *(volatile __attribute__((address_space(3))) bg_u32x4*)&s_ctl[4];
+    asm volatile("" ::: "memory");
+    const uint32_t hr = __builtin_amdgcn_readfirstlane(ch.x), hp = __builtin_amdgcn_readfirstlane(ch.y), ho = __builtin_amdgcn_readfirstlane(ch.z);
+    const uint32_t nr = __builtin_amdgcn_readfirstlane(ct.x) - hr;
+    const uint32_t np = can_serve ? __builtin_amdgcn_readfirstlane(ct.y) - hp : 0u, no = can_serve ? __builtin_amdgcn_readfirstlane(ct.z) - ho : 0u;
     int cls = -1;
     if (np >= a.th_play) cls = BG_Q_PLAY;          // a service-capable wave serves first: the long chains are the critical path
     else if (no >= a.th_other) cls = BG_Q_OTHER;
@@ -168,7 +174,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     else if (nr | np | no) {
       // nothing is full.  While other waves are inside batches their envs will be back in a moment, so a small batch now only
       // costs instructions at a low lane count; when no wave is busy nothing will ever arrive: take what there is.
-      const uint32_t busy = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_busy));
+      const uint32_t busy = __builtin_amdgcn_readfirstlane(ch.w);
       const uint32_t need = busy ? a.th_part : 1u; // (service queues only: a partial run batch is cheap)
       if (nr && nr >= np && nr >= no) cls = BG_Q_RUN;
       else if (np >= need && np >= no) cls = BG_Q_PLAY;
@@ -177,7 +183,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       else if (np >= need) cls = BG_Q_PLAY;
     }
     if (cls < 0) {
-      if (__builtin_amdgcn_readfirstlane(bg_lds_ld(&s_done)) >= (uint32_t)n_live) break; // every env has done its T steps
+      if (__builtin_amdgcn_readfirstlane(ct.w) >= (uint32_t)n_live) break; // every env has done its T steps
       __builtin_amdgcn_s_sleep(8);
       if (++polls > BG_SPIN_LIMIT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
 #ifdef BG_TIMING4
@@ -187,9 +193,19 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     }
     const uint32_t head = cls == BG_Q_RUN ? hr : (cls == BG_Q_PLAY ? hp : ho), navail = cls == BG_Q_RUN ? nr : (cls == BG_Q_PLAY ? np : no);
     const uint32_t nb = navail > BG_BLOCK ? BG_BLOCK : navail;
+    // the claim: one compare-and-swap on the queue head by lane 0; the slots of the batch are read BEFORE it in the same group of LDS
+    // operations (a read of a slot this wave does not get is harmless), so a successful claim is one LDS round trip, not two.  An item
+    // carries the GENERATION of its ring position ((position >> 8) & 255): a slot still holding the item of 256 positions ago is
+    // "not written yet", never a second copy of an old env -- so slots are not cleared after reading.  (A producer cannot lap an unread
+    // slot in practice: the reader's load precedes its claim; only a reader that found the slot not yet written polls it, and it would have
+    // to miss the item for the time of 256 further pushes.)
+    uint32_t item = 0;
+    uint32_t* const slotp = &s_q[cls][(head + (uint32_t)lane) & (NE - 1)];
     {
       uint32_t got = 0;
-      if (lane == 0) { got = atomicCAS(&s_head[cls], head, head + nb) == head ? 1u : 0u; if (got) __hip_atomic_fetch_add(&s_busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+      if ((uint32_t)lane < nb) item = bg_lds_ld(slotp);
+      if (lane == 0) got = atomicCAS(&s_head[cls], head, head + nb) == head ? 1u : 0u;
+      if (lane == 0 && got) __hip_atomic_fetch_add(&s_busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (__builtin_amdgcn_readfirstlane(got) == 0u) {
 #ifdef BG_TIMING4
         q_fail++; q_failt += __builtin_readcyclecounter() - q_l0;
@@ -212,15 +228,13 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     // action needs a service batch.
     bool active = false;           // this lane holds an env
     int l = 0, env = 0;
-    uint32_t t = 0, item = 0;
+    uint32_t t = 0;
     if ((uint32_t)lane < nb) {
-      uint32_t* slotp = &s_q[cls][(head + (uint32_t)lane) & (NE - 1)];
-      item = bg_lds_ld(slotp);
       uint32_t spin = 0;
-      while (!(item & BG_ITEM_VALID) && ++spin < BG_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); item = bg_lds_ld(slotp); }
-      bg_lds_st(slotp, 0u);
-      if (!(item & BG_ITEM_VALID)) atomicOr(d.err, BG_DEVERR_SPIN);
-      else { active = true; l = (int)(item & 0xffffu); env = env0 + l; t = s_t[l]; }
+      const uint32_t want = BG_ITEM_VALID | ((((head + (uint32_t)lane) >> 8) & 0xffu) << 8);
+      while ((item & (BG_ITEM_VALID | 0xff00u)) != want && ++spin < BG_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); item = bg_lds_ld(slotp); }
+      if ((item & (BG_ITEM_VALID | 0xff00u)) != want) atomicOr(d.err, BG_DEVERR_SPIN);
+      else { active = true; l = (int)(item & 0xffu); env = env0 + l; t = s_t[l]; }
     }
 #ifdef BG_TIMING4
     const unsigned long long q_i1 = __builtin_readcyclecounter();
@@ -283,7 +297,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       else {
         const int q = (!terminal && phase == 0u && action == 0) ? BG_Q_PLAY : BG_Q_OTHER;
         const uint32_t slot = __hip_atomic_fetch_add(&s_tail[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        bg_lds_st(&s_q[q][slot & (NE - 1)], (uint32_t)l | (((uint32_t)action & 0x7fffu) << 16) | BG_ITEM_VALID);
+        bg_lds_st(&s_q[q][slot & (NE - 1)], (uint32_t)l | (((slot >> 8) & 0xffu) << 8) | (((uint32_t)action & 0x7fffu) << 16) | BG_ITEM_VALID);
         active = false;                                                   // the env is the service queue's now
       }
       if (fin) {
@@ -445,7 +459,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     // ---- hand the remaining envs back to the run queue
     if (active) {
       const uint32_t slot = __hip_atomic_fetch_add(&s_tail[BG_Q_RUN], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      bg_lds_st(&s_q[BG_Q_RUN][slot & (NE - 1)], (uint32_t)l | BG_ITEM_VALID);
+      bg_lds_st(&s_q[BG_Q_RUN][slot & (NE - 1)], (uint32_t)l | (((slot >> 8) & 0xffu) << 8) | BG_ITEM_VALID);
     }
     if (lane == 0) __hip_atomic_fetch_sub(&s_busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // after the pushes of this batch
 #ifdef BG_TIMING4

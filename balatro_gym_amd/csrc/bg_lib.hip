@@ -1492,26 +1492,28 @@ int bg_set_max_ante(bg_handle* h, int max_ante, const int32_t* per_env_host, con
 
 // ---- measurement hook: streaming copy (bench.py's `peak_measured`: what this GPU's HBM sustains for a plain 16-byte-per-lane
 // copy, the yardstick SURVEY 8(d) asks the roofline fraction to be quoted against beside the 8 TB/s nominal) ----
-__global__ __launch_bounds__(256) void bg_stream_copy_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n16) {
-  const size_t stride = (size_t)gridDim.x * 256 * 4;
-  for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n16; i += stride) {
-    uint4 v[4];
+// Shape from a sweep on the MI355X (tools/micro/copybw.hip, profiles/r03_copybw.txt): ONE pass per workgroup (no grid-stride loop), four
+// 16-byte pieces per lane, non-temporal loads and stores: 6.5 TB/s read + written at 1 GiB (the guide's float4 copy: 6.29; the
+// grid-stride kernel of rounds 1-2: 5.1-5.6).  A plain one-pass fill writes 6.8 TB/s.
+typedef uint32_t bg_cp_u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void bg_stream_copy_kernel(const bg_cp_u32x4* __restrict__ src, bg_cp_u32x4* __restrict__ dst, size_t n16) {
+  const size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x;
+  bg_cp_u32x4 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) if (i + (size_t)k * 256 < n16) v[k] = src[i + (size_t)k * 256];
+  for (int k = 0; k < 4; k++) if (i + (size_t)k * 256 < n16) v[k] = __builtin_nontemporal_load(&src[i + (size_t)k * 256]);
 #pragma unroll
-    for (int k = 0; k < 4; k++) if (i + (size_t)k * 256 < n16) dst[i + (size_t)k * 256] = v[k];
-  }
+  for (int k = 0; k < 4; k++) if (i + (size_t)k * 256 < n16) __builtin_nontemporal_store(v[k], &dst[i + (size_t)k * 256]);
 }
 int bg_bench_copy(const void* src_dev, void* dst_dev, uint64_t bytes, int iters, double* gbps_out, void* stream) {
   if (!src_dev || !dst_dev || !gbps_out || bytes < 16 || iters < 1 || ((uintptr_t)src_dev & 15) || ((uintptr_t)dst_dev & 15)) { g_create_err = "bg_bench_copy: bad arguments"; return BG_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   const size_t n16 = bytes / 16;
-  const int grid = 256 * 16; // 16 workgroups per CU
+  const unsigned grid = (unsigned)((n16 + 1023) / 1024);
   hipEvent_t a, b;
   BG_HIP0(hipEventCreate(&a)); BG_HIP0(hipEventCreate(&b));
-  hipLaunchKernelGGL(bg_stream_copy_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)src_dev, (uint4*)dst_dev, n16); // warm-up
+  for (int i = 0; i < 2; i++) hipLaunchKernelGGL(bg_stream_copy_kernel, dim3(grid), dim3(256), 0, s, (const bg_cp_u32x4*)src_dev, (bg_cp_u32x4*)dst_dev, n16); // warm-up
   BG_HIP0(hipEventRecord(a, s));
-  for (int i = 0; i < iters; i++) hipLaunchKernelGGL(bg_stream_copy_kernel, dim3(grid), dim3(256), 0, s, (const uint4*)src_dev, (uint4*)dst_dev, n16);
+  for (int i = 0; i < iters; i++) hipLaunchKernelGGL(bg_stream_copy_kernel, dim3(grid), dim3(256), 0, s, (const bg_cp_u32x4*)src_dev, (bg_cp_u32x4*)dst_dev, n16);
   BG_HIP0(hipEventRecord(b, s));
   BG_HIP0(hipGetLastError());
   BG_HIP0(hipEventSynchronize(b));
@@ -1524,20 +1526,17 @@ int bg_bench_copy(const void* src_dev, void* dst_dev, uint64_t bytes, int iters,
 
 // write-only twin: the step engine's traffic is ~80 % stores (the record of every step), so the store bandwidth is its real ceiling
 __global__ __launch_bounds__(256) void bg_stream_fill_kernel(uint4* __restrict__ dst, size_t n16, uint32_t seed) {
-  const size_t stride = (size_t)gridDim.x * 256 * 4;
-  for (size_t i = (size_t)blockIdx.x * 256 * 4 + threadIdx.x; i < n16; i += stride) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) if (i + (size_t)k * 256 < n16) dst[i + (size_t)k * 256] = make_uint4(seed, (uint32_t)i, (uint32_t)k, seed ^ (uint32_t)i);
-  }
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i < n16) dst[i] = make_uint4(seed, (uint32_t)i, 0u, seed ^ (uint32_t)i);
 }
 int bg_bench_fill(void* dst_dev, uint64_t bytes, int iters, double* gbps_out, void* stream) {
   if (!dst_dev || !gbps_out || bytes < 16 || iters < 1 || ((uintptr_t)dst_dev & 15)) { g_create_err = "bg_bench_fill: bad arguments"; return BG_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
   const size_t n16 = bytes / 16;
-  const unsigned grid = 256 * 16;
+  const unsigned grid = (unsigned)((n16 + 255) / 256);
   hipEvent_t a, b;
   BG_HIP0(hipEventCreate(&a)); BG_HIP0(hipEventCreate(&b));
-  hipLaunchKernelGGL(bg_stream_fill_kernel, dim3(grid), dim3(256), 0, s, (uint4*)dst_dev, n16, 0u); // warm-up
+  for (int i = 0; i < 2; i++) hipLaunchKernelGGL(bg_stream_fill_kernel, dim3(grid), dim3(256), 0, s, (uint4*)dst_dev, n16, 0u); // warm-up
   BG_HIP0(hipEventRecord(a, s));
   for (int i = 0; i < iters; i++) hipLaunchKernelGGL(bg_stream_fill_kernel, dim3(grid), dim3(256), 0, s, (uint4*)dst_dev, n16, (uint32_t)i + 1u);
   BG_HIP0(hipEventRecord(b, s));

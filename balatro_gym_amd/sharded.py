@@ -27,6 +27,18 @@ def shard_range(total: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def all_gather_bytes(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
+    """all_gather_into_tensor(out, inp).  RCCL ("nccl") moves device buffers directly over xGMI.  The "gloo" backend -- CPU tests, and
+    the two-ranks-on-one-GPU test of the real engine -- gets device tensors staged through host memory."""
+    if inp.is_cuda and dist.get_backend(group) == "gloo":
+        h_in = inp.cpu()
+        h_out = torch.empty(out.numel(), dtype=out.dtype)
+        dist.all_gather_into_tensor(h_out, h_in.view(-1), group=group)
+        out.view(-1).copy_(h_out)
+        return
+    dist.all_gather_into_tensor(out, inp, group=group)
+
+
 class ShardedBalatroVecEnv:
     """total_envs games split over the process group; every rank drives its own shard on its own GPU."""
 
@@ -72,7 +84,7 @@ class ShardedBalatroVecEnv:
             flat = buf
         if self._gathered is None or self._gathered.numel() != self.world * n:
             self._gathered = torch.empty(self.world * n, dtype=torch.uint8, device=flat.device)
-        dist.all_gather_into_tensor(self._gathered, flat.contiguous(), group=self.group)
+        all_gather_bytes(self._gathered, flat.contiguous(), group=self.group)
         return self._gathered.view(self.world, n)
 
     def gather_records(self, rows: torch.Tensor) -> torch.Tensor:
@@ -82,7 +94,7 @@ class ShardedBalatroVecEnv:
             raise ValueError("gather_records needs equal shards")
         rows = rows.contiguous()
         out = torch.empty((self.world,) + tuple(rows.shape), dtype=rows.dtype, device=rows.device)
-        dist.all_gather_into_tensor(out.view(-1), rows.view(-1), group=self.group)
+        all_gather_bytes(out.view(-1), rows.view(-1), group=self.group)
         return out
 
     def close(self):

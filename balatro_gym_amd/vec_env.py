@@ -377,6 +377,48 @@ class BalatroVecEnv:
         buf = (C.c_uint8 * len(blob)).from_buffer_copy(blob)
         self._check(self._L.bg_set_state(self._h, int(env_index), buf, len(blob)), "bg_set_state")
 
+    @staticmethod
+    def parse_state_blob(blob: bytes) -> Dict[str, object]:
+        """Named views of a state blob (bg_get_state): what save_state() (balatro_env_2.py:1575-1593) leaves out -- the RNG streams --
+        is in here, so tests can look at a full shuffled deck, the pre-shuffled decks, the raw global-stream blocks and the shop seeds."""
+        b = np.frombuffer(blob, np.uint8)
+        hdr = b[:16].view(np.uint32)
+        kg, cards, ks, kd = int(hdr[2] & 0xffff), bool(hdr[2] & 0x10000), int(hdr[3] & 0xffff), int(hdr[3] >> 16)
+        out: Dict[str, object] = {"magic": int(hdr[0]), "version": int(hdr[1]), "KG": kg, "KS": ks, "KD": kd, "card_states": cards}
+        off = 16
+
+        def take(name, nbytes, dtype=np.uint8, shape=None):
+            nonlocal off
+            a = b[off:off + nbytes].view(dtype)
+            out[name] = a.reshape(shape) if shape else a
+            off += nbytes
+        take("hot", nat.BLOB_NHOT * 16, np.uint32, (nat.BLOB_NHOT, 4))
+        take("deck", nat.BLOB_NDECK * 16)                       # 52 card codes (rank - 2) * 4 + suit, then padding
+        take("cold", nat.BLOB_NCOLD * 16)
+        take("tmpl", nat.BLOB_NTMPL * 16)
+        take("ring_decks", kd * nat.BLOB_NDECK * 16, np.uint8, (kd, nat.BLOB_NDECK * 16))
+        take("global_blocks", kg * nat.BLOB_MTS * 4, np.uint32, (kg, nat.BLOB_MTS))   # RAW MT19937 words (tempered on read)
+        take("shop_slots", ks * nat.SHOP_SLOT_WORDS * 4, np.uint32, (ks, nat.SHOP_SLOT_WORDS))
+        take("shop_overflow", nat.BLOB_MTS * 4, np.uint32)
+        take("deck_stream", nat.BLOB_MTS * 4, np.uint32)
+        take("shopgen_stream", nat.BLOB_MTS * 4, np.uint32)
+        take("shop_seed_ring", nat.BLOB_SSEED * 4, np.uint32)
+        take("shop_seed_meta", 4, np.uint32)
+        take("producers", 4, np.uint32)
+        if cards:
+            take("card_states", nat.BLOB_NCST * 16, np.uint16)
+            take("card_template", nat.BLOB_NCST * 16, np.uint16)
+            take("card_stream", nat.BLOB_MTS * 4, np.uint32)
+            take("seal_stream", nat.BLOB_MTS * 4, np.uint32)
+        if off != len(b):
+            raise ValueError(f"state blob of {len(b)} bytes does not parse ({off} bytes understood)")
+        out["deck"] = out["deck"][:52]
+        out["ring_decks"] = out["ring_decks"][:, :52]
+        out["shop_slot_seeds"] = out["shop_slots"][:, nat.SHOP_SLOT_SEED_WORD]
+        hot7 = out["hot"][7]
+        out["shop_slot_current"] = int(hot7[1] & 0xff)
+        return out
+
     def set_profiling(self, enable: bool):
         self._check(self._L.bg_set_profiling(self._h, 1 if enable else 0), "bg_set_profiling")
 

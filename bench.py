@@ -18,6 +18,13 @@ multi-GPU is pure sharding with no data-path collective ("weak" scaling: 65 536 
 design -- an RCCL all_gather of the CURRENT observation record of every env ([N, 352] bytes per GPU, once per launch) --
 runs on a side stream beside the next launch and is inside the timed region when N > 1 (`gather` in the JSON line).
 
+`value` is the contract's K-step region.  `samples` repeats that same region (default 30 times, each its own launch sequence
+between two synchronisations, so the every-so-often lazy RNG refill falls inside some of them): median / p10 / p90; `sustained` times
+enough back-to-back repeats of the K-step region WITHOUT a synchronisation in between to span at least one refill period.
+
+`python bench.py --gpus N` without torchrun (WORLD_SIZE unset) starts N child ranks itself -- before this process touches a GPU -- and
+exits non-zero with a message if fewer than N devices are visible.
+
 Beside the headline the line carries `step_path`: the same workload driven through bg_step (one call per step, actions
 from a device tensor: the surface RL code calls, balatro_env_2.py:616-637) and bg_step_many (K steps per call), timed on a
 short sample outside the headline's timed region.
@@ -112,23 +119,51 @@ def measured_copy_gbps(dev):
     return float(g.value), float(gw.value)
 
 
-KERNEL_BUILD = "7 worker waves (6 / 4 for short launches) x 256 envs per workgroup, nt record stores"   # tools/hbm_traffic.py stamps the measurements it writes with the same string
+HBM_PEAK_GUIDE_GBPS = 6290.0                     # MI355X_MICROARCH.md: 6.29 TB/s measured for a float4 copy
 
 
 def matching_traffic(kernel: str, n: int, fused: float):
     """HBM bytes per launch of the dominant kernel from the PMC counters -- ONLY if a committed measurement of THIS launch
-    shape exists (profiles/*_hbm_traffic.json written by tools/hbm_traffic.py from separate rocprofv3 --pmc FETCH_SIZE /
-    WRITE_SIZE passes of this command); otherwise null.  Never a value scaled from another shape."""
+    shape on THIS device code exists (profiles/*_hbm_traffic.json written by tools/hbm_traffic.py from separate rocprofv3
+    --pmc FETCH_SIZE / WRITE_SIZE passes of this command, stamped with the sha256 of the library's .hip_fatbin section);
+    otherwise null.  Never a value scaled from another shape or taken on another build."""
+    from balatro_gym_amd import _native as nat
+    sig = nat.device_code_signature()
     best = None
     for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_hbm_traffic.json"))):
         try:
             with open(path) as f:
                 j = json.load(f)
-            if j.get("kernel") == kernel and j.get("kernel_build") == KERNEL_BUILD and int(j.get("envs", 0)) == n and int(round(j.get("fused_steps_per_launch", 0))) == int(round(fused)):
+            if j.get("kernel") == kernel and j.get("device_code_sha") == sig and int(j.get("envs", 0)) == n and int(round(j.get("fused_steps_per_launch", 0))) == int(round(fused)):
                 best = (float(j["hbm_bytes_per_launch"]), os.path.basename(path))
         except Exception:
             continue
     return best
+
+
+def spawn_ranks(n_gpus: int, need_devices: int) -> int:
+    """`--gpus N` without a launcher: start N ranks of this script as child processes.  Nothing in THIS process has touched a GPU
+    (torch.cuda.device_count() does not initialise HIP on this image), and it never re-executes itself."""
+    import socket
+    import subprocess
+    import torch
+    ndev = torch.cuda.device_count()
+    if ndev < need_devices:
+        print(f"bench.py: --gpus {n_gpus} asked for but only {ndev} GPU(s) are visible; run on a box with {n_gpus} GPUs "
+              f"(or under torch.distributed.run with one rank per GPU)", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n_gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
 
 
 def main():
@@ -141,31 +176,44 @@ def main():
     ap.add_argument("--keep-obs", type=int, default=1, help="write every step's observation to a [chunk, N] buffer")
     ap.add_argument("--obs-layout", choices=["rows", "keys"], default="rows",
                     help="rows: one packed 352-byte record per (step, env) (bg_rollout_rows); keys: one array per key")
-    ap.add_argument("--internal-warmup-s", type=float, default=0.5, help="untimed full-depth launches before --warmup")
+    ap.add_argument("--internal-warmup-launches", type=int, default=128,
+                    help="untimed full-depth launches before --warmup: a FIXED count (~0.5 s), identical on every rank -- a time-based loop "
+                         "would leave the ranks with different numbers of collectives")
+    ap.add_argument("--internal-warmup-s", type=float, default=None, help="(older spelling) converted to launches at 4 ms each")
+    ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL over xGMI (the product path); gloo only for the two-ranks-on-one-GPU test")
+    ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses GPU 0 (needs --dist-backend gloo: RCCL refuses two ranks on one device)")
+    ap.add_argument("--samples", type=int, default=30, help="repeats of the K-step region after the timed one (median / p10 / p90)")
     ap.add_argument("--row-stride", type=int, default=0, help="bytes between packed records (0 = 352, dense)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-path", action="store_true", help="skip the bg_step / bg_step_many sample")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the RCCL all_gather of the current observation out")
     ap.add_argument("--force-gather", action="store_true", help="N = 1: run the gather path anyway (a one-rank RCCL group; exercises the N > 1 code on a one-GPU box)")
     args = ap.parse_args()
+    if args.internal_warmup_s is not None:
+        args.internal_warmup_launches = int(round(args.internal_warmup_s / 0.004))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, 1 if args.share_gpu else args.gpus))
 
     import torch
     import torch.distributed as dist
     from balatro_gym_amd import BalatroVecEnv
-    from balatro_gym_amd.sharded import shard_range
+    from balatro_gym_amd.sharded import all_gather_bytes, shard_range
     from balatro_gym_amd.vec_env import ObsBuffers, RowBuffers
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     use_dist = world > 1 or args.force_gather
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: start one rank per GPU (torch.distributed.run --nproc-per-node "
+              f"{args.gpus}) or leave WORLD_SIZE unset and let bench.py start the ranks", file=sys.stderr)
+        sys.exit(2)
     dev = torch.device(f"cuda:{local_rank}")
     n = args.envs_per_gpu
     total = n * world
@@ -213,7 +261,7 @@ def main():
             if do_gather:
                 gather_stream.wait_stream(cur)
                 with torch.cuda.stream(gather_stream):
-                    dist.all_gather_into_tensor(gathered.view(-1), bufs[b].rows[c - 1][:, :352].reshape(-1))
+                    all_gather_bytes(gathered.view(-1), bufs[b].rows[c - 1][:, :352].reshape(-1))
                     ev = torch.cuda.Event()
                     ev.record(gather_stream)
                 gather_done[b] = ev
@@ -228,13 +276,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- untimed internal warm-up at full depth, then the W warm-up steps of the contract
-    t_w = time.perf_counter()
+    # ---- untimed internal warm-up at full depth (a fixed number of launches: every rank issues the same collectives), then the W
+    # warm-up steps of the contract
     t_off = 0
-    while time.perf_counter() - t_w < args.internal_warmup_s:
-        run(8 * chunk, t_off)  # eight launches back to back, as in the timed region (the refill of one runs beside the next)
+    left = args.internal_warmup_launches
+    while left > 0:
+        k = min(8, left)
+        run(k * chunk, t_off)  # launches back to back, as in the timed region (the refill of one runs beside the next)
         torch.cuda.synchronize(dev)
-        t_off += 8 * chunk
+        t_off += k * chunk
+        left -= k
     run(args.warmup, t_off)
     t_off += args.warmup
     env.check()
@@ -246,9 +297,37 @@ def main():
     run(args.steps, t_off)
     barrier()
     elapsed = time.perf_counter() - t_start
+    t_off += args.steps
     prof = env.get_profile()
-    env.set_profiling(False)
     stats = env.stats()  # also checks the device error word
+    gather_bytes_timed = gather_bytes
+
+    # ---- the same K-step region again, `--samples` times (each between two synchronisations; every rank runs the same count), then
+    # a SUSTAINED window: enough back-to-back repeats to span one lazy-refill period, no synchronisation in between
+    sample_s = []
+    for _ in range(max(0, args.samples)):
+        barrier()
+        t0s = time.perf_counter()
+        run(args.steps, t_off)
+        barrier()
+        sample_s.append(time.perf_counter() - t0s)
+        t_off += args.steps
+    prof_samples = env.get_profile()
+    reps = max(2, -(-env.max_fused_steps // max(1, args.steps)) + 1)
+    barrier()
+    t0s = time.perf_counter()
+    for _ in range(reps):
+        run(args.steps, t_off)
+        t_off += args.steps
+    barrier()
+    sustained_s = time.perf_counter() - t0s
+    prof_sustained = env.get_profile()
+    env.set_profiling(False)
+    env.check()
+    if world > 1 and sample_s:
+        ts = torch.tensor(sample_s + [sustained_s], dtype=torch.float64, device=dev)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        sample_s, sustained_s = ts[:-1].tolist(), float(ts[-1].item())
 
     tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     agg = torch.tensor([stats["steps"], stats["episodes"], stats["plays"]], dtype=torch.int64, device=dev)
@@ -285,16 +364,20 @@ def main():
                                       if args.obs_layout == "rows" else " as one [T, N] array per key"),
                        "obs_layout": args.obs_layout,
                        "envs_per_gpu": n, "total_envs": total, "fused_steps_per_launch": fused,
-                       "internal_warmup_s": args.internal_warmup_s,
+                       "internal_warmup_launches": args.internal_warmup_launches,
                        "ring_depths": {k: os.environ.get(k, "default") for k in ("BG_KG", "BG_KS", "BG_KD")},
                        "parallelism": f"shard{world} (independent envs, no data-path collective)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
+                         # the PMC counters cannot be read from inside this process: when `traffic` is not null it comes from a committed
+                         # rocprofv3 measurement of THIS device code and launch shape on another box
+                         "traffic_measured_in_run": False,
                          # the bytes the HBM really moved per second during a launch (PMC traffic / launch time), when known
                          "traffic_gbps": traffic[0] / mean_launch_s / 1e9 if (traffic and mean_launch_s > 0) else None,
                          "traffic_frac_of_measured": traffic[0] / mean_launch_s / 1e9 / peak_measured if (traffic and mean_launch_s > 0 and peak_measured) else None,
                          "peak_measured": peak_measured, "frac_of_measured": achieved / peak_measured if peak_measured else None,
+                         "peak_guide": HBM_PEAK_GUIDE_GBPS, "frac_of_guide": achieved / HBM_PEAK_GUIDE_GBPS,
                          # stores only: the records + the state written back, against a plain fill kernel on this GPU
                          "write_gbps": write_gbps, "peak_measured_write": peak_write, "write_frac_of_measured": write_gbps / peak_write if peak_write else None,
                          "kernel": kernel, "algorithmic_bytes_per_env_step": a_step,
@@ -306,9 +389,24 @@ def main():
             "episodes": int(agg[1].item()), "accepted_plays": int(agg[2].item()),
             "state_bytes_per_gpu": env.state_bytes(),
         }
+        if sample_s:
+            vs = sorted(total * args.steps / t for t in sample_s)
+            pick = lambda q: vs[min(len(vs) - 1, max(0, int(round(q * (len(vs) - 1)))))]
+            nl = max(1, prof_samples["rollout_launches"])
+            out["samples"] = {"n": len(vs), "what": f"the same {args.steps}-step region again, each between two synchronisations",
+                              "median": pick(0.5), "p10": pick(0.1), "p90": pick(0.9), "min": vs[0], "max": vs[-1],
+                              "value_inside_p10_p90": bool(pick(0.1) <= value <= pick(0.9)),
+                              "mean_launch_us": prof_samples["rollout_ms"] / nl * 1e3, "launches": nl,
+                              "refill_launches": prof_samples["refill_launches"],
+                              "median_roofline_frac": pick(0.5) * a_step / world / 1e9 / HBM_PEAK_GBPS}
+        out["sustained"] = {"value": total * args.steps * reps / sustained_s, "unit": "env-steps/s", "regions": reps,
+                            "what": f"{reps} back-to-back repeats of the {args.steps}-step region, no synchronisation in between (spans a lazy-refill period)",
+                            "refill_launches_inside": prof_sustained["refill_launches"], "launches": prof_sustained["rollout_launches"],
+                            "roofline_frac": total * args.steps * reps / sustained_s * a_step / world / 1e9 / HBM_PEAK_GBPS}
+        out["roofline"]["refill_launches_in_timed_region"] = prof["refill_launches"]
         if use_dist:
             out["gather"] = {"in_timed_region": bool(do_gather), "what": "all_gather_into_tensor of the current 352-byte record of every env, once per launch, side stream",
-                             "bytes_per_gpu_per_launch": (gather_bytes // max(1, launches)) if do_gather else 0}
+                             "bytes_per_gpu_per_launch": (gather_bytes_timed // max(1, launches)) if do_gather else 0}
     env.close()
     del ob, bufs
 

@@ -11,7 +11,9 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbalatro_oracle.so")
+# BALATRO_ORACLE_LIB: another build of the same sources -- the AddressSanitizer / UBSan build (`make -C oracle asan`) that
+# tests/test_oracle_sanitized.py runs the golden tests against
+LIB_PATH = os.environ.get("BALATRO_ORACLE_LIB") or os.path.join(HERE, "libbalatro_oracle.so")
 
 NACT = 60
 FLAG_SCORER_JOKERS = 1
@@ -100,6 +102,8 @@ def build(force: bool = False) -> str:
     """Compile oracle/libbalatro_oracle.so with gcc (building the checker is not using it)."""
     src = os.path.join(HERE, "balatro_oracle.c")
     deps = [src, os.path.join(HERE, "bo_sim.c"), os.path.join(HERE, "balatro_oracle.h"), os.path.join(HERE, "bo_tables.h")]
+    if os.environ.get("BALATRO_ORACLE_LIB"):
+        return LIB_PATH
     if force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps):
         subprocess.check_call(["make", "-C", HERE, "-s", "libbalatro_oracle.so"])
     return LIB_PATH

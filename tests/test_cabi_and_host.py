@@ -146,3 +146,38 @@ def test_packed_record_layout_matches_header():
     for (a0, a1, ka), (b0, b1, kb) in zip(spans, spans[1:]):
         assert a1 <= b0, (ka, kb)
     assert spans[-1][1] <= nat.ROW_BYTES
+
+
+def test_bench_gpus_flag_without_devices_fails_cleanly():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset starts the ranks itself; with fewer than 2 visible GPUs (none in the build
+    container) it must say so and exit 2 -- not die on an assertion, not re-exec."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs visible: the flag would really start two ranks")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5"],
+                         capture_output=True, text=True, timeout=300,
+                         env={k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")})
+    assert out.returncode == 2, (out.returncode, out.stderr[-500:])
+    assert "GPU(s) are visible" in out.stderr and "Traceback" not in out.stderr
+
+
+def test_blob_geometry_constants_match_the_device_header():
+    """balatro_gym_amd._native's state-blob constants are the device header's (csrc/bg_device.h)."""
+    from balatro_gym_amd import _native as nat
+    text = open(os.path.join(ROOT, "balatro_gym_amd", "csrc", "bg_device.h")).read()
+
+    def define(name):
+        m = re.search(rf"^#define {name} (\S+)", text, flags=re.M)
+        assert m, name
+        return m.group(1)
+    assert int(define("BG_NHOT")) == nat.BLOB_NHOT and int(define("BG_NDECK")) == nat.BLOB_NDECK
+    assert int(define("BG_NCOLD")) == nat.BLOB_NCOLD and int(define("BG_NTMPL")) == nat.BLOB_NTMPL
+    assert int(define("BG_MTS")) == nat.BLOB_MTS and int(define("BG_NCST")) == nat.BLOB_NCST
+    sw_a = int(define("BG_SW_A"))
+    assert nat.SHOP_SLOT_SEED_WORD == 2 * sw_a and nat.SHOP_SLOT_WORDS == (2 * sw_a + 1 + 7) // 8 * 8
+    m = re.search(r"^#define BG_SSEED (\d+)", open(os.path.join(ROOT, "balatro_gym_amd", "csrc", "bg_device.h")).read() +
+                  open(os.path.join(ROOT, "balatro_gym_amd", "csrc", "bg_lib.hip")).read(), flags=re.M)
+    assert m and int(m.group(1)) == nat.BLOB_SSEED

@@ -512,10 +512,12 @@ def test_service_wave_masks(monkeypatch):
     test_consumables_rollout_vs_oracle(True)
 
 
-@pytest.mark.parametrize("config", ["configs2_jokers_antes_1_4", "configs4_full_game_curriculum"])
+@pytest.mark.parametrize("config", ["configs2_jokers_antes_1_4", "configs3_consumables_all_jokers_antes_1_8", "configs4_full_game_curriculum"])
 def test_rollout_properties_full_size(config):
     """Size-independent properties at BASELINE.json's N = 65 536 on the REAL workloads -- configs[2] (5 random implemented jokers
-    per env, scorer-level joker chain, Antes 1-4 cap, blind 45/46/47 by env index) and the single-GPU share of configs[4] (full
+    per env, scorer-level joker chain, Antes 1-4 cap, blind 45/46/47 by env index), the single-GPU share of configs[3] (full joker
+    pool: 5 of all 150 ids, card states on, two consumables per env and episode out of all 52 planet / tarot / spectral ids, enhanced /
+    sealed cards in a third of the decks, Antes 1-8 cap, uniform policy) and the single-GPU share of configs[4] (full
     game: uniform policy incl. boss blinds and shop buys / rerolls / sells, all 150 joker ids, a per-env curriculum cap that
     rises 3 -> 8 between launches): determinism, chunking invariance (one T=48 call == 48 T=1 calls), sharding invariance (two
     half-size handles with env_index0 offsets == one full handle), by statistics + XOR checksums of every reward and every
@@ -525,14 +527,24 @@ def test_rollout_properties_full_size(config):
     n, T = 65536, 48
     seeds = [1000 + SEED_OFFSET + i for i in range(n)]
     full = config.startswith("configs4")
-    policy = (0 if full else 2) | 0x100
-    pool = list(range(1, 151)) if full else IMPLEMENTED
+    cons3 = config.startswith("configs3")
+    policy = (0 if (full or cons3) else 2) | 0x100
+    pool = list(range(1, 151)) if (full or cons3) else IMPLEMENTED
     jokers = [random.Random(i).sample(pool, 5) for i in range(n)]
     caps = np.array([3 + (i % 3) for i in range(n)], np.int32)
+    cons_ids = list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68))   # _get_consumable_ids (balatro_env_2.py:1545-1567)
+    cons = [[cons_ids[i % 52], cons_ids[(7 * i + 3) % 52]] for i in range(n)] if cons3 else None
+    cards = [[(d, [0, 1, 4, 6, 8][(i + d) % 5], [0, 1, 3][d % 3], [0, 1, 2, 3, 4][(i // 3 + d) % 5]) for d in range(16)] if i % 3 == 0 else []
+             for i in range(n)] if cons3 else None
 
     def run(count, index0, chunks):
-        env = _vec(count, seeds[index0:index0 + count], autoreset=True, scorer_jokers=True, max_ante=3 if full else 4, fused_steps=48)
+        env = _vec(count, seeds[index0:index0 + count], autoreset=True, scorer_jokers=True, max_ante=8 if cons3 else (3 if full else 4),
+                   fused_steps=48, card_states=cons3)
+        if cons3:
+            env.inject_cards(cards[index0:index0 + count], apply_now=True)
         env.inject(jokers=jokers[index0:index0 + count], apply_now=True)
+        if cons3:
+            env.inject_consumables(cons[index0:index0 + count], apply_now=True)
         t0 = 0
         for c in chunks:
             if full and t0 == 24:  # the curriculum: caps rise mid-run (CurriculumBalatroEnv.current_max_ante, per env)
@@ -843,3 +855,44 @@ def test_sb3_adapter_conventions():
                 assert obs["phase"][i, 0] == 2  # a fresh episode: blind select
     assert kills == 9 and truncs > 0
     venv.close()
+
+
+def test_mt_streams_on_device():
+    """F1 on the DEVICE (DeterministicRNG balatro_env_2.py:84-144): the reference's known answers of tests/golden/mt_streams.json
+    read back from the HIP state through bg_get_state blobs -- the FULL 52-card deck of the first reset shuffle (stream 0; an observation
+    only ever shows deck[0..7]), the first three `get_int('shop_generation', 0, 2**31 - 1)` draws (stream 2) as the seeds of the first
+    pre-seeded shop streams, and the first 16 words of random.Random(seed) as the head of the env's global-stream ring (raw MT19937
+    words, tempered here as genrand_uint32 does)."""
+    import json
+    from balatro_gym_amd import BalatroVecEnv
+    from tests.helpers import GOLD
+    g = json.load(open(os.path.join(GOLD, "mt_streams.json")))
+    seeds = [int(s) for s in g["seeds"]]
+    n = len(seeds)
+
+    def temper(y):
+        y = y.astype(np.uint32).copy()
+        y ^= y >> 11
+        y ^= (y << 7) & np.uint32(0x9D2C5680)
+        y ^= (y << 15) & np.uint32(0xEFC60000)
+        y ^= y >> 18
+        return y
+
+    env = _vec(n, seeds, autoreset=False)   # construction = DeterministicRNG(seed) + the first reset()
+    for i, seed in enumerate(seeds):
+        st = BalatroVecEnv.parse_state_blob(env.get_state(i))
+        assert st["deck"].tolist() == g["deck"][i], f"seed {seed}: the shuffled deck differs"
+        cur = st["shop_slot_current"]
+        got = [int(st["shop_slot_seeds"][(cur + 1 + k) % st["KS"]]) for k in range(3)]
+        assert got == g["shop_seed"][i], f"seed {seed}: shop seeds {got} vs {g['shop_seed'][i]}"
+    env.close()
+    # the global stream is random.Random((seed + 16000) % 2**32) (harness convention G): an env seeded s - 16000 owns random.Random(s)
+    small = [(i, s) for i, s in enumerate(seeds) if 16000 <= s < 2 ** 32]
+    env = _vec(len(small), [s - 16000 for _, s in small], autoreset=False)
+    for k, (i, seed) in enumerate(small):
+        st = BalatroVecEnv.parse_state_blob(env.get_state(k))
+        hot6 = st["hot"][6]
+        g_cur = int((hot6[3] >> 16) & 0xff)   # ring block the cursor is in (nothing has drawn from the global stream yet)
+        got = temper(st["global_blocks"][g_cur][:16]).tolist()
+        assert got == g["u32"][i], f"seed {seed}: global stream words"
+    env.close()

@@ -4,11 +4,14 @@
 
 usage: hbm_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> <envs> <fused_steps> <out.json> [note]
 """
-import csv, json, sys
+import csv, json, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from balatro_gym_amd import _native as nat
 
 
 KERNELS = ("bg_engine_kernel",)  # the step engine
-KERNEL_BUILD = "7 worker waves (6 / 4 for short launches) x 256 envs per workgroup, nt record stores"  # bench.py only uses a measurement of the kernel shape it runs (KERNEL_BUILD there)
+# bench.py only quotes a measurement taken on the device code it runs: the sha256 of the library's .hip_fatbin section (run this script
+# with the same BALATRO_MI355X_LIB / product library the profiled command used)
 
 
 def mean_counter(path, counter):
@@ -33,7 +36,7 @@ def main():
     json.dump({
         "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py "
                   "--no-cpu-baseline, " + full.split("(")[0] + ", mean over steady-state launches. " + note,
-        "kernel": kernel, "kernel_build": KERNEL_BUILD, "envs": envs, "fused_steps_per_launch": fused, "launches_averaged": [nf, nw],
+        "kernel": kernel, "device_code_sha": nat.device_code_signature(), "envs": envs, "fused_steps_per_launch": fused, "launches_averaged": [nf, nw],
         "FETCH_SIZE_KB_per_launch": f, "WRITE_SIZE_KB_per_launch": w,
         "correction": "gfx950 FETCH_SIZE counts 1/2 of wide (16 B/lane) coalesced reads (MI355X_MICROARCH.md HBM): fetch "
                       "bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE taken as reported (* 1024)",
