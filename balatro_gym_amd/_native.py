@@ -42,9 +42,9 @@ ROW_OFFSETS = {
     "phase": 339, "boss_blind_active": 340, "boss_blind_type": 341,
 }
 ROW_EXTRA = {"reward": (136, "float64"), "action": (172, "int32"), "terminated": (342, "uint8")}
-INFO_KEYS = ["final_score", "error", "flags", "aux", "hand_type", "cards_played", "reward_terms"]
+INFO_KEYS = ["final_score", "error", "flags", "aux", "hand_type", "cards_played", "reward_terms", "score_breakdown"]
 INFO_SPEC = {"final_score": ("int64", ()), "error": ("int32", ()), "flags": ("int32", ()), "aux": ("int32", ()),
-             "hand_type": ("int8", ()), "cards_played": ("int8", ()), "reward_terms": ("float64", (8,))}
+             "hand_type": ("int8", ()), "cards_played": ("int8", ()), "reward_terms": ("float64", (8,)), "score_breakdown": ("float64", (8,))}
 
 FLAG_SCORER_JOKERS = 1
 FLAG_AUTORESET = 2

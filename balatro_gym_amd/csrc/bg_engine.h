@@ -324,7 +324,11 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     // copy-out: the images of the finished envs to their rows, lane <-> piece (whole 352-byte runs per row); then envs that are
     // through leave (after their images have been READ)
     auto copy_out = [&](bool fin, size_t row) __attribute__((always_inline)) {
+#ifdef BG_ABL_NOCOPY   // development ablation: what is the copy-out worth (results are wrong: no record leaves the chip)
+    if (false) {
+#else
     if (a.obs.rows) {
+#endif
 #ifdef BG_TIMING4
       const unsigned long long q_c0 = __builtin_readcyclecounter();
 #endif
@@ -406,6 +410,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
         RngWin w;
         bg_win_init(w, &s_win[serve_idx][0][lane], &jt);
         bg_step_init(o);
+        if constexpr (INFO) if (a.info.score_breakdown) o.bd_dst = a.info.score_breakdown + row * 8;
         if (bg_step_guards(e, mask, action, o)) bg_env_dispatch(d, env, e, w, sr, dk, action, o);
         BG_PROBE(cls == BG_Q_PLAY ? 20 : 21);
         if (e.max_ante > 0 && e.ante > e.max_ante) { o.terminated = true; o.flags |= 256; }
@@ -415,7 +420,9 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
         BG_PROBE(24);
         mask = bg_action_mask(d, env, e, sr);
         BG_PROBE(25);
+#ifndef BG_ABL_NOIMG   // (development ablation: a service step that leaves the image stale)
         bg_write_obs_impl<false, 3>(d, env, row, e, dk, a.obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u}, RowStage{(lds_u4*)&s_img[l][0], nullptr});
+#endif
         BG_PROBE(26);
         bg_pack(e, c);
 #pragma unroll

@@ -21,6 +21,7 @@
 struct InfoPtrs {
   int64_t* final_score; int32_t* error; int32_t* flags; int32_t* aux; int8_t* hand_type; int8_t* cards_played;
   double* reward_terms;
+  double* score_breakdown;
 };
 
 static_assert(offsetof(ObsPtrs, rows) == sizeof(bg_obs_ptrs), "the first 31 members of ObsPtrs must mirror bg_obs_ptrs");
@@ -41,6 +42,11 @@ __device__ __forceinline__ void bg_emit_info(size_t row, const StepOut& o, uint8
     double2* q = (double2*)(info.reward_terms + row * 8);
 #pragma unroll
     for (int i = 0; i < 4; i++) q[i] = make_double2(o.terms[2 * i], o.terms[2 * i + 1]);
+  }
+  if (info.score_breakdown && o.hand_type < 0) { // an accepted play stored its row itself (bg_step_play_hand); every other step: zeros
+    double2* q = (double2*)(info.score_breakdown + row * 8);
+#pragma unroll
+    for (int i = 0; i < 4; i++) q[i] = make_double2(0.0, 0.0);
   }
 }
 
@@ -599,6 +605,7 @@ struct bg_handle {
   uint32_t* d_jtab;
   int steps_since_refill; // env steps launched (bg_step, bg_step_many, rollouts) since the last refill was LAUNCHED
   std::vector<uint4> h_tmpl;
+  std::vector<uint8_t> h_cap; // host mirror of every env's curriculum cap (0 = none): what template antes are validated against
   uint64_t bytes;
   std::string err;
   // optional per-kernel timing with HIP events on the launch stream (bench.py roofline leg)
@@ -823,6 +830,7 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
   hipLaunchKernelGGL(bg_tables_build_kernel, dim3(1), dim3(256), 0, 0, h->d_jtab);
   if (hipGetLastError() != hipSuccess || hipDeviceSynchronize() != hipSuccess) { g_create_err = "bg_create: table kernel failed"; bg_destroy(h); return BG_E_HIP; }
   h->h_tmpl.assign(BG_NTMPL * N, make_uint4(0, 0, 0, 0));
+  h->h_cap.assign(N, (uint8_t)(max_ante > 0 && max_ante < 256 ? max_ante : 0));
   if (max_ante < 0 || max_ante > 255) { g_create_err = "bg_create: max_ante must be in [0, 255]"; bg_destroy(h); return BG_E_ARG; }
   if (max_ante > 0) { // the cap lives in each env's state (bg_set_max_ante changes it later: a rising curriculum)
     hipLaunchKernelGGL(bg_set_cap_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, 0, d, (const int32_t*)nullptr, max_ante, (const uint8_t*)nullptr);
@@ -1016,6 +1024,7 @@ static void bg_obs_advance(ObsPtrs& o, size_t off) { // advance every non-null p
 static void bg_info_advance(InfoPtrs& p, size_t off) {
   if (p.final_score) p.final_score += off; if (p.error) p.error += off; if (p.flags) p.flags += off; if (p.aux) p.aux += off;
   if (p.hand_type) p.hand_type += off; if (p.cards_played) p.cards_played += off; if (p.reward_terms) p.reward_terms += off * 8;
+  if (p.score_breakdown) p.score_breakdown += off * 8;
 }
 
 int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void* stream) {
@@ -1283,7 +1292,7 @@ int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_h
     if (ante_host) {
       // an env that resets into ante > cap ends every episode on its first step: one pre-shuffled deck per STEP, three times
       // what the look-ahead rings are sized for (bg_chunk_limit)
-      if (ante_host[i] > 255 || (h->dev.max_ante > 0 && ante_host[i] > h->dev.max_ante)) { h->err = "bg_inject: template ante above the curriculum cap (max_ante)"; return BG_E_ARG; }
+      if (ante_host[i] > 255 || (h->h_cap[i] > 0 && ante_host[i] > (int)h->h_cap[i])) { h->err = "bg_inject: template ante above the env's curriculum cap (max_ante)"; return BG_E_ARG; }
       if (ante_host[i] > 0) { an = (uint32_t)ante_host[i] & 0xffu; fl |= 0x20u; } else fl &= ~0x20u;
     }
     if (levels_host) {
@@ -1413,6 +1422,7 @@ int bg_set_state(bg_handle* h, int env_index, const void* blob_host, uint64_t bl
     BG_HIP(hipMemcpy2D((uint8_t*)s.base + (size_t)env_index * s.elem, N * s.elem, in, s.elem, s.elem, s.rows, hipMemcpyHostToDevice));
     if (s.base == (void*)h->dev.tmpl) // the host mirror of the reset template follows (later bg_inject calls upload the whole mirror)
       for (size_t r = 0; r < s.rows; r++) memcpy(&h->h_tmpl[r * N + (size_t)env_index], in + r * s.elem, sizeof(uint4));
+    if (s.base == (void*)h->dev.hot) { uint4 c7; memcpy(&c7, in + 7 * s.elem, sizeof(uint4)); h->h_cap[env_index] = (uint8_t)((c7.w >> 16) & 0xffu); } // the cap travels in the blob
     in += s.rows * s.elem;
   }
   { // both producer-counter buffers must agree for this env (an overlapped rollout reads the older one)
@@ -1463,9 +1473,18 @@ int bg_set_max_ante(bg_handle* h, int max_ante, const int32_t* per_env_host, con
   const size_t N = h->dev.N;
   if (!per_env_host && (max_ante < 0 || max_ante > 255)) { h->err = "bg_set_max_ante: the cap must be in [0, 255] (0 = none)"; return BG_E_ARG; }
   int32_t* dc = nullptr;
+  for (size_t i = 0; i < N; i++) {
+    if (mask_host && !mask_host[i]) continue;
+    const int c = per_env_host ? per_env_host[i] : max_ante;
+    if (c < 0 || c > 255) { h->err = "bg_set_max_ante: every cap must be in [0, 255] (0 = none)"; return BG_E_ARG; }
+    // an env whose reset template puts it ABOVE its cap would end every episode on its first step: one pre-shuffled deck per step,
+    // three times what the look-ahead rings are budgeted for (bg_chunk_limit) -- refused here as in bg_inject
+    const uint32_t ty = h->h_tmpl[i].y;
+    if (c > 0 && ((ty >> 24) & 0x20u) && (int)((ty >> 16) & 0xffu) > c) { h->err = "bg_set_max_ante: a cap below the env's template ante (bg_inject)"; return BG_E_ARG; }
+  }
+  for (size_t i = 0; i < N; i++)
+    if (!mask_host || mask_host[i]) h->h_cap[i] = (uint8_t)(per_env_host ? per_env_host[i] : max_ante);
   if (per_env_host) {
-    for (size_t i = 0; i < N; i++)
-      if ((!mask_host || mask_host[i]) && (per_env_host[i] < 0 || per_env_host[i] > 255)) { h->err = "bg_set_max_ante: every cap must be in [0, 255] (0 = none)"; return BG_E_ARG; }
     BG_HIP(hipMalloc((void**)&dc, N * sizeof(int32_t)));
     BG_HIP(hipMemcpyAsync(dc, per_env_host, N * sizeof(int32_t), hipMemcpyHostToDevice, s));
   }
@@ -1475,8 +1494,7 @@ int bg_set_max_ante(bg_handle* h, int max_ante, const int32_t* per_env_host, con
   BG_HIP(hipGetLastError());
   BG_HIP(hipStreamSynchronize(s));
   if (dc) BG_HIP(hipFree(dc));
-  if (!per_env_host && !mask_host) h->dev.max_ante = max_ante; // what bg_inject validates template antes against
-  else if (h->dev.max_ante) h->dev.max_ante = 255;               // mixed caps: only the representable range is checked
+  if (!per_env_host && !mask_host) h->dev.max_ante = max_ante; // the handle-wide default (template antes are validated per env: h_cap)
   return 0;
 }
 

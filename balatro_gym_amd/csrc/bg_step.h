@@ -11,6 +11,11 @@ struct StepOut {
   int32_t error, flags, aux;
   int32_t hand_type, cards_played;
   bool terminated;
+  // info['score_breakdown'] of an accepted play (unified_scoring.py:129-137, :293-297): what the scorer itself reports, before the env's
+  // steel / boss / red-seal factors.  Only the bg_step instantiation of the engine emits these (dead code in the rollouts).
+  // They are stored where they are computed (bd_dst = the step's row of bg_info_ptrs.score_breakdown, or null): carried to the end of
+  // the step they would cost nine more live registers in a kernel that is out of them.
+  double* bd_dst;
 };
 
 // ---------------------------------------------------------------------------------------------------------
@@ -727,7 +732,12 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     else if (e.boss_type == 12 && (e.boss_types & (1u << ht))) err = 3;
     else if (e.boss_type == 13 && e.boss_types && !(e.boss_types & (1u << ht))) err = 4;
     else if (e.boss_type == 25 && n < e.boss_req) err = 5;
-    if (err) { o.reward = -1.0; o.error = err; return; }
+    if (err) {
+      o.reward = -1.0; o.error = err;
+      // what the reference's message names (boss_blinds.py:393,399,405): the hand type played again, the ONE allowed type, the cards required
+      o.aux = err == 3 ? ht : (err == 4 ? __ffs((int)e.boss_types) - 1 : (err == 5 ? e.boss_req : 0));
+      return;
+    }
   }
   // :683-692 UnifiedScorer.score_hand
   int level = bg_level(e, ht);
@@ -743,6 +753,16 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     bg_joker_chain<false, DK>(d, env, e, w, in, chips, mult, x_mult, chain_money, &pre);
   }
   int64_t final_score = (int64_t)((double)(chips * mult) * x_mult); // unified_scoring.py:286
+  if (o.bd_dst) { // info['score_breakdown'] (bg_step only): final_chips, final_mult, final_x_mult, card_chips, base_chips, base_mult, money_gained, 0
+    int gems = 0; // money_gained: Rough Gem pays $1 per Diamond scored (complete_joker_effects.py:160); the env drops it (unified_scoring.py:292-294)
+    if ((d.flags & 1u) && e.njokers > 0) {
+#pragma unroll
+      for (int j = 0; j < 5; j++) gems += (j < e.njokers && bg_get8(e.jokers, j) == 116) ? 1 : 0;
+    }
+    double2* q = (double2*)o.bd_dst;
+    q[0] = make_double2((double)chips, (double)mult); q[1] = make_double2(x_mult, (double)chip_sum);
+    q[2] = make_double2((double)bchips, (double)bmult); q[3] = make_double2((double)(gems * (int)((scnt >> 4) & 0xfu)), 0.0);
+  }
   int retriggers = 0;
   if constexpr (DK::kCards) {
     // :703-734 per played card: GLASS rolls once, LUCKY twice on the 'card_enhancement' stream (the second roll < 0.0667
@@ -1045,6 +1065,7 @@ __device__ __forceinline__ void bg_step_blind(const BgDev& d, int env, Env& e, R
 __device__ __forceinline__ void bg_step_init(StepOut& o) {
   o.reward = 0.0; o.final_score = 0; o.error = 0; o.flags = 0; o.aux = 0; o.hand_type = -1; o.cards_played = 0;
   o.terminated = false;
+  o.bd_dst = nullptr;
 #pragma unroll
   for (int i = 0; i < 8; i++) o.terms[i] = 0.0;
 }
@@ -1299,6 +1320,9 @@ __device__ __forceinline__ void bg_env_dispatch(const BgDev& d, int env, Env& e,
     else bg_use_consumable(d, env, e, w, dk, action - 10, o); // 10..14
   } else if (e.phase == 1) bg_step_shop(d, env, e, w, sr, action, o);
   else if (e.phase == 2) bg_step_blind<DK::kCards>(d, env, e, w, sr, action, o);
+#ifdef BG_ABL_NOSHOP   // development ablation: what is the shop inventory worth (the shop rows stay stale)
+  w.need_inv = false;
+#endif
   if (w.need_inv) { BG_PROBE_BEGIN(); bg_shop_inventory(d, env, e, w, sr); w.need_inv = false; BG_PROBE(22); }
 }
 

@@ -139,9 +139,10 @@ class BalatroEnv(_EnvBase):
         err, flags, ht = int(inf["error"]), int(inf["flags"]), int(inf["hand_type"])
         if err in (9, 10):
             out["terminated"] = "max_ante_reached" if err == 9 else "max_score_reached"
-        elif err in (3, 4, 5):
-            out["error"] = {3: "Cannot play this hand type again", 4: "Can only play the first hand type",
-                            5: "Must play more cards"}[err]
+        elif err in (3, 4, 5):  # the boss blind's own messages (boss_blinds.py:393,399,405); info.aux holds what they name
+            aux = int(inf["aux"])
+            out["error"] = (f"Cannot play {HAND_TYPE_NAMES[aux]} again" if err == 3 else
+                            f"Can only play {HAND_TYPE_NAMES[aux]}" if err == 4 else f"Must play at least {aux} cards")
         elif err:
             out["error"] = _ERRORS.get(err, "error")
         if ht >= 0:
@@ -149,6 +150,12 @@ class BalatroEnv(_EnvBase):
             if terms is not None:
                 rb = {k: float(terms[i]) for i, k in enumerate(_TERMS)}
                 out["reward_breakdown"] = rb
+            bd = inf.get("score_breakdown")
+            if bd is not None:  # balatro_env_2.py:909 (unified_scoring.py:129-137, :293-297); 'effects_applied' (display strings) is not produced
+                fc, fm, fx, cc, bc, bm, mg = int(bd[0]), int(bd[1]), float(bd[2]), int(bd[3]), int(bd[4]), int(bd[5]), int(bd[6])
+                out["score_breakdown"] = {"base_chips": bc, "base_mult": bm, "card_chips": cc, "joker_chips": fc - bc - cc,
+                                          "joker_mult": fm - bm, "joker_x_mult": fx, "final_chips": fc, "final_mult": fm,
+                                          "final_x_mult": fx, "final_score": int(fc * fm * fx), "money_gained": mg}
             out["final_score"] = int(inf["final_score"])
             out["hand_type"] = ht
             out["hand_type_name"] = HAND_TYPE_NAMES[ht]

@@ -113,7 +113,7 @@ class BalatroVecEnv:
             self.terminated = torch.zeros(n, dtype=torch.uint8, device=dev)
             self.truncated = torch.zeros(n, dtype=torch.uint8, device=dev)
             self.info = {k: torch.zeros((n,) + nat.INFO_SPEC[k][1], dtype=_TORCH_DT[nat.INFO_SPEC[k][0]], device=dev)
-                         for k in nat.INFO_KEYS if info_terms or k != "reward_terms"}
+                         for k in nat.INFO_KEYS if info_terms or k not in ("reward_terms", "score_breakdown")}
             self._info_ptrs = nat.InfoPtrs(**{k: (self.info[k].data_ptr() if k in self.info else None)
                                               for k in nat.INFO_KEYS})
             self._stats = torch.zeros(6, dtype=torch.int64, device=dev)
@@ -442,8 +442,9 @@ def classify_batch(cards: torch.Tensor, n: torch.Tensor, lanes_per_case: int = 1
     lanes_per_case: 1 (lane = hand) or 8 (lane = card, shuffle reductions inside 8-lane groups); identical results.
     timing=True returns (out, kernel milliseconds)."""
     L = nat.load()
-    if cards.dtype != torch.uint8 or n.dtype != torch.uint8 or cards.dim() != 2 or cards.shape[1] != 8 or not cards.is_cuda:
-        raise ValueError("cards must be a uint8 [M, 8] device tensor, n a uint8 [M] device tensor")
+    if cards.dtype != torch.uint8 or n.dtype != torch.uint8 or cards.dim() != 2 or cards.shape[1] != 8 or not cards.is_cuda \
+            or tuple(n.shape) != (cards.shape[0],) or n.device != cards.device:
+        raise ValueError("cards must be a uint8 [M, 8] device tensor, n a uint8 [M] tensor on the same device")
     cards, n = cards.contiguous(), n.contiguous()
     out = torch.empty(cards.shape[0], dtype=torch.uint8, device=cards.device)
     ms = C.c_float(0.0)
@@ -480,9 +481,12 @@ def sim_evaluate_batch(hands: torch.Tensor, n: torch.Tensor, flags: torch.Tensor
     base_value, enhancement, edition, seal), n int32 [M], flags int32 [M] (1 Four Fingers, 2 Shortcut) -> int8 [M, 128]
     (layout: include/balatro_mi355x.h bg_sim_evaluate_batch)."""
     L = nat.load()
-    if hands.dtype != torch.int32 or tuple(hands.shape[1:]) != (8, 6) or not hands.is_cuda:
+    if hands.dtype != torch.int32 or hands.dim() != 3 or tuple(hands.shape[1:]) != (8, 6) or not hands.is_cuda:
         raise ValueError("hands must be an int32 [M, 8, 6] device tensor")
-    hands, n, flags = hands.contiguous(), n.to(torch.int32).contiguous(), flags.to(torch.int32).contiguous()
+    if tuple(n.shape) != (hands.shape[0],) or tuple(flags.shape) != (hands.shape[0],):
+        raise ValueError("n and flags must have shape [M]")
+    hands = hands.contiguous()   # n / flags may come from the host or as other integer types: moved and converted, never handed over as they are
+    n, flags = n.to(device=hands.device, dtype=torch.int32).contiguous(), flags.to(device=hands.device, dtype=torch.int32).contiguous()
     out = torch.zeros((hands.shape[0], nat.SIM_EVAL_BYTES), dtype=torch.int8, device=hands.device)
     with torch.cuda.device(hands.device):
         rc = L.bg_sim_evaluate_batch(C.c_void_p(hands.data_ptr()), C.c_void_p(n.data_ptr()), C.c_void_p(flags.data_ptr()),

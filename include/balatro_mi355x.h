@@ -115,10 +115,16 @@ typedef struct bg_info_ptrs {
   int64_t* final_score;  /* [N] info['final_score'] on an accepted play, else 0 */
   int32_t* error;        /* [N] BG_ERR_* */
   int32_t* flags;        /* [N] BG_INFO_* */
-  int32_t* aux;          /* [N] boss type on action 47 / joker id bought or sold / first pack card */
+  int32_t* aux;          /* [N] boss type on action 47 / joker id bought or sold / first pack card; on a boss rejection what the reference's
+                          * message names (boss_blinds.py:393,399,405): BG_ERR_EYE the hand type played again, BG_ERR_MOUTH the one allowed
+                          * hand type, BG_ERR_VERDANT the number of cards required */
   int8_t* hand_type;     /* [N] info['hand_type'] on an accepted play, else -1 */
   int8_t* cards_played;  /* [N] info['cards_played'] */
   double* reward_terms;  /* [N,8] info['reward_breakdown'] without 'total' */
+  double* score_breakdown; /* [N,8] info['score_breakdown'] of an accepted play (balatro_env_2.py:909, unified_scoring.py:129-137,293-297):
+                          * final_chips, final_mult, final_x_mult, card_chips, base_chips, base_mult, money_gained, 0 (integers are exact:
+                          * below 2**53); joker_chips = final_chips - base_chips - card_chips, joker_mult = final_mult - base_mult,
+                          * joker_x_mult = final_x_mult.  Zeros on every other step. */
 } bg_info_ptrs;
 
 /* Aggregate counters of a rollout (device, one struct per call; all ranks of a sharded job sum them on the host). */

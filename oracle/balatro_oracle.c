@@ -739,7 +739,15 @@ static void step_play_hand(bo_env* e, double* reward, uint8_t* terminated, bo_in
   /* :677-680 */
   if (e->boss_type) {
     int err = boss_can_play(e, n, hand_type);
-    if (err) { *reward = -1.0; info->error = err; return; }
+    if (err) {
+      *reward = -1.0; info->error = err;
+      /* what the reference's message names: f"Cannot play {hand_type} again" / f"Can only play {allowed}" (the set holds ONE type once
+       * The Mouth has seen a play) / f"Must play at least {required} cards" */
+      if (err == BO_ERR_EYE) info->aux = hand_type;
+      else if (err == BO_ERR_MOUTH) { int a = 0; while (a < 12 && !(e->boss_played_types & (1u << a))) a++; info->aux = a; }
+      else if (err == BO_ERR_VERDANT) info->aux = e->boss_cards_required;
+      return;
+    }
   }
   /* :683-692 */
   bo_score_out so;
@@ -747,6 +755,15 @@ static void step_play_hand(bo_env* e, double* reward, uint8_t* terminated, bo_in
   bo_score_hand(sc, n, sc, n, hand_type, BO_NAMES_ENV, e->hand_levels[hand_type], e->jokers, nj, e->hands_left,
                 e->discards_left, e->ndeck + e->nforeign, &e->grand, &so);
   int64_t base_score = so.score;
+  { /* info['score_breakdown'] (:909): the scorer's own numbers, before the env's steel / boss / red-seal factors */
+    int64_t bc0, bm0;
+    int card_chips = 0;
+    for (int i = 0; i < n; i++) card_chips += sc[i].chips;
+    bo_hand_chips_mult(hand_type, e->hand_levels[hand_type], &bc0, &bm0);
+    info->breakdown[0] = (double)so.chips; info->breakdown[1] = (double)so.mult; info->breakdown[2] = so.x_mult;
+    info->breakdown[3] = (double)card_chips; info->breakdown[4] = (double)bc0; info->breakdown[5] = (double)bm0;
+    info->breakdown[6] = (double)so.money; info->breakdown[7] = 0.0;
+  }
   /* :703-734 per-card enhancement / seal effects */
   int64_t extra_money = 0;
   int retriggers = 0, blue = 0;

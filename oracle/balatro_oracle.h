@@ -106,9 +106,12 @@ typedef struct {
   double reward_terms[8];  /* info['reward_breakdown']: progress, milestone, score, hand_quality, efficiency, synergy, strategy, ante_bonus */
   int32_t error;           /* BO_ERR_* */
   int32_t flags;           /* BO_INFO_* */
-  int32_t aux;             /* boss type on 47 / sold or bought joker id / pack first card */
+  int32_t aux;             /* boss type on 47 / sold or bought joker id / pack first card; on a boss rejection what the message names
+                            * (boss_blinds.py:393,399,405): the hand type played again (Eye), the one allowed type (Mouth), the cards required (Verdant) */
   int8_t hand_type;        /* info['hand_type'] on an accepted play, else -1 */
   int8_t cards_played;     /* info['cards_played'] */
+  double breakdown[8];     /* info['score_breakdown'] of an accepted play (unified_scoring.py:129-137, :293-297): final_chips, final_mult,
+                            * final_x_mult, card_chips, base_chips, base_mult, money_gained, 0 */
 } bo_info;
 
 typedef struct { uint8_t type; uint8_t payload; int32_t cost; } bo_item;

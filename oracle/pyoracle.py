@@ -64,7 +64,7 @@ OBS_SHAPES = {
 class Info(C.Structure):
     _fields_ = [
         ("final_score", C.c_int64), ("reward_terms", C.c_double * 8), ("error", C.c_int32), ("flags", C.c_int32),
-        ("aux", C.c_int32), ("hand_type", C.c_int8), ("cards_played", C.c_int8),
+        ("aux", C.c_int32), ("hand_type", C.c_int8), ("cards_played", C.c_int8), ("breakdown", C.c_double * 8),
     ]
 
 

@@ -181,3 +181,16 @@ def test_blob_geometry_constants_match_the_device_header():
     m = re.search(r"^#define BG_SSEED (\d+)", open(os.path.join(ROOT, "balatro_gym_amd", "csrc", "bg_device.h")).read() +
                   open(os.path.join(ROOT, "balatro_gym_amd", "csrc", "bg_lib.hip")).read(), flags=re.M)
     assert m and int(m.group(1)) == nat.BLOB_SSEED
+
+
+def test_operator_wrappers_validate_every_tensor():
+    """classify_batch / sim_evaluate_batch refuse a length-mismatched or wrong-device `n` / `flags` before any pointer reaches the
+    library (a host pointer or a short buffer would be a GPU fault, not an exception)."""
+    import torch
+    from balatro_gym_amd import vec_env as ve
+    cards = torch.zeros((4, 8), dtype=torch.uint8)
+    with pytest.raises(ValueError):
+        ve.classify_batch(cards, torch.zeros(4, dtype=torch.uint8))           # not on a device at all
+    src = open(os.path.join(ROOT, "balatro_gym_amd", "vec_env.py")).read()
+    assert "n.device != cards.device" in src and "tuple(n.shape) != (cards.shape[0],)" in src
+    assert "n.to(device=hands.device, dtype=torch.int32)" in src and "flags.to(device=hands.device, dtype=torch.int32)" in src

@@ -11,6 +11,9 @@ import pytest
 
 from tests.helpers import OBS_KEYS, load_trace, trace_injection
 
+HAND_TYPE_NAMES = ["High Card", "One Pair", "Two Pair", "Three Kind", "Straight", "Flush", "Full House", "Four Kind", "Straight Flush",
+                   "Five Kind", "Flush House", "Flush Five"]
+
 pytestmark = pytest.mark.gpu
 
 # BG_TEST_SEED_OFFSET=<k> moves every oracle-compared test below to other games (a soak runs the suite under several offsets)
@@ -83,6 +86,18 @@ def test_golden_trace(name):
         fl = info["flags"].cpu().numpy()
         assert np.array_equal((fl & 1) != 0, tr["beat_blind"][:, t] != 0) and np.array_equal((fl & 2) != 0, tr["failed"][:, t] != 0), ctx
         assert np.array_equal(info["reward_terms"].cpu().numpy().view(np.uint64), tr["reward_terms"][:, t].view(np.uint64)), ctx
+        # info['score_breakdown'] (:909) of the accepted plays, and what the boss blinds' rejection messages name (boss_blinds.py:393-405)
+        bd = info["score_breakdown"].cpu().numpy()
+        bi, bf = tr["breakdown_int"][:, t], tr["breakdown_f64"][:, t]
+        want = np.stack([bi[:, 5], bi[:, 6], bf[:, 1], bi[:, 2], bi[:, 0], bi[:, 1], bi[:, 7]], axis=1).astype(np.float64)
+        played = tr["hand_type"][:, t] >= 0
+        assert np.array_equal(bd[played, :7].view(np.uint64), want[played].view(np.uint64)), f"{ctx}: score_breakdown"
+        aux = info["aux"].cpu().numpy()
+        for si in np.nonzero((err >= 3) & (err <= 5))[0]:
+            msg = str(tr["error_msg"][si, t])
+            wantmsg = (f"Cannot play {HAND_TYPE_NAMES[aux[si]]} again" if err[si] == 3 else
+                       f"Can only play {HAND_TYPE_NAMES[aux[si]]}" if err[si] == 4 else f"Must play at least {aux[si]} cards")
+            assert msg == wantmsg, (ctx, si, msg, wantmsg)
         _assert_obs(_obs_np(env), {k: tr["obs_" + k][:, t] for k in OBS_KEYS}, ctx)
         if tm.any():
             env.reset(mask=torch.from_numpy(tm).to(env.device))  # un-seeded reset() + reset template
@@ -627,7 +642,57 @@ def test_curriculum_caps_vs_oracle():
     env.set_max_ante(4)
     with pytest.raises(NativeError, match="cap"):
         env.inject(ante=[5] * n)
+    # PER-ENV caps on a handle created without one (what CurriculumTracker does): template antes are validated against each env's own
+    # cap, in both orders -- an env that resets above its cap would end an episode per step and drain the deck ring
+    per_env = [2 + i % 3 for i in range(n)]
+    env.set_max_ante(per_env)
+    env.inject(ante=per_env)                                   # exactly at the cap: fine
+    with pytest.raises(NativeError, match="cap"):
+        env.inject(ante=[c + 1 for c in per_env])
+    with pytest.raises(NativeError, match="template ante"):
+        env.set_max_ante([c - 1 for c in per_env])
+    env.rollout(12, policy=0, policy_seed=5)
+    env.check()
     env.close()
+
+
+def test_single_env_info_dict_vs_reference():
+    """The info dict of the N = 1 drop-in (balatro_env_2.py:894-925, :1283-1288): the boss blinds' formatted rejection messages
+    (boss_blinds.py:388-405), 'score_breakdown' / 'reward_breakdown' / 'final_score' / 'hand_type' / 'cards_played' of a play,
+    'beat_blind' / 'failed', 'boss_blind' -- against what the reference returned (golden trace boss_forced: The Psychic, The Eye, The
+    Mouth and The Verdant each reject at least once in the seeds replayed here)."""
+    from balatro_gym_amd import BalatroEnv
+    tr = load_trace("boss_forced")
+    first = tr["obs_boss_blind_type"][:, 0].astype(int)
+    seen = set()
+    for boss in (7, 12, 13, 25, 2):
+        for si in np.nonzero(first == boss)[0][:4]:
+            env = BalatroEnv(seed=int(tr["seeds"][si]))
+            for t in range(tr["actions"].shape[1]):
+                obs, r, term, trunc, info = env.step(int(tr["actions"][si, t]))
+                ctx = (boss, int(si), t)
+                assert r == tr["rewards"][si, t] and term == bool(tr["terminated"][si, t]), ctx
+                msg = str(tr["error_msg"][si, t])
+                assert info.get("error", "") == msg, (ctx, info.get("error"), msg)
+                if msg:
+                    seen.add(msg.split(" ")[0] + " " + msg.split(" ")[1])
+                assert info.get("boss_blind", "") == str(tr["boss_blind"][si, t]), ctx
+                assert bool(info.get("beat_blind")) == bool(tr["beat_blind"][si, t]) and bool(info.get("failed")) == bool(tr["failed"][si, t]), ctx
+                if tr["hand_type"][si, t] >= 0:
+                    bi, bf = tr["breakdown_int"][si, t], tr["breakdown_f64"][si, t]
+                    want = {"base_chips": int(bi[0]), "base_mult": int(bi[1]), "card_chips": int(bi[2]), "joker_chips": int(bi[3]),
+                            "joker_mult": int(bi[4]), "joker_x_mult": float(bf[0]), "final_chips": int(bi[5]), "final_mult": int(bi[6]),
+                            "final_x_mult": float(bf[1]), "final_score": int(int(bi[5]) * int(bi[6]) * float(bf[1])), "money_gained": int(bi[7])}
+                    assert info["score_breakdown"] == want, (ctx, info["score_breakdown"], want)
+                    assert info["final_score"] == tr["final_score"][si, t] and info["cards_played"] == tr["cards_played"][si, t], ctx
+                    assert [info["reward_breakdown"][k] for k in ("progress", "milestone", "score", "hand_quality", "efficiency", "synergy",
+                                                                   "strategy", "ante_bonus")] == tr["reward_terms"][si, t].tolist(), ctx
+                else:
+                    assert "score_breakdown" not in info, ctx
+                if term:
+                    env.reset()
+            env.close()
+    assert {"Must play", "Cannot play", "Can only"} <= seen, seen
 
 
 def test_single_env_gym_surface():

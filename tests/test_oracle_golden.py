@@ -149,6 +149,10 @@ def test_sim_score_golden():
         assert po.sim_score(cards, [], 1, 0, 0, 1).score == k["score"], k
 
 
+HAND_NAMES = ["High Card", "One Pair", "Two Pair", "Three Kind", "Straight", "Flush", "Full House", "Four Kind", "Straight Flush",
+              "Five Kind", "Flush House", "Flush Five"]   # HandType.name.replace('_', ' ').title() (balatro_env_2.py:674)
+
+
 def replay_trace(name, make_env):
     tr = load_trace(name)
     S, T = tr["actions"].shape
@@ -187,6 +191,18 @@ def replay_trace(name, make_env):
             assert info.cards_played == tr["cards_played"][si, t], ctx
             assert bool(info.flags & BG_INFO_BEAT_BLIND) == bool(tr["beat_blind"][si, t]) and bool(info.flags & BG_INFO_FAILED) == bool(tr["failed"][si, t]), ctx
             assert [float(x).hex() for x in info.reward_terms] == [float(x).hex() for x in tr["reward_terms"][si, t]], ctx
+            if info.hand_type >= 0:  # info['score_breakdown'] (:909): base / card / joker / final chips, mult, x_mult, money_gained
+                bi, bf, bd = tr["breakdown_int"][si, t], tr["breakdown_f64"][si, t], list(info.breakdown)
+                want = [bi[5], bi[6], bf[1], bi[2], bi[0], bi[1], bi[7]]
+                assert [float(x).hex() for x in bd[:7]] == [float(x).hex() for x in want], f"{ctx}: breakdown {bd} vs {want}"
+                assert bi[3] == bi[5] - bi[0] - bi[2] and bi[4] == bi[6] - bi[1] and bf[0] == bf[1], ctx  # joker_* are differences
+            msg = str(tr["error_msg"][si, t])
+            if info.error == 3:
+                assert msg == f"Cannot play {HAND_NAMES[info.aux]} again", (ctx, msg, info.aux)
+            elif info.error == 4:
+                assert msg == f"Can only play {HAND_NAMES[info.aux]}", (ctx, msg, info.aux)
+            elif info.error == 5:
+                assert msg == f"Must play at least {info.aux} cards", (ctx, msg, info.aux)
             assert_obs_equal(obs, {k: tr["obs_" + k][si, t] for k in OBS_KEYS}, ctx)
             if term:
                 env.reset()
