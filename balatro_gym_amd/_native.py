@@ -33,6 +33,7 @@ OBS_SPEC = {
 OBS_BYTES = 330
 # packed record of bg_rollout_rows (include/balatro_mi355x.h BG_ROW_*): key -> byte offset; reward / action / terminated ride along
 ROW_BYTES = 352
+ROW_STRIDE_LINES = 384   # BG_ROW_STRIDE_LINES: records as three whole 128-byte lines (the fast layout of bg_rollout_rows)
 ROW_OFFSETS = {
     "selected_cards": 0, "face_down_cards": 64, "chips_scored": 128, "round_chips_scored": 144, "progress_ratio": 148,
     "mult": 152, "chips_needed": 156, "money": 160, "hands_played": 164, "best_hand_this_ante": 168, "action_mask": 176,

@@ -62,6 +62,7 @@ struct EngineArgs {
   uint32_t n_waves;            // worker waves that stay (BG_ENG_NSV .. BG_ENG_NW): the others retire before the worker loop
   uint32_t th_more;            // further cheap steps an env may take inside the batch that has it
   uint32_t autoreset;          // SAME_STEP auto-reset of terminated envs
+  uint32_t copier;             // packed records: wave `n_waves` is the COPIER (it writes the records and hands the envs back), the workers never copy
 };
 
 __device__ __forceinline__ uint32_t bg_lds_ld(uint32_t* p) {
@@ -75,7 +76,6 @@ __device__ __forceinline__ void bg_lds_st(uint32_t* p, uint32_t v) {
 }
 __device__ __forceinline__ void bg_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-struct CopyEnt { uint32_t l, pad; unsigned long long row; }; // one finished env of a batch: its image, its destination row
 
 // INFO: the launch serves bg_step / bg_step_many (per-step info arrays); false for the rollouts
 template <bool HASH, bool CARDS, bool INFO>
@@ -95,7 +95,11 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
 #define s_done s_ctl[3]
 #define s_busy s_ctl[7]
   __shared__ uint32_t s_win[NSV][BG_WIN][BG_BLOCK]; // RNG windows of the service-capable waves
-  __shared__ CopyEnt s_list[NW][BG_BLOCK];    // copy-out lists
+  // copy queue (packed records): one entry per finished step -- .x = record row of this launch, .y = env lane | done << 8 | generation of the
+  // ring position << 16 | VALID -- written by the workers, read by the copier wave alone (its head is a register)
+  __shared__ uint2 s_cq[NE];
+  __shared__ uint32_t s_cqt;                  // entries ever queued
+  __shared__ bg_u32x4 s_zero;                 // the two padding pieces of a 384-byte record are read from here
   __shared__ JTables jt;
   __builtin_amdgcn_s_setprio(3);
 #ifdef BG_TIMING4
@@ -113,10 +117,10 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   const size_t N = (size_t)d.N;
   // ---------------------------------------------------------------- prologue: HBM -> LDS, images built, lane = env
   if (tid < 3) { s_tail[tid] = tid == BG_Q_RUN ? (uint32_t)n_live : 0u; s_head[tid] = 0; }
-  if (tid == 0) { s_done = 0; s_busy = 0; }
+  if (tid == 0) { s_done = 0; s_busy = 0; s_cqt = 0; s_zero = bg_u32x4{0u, 0u, 0u, 0u}; }
   if (tid < NE) {
     const int l = tid, env = env0 + l;
-    s_q[BG_Q_PLAY][l] = 0; s_q[BG_Q_OTHER][l] = 0;
+    s_q[BG_Q_PLAY][l] = 0; s_q[BG_Q_OTHER][l] = 0; s_cq[l] = make_uint2(0u, 0u);
     s_q[BG_Q_RUN][l] = l < n_live ? ((uint32_t)l | BG_ITEM_VALID) : 0u;
     s_t[l] = 0;
     if (l < n_live) {
@@ -144,7 +148,141 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   // stragglers -- the envs with many service steps, which decide when a 20-step launch ends -- through sooner (20 steps: 381 us on
   // seven waves, 330 on four; 200 steps: the other way round).  The surplus waves end here; the workgroup's later barriers count the
   // waves that are left.
-  if (wave >= (int)a.n_waves) return;
+  if (wave >= (int)(a.n_waves + a.copier)) return;
+  // ---------------------------------------------------------------- the copier wave (packed records)
+  // The record copy-out used to close every batch: ~2 700 cycles of list / image reads and a dozen store instructions on the wave that
+  // the envs of the batch -- and every env queued behind them -- were waiting for, a sixth of all wave time; without it the same launch
+  // ran a third shorter.  Now a worker only QUEUES the finished env (its image is complete and nobody touches it until the env's next
+  // step); one wave does nothing but copy images to their rows, lane <-> 16-byte piece, and hands each env back to the run queue (or
+  // counts it as through) once its image has been read.  One consumer: no claim, no list, the loop is all loads and stores.
+  if (a.copier && wave >= (int)a.n_waves) {
+    __builtin_amdgcn_s_setprio(2);
+    // TWO copier waves (a.copier == 2) split the queue into blocks of 32 positions: even blocks to one, odd blocks to the other (no claim)
+    const uint32_t cid = (uint32_t)wave - a.n_waves, two = a.copier > 1u ? 1u : 0u;
+    uint32_t head = two ? 32u * cid : 0u, cpolls = 0;
+    const bool whole = a.obs.row_stride == 384u;   // WHOLE LINES, see below
+    const uint32_t PR = 22u, rcp = 2979u;          // dense layout: pieces per record; q / 22 = (q * 2979) >> 16 (exact below 8 000)
+    for (;;) {
+      const uint32_t tail = __builtin_amdgcn_readfirstlane(bg_lds_ld(&s_cqt));
+      uint32_t navail = (int32_t)(tail - head) > 0 ? tail - head : 0u;
+      if (two) { const uint32_t left = 32u - (head & 31u); navail = navail > left ? left : navail; }   // the rest of this wave's block
+      if (navail == 0u) {
+        if (__builtin_amdgcn_readfirstlane(bg_lds_ld(&s_done)) >= (uint32_t)n_live) break;
+        __builtin_amdgcn_s_sleep(2);
+        if (++cpolls > BG_SPIN_LIMIT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
+        continue;
+      }
+      cpolls = 0;
+      const uint32_t nb = navail > BG_BLOCK ? BG_BLOCK : navail;
+      // this lane's entry (a producer bumps the tail first and writes the entry next: poll until the generation matches)
+      uint2 ent = make_uint2(0u, 0u);
+      if ((uint32_t)lane < nb) {
+        const uint32_t pos = head + (uint32_t)lane, want = BG_ITEM_VALID | (((pos >> 8) & 0x7fu) << 16);
+        lds_u32* ep = (lds_u32*)&s_cq[pos & (NE - 1)];
+        uint32_t spin = 0, y = ep[1];
+        while ((y & (BG_ITEM_VALID | 0x7f0000u)) != want && ++spin < BG_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); asm volatile("" ::: "memory"); y = ep[1]; }
+        if ((y & (BG_ITEM_VALID | 0x7f0000u)) != want) atomicOr(d.err, BG_DEVERR_SPIN);
+        asm volatile("" ::: "memory");
+        ent = make_uint2(ep[0], y);
+      }
+      BG_WAVE_SYNC();
+      // WHOLE LINES.  The HBM takes scattered 352-byte records (22 pieces: two partial 128-byte lines each) at 2.6 TB/s, and scattered
+      // 384-byte records whose three lines are written completely at 4.5 TB/s of the same payload (tools/micro/recwrite.hip,
+      // profiles/r03_recwrite.txt): a record stride of 384 makes the copier write 24 pieces per record -- the image's 22 and two of
+      // zeros.  Any other stride: the 22 pieces of the dense layout.
+      // (Entries of records beyond nb are read but never used: the ring always holds 256 readable entries.)
+      typedef __attribute__((address_space(3))) const char lds_cc;
+      typedef uint32_t bg_u32x2 __attribute__((ext_vector_type(2)));
+      if (whole) {
+        // 24 pieces per record: EIGHT records are exactly three rounds of the wave, so which record of its group of eight and which piece
+        // a lane handles in round j is a per-lane CONSTANT (no division, no selects in the loop); the padding pieces read a zero piece.
+        // Four groups (32 records) per iteration: the 12 entry reads, the 12 image reads and the 12 stores are each issued back to back.
+        uint32_t rsel[3], mul[3], ib[3], gl[3];
+        lds_cc* const imgb = (lds_cc*)&s_img[0][0];
+        lds_cc* const cqb = (lds_cc*)&s_cq[0];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+          const uint32_t pidx = (uint32_t)j * BG_BLOCK + (uint32_t)lane, rs = (pidx * 2731u) >> 16, c = pidx - 24u * rs;
+          rsel[j] = rs; gl[j] = 16u * c;
+          mul[j] = c < 22u ? 352u : 0u;                                        // image byte address = l * mul + ib
+          ib[j] = c < 22u ? 16u * c : (uint32_t)((lds_cc*)&s_zero - imgb);
+        }
+        for (uint32_t g0 = 0; g0 < nb; g0 += 32u) {
+          bg_u32x2 ce[4][3];
+          bg_u32x4 v[4][3];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+              ce[u][j] = *(__attribute__((address_space(3))) const bg_u32x2*)(cqb + (((head + g0 + 8u * (uint32_t)u + rsel[j]) & (NE - 1)) << 3));
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+              v[u][j] = *(__attribute__((address_space(3))) const bg_u32x4*)(imgb + __umul24(ce[u][j].y & 0xffu, mul[j]) + ib[j]);
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+#ifdef BG_ABL_NOSTORE   // development ablation: everything but the store itself (the value is kept alive)
+              { if (g0 + 8u * (uint32_t)u + rsel[j] < nb) asm volatile("" :: "v"(v[u][j]), "v"(ce[u][j].x)); }
+#else
+              // NON-TEMPORAL stores: the records are a write-once stream nothing on the GPU reads back; written through the L2 as ordinary
+              // stores they evicted the env state, the RNG rings and the shop streams every service step reads (+15 % with the `nt` bit)
+              if (g0 + 8u * (uint32_t)u + rsel[j] < nb)
+#ifdef BG_COPIER_PLAIN
+                *(__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)ce[u][j].x * 384u + gl[j])) = v[u][j];
+#else
+                __builtin_nontemporal_store(v[u][j], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)ce[u][j].x * 384u + gl[j])));
+#endif
+#endif
+        }
+      } else {
+      const uint32_t total = PR * nb;
+      // the dense layout (or any other stride): KU pieces per lane and iteration, the record of a piece by a division
+#ifndef BG_COPIER_KU
+#define BG_COPIER_KU 12
+#endif
+      constexpr int KU = BG_COPIER_KU;
+      for (uint32_t q0 = (uint32_t)lane; q0 < total; q0 += (uint32_t)KU * BG_BLOCK) {
+        uint2 ce[KU];
+        uint32_t cpc[KU];
+        bg_u32x4 v[KU];
+#pragma unroll
+        for (int k = 0; k < KU; k++) {
+          const uint32_t q = q0 + (uint32_t)k * BG_BLOCK;
+          const uint32_t r = (q * rcp) >> 16;
+          cpc[k] = q - PR * r;
+          ce[k] = s_cq[(head + (r < nb ? r : 0u)) & (NE - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < KU; k++) v[k] = s_img[ce[k].y & 0xffu][cpc[k]];
+#pragma unroll
+        for (int k = 0; k < KU; k++)
+          if (q0 + (uint32_t)k * BG_BLOCK < total)
+            __builtin_nontemporal_store(v[k], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + (size_t)ce[k].x * (size_t)a.obs.row_stride + 16u * cpc[k]));
+      }
+      }
+      BG_WAVE_SYNC();   // every image of the batch has been read (LDS operations of a wave complete in order): the envs may move on
+      const bool valid = (uint32_t)lane < nb, through = valid && ((ent.y >> 8) & 1u);
+      const unsigned long long rm = __ballot(valid && !through), dm = __ballot(through);
+      if (rm) {
+        uint32_t base = 0;
+        if (lane == (int)(__ffsll((long long)rm) - 1)) base = __hip_atomic_fetch_add(&s_tail[BG_Q_RUN], (uint32_t)__popcll(rm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = __builtin_amdgcn_readlane(base, __ffsll((long long)rm) - 1);
+        if (valid && !through) {
+          const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
+          bg_lds_st(&s_q[BG_Q_RUN][slot & (NE - 1)], (ent.y & 0xffu) | (((slot >> 8) & 0xffu) << 8) | BG_ITEM_VALID);
+        }
+      }
+      if (dm && lane == 0) __hip_atomic_fetch_add(&s_done, (uint32_t)__popcll(dm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      head += nb;
+      if (two && (head & 31u) == 0u) head += 32u;   // the next block is the other copier's
+    }
+    BG_PROBE_FLUSH(d);
+    __syncthreads();   // (the workers' epilogue barrier)
+    return;
+  }
   // ---------------------------------------------------------------- worker loop
   uint64_t n_steps = 0, n_eps = 0, n_plays = 0, rbits = 0, ohash = 0;
   int64_t ssum = 0;
@@ -161,12 +299,17 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
 #endif
     // -- pick a queue: the eight control words with two 16-byte loads (one LDS round trip; each word is written atomically by its
     // owner, so a torn pair of words is no worse than two separate loads)
+    // The HEADS are read first, the tails after them (a wave's LDS loads execute in order): a tail read BEFORE its head could be older
+    // than the head, the difference wraps to 4 billion "items", and a wave that claims them sends the head past the tail for good.
     asm volatile("" ::: "memory");
-    const bg_u32x4 ct = *(volatile __attribute__((address_space(3))) bg_u32x4*)&s_ctl[0], ch = *(volatile __attribute__((address_space(3))) bg_u32x4*)&s_ctl[4];
+    const bg_u32x4 ch = *(volatile __attribute__((address_space(3))) bg_u32x4*)&s_ctl[4];
+    asm volatile("" ::: "memory");
+    const bg_u32x4 ct = *(volatile __attribute__((address_space(3))) bg_u32x4*)&s_ctl[0];
     asm volatile("" ::: "memory");
     const uint32_t hr = __builtin_amdgcn_readfirstlane(ch.x), hp = __builtin_amdgcn_readfirstlane(ch.y), ho = __builtin_amdgcn_readfirstlane(ch.z);
-    const uint32_t nr = __builtin_amdgcn_readfirstlane(ct.x) - hr;
-    const uint32_t np = can_serve ? __builtin_amdgcn_readfirstlane(ct.y) - hp : 0u, no = can_serve ? __builtin_amdgcn_readfirstlane(ct.z) - ho : 0u;
+    auto queued = [&](uint32_t tail, uint32_t head) -> uint32_t { const uint32_t k = tail - head; return k <= (uint32_t)NE ? k : 0u; }; // (never more than the envs there are)
+    const uint32_t nr = queued(__builtin_amdgcn_readfirstlane(ct.x), hr);
+    const uint32_t np = can_serve ? queued(__builtin_amdgcn_readfirstlane(ct.y), hp) : 0u, no = can_serve ? queued(__builtin_amdgcn_readfirstlane(ct.z), ho) : 0u;
     int cls = -1;
     if (np >= a.th_play) cls = BG_Q_PLAY;          // a service-capable wave serves first: the long chains are the critical path
     else if (no >= a.th_other) cls = BG_Q_OTHER;
@@ -324,63 +467,26 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     // copy-out: the images of the finished envs to their rows, lane <-> piece (whole 352-byte runs per row); then envs that are
     // through leave (after their images have been READ)
     auto copy_out = [&](bool fin, size_t row) __attribute__((always_inline)) {
-#ifdef BG_ABL_NOCOPY   // development ablation: what is the copy-out worth (results are wrong: no record leaves the chip)
-    if (false) {
-#else
-    if (a.obs.rows) {
-#endif
-#ifdef BG_TIMING4
-      const unsigned long long q_c0 = __builtin_readcyclecounter();
-#endif
+    if (a.copier) {
+      // packed records: the finished envs go to the copier wave, which writes their records and hands them back (or counts them as through)
       const unsigned long long fm = __ballot(fin);
-      const uint32_t A = (uint32_t)__popcll(fm);
-      if (fin) {
-        const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
-        CopyEnt ce; ce.l = (uint32_t)l; ce.pad = 0; ce.row = (unsigned long long)(a.obs.rows + row * (size_t)a.obs.row_stride);
-        s_list[wave][rank] = ce;
-      }
-      BG_WAVE_SYNC();
-      const uint32_t total = 22u * A;
-      // four pieces per lane and round: the four list reads, then the four image reads, then the four stores are each issued
-      // back to back (one LDS round trip per group instead of two per piece)
-      for (uint32_t q0 = (uint32_t)lane; q0 < total; q0 += 4u * BG_BLOCK) {
-        CopyEnt ce[4];
-        uint32_t cpc[4];
-        bg_u32x4 v[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const uint32_t q = q0 + (uint32_t)k * BG_BLOCK;
-          const uint32_t r = (q * 2979u) >> 16;   // q / 22 (exact for q < 64 * 22)
-          cpc[k] = q - 22u * r;
-          ce[k] = s_list[wave][r < BG_BLOCK ? r : 0u];
+      if (fm) {
+        uint32_t base = 0;
+        if (lane == (int)(__ffsll((long long)fm) - 1)) base = __hip_atomic_fetch_add(&s_cqt, (uint32_t)__popcll(fm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = __builtin_amdgcn_readlane(base, __ffsll((long long)fm) - 1);
+        if (fin) {
+          const uint32_t pos = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u));
+          lds_u32* ep = (lds_u32*)&s_cq[pos & (NE - 1)];
+          ep[0] = (uint32_t)row;
+          asm volatile("" ::: "memory");
+          ep[1] = (uint32_t)l | (t >= (uint32_t)a.T ? 0x100u : 0u) | (((pos >> 8) & 0x7fu) << 16) | BG_ITEM_VALID;
+          asm volatile("" ::: "memory");
+          active = false;
         }
-#pragma unroll
-        for (int k = 0; k < 4; k++) v[k] = s_img[ce[k].l & (NE - 1)][cpc[k]];
-#pragma unroll
-        for (int k = 0; k < 4; k++)
-          // NON-TEMPORAL stores: the records are a write-once stream (2 TB/s) nothing on the GPU reads back; written through the L2
-          // as ordinary stores they evicted the env state, the RNG rings and the shop streams every service step reads, and every
-          // such read became a trip to HBM (+15 % env-steps/s with the `nt` bit, same box)
-          if (q0 + (uint32_t)k * BG_BLOCK < total)
-            __builtin_nontemporal_store(v[k], (__attribute__((address_space(1))) bg_u32x4*)(ce[k].row + 16ull * cpc[k]));
       }
-      BG_WAVE_SYNC();
-#ifdef BG_TIMING4
-      q_copy += __builtin_readcyclecounter() - q_c0;
-#endif
+      return;
     }
-#ifdef BG_TIMING4
-      if (active && t >= (uint32_t)a.T) {
-        const uint32_t dn = __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) + 1u; active = false;
-        if (d.dbg) {  // when half / 15 of 16 / all of the workgroup's envs were through (100 MHz ticks since the kernel started here)
-          if (dn == (uint32_t)n_live / 2u) atomicAdd(&d.dbg[24], wall_clock64() - q_w0);
-          if (dn == (uint32_t)n_live - (uint32_t)n_live / 16u) atomicAdd(&d.dbg[25], wall_clock64() - q_w0);
-          if (dn == (uint32_t)n_live) { atomicAdd(&d.dbg[22], wall_clock64() - q_w0); atomicMax(&d.dbg[21], wall_clock64()); atomicMax(&d.dbg[23], wall_clock64() - q_w0); }
-        }
-      }
-#else
       if (active && t >= (uint32_t)a.T) { __hip_atomic_fetch_add(&s_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); active = false; }
-#endif
     };
     // ---------------- the step the batch was claimed for
     {
@@ -450,7 +556,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
 #endif
     // ---------------- further cheap steps of the envs this wave still holds
     // (run batches only: a service wave hands its envs back at once -- service capacity is what the whole workgroup waits for)
-    for (uint32_t sub = 0; cls == BG_Q_RUN && sub < a.th_more && __ballot(active) != 0ull; sub++) {
+    for (uint32_t sub = 0; cls == BG_Q_RUN && !a.copier && sub < a.th_more && __ballot(active) != 0ull; sub++) {
       bool fin = false;
       size_t row = 0;
       if (active) {

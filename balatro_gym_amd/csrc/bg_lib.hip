@@ -623,7 +623,7 @@ struct bg_handle {
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
   // tunables read ONCE per handle in bg_create (environment variables)
   int refill_blocks, refill_blocks_shop, dev_skip_refill;
-  uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_smask; int eng_waves; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
+  uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_smask; int eng_waves, eng_copiers; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
 };
 
 static std::string g_create_err;
@@ -745,7 +745,7 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->refill_blocks = geti("BG_REFILL_BLOCKS", 4096); h->refill_blocks_shop = geti("BG_REFILL_BLOCKS_SHOP", 0);
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0);
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
-    h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0);
+    h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0); h->eng_copiers = geti("BG_ENG_COPIERS", 2) == 1 ? 1 : 2;
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
   }
   h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->view_min = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
@@ -1053,6 +1053,10 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
   const bool cards = h->dev.cstate != nullptr;
   EngineArgs a = a0;
   a.n_waves = (uint32_t)bg_engine_waves(h, (int)a.T);
+  // packed records: one more wave, the COPIER (bg_engine.h), takes the record copy-out off the workers; with the seven-wave shape that
+  // leaves room for the refill beside the launch it is one of the seven
+  a.copier = a.obs.rows ? (uint32_t)h->eng_copiers : 0u;
+  if (a.copier && a.n_waves > BG_ENG_NW - a.copier) a.n_waves = BG_ENG_NW - a.copier;
   if (a.n_waves < BG_ENG_NW && a.serve_mask == BG_ENG_SMASK_DEFAULT) a.serve_mask = ((1u << BG_ENG_NSV) - 1u) << (a.n_waves - BG_ENG_NSV);
   const dim3 g((h->dev.N + BG_ENG_NE - 1) / BG_ENG_NE), b(BG_ENG_NW * BG_BLOCK);
 #define BG_ENG(HASHV, CARDSV, INFOV) hipLaunchKernelGGL((bg_engine_kernel<HASHV, CARDSV, INFOV>), g, b, 0, st, dv, a)
@@ -1218,6 +1222,7 @@ int bg_rollout_rows(bg_handle* h, int T, int policy, uint64_t policy_seed, uint6
                     uint8_t* rows_dev, uint64_t row_stride_bytes, int rows_stride_steps, bg_rollout_stats* stats_dev,
                     void* stream) {
   if (!h) return BG_E_ARG;
+  if ((uint64_t)h->dev.N * (uint64_t)bg_max_fused_steps(h) > 0xffffffffull) { h->err = "bg_rollout_rows: more than 2**32 records per launch (envs x fused steps)"; return BG_E_ARG; }
   if (!rows_dev || row_stride_bytes < BG_ROW_BYTES || (row_stride_bytes & 15) || ((uintptr_t)rows_dev & 15) || row_stride_bytes > 0xffffffffull) {
     h->err = "bg_rollout_rows: rows_dev must be 16-byte aligned and row_stride_bytes a multiple of 16, >= BG_ROW_BYTES";
     return BG_E_ARG;

@@ -54,7 +54,9 @@ class RowBuffers:
     """
 
     def __init__(self, n: int, device: torch.device, steps: int = 1, row_stride: int = 0):
-        """row_stride: bytes from one record to the next (a multiple of 16, >= 352; 0 = 352, densely packed)."""
+        """row_stride: bytes from one record to the next (a multiple of 16, >= 352; 0 = 352, densely packed).  384
+        (`_native.ROW_STRIDE_LINES`) is the FAST layout: every record is written as three whole 128-byte lines (bytes 352..383 zeros),
+        which the HBM takes 1.7x faster than records that end in partial lines."""
         self.n, self.steps = n, steps
         self.row_stride = int(row_stride) or nat.ROW_BYTES
         if self.row_stride < nat.ROW_BYTES or self.row_stride % 16:

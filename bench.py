@@ -183,7 +183,8 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", help="nccl = RCCL over xGMI (the product path); gloo only for the two-ranks-on-one-GPU test")
     ap.add_argument("--share-gpu", action="store_true", help="testing only: every rank uses GPU 0 (needs --dist-backend gloo: RCCL refuses two ranks on one device)")
     ap.add_argument("--samples", type=int, default=30, help="repeats of the K-step region after the timed one (median / p10 / p90)")
-    ap.add_argument("--row-stride", type=int, default=0, help="bytes between packed records (0 = 352, dense)")
+    ap.add_argument("--row-stride", type=int, default=384,
+                    help="bytes between packed records: 384 = every record as three whole 128-byte lines (the fast layout), 352 = dense")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-step-path", action="store_true", help="skip the bg_step / bg_step_many sample")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the RCCL all_gather of the current observation out")
@@ -360,8 +361,10 @@ def main():
                                    "(scorer-level joker chain), Antes 1-4 cap, counter-hash random policy (blind "
                                    "45/46/47 by env index, shop->31, else uniform over valid), SAME_STEP auto-reset, "
                                    "every step's 330-byte observation written to HBM"
-                                   + (" as one packed 352-byte record per (step, env) incl. reward/action/terminated"
+                                   + ((" as one packed 352-byte record per (step, env) incl. reward/action/terminated"
+                                       + (", records 384 bytes apart and written as three whole 128-byte lines" if args.row_stride == 384 else ""))
                                       if args.obs_layout == "rows" else " as one [T, N] array per key"),
+                       "row_stride_bytes": args.row_stride if args.obs_layout == "rows" else None,
                        "obs_layout": args.obs_layout,
                        "envs_per_gpu": n, "total_envs": total, "fused_steps_per_launch": fused,
                        "internal_warmup_launches": args.internal_warmup_launches,

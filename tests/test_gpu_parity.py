@@ -350,14 +350,15 @@ def test_many_short_launches_vs_oracle(monkeypatch, rings, async_refill):
 
 
 def test_packed_records_padded_stride():
-    """bg_rollout_rows with a record stride of 384 bytes (line-aligned records): the same 352 bytes per record as the dense
-    layout, the 32 bytes behind each record untouched."""
+    """bg_rollout_rows with padded records: the same 352 bytes per record as the dense layout.  Stride 384 is the FAST layout (every
+    record written as three whole 128-byte lines): its bytes 352..383 are zeros; with any other stride (416 here) the bytes behind a
+    record are left untouched."""
     import torch
     from balatro_gym_amd.vec_env import RowBuffers
     n, T = 300, 40
     seeds = [5_000 + SEED_OFFSET + i for i in range(n)]
     outs = []
-    for stride in (0, 384):
+    for stride in (0, 384, 416):
         env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4)
         rb = RowBuffers(n, env.device, steps=T, row_stride=stride)
         rb.rows.fill_(0xAB)
@@ -366,7 +367,9 @@ def test_packed_records_padded_stride():
         outs.append(rb.rows.cpu().numpy())
         env.close()
     assert outs[1].shape[-1] == 384 and np.array_equal(outs[0], outs[1][:, :, :352])
-    assert (outs[1][:, :, 352:] == 0xAB).all()
+    assert (outs[1][:, :, 352:] == 0).all()
+    assert outs[2].shape[-1] == 416 and np.array_equal(outs[0], outs[2][:, :, :352])
+    assert (outs[2][:, :, 352:] == 0xAB).all()
 
 
 @pytest.mark.parametrize("policy,scorer,n", [(0, False, 256), (2, True, 256), (2, True, 200), (0, True, 77)])

@@ -15,19 +15,19 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned long long mix(unsigned long long x) {
   x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31; return x;
 }
-template <int PATTERN, bool NT>
+template <int PATTERN, bool NT, int P = 22>
 __global__ __launch_bounds__(64) void rec_k(unsigned char* base, size_t nrows, int stride, int batches, size_t n_windows) {
   const int lane = threadIdx.x;
   const size_t w = blockIdx.x;
   for (int b = 0; b < batches; b++) {
     // 32 records x 22 pieces = 704 pieces = 11 rounds of 64 lanes
 #pragma unroll 1
-    for (int q0 = lane; q0 < 704; q0 += 256) {
+    for (int q0 = lane; q0 < 32 * P; q0 += 256) {
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const int q = q0 + 64 * k;
-        if (q < 704) {
-          const int j = (q * 2979) >> 16, pc = q - 22 * j;
+        if (q < 32 * P) {
+          const int j = q / P, pc = q - P * j;
           size_t row;
           const size_t win = (w + (size_t)b * gridDim.x) % n_windows; // the wave's window for this batch (advances like t)
           if (PATTERN == 0) row = ((w * batches + b) * 32 + j) % nrows;
@@ -67,6 +67,25 @@ int main() {
       for (int p = 0; p < 4; p++) printf("  %s %7.1f GB/s", names[p], payload / t[p] / 1e9);
       printf("\n");
     }
+  }
+  // FULL-LINE records: every 16-byte piece of the stride is written (24 pieces = 384 bytes = 3 lines, 32 pieces = 512 bytes = 4 lines)
+  {
+    const double payload = (double)waves * batches * 32 * 352;
+    size_t nrows = bytes / 384, n_windows = nrows / 256;
+    double a = time_it([&] { hipLaunchKernelGGL((rec_k<1, true, 24>), dim3(waves), dim3(64), 0, 0, buf, nrows, 384, batches, n_windows); });
+    double b = time_it([&] { hipLaunchKernelGGL((rec_k<3, true, 24>), dim3(waves), dim3(64), 0, 0, buf, nrows, 384, batches, n_windows); });
+    double c = time_it([&] { hipLaunchKernelGGL((rec_k<1, false, 24>), dim3(waves), dim3(64), 0, 0, buf, nrows, 384, batches, n_windows); });
+    printf("384-byte records written WHOLE (24 pieces): nt win90k %7.1f  nt random %7.1f  plain win90k %7.1f GB/s of 352-byte payload (x 384/352 raw)\n", payload / a / 1e9, payload / b / 1e9, payload / c / 1e9);
+    nrows = bytes / 512; n_windows = nrows / 256;
+    a = time_it([&] { hipLaunchKernelGGL((rec_k<1, true, 32>), dim3(waves), dim3(64), 0, 0, buf, nrows, 512, batches, n_windows); });
+    b = time_it([&] { hipLaunchKernelGGL((rec_k<3, true, 32>), dim3(waves), dim3(64), 0, 0, buf, nrows, 512, batches, n_windows); });
+    printf("512-byte records written WHOLE (32 pieces): nt win90k %7.1f  nt random %7.1f GB/s of 352-byte payload (x 512/352 raw)\n", payload / a / 1e9, payload / b / 1e9);
+    nrows = bytes / 320; n_windows = nrows / 256;
+    a = time_it([&] { hipLaunchKernelGGL((rec_k<1, true, 20>), dim3(waves), dim3(64), 0, 0, buf, nrows, 320, batches, n_windows); });
+    printf("320-byte records (20 pieces, 64-byte multiples, stride 320): nt win90k %7.1f GB/s raw\n", (double)waves * batches * 32 * 320 / a / 1e9);
+    nrows = bytes / 256; n_windows = nrows / 256;
+    a = time_it([&] { hipLaunchKernelGGL((rec_k<1, true, 16>), dim3(waves), dim3(64), 0, 0, buf, nrows, 256, batches, n_windows); });
+    printf("256-byte records (16 pieces): nt win90k %7.1f GB/s raw\n", (double)waves * batches * 32 * 256 / a / 1e9);
   }
   return 0;
 }
