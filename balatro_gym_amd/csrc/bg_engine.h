@@ -43,7 +43,9 @@
 #ifndef BG_ENG_OCC
 #define BG_ENG_OCC 2     // waves per SIMD the register budget is set for (2 = 256 VGPRs; 3 = 168: measured, spills)
 #endif
+#ifndef BG_ENG_NSV
 #define BG_ENG_NSV 4    // of them, how many own an RNG window and may run service batches
+#endif
 #define BG_ENG_SMASK_DEFAULT (((1u << BG_ENG_NSV) - 1u) << (BG_ENG_NW - BG_ENG_NSV)) // which: the last NSV waves (BG_ENG_SMASK)
 
 struct EngineArgs {
@@ -157,7 +159,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   // counts it as through) once its image has been read.  One consumer: no claim, no list, the loop is all loads and stores.
   if (a.copier && wave >= (int)a.n_waves) {
     __builtin_amdgcn_s_setprio(2);
-    // TWO copier waves (a.copier == 2) split the queue into blocks of 32 positions: even blocks to one, odd blocks to the other (no claim)
+    // SEVERAL copier waves (a.copier = 2 or 3) split the queue into blocks of 32 positions, dealt round robin (no claim)
     const uint32_t cid = (uint32_t)wave - a.n_waves, two = a.copier > 1u ? 1u : 0u;
     uint32_t head = two ? 32u * cid : 0u, cpolls = 0;
     const bool whole = a.obs.row_stride == 384u;   // WHOLE LINES, see below
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       }
       if (dm && lane == 0) __hip_atomic_fetch_add(&s_done, (uint32_t)__popcll(dm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       head += nb;
-      if (two && (head & 31u) == 0u) head += 32u;   // the next block is the other copier's
+      if (two && (head & 31u) == 0u) head += 32u * (a.copier - 1u);   // the next blocks are the other copiers'
     }
     BG_PROBE_FLUSH(d);
     __syncthreads();   // (the workers' epilogue barrier)

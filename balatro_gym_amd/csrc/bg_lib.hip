@@ -745,7 +745,7 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->refill_blocks = geti("BG_REFILL_BLOCKS", 4096); h->refill_blocks_shop = geti("BG_REFILL_BLOCKS_SHOP", 0);
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0);
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
-    h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0); h->eng_copiers = geti("BG_ENG_COPIERS", 2) == 1 ? 1 : 2;
+    h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0); h->eng_copiers = geti("BG_ENG_COPIERS", 2); if (h->eng_copiers < 1 || h->eng_copiers > 3) h->eng_copiers = 2;
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
   }
   h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->view_min = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
@@ -1042,11 +1042,11 @@ int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void
 // one launch of the step engine (bg_engine.h): T steps of every env of the handle
 // worker waves for a launch of T fused steps (BG_ENG_WAVES overrides)
 static int bg_engine_waves(const bg_handle* h, int T) {
-  if (h->eng_waves >= BG_ENG_NSV && h->eng_waves <= BG_ENG_NW) return h->eng_waves;
+  if (h->eng_waves >= 4 && h->eng_waves <= BG_ENG_NW) return h->eng_waves;
   // measured (tools/ab_waves.sh, us per launch at 4 / 5 / 6 / 7 waves): T = 4: 157 / 182 / 203 / 226; 20: 312 / 326 / 347 / 380; 40: 589 / 572 /
   // 532 / 615; 160: 1 714 / 1 611 / 1 562 / 1 660; 372: 3 790 / 3 628 / 3 671 / 3 506
-  if (T <= 24) return BG_ENG_NSV;
-  if (T <= 192) return BG_ENG_NW - 1 > BG_ENG_NSV ? BG_ENG_NW - 1 : BG_ENG_NSV;
+  if (T <= 24) return 4;
+  if (T <= 192) return BG_ENG_NW - 1;
   return BG_ENG_NW;
 }
 static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0, bool hash, bool info, hipStream_t st) {
@@ -1057,7 +1057,8 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
   // leaves room for the refill beside the launch it is one of the seven
   a.copier = a.obs.rows ? (uint32_t)h->eng_copiers : 0u;
   if (a.copier && a.n_waves > BG_ENG_NW - a.copier) a.n_waves = BG_ENG_NW - a.copier;
-  if (a.n_waves < BG_ENG_NW && a.serve_mask == BG_ENG_SMASK_DEFAULT) a.serve_mask = ((1u << BG_ENG_NSV) - 1u) << (a.n_waves - BG_ENG_NSV);
+  if (a.n_waves < BG_ENG_NW && a.serve_mask == BG_ENG_SMASK_DEFAULT) // the last NSV of the workers (all of them when there are no more)
+    a.serve_mask = a.n_waves <= BG_ENG_NSV ? (1u << a.n_waves) - 1u : ((1u << BG_ENG_NSV) - 1u) << (a.n_waves - BG_ENG_NSV);
   const dim3 g((h->dev.N + BG_ENG_NE - 1) / BG_ENG_NE), b(BG_ENG_NW * BG_BLOCK);
 #define BG_ENG(HASHV, CARDSV, INFOV) hipLaunchKernelGGL((bg_engine_kernel<HASHV, CARDSV, INFOV>), g, b, 0, st, dv, a)
   if (info) { if (cards) BG_ENG(false, true, true); else BG_ENG(false, false, true); }

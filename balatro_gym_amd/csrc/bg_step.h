@@ -161,7 +161,9 @@ __device__ __forceinline__ int bg_candidate(uint64_t sorted, int j) {
 }
 
 __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr) {
+  BG_PROBE_BEGIN();
   bg_sprefetch(d, env, e, w, 24); // shop.py:111-139
+  BG_PROBE(18);
   double mult = bg_shop_cost_mult(e, w.jt);
   const uint64_t sj = bg_sorted_jokers(e);
   int owned145 = 0;
@@ -752,6 +754,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     int chain_money = 0; // game_state is state.to_dict(): the scorer's money goes nowhere (unified_scoring.py:292-294)
     bg_joker_chain<false, DK>(d, env, e, w, in, chips, mult, x_mult, chain_money, &pre);
   }
+  BG_PROBE(15);
   int64_t final_score = (int64_t)((double)(chips * mult) * x_mult); // unified_scoring.py:286
   if (o.bd_dst) { // info['score_breakdown'] (bg_step only): final_chips, final_mult, final_x_mult, card_chips, base_chips, base_mult, money_gained, 0
     int gems = 0; // money_gained: Rough Gem pays $1 per Diamond scored (complete_joker_effects.py:160); the env drops it (unified_scoring.py:292-294)
@@ -795,6 +798,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
     final_score = (int64_t)((double)final_score * steel);
     e.money += extra_money;
   }
+  BG_PROBE(16);
   // :745-755 boss scoring ratio (boss_blinds.py:409-445)
   if (e.boss_type) {
     int64_t mc = bchips, mm = bmult;
@@ -815,6 +819,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   }
   // :758-759 int(final * (1 + 0.5 * red seals))
   if constexpr (DK::kCards) final_score = (int64_t)((double)final_score * (1.0 + (double)retriggers * 0.5));
+  BG_PROBE(17);
   // :775-786
   int64_t need1 = e.chips_needed > 1 ? e.chips_needed : 1;
   double old_progress = (double)e.round_chips / (double)need1;

@@ -25,7 +25,7 @@ torch.cuda.synchronize()
 p = env.get_profile()
 L.bg_debug_counters(env._h, out)
 o = list(out)
-waves = max(1, o[1]); wgs = waves / 7  # BG_ENG_NW
+waves = max(1, o[1]); wgs = n / 256  # o[1] counts WORKER waves
 print(f"launch {p['rollout_ms']*1e3:.0f} us, waves {waves}, T {T}; wave cycles {o[0]/waves:.0f}, idle {o[11]/max(1,o[0]):.2f} of it, failed claims per wave {o[12]/waves:.1f}")
 tot_busy = 0
 for c, nm in ((0, "run"), (1, "play"), (2, "other")):
