@@ -248,3 +248,24 @@ def test_sim_score_batch_golden():
     bad = np.nonzero((out[:M, 0] != g["s_score"]) | (out[:M, 4] != g["s_money"]) | (out[:M, 6] != g["s_probe"].astype(np.int64)))[0]
     assert bad.size == 0, f"case {bad[0]}: {rec[bad[0]].tolist()} got {out[bad[0]].tolist()} want {g['s_score'][bad[0]], g['s_money'][bad[0]], g['s_probe'][bad[0]]}"
     assert [int(x) for x in out[M:, 0]] == [k["score"] for k in kat]
+
+
+def test_cross_wave_state_handover_litmus():
+    """The step engine hands an env from one service wave to another of the same workgroup through an LDS word, after plain GLOBAL stores
+    of the env's state and with plain global loads on the other side (bg_engine.h: no vmcnt drain, no cache-bypassing loads; it relies on
+    the CU's one in-order vector-memory pipeline).  tools/micro/litmus_hot.hip runs that hand-over 1 000 workgroups x 2 000 rounds x 512
+    16-byte chunks with the reader holding the OLD lines in L1 and two more waves streaming non-temporal stores: no stale read."""
+    import os
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tools", "micro", "litmus_hot")
+    src = exe + ".hip"
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        if not os.path.exists(hipcc):
+            pytest.skip("hipcc not available and tools/micro/litmus_hot not built")
+        subprocess.check_call([hipcc, "-O3", "--offload-arch=gfx950", "-o", exe, src])
+    out = subprocess.run([exe, "2000"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert out.stdout.startswith("stale 0 of ") and int(out.stdout.split()[-1]) >= 1_000_000_000, out.stdout
