@@ -33,7 +33,7 @@ OBS_SPEC = {
 OBS_BYTES = 330
 # packed record of bg_rollout_rows (include/balatro_mi355x.h BG_ROW_*): key -> byte offset; reward / action / terminated ride along
 ROW_BYTES = 352
-ROW_STRIDE_LINES = 384   # BG_ROW_STRIDE_LINES: records as three whole 128-byte lines (the fast layout of bg_rollout_rows)
+ROW_STRIDE_LINES = 384   # BG_RECORD_STRIDE_LINES: records as three whole 128-byte lines (the fast layout of bg_rollout_rows)
 ROW_OFFSETS = {
     "selected_cards": 0, "face_down_cards": 64, "chips_scored": 128, "round_chips_scored": 144, "progress_ratio": 148,
     "mult": 152, "chips_needed": 156, "money": 160, "hands_played": 164, "best_hand_this_ante": 168, "action_mask": 176,
@@ -60,7 +60,7 @@ EXPORTS = ["bg_create", "bg_destroy", "bg_last_error", "bg_num_envs", "bg_max_fu
 # state-blob geometry (csrc/bg_device.h; tests/test_cabi_and_host.py checks these against the header): 16-byte chunks per env of the
 # hot / deck / cold / template arrays, words per stored MT19937 block, words per shop-stream ring slot and where its seed sits
 BLOB_NHOT, BLOB_NDECK, BLOB_NCOLD, BLOB_NTMPL, BLOB_NCST, BLOB_MTS, BLOB_SSEED = 8, 4, 7, 2, 7, 640, 128
-SHOP_SLOT_WORDS, SHOP_SLOT_SEED_WORD = 144, 136
+SHOP_SLOT_WORDS, SHOP_SLOT_SEED_WORD = 64, 62
 SCORE_CASE_WORDS, SCORE_OUT_WORDS = 40, 8
 SIM_EVAL_BYTES, SIM_CASE_WORDS = 128, 64
 

@@ -201,20 +201,18 @@ __device__ __forceinline__ int bg_level(const Env& e, int ht) { return (int)((e.
 // subset of deck[0..hand_size), so the global-memory path below is the rare general case.
 // ---------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t* bg_gblock(const BgDev& d, int env, int slot) { return d.gblk + ((size_t)env * d.KG + slot) * BG_MTS; }
-// A shop-stream ring slot keeps only the part of the seeded state S a visit reads: word k of the first output block needs
-// S[k], S[k+1] and S[k+397] (k < 227), and an inventory reads ~13 words -- so words 0..BG_SW_A-1 and 396..396+BG_SW_A-1 plus the
-// seed.  BG_SW_A = 68 (k <= 66: four or five inventories, i.e. a visit with three or four rerolls) makes a slot 576 bytes instead
-// of the state's 2.5 KB: the refill's shop kernel, the ring's footprint (KS x 576 B per env) and what the refill pushes through
-// the L2 beside the step engine all scale with it (132 words per window = 1 152 B was round 1's choice).  A visit that reads
-// further re-seeds the FULL state into the env's overflow block once (bg_shop_overflow) and carries on there.
-#ifndef BG_SW_A
-#define BG_SW_A 68                 // words 0..BG_SW_A-1 of S (a multiple of 4, >= 28: bg_swin_fill0 reads 7 groups of each window)
-#endif
-#define BG_SW_F (BG_MT_M - 1)      // 396: first word of the far window
-#define BG_SW_SEED (2 * BG_SW_A)   // slot word holding the seed
-#define BG_SLOT_WORDS ((2 * BG_SW_A + 1 + 7) / 8 * 8) // both windows + the seed, rounded up to 32 bytes
-#define BG_S_FASTMAX (BG_SW_A - 2) // largest k whose operands all sit in the slot
-static_assert(BG_SW_A % 4 == 0 && BG_SW_A >= 28 && BG_SW_A <= 132, "shop slot window");
+// A shop-stream ring slot holds the first BG_SW_T OUTPUT words of random.Random(shop_seed) -- regenerated and tempered by the refill
+// kernel that seeds the stream (word k of the first output block is S[k+397] ^ twist(S[k], S[k+1]) for k < 227: the seeding pass has all
+// three in hand) -- plus the seed: 256 bytes = two lines.  An inventory reads ~11 words (a 24-word window covers the rejection loops of all
+// but one visit in thousands), so 62 words are a visit with three or four rerolls; a visit that reads further re-seeds the FULL state into
+// the env's overflow block once (bg_shop_overflow) and carries on there.  Rounds 1-2 kept the seeded state itself (two 68-word windows,
+// 576 bytes) and the consumer regenerated what it read: 14 scattered 16-byte loads, 24 twists and 31 temperings on the winning play's
+// critical path (~13 k cycles of a play batch); now it is six loads of finished words.
+#define BG_SW_T 62                 // output words per slot
+#define BG_SW_SEED BG_SW_T         // slot word holding the seed
+#define BG_SLOT_WORDS 64           // 62 words + the seed + one of padding = 256 bytes
+#define BG_S_FASTMAX (BG_SW_T - 1) // largest k the slot holds
+static_assert(BG_SW_T >= 28 && BG_SW_T + 1 <= BG_SLOT_WORDS && BG_SLOT_WORDS % 4 == 0, "shop slot");
 #define BG_BF_SHOP_OVF 4           // bflags: the current shop stream lives in the overflow block (full state)
 __device__ __forceinline__ uint32_t* bg_sblock(const BgDev& d, int env, int slot) { return d.sblk + ((size_t)env * d.KS + slot) * BG_SLOT_WORDS; }
 __device__ __forceinline__ uint32_t* bg_sovf(const BgDev& d, int env) { return d.sovf + (size_t)env * BG_MTS; }
@@ -482,20 +480,19 @@ __device__ __forceinline__ void bg_gprefetch(const BgDev& d, int env, Env& e, Rn
 //   far = k < 227 ? S[k + 397] : B(k - 227),   nxt = k < 623 ? S[k + 1] : B(0)
 // i.e. at most three levels deep.  A shop visit reads ~13 words per inventory, so the window below (k + len <= 227: every
 // operand is a seeded word) covers everything but many-reroll visits, which take the slow exact path.
-// S[j] of the current shop stream: `full` = the overflow block (plain indexing), else the compact slot
-__device__ __forceinline__ uint32_t bg_sget(const uint32_t* S, bool full, int j) { return S[(full || j < BG_SW_A) ? j : j - (BG_SW_F - BG_SW_A)]; }
-__device__ __noinline__ uint32_t bg_sword_slow(const uint32_t* S, bool full, int k) {
+// word k of the first output block from the FULL seeded state S (the overflow block), untempered
+__device__ __noinline__ uint32_t bg_sword_slow(const uint32_t* S, int k) {
   uint32_t far;
-  if (k < BG_MT_N - BG_MT_M) far = bg_sget(S, full, k + BG_MT_M);
-  else { // only reachable in the full state
+  if (k < BG_MT_N - BG_MT_M) far = S[k + BG_MT_M];
+  else {
     const int k1 = k - (BG_MT_N - BG_MT_M); // 0..396
     uint32_t far1;
     if (k1 < BG_MT_N - BG_MT_M) far1 = S[k1 + BG_MT_M];
     else { const int k2 = k1 - (BG_MT_N - BG_MT_M); far1 = bg_twist(S[k2], S[k2 + 1], S[k2 + BG_MT_M]); } // k2 < 170
     far = bg_twist(S[k1], S[k1 + 1], far1);
   }
-  const uint32_t nxt = k < BG_MT_N - 1 ? bg_sget(S, full, k + 1) : bg_twist(S[0], S[1], S[BG_MT_M]);
-  return bg_twist(bg_sget(S, full, k), nxt, far);
+  const uint32_t nxt = k < BG_MT_N - 1 ? S[k + 1] : bg_twist(S[0], S[1], S[BG_MT_M]);
+  return bg_twist(S[k], nxt, far);
 }
 // the visit reads past what the slot holds: random.Random(seed) once more, whole state, into the env's overflow block
 __device__ __forceinline__ void bg_shop_overflow(const BgDev& d, int env, Env& e) {
@@ -508,6 +505,7 @@ __device__ __forceinline__ const uint32_t* bg_sbase(const BgDev& d, int env, con
   full = (e.bflags & BG_BF_SHOP_OVF) != 0;
   return full ? bg_sovf(d, env) : bg_sblock(d, env, e.s_cur);
 }
+// next output word of the shop stream; the window (w.lds) holds TEMPERED words
 __device__ __forceinline__ uint32_t bg_sdraw(const BgDev& d, int env, Env& e, RngWin& w) {
   if (e.s_idx >= BG_MT_N) { atomicOr(d.err, BG_DEVERR_SHOPBLK); return 0u; }
   uint32_t off = (uint32_t)(e.s_idx - w.s_start);
@@ -517,37 +515,43 @@ __device__ __forceinline__ uint32_t bg_sdraw(const BgDev& d, int env, Env& e, Rn
     if (e.s_idx > BG_S_FASTMAX && !(e.bflags & BG_BF_SHOP_OVF)) bg_shop_overflow(d, env, e);
     bool full;
     const uint32_t* S = bg_sbase(d, env, e, full);
-    y = bg_sword_slow(S, full, e.s_idx);
+    y = full ? bg_temper(bg_sword_slow(S, e.s_idx)) : S[e.s_idx];
   }
   e.s_idx++;
-  return bg_temper(y);
+  return y;
 }
-// regenerate the next `count` (<= 24) words of the shop stream into the window: 14 independent 16-byte loads for a
-// fresh stream (s_idx == 0, every generate_shop), scalar loads at other positions (rerolls)
-__device__ __forceinline__ void bg_swin_fill0(lds_u32* lds, const uint32_t* S) { // compact slot only (a fresh stream)
+// the next `count` (<= 24) words of the shop stream into the window: six 16-byte loads of finished words for a fresh stream (s_idx == 0,
+// every generate_shop); the overflow block (full seeded state) regenerates and tempers them
+__device__ __forceinline__ void bg_swin_fill0(lds_u32* lds, const uint32_t* S) { // the slot of a fresh stream
   const uint4* S4 = (const uint4*)S;
-  uint32_t A[28], F[28];
+  uint4 v[6];
 #pragma unroll
-  for (int g = 0; g < 7; g++) { uint4 v = S4[g]; A[4 * g] = v.x; A[4 * g + 1] = v.y; A[4 * g + 2] = v.z; A[4 * g + 3] = v.w; }
+  for (int g = 0; g < 6; g++) v[g] = S4[g];
 #pragma unroll
-  for (int g = 0; g < 7; g++) { uint4 v = S4[BG_SW_A / 4 + g]; F[4 * g] = v.x; F[4 * g + 1] = v.y; F[4 * g + 2] = v.z; F[4 * g + 3] = v.w; } // words 396..423
-#pragma unroll
-  for (int i = 0; i < 24; i++) lds[i * BG_BLOCK] = bg_twist(A[i], A[i + 1], F[i + 1]);
+  for (int g = 0; g < 6; g++) { lds[(4 * g) * BG_BLOCK] = v[g].x; lds[(4 * g + 1) * BG_BLOCK] = v[g].y; lds[(4 * g + 2) * BG_BLOCK] = v[g].z; lds[(4 * g + 3) * BG_BLOCK] = v[g].w; }
 }
 __device__ __forceinline__ void bg_swin_fill(lds_u32* lds, const uint32_t* S, bool full, int k0, int len) {
+  if (!full) { // finished words
+    uint32_t A[24];
+#pragma unroll
+    for (int j = 0; j < 24; j++) A[j] = (j < len) ? S[k0 + j] : 0u;
+#pragma unroll
+    for (int j = 0; j < 24; j++) if (j < len) lds[j * BG_BLOCK] = A[j];
+    return;
+  }
   uint32_t A[25], F[24];
-  const uint32_t* SF = S + k0 + BG_MT_M - (full ? 0 : BG_SW_F - BG_SW_A); // &S[k0 + 397] in either layout
+  const uint32_t* SF = S + k0 + BG_MT_M; // &S[k0 + 397]
 #pragma unroll
   for (int j = 0; j < 25; j++) A[j] = (j <= len) ? S[k0 + j] : 0u;
 #pragma unroll
   for (int j = 0; j < 24; j++) F[j] = (j < len) ? SF[j] : 0u;
 #pragma unroll
-  for (int j = 0; j < 24; j++) if (j < len) lds[j * BG_BLOCK] = bg_twist(A[j], A[j + 1], F[j]);
+  for (int j = 0; j < 24; j++) if (j < len) lds[j * BG_BLOCK] = bg_temper(bg_twist(A[j], A[j + 1], F[j]));
 }
 __device__ __forceinline__ void bg_sprefetch(const BgDev& d, int env, Env& e, RngWin& w, int count) {
   bool full;
   const uint32_t* S = bg_sbase(d, env, e, full);
-  // stay where every operand is a stored seeded word: k <= BG_S_FASTMAX in the slot, k < 227 in the full state
+  // stay where the words are at hand: k <= BG_S_FASTMAX in the slot, k < 227 (every operand a seeded word) in the full state
   int len = (full ? (BG_MT_N - BG_MT_M) : (BG_S_FASTMAX + 1)) - e.s_idx;
   if (len > count) len = count;
   if (len > 24) len = 24;

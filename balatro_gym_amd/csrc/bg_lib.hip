@@ -103,10 +103,13 @@ struct BgGenrandTab {
 static_assert(BG_MT_N % 16 == 0, "624 = 39 blocks of 16");
 static constexpr BgGenrandTab BG_GENRAND{};
 
-// SLOT = false: the whole seeded state (156 16-byte stores); true: a shop-stream ring slot -- only words 0..131 and 396..527 of the
-// state are kept (BG_SW_*), plus the seed
+// SLOT = false: the whole seeded state (156 16-byte stores).  SLOT = true: a shop-stream ring slot -- the first BG_SW_T OUTPUT words of
+// the stream, tempered, plus the seed (bg_device.h): output word k = temper(S[k+397] ^ twist(S[k], S[k+1])).  The pass produces S in index
+// order, so the near words S[2..63] are parked RAW in the slot as they appear (blocks 0..3) and, when S[k+397] appears (blocks 24..28),
+// read back (they are this lane's own stores of ~20 000 cycles ago), combined, tempered and written over S[k] -- which nothing needs any
+// more.  S[1] is the last word the seeding produces, so outputs 0 and 1 (and the group they share with 2 and 3) are written at the end.
 template <bool SLOT>
-__device__ __forceinline__ void bg_mt_seed_impl(uint32_t* __restrict__ p, uint32_t key) {
+__device__ __forceinline__ void bg_mt_seed_impl(uint32_t* p, uint32_t key) {
   constexpr int NB = BG_MT_N / 16;
   uint4* p4 = (uint4*)p;
   uint32_t a = BG_GENRAND.blk[0].v[0], a1 = 0; // a: pass-1 recurrence
@@ -131,6 +134,7 @@ __device__ __forceinline__ void bg_mt_seed_impl(uint32_t* __restrict__ p, uint32
   a = BG_GENRAND.blk[0].v[0];
   a = (BG_GENRAND.blk[0].v[1] ^ ((a ^ (a >> 30)) * 1664525u)) + key; // pass-1 mt[1] (before the wrap)
   uint32_t bprev = a1w, w2 = 0, w3 = 0;
+  uint32_t far0 = 0, far1 = 0, out2 = 0, out3 = 0;   // SLOT: S[397], S[398]; output words 2 and 3 (group 0 is written last)
   {
     BgG16 cur = BG_GENRAND.blk[0];
 #pragma unroll 1
@@ -147,21 +151,52 @@ __device__ __forceinline__ void bg_mt_seed_impl(uint32_t* __restrict__ p, uint32
         }
       }
       if (b == 0) { w2 = v[2]; w3 = v[3]; }
+      if constexpr (!SLOT) {
 #pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int q = 4 * b + k; // 16-byte group of the state
-        const uint4 val = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
-        if (q == 0) continue;
-        if (!SLOT) p4[q] = val;
-        else if (q < BG_SW_A / 4) p4[q] = val;
-        else if (q >= BG_SW_F / 4 && q < BG_SW_F / 4 + BG_SW_A / 4) p4[q - (BG_SW_F - BG_SW_A) / 4] = val;
+        for (int k = 0; k < 4; k++) {
+          const int q = 4 * b + k; // 16-byte group of the state
+          if (q == 0) continue;
+          p4[q] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        }
+      } else {
+        if (b < 4) { // park S[4..63] raw in the slot (group 0 holds S[0..3]: S[2], S[3] stay in registers)
+#pragma unroll
+          for (int k = 0; k < 4; k++) if (4 * b + k > 0) p4[4 * b + k] = make_uint4(v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]);
+        } else if (b >= 24 && b <= 28) {
+          // words 16 b .. 16 b + 15 = S[k + 397] for k = 16 b - 397 + c
+          const int kb = 16 * b - BG_MT_M;                 // k of c = 0: -13, 3, 19, 35, 51
+          if (b == 24) { far0 = v[13]; far1 = v[14]; out2 = bg_temper(bg_twist(w2, w3, v[15])); }
+          else {
+            // near words S[kb .. kb + 16] back from the slot: five 16-byte groups starting at the group that holds word kb
+            const int g0 = kb >> 2;                        // 0, 4, 8, 12 (kb = 3, 19, 35, 51 -> the word is the group's fourth)
+            uint32_t nr[20];
+#pragma unroll
+            for (int g = 0; g < 5; g++) {
+              uint4 t = make_uint4(0u, 0u, 0u, 0u);
+              if (g0 + g > 0 && g0 + g < BG_SLOT_WORDS / 4) t = p4[g0 + g];   // (not restrict-qualified reads of this lane's own earlier stores)
+              nr[4 * g] = t.x; nr[4 * g + 1] = t.y; nr[4 * g + 2] = t.z; nr[4 * g + 3] = t.w;
+            }
+            if (b == 25) nr[3] = w3;                       // (group 0 is not in memory: S[3])
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+              const int k = kb + c;                        // output word index; its near words are nr[3 + c], nr[4 + c]
+              if (k < BG_SW_T) {
+                const uint32_t o = bg_temper(bg_twist(nr[3 + c], nr[4 + c], v[c]));
+                if (k == 3) out3 = o; else p[k] = o;       // S[k] is dead: its place takes the output word
+              }
+            }
+          }
+        }
       }
       cur = nxt;
     }
   }
   const uint32_t w1 = (a1w ^ ((bprev ^ (bprev >> 30)) * 1566083941u)) - 1u; // mt[0] = mt[623], wrapped step at i = 1
-  p4[0] = make_uint4(0x80000000u, w1, w2, w3);
-  if (SLOT) p[BG_SW_SEED] = key;
+  if constexpr (!SLOT) p4[0] = make_uint4(0x80000000u, w1, w2, w3);
+  else {
+    p4[0] = make_uint4(bg_temper(bg_twist(0x80000000u, w1, far0)), bg_temper(bg_twist(w1, w2, far1)), out2, out3);
+    p[BG_SW_SEED] = key;
+  }
 }
 __device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) { bg_mt_seed_impl<false>(p, key); }
 __device__ void bg_mt_seed_slot(uint32_t* __restrict__ p, uint32_t key) { bg_mt_seed_impl<true>(p, key); }
@@ -1373,7 +1408,7 @@ uint64_t bg_state_blob_bytes(const bg_handle* h) {
   return b;
 }
 #define BG_BLOB_MAGIC 0x42474d58u
-#define BG_BLOB_VERSION 5u // 5: 576-byte shop-stream slots; 4: the curriculum cap in the hot state, card-state flag in the header; 3: compact shop-stream slots + overflow block; 2: stream 13 ('seal_applications') joins the card-state slices, consumables in the reset template
+#define BG_BLOB_VERSION 6u // 6: shop-stream slots hold finished output words (256 bytes); 5: 576-byte shop-stream slots; 4: the curriculum cap in the hot state, card-state flag in the header; 3: compact shop-stream slots + overflow block; 2: stream 13 ('seal_applications') joins the card-state slices, consumables in the reset template
 // what is wrong with a blob handed to bg_set_state (or with the buffer handed to bg_get_state), as text
 static int bg_blob_args(bg_handle* h, const char* fn, int env_index, const void* blob, uint64_t blob_bytes) {
   if (!h) return BG_E_ARG;

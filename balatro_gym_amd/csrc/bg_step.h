@@ -181,14 +181,14 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
     uint32_t r8[6] = {0, 0, 0, 0, 0, 0}; // the 8-bit candidates, packed (kept for the "until new" tests)
 #pragma unroll
     for (int i = 0; i < 24; i++) {
-      const uint32_t y = bg_temper(w.lds[i * BG_BLOCK]);
+      const uint32_t y = w.lds[i * BG_BLOCK];   // (the shop window holds finished, tempered words)
       m3 |= ((y >> 30) < 3u ? 1u : 0u) << i; m2 |= ((y >> 30) < 2u ? 1u : 0u) << i;
       m8 |= ((y >> 24) < nc ? 1u : 0u) << i; m52 |= ((y >> 26) < 52u ? 1u : 0u) << i;
       r8[i >> 2] |= (y >> 24) << (8 * (i & 3));
       if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0); // four words in flight are enough; 24 would cost ~30 registers
     }
     // word of accepted position i (dynamic): re-read from the window
-#define BG_SW(i) bg_temper(w.lds[(i) * BG_BLOCK])
+#define BG_SW(i) (w.lds[(i) * BG_BLOCK])
     uint32_t rem = 0xffffffu; // words not consumed yet
     int i0 = __ffs((int)(m3 & rem)) - 1; fast = fast && i0 >= 0; rem &= ~((2u << (i0 & 31)) - 1u);
     int i1 = __ffs((int)(m8 & rem)) - 1; fast = fast && i1 >= 0; rem &= ~((2u << (i1 & 31)) - 1u);
@@ -677,7 +677,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   uint32_t touch0 = 0, touch1 = 0;
   if (e.s_ready > 0) {
     const uint32_t* nxt = bg_sblock(d, env, (e.s_cur + 1 == d.KS) ? 0 : e.s_cur + 1);
-    touch0 = nxt[0]; touch1 = nxt[BG_SW_A];
+    touch0 = nxt[0]; touch1 = nxt[32];   // (a slot is two lines)
   }
   // card states (CardAdapter.to_scoring_format :287-325): BONUS +30, STONE +50 and no rank / suit, FOIL +50; the seals
   // and the GLASS / LUCKY rolls are settled after the scorer (:703-734)

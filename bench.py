@@ -287,10 +287,12 @@ def main():
         torch.cuda.synchronize(dev)
         t_off += k * chunk
         left -= k
-    run(args.warmup, t_off)
-    t_off += args.warmup
+    # (the error check and the zeroing of the statistics come BEFORE the W warm-up steps: nothing but the barrier may stand between the
+    #  warm-up and the timed region, or the timed launch starts on a GPU that has idled through a host round trip)
     env.check()
     env._stats.zero_()
+    run(args.warmup, t_off)
+    t_off += args.warmup
     env.set_profiling(True)
     gather_bytes = 0
     barrier()
@@ -301,6 +303,7 @@ def main():
     t_off += args.steps
     prof = env.get_profile()
     stats = env.stats()  # also checks the device error word
+    stats["steps"] -= n * args.warmup   # (the statistics were zeroed before the warm-up steps)
     gather_bytes_timed = gather_bytes
 
     # ---- the same K-step region again, `--samples` times (each between two synchronisations; every rank runs the same count), then
@@ -389,7 +392,7 @@ def main():
                          "refill": "RNG look-ahead refill of launch i runs BESIDE launch i+1 (one SIMD per CU is left to it): its time is inside mean_launch_us, not between launches",
                          # the same fraction for the whole job (everything between the two synchronisations, per GPU)
                          "end_to_end_gbps": value * a_step / world / 1e9, "end_to_end_frac": value * a_step / world / 1e9 / HBM_PEAK_GBPS},
-            "episodes": int(agg[1].item()), "accepted_plays": int(agg[2].item()),
+            "episodes": int(agg[1].item()), "accepted_plays": int(agg[2].item()), "episode_counts_cover": "warm-up steps + timed steps",
             "state_bytes_per_gpu": env.state_bytes(),
         }
         if sample_s:

@@ -200,12 +200,12 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
  * step's reward, action and terminated flag ride in the record.  A record is written by one lane with whole 16-byte
  * stores, which keeps HBM write traffic at the record size however far the envs of a workgroup drift apart in time.
  * rows_dev must be 16-byte aligned, row_stride_bytes a multiple of 16 and >= BG_ROW_BYTES.
- * FAST LAYOUT: row_stride_bytes == BG_ROW_STRIDE_LINES (384) with rows_dev 128-byte aligned.  The library then writes every record as
+ * FAST LAYOUT: row_stride_bytes == BG_RECORD_STRIDE_LINES (384) with rows_dev 128-byte aligned.  The library then writes every record as
  * three WHOLE 128-byte lines (bytes 352..383 as zeros): the MI355X's HBM takes records scattered over a buffer at 4.5 TB/s when their
  * lines are written completely and at 2.6 TB/s when each record ends in partial lines, which is what bounds a fused rollout
  * (tools/micro/recwrite.hip).  With any other stride bytes 352.. of a record are left untouched. */
 #define BG_ROW_BYTES 352
-#define BG_ROW_STRIDE_LINES 384
+#define BG_RECORD_STRIDE_LINES 384
 #define BG_ROW_SELECTED_CARDS 0       /* int64[8] */
 #define BG_ROW_FACE_DOWN_CARDS 64     /* int64[8] */
 #define BG_ROW_CHIPS_SCORED 128       /* int64 */

@@ -176,8 +176,7 @@ def test_blob_geometry_constants_match_the_device_header():
     assert int(define("BG_NHOT")) == nat.BLOB_NHOT and int(define("BG_NDECK")) == nat.BLOB_NDECK
     assert int(define("BG_NCOLD")) == nat.BLOB_NCOLD and int(define("BG_NTMPL")) == nat.BLOB_NTMPL
     assert int(define("BG_MTS")) == nat.BLOB_MTS and int(define("BG_NCST")) == nat.BLOB_NCST
-    sw_a = int(define("BG_SW_A"))
-    assert nat.SHOP_SLOT_SEED_WORD == 2 * sw_a and nat.SHOP_SLOT_WORDS == (2 * sw_a + 1 + 7) // 8 * 8
+    assert nat.SHOP_SLOT_SEED_WORD == int(define("BG_SW_T")) and nat.SHOP_SLOT_WORDS == int(define("BG_SLOT_WORDS"))
     m = re.search(r"^#define BG_SSEED (\d+)", open(os.path.join(ROOT, "balatro_gym_amd", "csrc", "bg_device.h")).read() +
                   open(os.path.join(ROOT, "balatro_gym_amd", "csrc", "bg_lib.hip")).read(), flags=re.M)
     assert m and int(m.group(1)) == nat.BLOB_SSEED
