@@ -287,6 +287,14 @@ def main():
         torch.cuda.synchronize(dev)
         t_off += k * chunk
         left -= k
+    if args.steps < chunk:
+        # ... and a few launches of the TIMED shape: the first short launch behind the full-depth ones queues the lazy refill (a gigabyte of ring
+        # writes through the L2 beside it); the timed launch should see the steady state of its own shape, as every later launch does -- what the
+        # refill costs a caller who sustains this shape is in `samples` (the slow ones) and `sustained`
+        for _ in range(4):
+            run(args.steps, t_off)
+            t_off += args.steps
+        torch.cuda.synchronize(dev)
     # (the error check and the zeroing of the statistics come BEFORE the W warm-up steps: nothing but the barrier may stand between the
     #  warm-up and the timed region, or the timed launch starts on a GPU that has idled through a host round trip)
     env.check()
