@@ -31,7 +31,7 @@ def run(n, T, policy, scorer, cards_on, seed0, max_ante, cons_on=False):
     if cons_on:  # two consumables per episode out of all 52 ids (tarots, planets, spectrals)
         cons = [random.Random(seed0 * 13 + i).sample(POOL, 1 + (i % 5 != 0)) for i in range(n)]
         env.inject_consumables(cons, apply_now=True)
-    rb = RowBuffers(n, env.device, steps=T)
+    rb = RowBuffers(n, env.device, steps=T, row_stride=int(os.environ.get("STRIDE", "0")))   # STRIDE=384: the whole-line record layout
     t = time.time()
     env.rollout(T, policy=policy, policy_seed=seed0, obs_buffers=rb)
     env.check()
