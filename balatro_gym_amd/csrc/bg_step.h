@@ -675,18 +675,25 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   // A play that beats the blind generates a shop, whose inventory reads two lines of the next pre-seeded shop stream: touch
   // them now (two dword loads nobody waits for) so that they come from L2, not from HBM, if the play wins
   uint32_t touch0 = 0, touch1 = 0;
+#ifndef BG_NO_SHOP_TOUCH
   if (e.s_ready > 0) {
     const uint32_t* nxt = bg_sblock(d, env, (e.s_cur + 1 == d.KS) ? 0 : e.s_cur + 1);
     touch0 = nxt[0]; touch1 = nxt[32];   // (a slot is two lines)
   }
+#endif
   // card states (CardAdapter.to_scoring_format :287-325): BONUS +30, STONE +50 and no rank / suit, FOIL +50; the seals
   // and the GLASS / LUCKY rolls are settled after the scorer (:703-734)
   uint32_t stone = 0;                      // bit per play index
   uint64_t dhist = 0;                      // rank histogram of the DECK cards played (boss Plant, face synergy)
   uint64_t cst = 0;                        // enh | seal << 4 per play index, one byte each
   const DeckHead dh = bg_deck_head(d, env, dk); // deck[0..15]: the cards under the hand's indexes AND the classifier's positions
+#ifdef BG_GATHER_UNROLL
+#pragma unroll
+  for (int i = 0; i < 8; i++) if (i < e.nsel) {
+#else
 #pragma unroll 1
   for (int i = 0; i < e.nsel; i++) {
+#endif
     int pos = bg_get8(e.sel, i);
     if (pos < e.nhand) {
       int ci = bg_get8(e.hand, pos);
