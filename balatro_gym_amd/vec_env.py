@@ -251,7 +251,7 @@ class BalatroVecEnv:
             #  two device exchanges of the context manager are a few per cent of the call)
             rc = self._L.bg_rollout_rows(
                 self._h, int(steps), int(policy), C.c_uint64(policy_seed), C.c_uint64(env_index0), C.c_uint64(t0),
-                C.c_void_p(obs_buffers.rows.data_ptr()), C.c_uint64(obs_buffers.row_stride), 1 if obs_buffers.steps > 1 else 0,
+                C.c_void_p(obs_buffers.rows.data_ptr()), C.c_uint64(getattr(obs_buffers, "row_stride", nat.ROW_BYTES)), 1 if obs_buffers.steps > 1 else 0,
                 C.c_void_p(self._stats.data_ptr()), self._stream())
             if rc != 0:
                 self._check(rc, "bg_rollout_rows")
