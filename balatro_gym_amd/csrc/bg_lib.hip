@@ -640,6 +640,7 @@ struct bg_handle {
   uint32_t* d_jtab;
   int steps_since_refill; // env steps launched (bg_step, bg_step_many, rollouts) since the last refill was LAUNCHED
   std::vector<uint4> h_tmpl;
+  std::vector<hipEvent_t> ev_pool;   // events of the per-launch profile, re-used (bg_set_profiling fills it)
   std::vector<uint8_t> h_cap; // host mirror of every env's curriculum cap (0 = none): what template antes are validated against
   uint64_t bytes;
   std::string err;
@@ -695,10 +696,17 @@ static hipError_t bg_alloc(bg_handle* h, T** p, size_t count) {
 
 static int bg_grid(const bg_handle* h) { return (h->dev.N + BG_BLOCK - 1) / BG_BLOCK; }
 
+// HIP events of the per-launch profile come from a pool filled when profiling is switched on: creating two events per launch inside a
+// caller's timed region cost a 20-step launch a few microseconds of its 330
+static hipEvent_t bg_ev_take(bg_handle* h) {
+  if (!h->ev_pool.empty()) { hipEvent_t e = h->ev_pool.back(); h->ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  return hipEventCreate(&e) == hipSuccess ? e : nullptr;
+}
 static void bg_ev_begin(bg_handle* h, std::vector<hipEvent_t>& v, hipStream_t s) {
   if (!h->profiling) return;
-  hipEvent_t a, b;
-  if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+  hipEvent_t a = bg_ev_take(h), b = bg_ev_take(h);
+  if (!a || !b) { if (a) h->ev_pool.push_back(a); if (b) h->ev_pool.push_back(b); return; }
   v.push_back(a); v.push_back(b);
   (void)hipEventRecord(a, s);
 }
@@ -706,12 +714,12 @@ static void bg_ev_end(bg_handle* h, std::vector<hipEvent_t>& v, hipStream_t s) {
   if (!h->profiling || v.empty()) return;
   (void)hipEventRecord(v.back(), s);
 }
-static double bg_ev_sum(std::vector<hipEvent_t>& v) {
+static double bg_ev_sum(bg_handle* h, std::vector<hipEvent_t>& v) {
   double ms = 0;
   for (size_t i = 0; i + 1 < v.size(); i += 2) {
     float f = 0;
     if (hipEventElapsedTime(&f, v[i], v[i + 1]) == hipSuccess) ms += f;
-    (void)hipEventDestroy(v[i]); (void)hipEventDestroy(v[i + 1]);
+    h->ev_pool.push_back(v[i]); h->ev_pool.push_back(v[i + 1]);
   }
   v.clear();
   return ms;
@@ -744,6 +752,7 @@ int bg_debug_worklists(bg_handle* h, unsigned int* out4) {
 int bg_set_profiling(bg_handle* h, int enable) {
   if (!h) return BG_E_ARG;
   h->profiling = enable != 0;
+  if (h->profiling) { BG_GUARD(h); while (h->ev_pool.size() < 128) { hipEvent_t e = nullptr; if (hipEventCreate(&e) != hipSuccess) break; h->ev_pool.push_back(e); } }
   return 0;
 }
 
@@ -756,9 +765,9 @@ int bg_get_profile(bg_handle* h, double* out8) {
   double steps = 0;
   for (int t : h->rollout_steps) steps += t;
   h->rollout_steps.clear();
-  out8[0] = bg_ev_sum(h->ev_rollout_t); out8[1] = nr; out8[2] = steps;
-  out8[3] = bg_ev_sum(h->ev_refill_t); out8[4] = nf;
-  out8[5] = bg_ev_sum(h->ev_step_t); out8[6] = ns; out8[7] = 0;
+  out8[0] = bg_ev_sum(h, h->ev_rollout_t); out8[1] = nr; out8[2] = steps;
+  out8[3] = bg_ev_sum(h, h->ev_refill_t); out8[4] = nf;
+  out8[5] = bg_ev_sum(h, h->ev_step_t); out8[6] = ns; out8[7] = 0;
   return 0;
 }
 
@@ -888,6 +897,8 @@ int bg_destroy(bg_handle* h) {
   if (h->ev_gblk) (void)hipEventDestroy(h->ev_gblk);
   for (int i = 0; i < 2; i++) if (h->ev_refill[i]) (void)hipEventDestroy(h->ev_refill[i]);
   if (h->ev_rollout) (void)hipEventDestroy(h->ev_rollout);
+  for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
+  for (auto* v : {&h->ev_rollout_t, &h->ev_refill_t, &h->ev_step_t}) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
   hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
   hipFree(d.hot); hipFree(d.deck); hipFree(d.cold); hipFree(d.tmpl); hipFree(d.ndeck); hipFree(d.gblk); hipFree(d.sblk); hipFree(d.sovf);
   hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.wl_shop); hipFree(d.sseed); hipFree(d.smeta); hipFree(d.dbg); hipFree(h->d_jtab); hipFree(d.cstate); hipFree(d.ctmpl); hipFree(d.cardmt); hipFree(d.sealmt);

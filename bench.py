@@ -275,6 +275,11 @@ def main():
     def barrier():
         if world > 1:
             dist.barrier()
+        # (poll an event first: the synchronize that follows then returns at once instead of after the runtime's wake-up latency)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(dev))
+        while not ev.query():
+            pass
         torch.cuda.synchronize(dev)
 
     # ---- untimed internal warm-up at full depth (a fixed number of launches: every rank issues the same collectives), then the W
