@@ -530,6 +530,17 @@ def test_service_wave_masks(monkeypatch):
     test_consumables_rollout_vs_oracle(True)
 
 
+@pytest.mark.parametrize("copiers", ["1", "3"])
+def test_copier_wave_counts(monkeypatch, copiers):
+    """Packed records with ONE and with THREE copier waves instead of two (BG_ENG_COPIERS; the copy queue is dealt out in blocks of 32
+    positions, round robin): every record byte against the oracle, dense and whole-line layouts, many short launches."""
+    monkeypatch.setenv("BG_ENG_COPIERS", copiers)
+    test_packed_record_rollout_vs_oracle(2, True, 256)
+    test_packed_record_rollout_vs_oracle(0, True, 77)
+    test_packed_records_padded_stride()
+    test_many_short_launches_vs_oracle(monkeypatch, "8,13,12", "1")
+
+
 @pytest.mark.parametrize("config", ["configs2_jokers_antes_1_4", "configs3_consumables_all_jokers_antes_1_8", "configs4_full_game_curriculum"])
 def test_rollout_properties_full_size(config):
     """Size-independent properties at BASELINE.json's N = 65 536 on the REAL workloads -- configs[2] (5 random implemented jokers
