@@ -56,7 +56,7 @@ EXPORTS = ["bg_create", "bg_destroy", "bg_last_error", "bg_num_envs", "bg_max_fu
            "bg_step", "bg_observe", "bg_rollout", "bg_rollout_rows", "bg_inject", "bg_inject_cards", "bg_inject_consumables", "bg_state_blob_bytes", "bg_get_state", "bg_set_state",
            "bg_refill", "bg_check", "bg_set_profiling", "bg_get_profile", "bg_set_max_ante", "bg_inject_deck",
            "bg_classify_batch", "bg_score_hand_batch", "bg_classify_batch_ex", "bg_score_hand_batch_ex", "bg_bench_copy", "bg_bench_fill", "bg_step_many",
-           "bg_sim_evaluate_batch", "bg_sim_score_batch", "bg_create_ex"]
+           "bg_sim_evaluate_batch", "bg_sim_score_batch", "bg_create_ex", "bg_step_rows", "bg_observe_rows"]
 # state-blob geometry (csrc/bg_device.h; tests/test_cabi_and_host.py checks these against the header): 16-byte chunks per env of the
 # hot / deck / cold / template arrays, words per stored MT19937 block, words per shop-stream ring slot and where its seed sits
 BLOB_NHOT, BLOB_NDECK, BLOB_NCOLD, BLOB_NTMPL, BLOB_NCST, BLOB_MTS, BLOB_SSEED = 8, 4, 7, 2, 7, 640, 128
@@ -154,6 +154,8 @@ def load(build_if_missing: bool = True):
     L.bg_reset.argtypes = [vp, vp, C.POINTER(ObsPtrs), vp]
     L.bg_step.argtypes = [vp, vp, C.POINTER(ObsPtrs), vp, vp, vp, C.POINTER(InfoPtrs), vp]
     L.bg_observe.argtypes = [vp, C.POINTER(ObsPtrs), vp]
+    L.bg_step_rows.argtypes = [vp, vp, vp, u64, vp, vp, vp, C.POINTER(InfoPtrs), vp]
+    L.bg_observe_rows.argtypes = [vp, vp, u64, vp]
     L.bg_step_many.argtypes = [vp, i32, vp, C.POINTER(ObsPtrs), i32, vp, vp, vp, C.POINTER(InfoPtrs), vp]
     L.bg_rollout.argtypes = [vp, i32, i32, u64, u64, u64, C.POINTER(ObsPtrs), i32, vp, vp, vp, vp, vp]
     L.bg_rollout_rows.argtypes = [vp, i32, i32, u64, u64, u64, vp, u64, i32, vp, vp]

@@ -1127,7 +1127,8 @@ static int bg_step_budget(const bg_handle* h) {
 // K consecutive step() calls per env, actions [K, N]: ONE launch of the step engine per refill budget.  The look-ahead rings are
 // topped up only when the steps since the last refill could exhaust them (a refill per step was 5 kernel launches per step).
 static int bg_step_impl(bg_handle* h, int K, const int32_t* actions_dev, const bg_obs_ptrs* obs, int obs_stride_steps, double* reward_dev,
-                        uint8_t* terminated_dev, uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream) {
+                        uint8_t* terminated_dev, uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream,
+                        uint8_t* rows_dev = nullptr, uint64_t row_stride = 0) {
   int rc = bg_require_seeded(h);
   if (rc) return rc;
   BG_GUARD(h);
@@ -1151,6 +1152,7 @@ static int bg_step_impl(bg_handle* h, int K, const int32_t* actions_dev, const b
       ea.obs = bg_obs(obs); ea.obs_stride_steps = obs_stride_steps;
       const size_t off = obs_stride_steps ? (size_t)done * N : 0;
       if (off) bg_obs_advance(ea.obs, off);
+      if (rows_dev) { ea.obs.rows = rows_dev; ea.obs.row_stride = (uint32_t)row_stride; } // packed records: the copier waves write them
       ea.reward = reward_dev ? reward_dev + off : nullptr; ea.term = terminated_dev ? terminated_dev + off : nullptr;
       ea.trunc = truncated_dev ? truncated_dev + off : nullptr;
       ea.info = bg_info(info);
@@ -1175,6 +1177,30 @@ int bg_step(bg_handle* h, const int32_t* actions_dev, const bg_obs_ptrs* obs, do
 int bg_step_many(bg_handle* h, int K, const int32_t* actions_dev, const bg_obs_ptrs* obs, int obs_stride_steps, double* reward_dev,
                  uint8_t* terminated_dev, uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream) {
   return bg_step_impl(h, K, actions_dev, obs, obs_stride_steps, reward_dev, terminated_dev, truncated_dev, info, stream);
+}
+
+static const char* bg_rows_args(const void* rows_dev, uint64_t row_stride_bytes) {
+  if (!rows_dev || row_stride_bytes < BG_ROW_BYTES || (row_stride_bytes & 15) || ((uintptr_t)rows_dev & 15) || row_stride_bytes > 0xffffffffull)
+    return "rows_dev must be 16-byte aligned and row_stride_bytes a multiple of 16, >= BG_ROW_BYTES";
+  return nullptr;
+}
+
+int bg_step_rows(bg_handle* h, const int32_t* actions_dev, uint8_t* rows_dev, uint64_t row_stride_bytes, double* reward_dev,
+                 uint8_t* terminated_dev, uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream) {
+  if (!h) return BG_E_ARG;
+  if (const char* m = bg_rows_args(rows_dev, row_stride_bytes)) { h->err = std::string("bg_step_rows: ") + m; return BG_E_ARG; }
+  return bg_step_impl(h, 1, actions_dev, nullptr, 0, reward_dev, terminated_dev, truncated_dev, info, stream, rows_dev, row_stride_bytes);
+}
+
+int bg_observe_rows(bg_handle* h, uint8_t* rows_dev, uint64_t row_stride_bytes, void* stream) {
+  if (!h) return BG_E_ARG;
+  if (const char* m = bg_rows_args(rows_dev, row_stride_bytes)) { h->err = std::string("bg_observe_rows: ") + m; return BG_E_ARG; }
+  BG_GUARD(h);
+  ObsPtrs o = bg_obs(nullptr);
+  o.rows = rows_dev; o.row_stride = (uint32_t)row_stride_bytes;
+  hipLaunchKernelGGL(bg_observe_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), o);
+  BG_HIP(hipGetLastError());
+  return 0;
 }
 
 int bg_observe(bg_handle* h, const bg_obs_ptrs* obs, void* stream) {

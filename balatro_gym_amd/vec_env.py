@@ -89,7 +89,13 @@ class BalatroVecEnv:
 
     def __init__(self, num_envs: int, seeds: Optional[Sequence[int]] = None, *, device: int | str | torch.device = 0,
                  scorer_jokers: bool = False, autoreset: bool = True, max_ante: int = 0, info_terms: bool = True,
-                 card_states: bool = False, fused_steps: int = 0):
+                 card_states: bool = False, fused_steps: int = 0, obs_layout: str = "keys"):
+        """obs_layout: "keys" -- one contiguous tensor per observation key (bg_step / bg_observe, the reference's dict of arrays);
+        "rows" -- ONE packed 384-byte record per env (bg_step_rows / bg_observe_rows): `obs[key]` are strided, correctly typed views of it
+        (`obs_rows` is the [N, 384] byte tensor, what a policy network would concatenate anyway) and `step()` is a third shorter."""
+        if obs_layout not in ("keys", "rows"):
+            raise ValueError("obs_layout must be 'keys' or 'rows'")
+        self.obs_layout = obs_layout
         if not torch.cuda.is_available():
             raise nat.NativeError("BalatroVecEnv needs a HIP device (torch.cuda.is_available() is False); "
                                   "there is no CPU fallback")
@@ -111,6 +117,8 @@ class BalatroVecEnv:
         n, dev = self.num_envs, self.device
         with torch.cuda.device(dev):
             self._obs = ObsBuffers(n, dev)
+            self._rowbuf = RowBuffers(n, dev, steps=1, row_stride=nat.ROW_STRIDE_LINES) if obs_layout == "rows" else None
+            self._row_tensors = {k: v[0] for k, v in self._rowbuf.tensors.items()} if self._rowbuf is not None else None
             self.reward = torch.zeros(n, dtype=torch.float64, device=dev)
             self.terminated = torch.zeros(n, dtype=torch.uint8, device=dev)
             self.truncated = torch.zeros(n, dtype=torch.uint8, device=dev)
@@ -122,6 +130,8 @@ class BalatroVecEnv:
         # the constant arguments of bg_step, converted once
         self._step_args = (C.byref(self._obs.ptrs), C.c_void_p(self.reward.data_ptr()), C.c_void_p(self.terminated.data_ptr()),
                            C.c_void_p(self.truncated.data_ptr()), C.byref(self._info_ptrs))
+        if self._rowbuf is not None:
+            self._rows_args = (C.c_void_p(self._rowbuf.rows.data_ptr()), C.c_uint64(self._rowbuf.row_stride))
         self.seed(seeds)
         self.reset()
 
@@ -135,12 +145,19 @@ class BalatroVecEnv:
 
     @property
     def obs(self) -> Dict[str, torch.Tensor]:
-        """The live observation tensors (updated in place by reset/step; clone() to keep a copy)."""
-        return self._obs.tensors
+        """The live observation tensors (updated in place by reset/step; clone() to keep a copy).  obs_layout "rows": views of `obs_rows`."""
+        return self._row_tensors if self._row_tensors is not None else self._obs.tensors
+
+    @property
+    def obs_rows(self) -> torch.Tensor:
+        """obs_layout "rows": the [N, 384] byte tensor of packed records (BG_ROW_* offsets) behind `obs`."""
+        if self._rowbuf is None:
+            raise AttributeError("obs_rows exists with obs_layout='rows'")
+        return self._rowbuf.rows[0]
 
     @property
     def obs_flat(self) -> torch.Tensor:
-        return self._obs.flat
+        return self._rowbuf.rows[0].reshape(-1) if self._rowbuf is not None else self._obs.flat
 
     def state_bytes(self) -> int:
         return int(self._L.bg_state_bytes(self._h))
@@ -188,7 +205,11 @@ class BalatroVecEnv:
             mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
             mptr = C.c_void_p(mask.data_ptr())
         with torch.cuda.device(self.device):
-            self._check(self._L.bg_reset(self._h, mptr, C.byref(self._obs.ptrs), self._stream()), "bg_reset")
+            if self._rowbuf is not None:
+                self._check(self._L.bg_reset(self._h, mptr, None, self._stream()), "bg_reset")
+                self._check(self._L.bg_observe_rows(self._h, self._rows_args[0], self._rows_args[1], self._stream()), "bg_observe_rows")
+            else:
+                self._check(self._L.bg_reset(self._h, mptr, C.byref(self._obs.ptrs), self._stream()), "bg_reset")
         return self.obs
 
     def step(self, actions: torch.Tensor):
@@ -198,6 +219,13 @@ class BalatroVecEnv:
         # (no torch.cuda.device() context: every entry point of the library switches to the handle's device itself, and a step is
         #  short enough for two extra hipSetDevice calls and seven ctypes conversions to show)
         a = self._step_args
+        if self._rowbuf is not None:
+            r = self._rows_args
+            rc = self._L.bg_step_rows(self._h, actions.data_ptr(), r[0], r[1], a[1], a[2], a[3], a[4],
+                                      torch.cuda.current_stream(self.device).cuda_stream)
+            if rc != 0:
+                self._check(rc, "bg_step_rows")
+            return self._row_tensors, self.reward, self.terminated, self.truncated, self.info
         rc = self._L.bg_step(self._h, actions.data_ptr(), a[0], a[1], a[2], a[3], a[4],
                              torch.cuda.current_stream(self.device).cuda_stream)
         if rc != 0:
@@ -225,11 +253,18 @@ class BalatroVecEnv:
                 self._h, K, C.c_void_p(actions.data_ptr()), C.byref(ob.ptrs), 1 if keep else 0, C.c_void_p(rw.data_ptr()),
                 C.c_void_p(tm.data_ptr()), None if keep else C.c_void_p(self.truncated.data_ptr()),
                 None if keep else C.byref(self._info_ptrs), self._stream()), "bg_step_many")
+        if self._rowbuf is not None:
+            self.observe()   # (obs_layout "rows": the live records follow)
+            if not keep:
+                return self._row_tensors, rw, tm, self.truncated, self.info
         return ob.tensors, rw, tm, self.truncated, self.info
 
     def observe(self):
         with torch.cuda.device(self.device):
-            self._check(self._L.bg_observe(self._h, C.byref(self._obs.ptrs), self._stream()), "bg_observe")
+            if self._rowbuf is not None:
+                self._check(self._L.bg_observe_rows(self._h, self._rows_args[0], self._rows_args[1], self._stream()), "bg_observe_rows")
+            else:
+                self._check(self._L.bg_observe(self._h, C.byref(self._obs.ptrs), self._stream()), "bg_observe")
         return self.obs
 
     # ------------------------------------------------------------------ extras
@@ -255,6 +290,8 @@ class BalatroVecEnv:
                 C.c_void_p(self._stats.data_ptr()), self._stream())
             if rc != 0:
                 self._check(rc, "bg_rollout_rows")
+            if self._rowbuf is not None:
+                self.observe()
             return self._stats
         ob = obs_buffers or self._obs
         stride = 1 if (obs_buffers is not None and obs_buffers.steps > 1) else 0
@@ -270,6 +307,8 @@ class BalatroVecEnv:
                 None if terminated is None else C.c_void_p(terminated.data_ptr()),
                 None if actions is None else C.c_void_p(actions.data_ptr()),
                 C.c_void_p(self._stats.data_ptr()), self._stream()), "bg_rollout")
+        if self._rowbuf is not None:
+            self.observe()   # (obs_layout "rows": the live records follow)
         return self._stats
 
     def stats(self) -> Dict[str, int]:

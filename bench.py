@@ -221,9 +221,9 @@ def main():
     lo, hi = shard_range(total, world, rank)
     assert hi - lo == n
 
-    def make_env():
+    def make_env(**kw):
         e = BalatroVecEnv(n, [1000 + g for g in range(lo, hi)], device=local_rank, scorer_jokers=True, autoreset=True,
-                          max_ante=MAX_ANTE)
+                          max_ante=MAX_ANTE, **kw)
         e.inject(jokers=[jokers_for(g) for g in range(lo, hi)], apply_now=True)
         return e
 
@@ -439,19 +439,20 @@ def main():
         twin_stats = twin.stats()
         twin.close()
         res = {}
-        for mode in ("bg_step", "bg_step_many"):
-            e2 = make_env()
+        for mode in ("bg_step", "bg_step_rows", "bg_step_many"):
+            kw = {"obs_layout": "rows"} if mode == "bg_step_rows" else {}   # bg_step_rows: the observation as one packed 384-byte record per env
+            e2 = make_env(**kw)
             e2.step(acts[0]); e2.reset(); torch.cuda.synchronize(dev)  # first-call costs out of the way
             e2.close()
             # two passes over the same 200 steps: the wall clock WITHOUT the profiling events (two hipEventRecord per launch cost a
             # one-step launch a fifth of its time), then the kernel time WITH them
             dt, p = None, None
             for profiled in (False, True):
-                e2 = make_env()
+                e2 = make_env(**kw)
                 e2.set_profiling(profiled)
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
-                if mode == "bg_step":
+                if mode != "bg_step_many":
                     for k in range(ks):
                         e2.step(acts[k])
                 else:
@@ -465,12 +466,13 @@ def main():
                 e2.close()
             a1 = OBS_BYTES + IO_BYTES + 2 * STATE_BYTES  # one launch per step: the state crosses HBM every step
             a_k = OBS_BYTES + IO_BYTES + 2 * STATE_BYTES / ks
-            alg = (a1 if mode == "bg_step" else a_k) * n * ks
+            alg = (a_k if mode == "bg_step_many" else a1) * n * ks
             res[mode] = {"value": n * ks / dt, "unit": "env-steps/s", "steps": ks, "ms_per_step": dt / ks * 1e3,
                          "kernel_ms_per_step": p["step_ms"] / ks, "launches": p["step_launches"],
                          "wall_over_kernel": (dt / ks * 1e3) / (p["step_ms"] / ks) if p["step_ms"] > 0 else None,
                          "roofline_frac": alg / (p["step_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if p["step_ms"] > 0 else None}
-        out["step_path"] = {"what": f"{ks} steps of the same workload, actions from a device tensor [K, N], observation as one array per key",
+        out["step_path"] = {"what": f"{ks} steps of the same workload, actions from a device tensor [K, N]; bg_step / bg_step_many: observation as one array per key, "
+                                    "bg_step_rows: as one packed 384-byte record per env (every key a strided view)",
                             "twin_rollout_plays": twin_stats["plays"], **res}
 
     if rank == 0:

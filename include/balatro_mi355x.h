@@ -185,6 +185,17 @@ int bg_step_many(bg_handle* h, int K, const int32_t* actions_dev, const bg_obs_p
 /* Replaces: `_get_observation()` / `_get_action_mask()` (balatro_env_2.py:1426-1541) without stepping. */
 int bg_observe(bg_handle* h, const bg_obs_ptrs* obs, void* stream);
 
+/* bg_step / bg_observe with the observation as ONE packed record per env (the BG_ROW_* layout of bg_rollout_rows below: every key a
+ * strided view of a [N, row_stride_bytes] byte tensor, plus the step's reward / action / terminated) instead of 31 arrays: what a
+ * policy network reads after `obs_as_tensor` + concatenation anyway.  A cheap step then patches the record image and the copier waves
+ * write it (a step that emits 31 arrays spends most of its instructions on address arithmetic): the one-step launch is a third shorter.
+ * Same step semantics, same reward / terminated / truncated / info arrays as bg_step (balatro_env_2.py:616-637, :1473-1541);
+ * bg_observe_rows (bytes 352.. of a record untouched) after bg_reset(h, mask, NULL, stream) gives the records of a reset.
+ * rows_dev: 16-byte aligned, row_stride_bytes a multiple of 16, >= BG_ROW_BYTES; BG_RECORD_STRIDE_LINES on a 128-byte aligned buffer is the fast layout. */
+int bg_step_rows(bg_handle* h, const int32_t* actions_dev, uint8_t* rows_dev, uint64_t row_stride_bytes, double* reward_dev,
+                 uint8_t* terminated_dev, uint8_t* truncated_dev, const bg_info_ptrs* info, void* stream);
+int bg_observe_rows(bg_handle* h, uint8_t* rows_dev, uint64_t row_stride_bytes, void* stream);
+
 /* Fused random-policy rollout: T steps of every env with the counter-hash policy computed on device and SAME_STEP
  * auto-reset, observations of step t written to row t of [T, N, ...] buffers when obs_stride_steps != 0 (or
  * overwritten in place when 0).  env_index0 = global index of this handle's env 0 (sharding); t0 = first step number.

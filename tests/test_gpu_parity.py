@@ -975,3 +975,51 @@ def test_mt_streams_on_device():
         got = temper(st["global_blocks"][g_cur][:16]).tolist()
         assert got == g["u32"][i], f"seed {seed}: global stream words"
     env.close()
+
+
+def test_step_rows_layout_vs_oracle():
+    """`BalatroVecEnv(obs_layout="rows")`: bg_step_rows / bg_observe_rows -- the observation as one packed 384-byte record per env, written by
+    the copier waves, `obs[key]` strided views of it -- in lockstep with the oracle (every key, reward bits, terminated, the info arrays),
+    masked resets and an injection included; and against the "keys" layout of the same env."""
+    import torch
+    from oracle import pyoracle as po
+    from oracle.gen_golden import IMPLEMENTED
+    n, T = 320, 160
+    seeds = [733_000 + SEED_OFFSET + 5 * i for i in range(n)]
+    jokers = [random.Random(i).sample(IMPLEMENTED, i % 6) for i in range(n)]
+    env = _vec(n, seeds, scorer_jokers=True, autoreset=False, max_ante=4, obs_layout="rows")
+    twin = _vec(n, seeds, scorer_jokers=True, autoreset=False, max_ante=4)
+    for e in (env, twin):
+        e.inject(jokers=jokers, apply_now=True)
+        e.observe()
+    orc = _oracle_envs(n, seeds, True, 4, jokers)
+    assert env.obs_rows.shape == (n, 384) and (env.obs_rows[:, 352:] == 0).all()
+    _assert_obs(_obs_np(env), {k: np.stack([o.obs()[k] for o in orc]) for k in OBS_KEYS}, "initial")
+    for t in range(T):
+        acts = np.array([o.policy_action(0, 99, i, t) for i, o in enumerate(orc)], dtype=np.int32)
+        res = [o.step(int(a)) for o, a in zip(orc, acts)]
+        a = torch.from_numpy(acts).to(env.device)
+        _, reward, term, _, info = env.step(a)
+        _, reward2, term2, _, info2 = twin.step(a)
+        ctx = f"rows layout t {t}"
+        wr = np.array([r[1] for r in res])
+        assert np.array_equal(reward.cpu().numpy().view(np.uint64), wr.view(np.uint64)), ctx
+        wt = np.array([r[2] for r in res], dtype=np.uint8)
+        assert np.array_equal(term.cpu().numpy(), wt), ctx
+        for k in ("final_score", "error", "hand_type", "cards_played", "aux"):
+            assert torch.equal(info[k], info2[k]), (ctx, k)
+        assert np.array_equal(info["error"].cpu().numpy(), np.array([r[4].error for r in res], dtype=np.int32)), ctx
+        assert torch.equal(info["reward_terms"].view(torch.int64), info2["reward_terms"].view(torch.int64)), ctx
+        _assert_obs(_obs_np(env), {k: np.stack([r[0][k] for r in res]) for k in OBS_KEYS}, ctx)
+        rows = env.obs_rows.cpu().numpy()
+        assert np.array_equal(rows[:, 136:144].copy().view(np.float64)[:, 0].view(np.uint64), wr.view(np.uint64)), ctx   # reward rides in the record
+        assert np.array_equal(rows[:, 172:176].copy().view(np.int32)[:, 0], acts) and np.array_equal(rows[:, 342], wt), ctx
+        if wt.any():
+            for i in np.nonzero(wt)[0]:
+                orc[i].reset()
+                orc[i].set_jokers(jokers[i])
+            m = torch.from_numpy(wt).to(env.device)
+            env.reset(mask=m); twin.reset(mask=m)
+            _assert_obs(_obs_np(env), {k: np.stack([o.obs()[k] for o in orc]) for k in OBS_KEYS}, ctx + " after reset")
+    env.check(); twin.check()
+    env.close(); twin.close()
