@@ -120,6 +120,9 @@ def measured_copy_gbps(dev):
 
 
 HBM_PEAK_GUIDE_GBPS = 6290.0                     # MI355X_MICROARCH.md: 6.29 TB/s measured for a float4 copy
+# what the HBM takes for THIS kernel's output pattern -- 352-byte records scattered over a buffer, written as three whole 128-byte lines
+# each (tools/micro/recwrite.hip, profiles/r03_recwrite.txt: 4.5 TB/s of payload; 2.6 TB/s when a record ends in partial lines)
+HBM_PEAK_SCATTERED_RECORDS_GBPS = 4500.0
 
 
 def matching_traffic(kernel: str, n: int, fused: float):
@@ -397,6 +400,9 @@ def main():
                          "traffic_frac_of_measured": traffic[0] / mean_launch_s / 1e9 / peak_measured if (traffic and mean_launch_s > 0 and peak_measured) else None,
                          "peak_measured": peak_measured, "frac_of_measured": achieved / peak_measured if peak_measured else None,
                          "peak_guide": HBM_PEAK_GUIDE_GBPS, "frac_of_guide": achieved / HBM_PEAK_GUIDE_GBPS,
+                         # a microbenchmark constant, not measured in this run: the ceiling of the output pattern (records scattered over the buffer)
+                         "peak_scattered_records": HBM_PEAK_SCATTERED_RECORDS_GBPS if (args.obs_layout == "rows" and args.row_stride == 384) else None,
+                         "frac_of_scattered_records": achieved / HBM_PEAK_SCATTERED_RECORDS_GBPS if (args.obs_layout == "rows" and args.row_stride == 384) else None,
                          # stores only: the records + the state written back, against a plain fill kernel on this GPU
                          "write_gbps": write_gbps, "peak_measured_write": peak_write, "write_frac_of_measured": write_gbps / peak_write if peak_write else None,
                          "kernel": kernel, "algorithmic_bytes_per_env_step": a_step,
