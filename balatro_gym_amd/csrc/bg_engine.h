@@ -110,7 +110,11 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
 #endif
   BG_PROBE_INIT();
   bg_tables_load(&jt, d.jtab);
+#ifdef BG_ENG_WAVE_PERM // development: which ROLE (wave index below) each physical wave takes, a hex digit per physical wave (0x6543210 = identity)
+  const int lane = threadIdx.x & 63, wave = (int)(((unsigned)BG_ENG_WAVE_PERM >> (4 * (threadIdx.x >> 6))) & 15u), tid = wave * 64 + lane;
+#else
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#endif
   const int env0 = blockIdx.x * NE;
   const int n_live = d.N - env0 < NE ? d.N - env0 : NE;
   const bool can_serve = ((a.serve_mask >> wave) & 1u) != 0;

@@ -218,12 +218,14 @@ __device__ __forceinline__ uint32_t bg_q156(uint32_t q) { return q >= 156u ? q -
 #ifndef BG_LAZY_U
 #define BG_LAZY_U 4 // 16-byte groups per iteration of bg_lazy_stream
 #endif
+#ifndef BG_LAZY_U_SEEDRING
+#define BG_LAZY_U_SEEDRING 2 // the seed ring draws ~34 words per env and refill: shorter iterations, 70 registers -> three waves beside the engine
+#endif
 #ifndef BG_REFILL_WAVE_PRIO
 #define BG_REFILL_WAVE_PRIO 0 // s_setprio of the deck / seed-ring / block waves (the shop seeding stays at 0, the step engine runs at 3)
 #endif
-template <class F>
+template <int U = BG_LAZY_U, class F>
 __device__ __forceinline__ uint32_t bg_lazy_stream(uint32_t* S, uint32_t c, bool active, F&& take) {
-  constexpr int U = BG_LAZY_U;
   uint4* S4 = (uint4*)S;
   uint32_t q = c >> 2, off = c & 3u, fq = bg_q156(q + 99u); // fq: group of word (4*q + 396) mod 624
   uint4 a[U + 1], f[U + 1]; // groups q .. q+U and fq .. fq+U
@@ -370,7 +372,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_
 //   * shops : `shop_seed = rng.get_int('shop_generation', 0, 2**31 - 1)` (:1389), `random.Random(shop_seed)` (shop.py:96)
 //   * gblk  : next 624-word block(s) of the per-env global stream
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BG_BLOCK) void bg_refill_zero_kernel(BgDev d) { if (threadIdx.x < 4) d.wl_count[threadIdx.x] = 0; }
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_zero_kernel(BgDev d) { if (threadIdx.x < 8) d.wl_count[threadIdx.x] = 0; } // [4]: the deck kernel's list cursor
 
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
   int env = blockIdx.x * BG_BLOCK + threadIdx.x;
@@ -416,59 +418,77 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
   if (g_valid > 0 && g_valid < d.KG) { uint32_t i = atomicAdd(&d.wl_count[2], 1u); d.wl[2 * N + i] = (uint32_t)env; }
 }
 
-// One lane per env that is short of pre-shuffled decks; rounds of one shuffle each until every lane of the wave has its ring
-// full (~1.7 decks per env and 372-step launch).  The deck under construction is the kernel's only LDS (52 bytes per lane:
-// random.shuffle indexes it with a per-lane j): 3.3 KB per wave, which fits beside a step-engine workgroup.
-__global__ __launch_bounds__(BG_BLOCK) void bg_refill_deck_kernel(BgDev d) {
+// Lane = an env that is short of pre-shuffled decks; rounds of one shuffle each.  An env needs a deck per blind it started (~18 per
+// 372-step launch under a uniform policy: 1.2 M shuffles per refill at 65 536 envs) and its shuffles are serial (one stream), so a wave
+// that kept its 64 envs until the last of them was full ran max-over-lanes rounds: a lane whose env is full takes the NEXT env of the
+// work list instead (one atomic per wave and round), and the kernel runs ~ (decks / 64) wave-rounds of ~17 us (instruction-bound: ~70
+// draws x ~45 instructions).  The deck under construction is the kernel's only LDS (52 bytes per lane: random.shuffle indexes
+// it with a per-lane j): 3.3 KB per wave, 128 registers: two waves fit beside a step-engine workgroup (it leaves 256 registers of one SIMD
+// and 10 KB of LDS per CU).
+__global__ __launch_bounds__(BG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void bg_refill_deck_kernel(BgDev d) {
   __builtin_amdgcn_s_setprio(BG_REFILL_WAVE_PRIO);
   __shared__ uint8_t sdeck[52][BG_BLOCK];
-  size_t N = d.N;
+  const size_t N = d.N;
   const int tid = threadIdx.x;
   const uint32_t count = d.wl_count[0];
-  for (uint32_t base = blockIdx.x * BG_BLOCK; base < count; base += gridDim.x * BG_BLOCK) {
-    const bool valid = base + tid < count;
-    const int env = valid ? (int)d.wl[base + tid] : 0;
-    uint32_t prod = 0, cur = 0;
-    int d_head = 0, d_ready = d.KD, made = 0;
-    uint32_t* mt = bg_deckmt(d, env);
-    if (valid) {
-      const uint32_t w5 = ((const uint32_t*)&d.hot[(size_t)5 * N + env])[3];
-      prod = d.prod_out[env];
-      d_head = bg_b(w5, 2);
-      d_ready = (int)((prod - (uint32_t)bg_b(w5, 3)) & 0xffu);
-      cur = mt[BG_MT_N] & 0x3ffu;
-    }
-    bool need = valid && d_ready < d.KD;
+  int env = 0, d_head = 0, d_ready = 0, made = 0;
+  uint32_t prod = 0, cur = 0;
+  uint32_t* mt = bg_deckmt(d, 0);
+  bool have = false, need = false, dry = false; // dry (wave-uniform): the list has no more envs
 #pragma unroll 1
-    while (__ballot(need) != 0ull) {
-      if (need) { int p = 0; for (int s = 0; s < 4; s++) for (int r = 0; r < 13; r++) sdeck[p++][tid] = (uint8_t)(r * 4 + s); } // :519-522
-      int i = 51; // random.shuffle: for i = 51..1: j = _randbelow(i + 1), swap
-      cur = bg_lazy_stream(mt, cur, need, [&](uint32_t y) {
-        const int k = 32 - __clz((uint32_t)(i + 1));
-        const uint32_t j = bg_temper(y) >> (32 - k);
-        if (j <= (uint32_t)i) {
-          const uint8_t a = sdeck[i][tid], b = sdeck[j][tid];
-          sdeck[i][tid] = b; sdeck[j][tid] = a;
-          i--;
+  while (true) {
+    if (!dry) {
+      const unsigned long long freem = __ballot(!have);
+      if (freem != 0ull) {
+        const int leader = __ffsll(freem) - 1, nfree = __popcll(freem);
+        uint32_t base = 0;
+        if (tid == leader) base = atomicAdd(&d.wl_count[4], (uint32_t)nfree);
+        base = (uint32_t)__shfl((int)base, leader);
+        dry = base + (uint32_t)nfree >= count;
+        const uint32_t my = base + (uint32_t)__popcll(freem & ((1ull << tid) - 1ull));
+        if (!have && my < count) {
+          env = (int)d.wl[my];
+          mt = bg_deckmt(d, env);
+          const uint32_t w5 = ((const uint32_t*)&d.hot[(size_t)5 * N + env])[3];
+          prod = d.prod_out[env];
+          d_head = bg_b(w5, 2);
+          d_ready = (int)((prod - (uint32_t)bg_b(w5, 3)) & 0xffu);
+          cur = mt[BG_MT_N] & 0x3ffu;
+          made = 0;
+          need = d_ready < d.KD;
+          have = need;
         }
-        return i >= 1;
-      });
-      if (need) {
-        const int slot = (d_head + d_ready) % d.KD;
-#pragma unroll
-        for (int k = 0; k < BG_NDECK; k++) {
-          uint32_t wv[4] = {0, 0, 0, 0};
-#pragma unroll
-          for (int b = 0; b < 16; b++) { int i2 = k * 16 + b; if (i2 < 52) wv[b >> 2] |= (uint32_t)sdeck[i2][tid] << (8 * (b & 3)); }
-          d.ndeck[((size_t)slot * BG_NDECK + k) * N + env] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
-        }
-        d_ready++; made++;
-        need = d_ready < d.KD;
       }
     }
-    if (valid) {
-      mt[BG_MT_N] = cur | BG_LAZY_SEEDED;
-      ((uint8_t*)&d.prod_out[env])[0] = (uint8_t)((prod + (uint32_t)made) & 0xffu); // byte store: the block kernel may run concurrently
+    if (__ballot(need) == 0ull) { if (dry) break; continue; }
+    if (need) { int p = 0; for (int s = 0; s < 4; s++) for (int r = 0; r < 13; r++) sdeck[p++][tid] = (uint8_t)(r * 4 + s); } // :519-522
+    int i = 51; // random.shuffle: for i = 51..1: j = _randbelow(i + 1), swap
+    cur = bg_lazy_stream(mt, cur, need, [&](uint32_t y) {
+      const int k = 32 - __clz((uint32_t)(i + 1));
+      const uint32_t j = bg_temper(y) >> (32 - k);
+      if (j <= (uint32_t)i) {
+        const uint8_t a = sdeck[i][tid], b = sdeck[j][tid];
+        sdeck[i][tid] = b; sdeck[j][tid] = a;
+        i--;
+      }
+      return i >= 1;
+    });
+    if (need) {
+      const int slot = (d_head + d_ready) % d.KD;
+#pragma unroll
+      for (int k = 0; k < BG_NDECK; k++) {
+        uint32_t wv[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int b = 0; b < 16; b++) { int i2 = k * 16 + b; if (i2 < 52) wv[b >> 2] |= (uint32_t)sdeck[i2][tid] << (8 * (b & 3)); }
+        d.ndeck[((size_t)slot * BG_NDECK + k) * N + env] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
+      }
+      d_ready++; made++;
+      need = d_ready < d.KD;
+      if (!need) { // this env's ring is full: cursor and producer byte back, the lane is free for the next env
+        mt[BG_MT_N] = cur | BG_LAZY_SEEDED;
+        ((uint8_t*)&d.prod_out[env])[0] = (uint8_t)((prod + (uint32_t)made) & 0xffu); // byte store: the block kernel may run concurrently
+        have = false;
+      }
     }
   }
 }
@@ -491,7 +511,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_seedring_kernel(BgDev d) {
       cur = mt[BG_MT_N] & 0x3ffu;
     }
     const bool need = valid && cnt < BG_SSEED;
-    cur = bg_lazy_stream(mt, cur, need, [&](uint32_t y) {
+    cur = bg_lazy_stream<BG_LAZY_U_SEEDRING>(mt, cur, need, [&](uint32_t y) {
       const uint32_t r = bg_temper(y);
       if (r < 2147483648u) { d.sseed[(size_t)env * BG_SSEED + ((head + cnt) & (BG_SSEED - 1))] = r; cnt++; }
       return cnt < BG_SSEED;
@@ -658,7 +678,7 @@ struct bg_handle {
   std::vector<hipEvent_t> ev_rollout_t, ev_refill_t, ev_step_t; // start/stop pairs
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
   // tunables read ONCE per handle in bg_create (environment variables)
-  int refill_blocks, refill_blocks_shop, dev_skip_refill;
+  int refill_blocks, refill_blocks_shop, dev_skip_refill, refill_order;
   uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_smask; int eng_waves, eng_copiers; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
 };
 
@@ -737,6 +757,26 @@ int bg_debug_counters(bg_handle* h, unsigned long long* out16) {
   return 0;
 }
 
+// Words of the per-env GLOBAL stream a run of `steps` consecutive steps can draw (the bound the block ring is sized by).
+//   * an ACCEPTED play of c scoring cards (c <= 5) with j <= 5 jokers: one random() per (card, joker) pair = 2 c j words, a second one
+//     per (8, 8 Ball) pair (four 8s in a deck: <= 2 * min(c, 4) * j), one randint(0, 23) per joker (>= 1 word, 1.33 expected), then the
+//     next hand's on_hand_drawn (The Wheel: 8 x random() = 16 words; The Hook: two _randbelow): <= 20 c + 21 + rejections
+//     (complete_joker_effects.py:35-184, boss_blinds.py:343-378);
+//   * the play clears the selection and a play of c cards needs c card toggles first, which draw nothing (a REJECTED play --
+//     boss_blinds.py:380-445, before the scorer -- draws nothing either): (20 c + 21) / (c + 1) <= 20.5 words per step;
+//   * every other step draws less in one step than that (blind select: boss choice + on_hand_drawn <= 18; discard: on_hand_drawn <= 16
+//     and needs a toggle too; a tarot / spectral <= 10).
+// So the pathological policy (five 8 Balls, The Wheel on every blind, an 8 in every play) draws <= 20.5 T + 111 words in T steps plus
+// ~1.7 expected rejection words per play; an ordinary random policy draws 2-4 per step.  The ring is priced at 32 T + 128 (24 T without
+// the scorer-level chain: <= 18 per step).  Rounds 1-2 priced EVERY step as a five-card play (110 words): 137 blocks instead of 41.
+// Underflow is loud (BG_DEVERR_GSTREAM -> BG_E_INTERNAL), never a wrong word.
+static long bg_gwords(int flags, int steps) { return (flags & BG_FLAG_SCORER_JOKERS) ? 32l * steps + 128 : 24l * steps; }
+static int bg_gsteps(int flags, int blocks) { // inverse: steps that `blocks` full blocks ahead of the cursor cover
+  const long w = (long)blocks * BG_MT_N;
+  const long t = (flags & BG_FLAG_SCORER_JOKERS) ? (w - 128) / 32 : w / 24;
+  return t < 0 ? 0 : (int)t;
+}
+
 // development aid: choose which refill kernels run (bit set = skipped; tools/refill_alone.py)
 int bg_debug_set_skip(bg_handle* h, int skip) { if (!h) return BG_E_ARG; h->dev_skip_refill = skip; return 0; }
 
@@ -788,6 +828,7 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     auto geti = [](const char* k, int dflt) { const char* v = getenv(k); return v ? atoi(v) : dflt; };
     h->refill_blocks = geti("BG_REFILL_BLOCKS", 4096); h->refill_blocks_shop = geti("BG_REFILL_BLOCKS_SHOP", 0);
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0);
+    h->refill_order = geti("BG_REFILL_ORDER", 2);
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
     h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0); h->eng_copiers = geti("BG_ENG_COPIERS", 2); if (h->eng_copiers < 1 || h->eng_copiers > 3) h->eng_copiers = 2;
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
@@ -802,17 +843,18 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
   // Look-ahead depth = how many steps one bg_rollout launch may fuse (bg_max_fused_steps).  Deeper rings amortise the
   // refill over more steps and the end-of-launch tail (lanes that finished early wait for the slowest env of their
   // workgroup) over more work: 128 -> 256 -> 372 fused steps measured +6 % / +9 % at 65 536 envs.  Per env they cost 2.5 KB
-  // per global / shop slot and 64 B per deck: ~1 MB (372 fused steps; 64 GB of the 288 at 65 536 envs), ~198 KB (64),
-  // ~105 KB (32) or ~60 KB (16).  Ring positions are bytes, so 250 is the deepest ring.
-  // (0.66 MB per env at full depth since the shop-stream slots are compact: 43 GB at 65 536 envs, 86 GB at 131 072)
-  int dg = n_envs <= 131072 ? 137 : (n_envs <= 262144 ? 73 : (n_envs <= 1048576 ? 13 : 8));
+  // per global block, 256 B per shop slot and 64 B per deck: 0.2 MB at full depth (372 fused steps: 12.8 GB of the 288 at 65 536 envs;
+  // 0.43 MB in round 3's first half, 0.51 in round 2, ~1 MB in round 1).  Ring positions are bytes, so 250 is the deepest ring.
   int dsd = n_envs <= 131072 ? 248 : (n_envs <= 262144 ? 124 : (n_envs <= 1048576 ? 24 : 12));
+  // global-stream blocks: two launches' worth of what 3 * dsd / 2 fused steps can draw (bg_gwords) + the block under the cursor:
+  // 41 / 21 / 7 / 5 with the scorer-level joker chain (137 / 73 / 13 / 8 while every step was priced as a five-card play), 31 / 17 / 5 / 5 without
+  int dg = 2 * (int)((bg_gwords(flags, 3 * (dsd / 2)) + BG_MT_N - 1) / BG_MT_N) + 1; if (dg < 5) dg = 5;
   if (fused_steps_hint > 0) {
     // the caller says how many steps it will ever fuse into one launch (bg_step users: a handful): rings only as deep as that
     // needs -- two launches' worth (the refill is overlapped), a deck / shop stream per 3 steps, 110 global words per step
     const int hint = fused_steps_hint > 372 ? 372 : fused_steps_hint;
     int ring = 2 * ((hint + 2) / 3); if (ring < 4) ring = 4;
-    int gb = 2 * ((hint * ((flags & BG_FLAG_SCORER_JOKERS) ? 110 : 24) + BG_MT_N - 1) / BG_MT_N) + 1; if (gb < 5) gb = 5;
+    int gb = 2 * (int)((bg_gwords(flags, hint) + BG_MT_N - 1) / BG_MT_N) + 1; if (gb < 5) gb = 5;
     if (ring < dsd) dsd = ring;
     if (gb < dg) dg = gb;
   }
@@ -837,7 +879,7 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
   }
   if (e == hipSuccess) e = bg_alloc(h, &d.deckmt, (size_t)BG_MTS * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.shopgenmt, (size_t)BG_MTS * N);
-  if (e == hipSuccess) e = bg_alloc(h, &d.wl_count, 4);
+  if (e == hipSuccess) e = bg_alloc(h, &d.wl_count, 8);
   if (e == hipSuccess) e = bg_alloc(h, &d.wl, 3 * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.wl_shop, 2 * N * (size_t)(d.KS - 1));
   if (e == hipSuccess) e = bg_alloc(h, &d.sseed, (size_t)BG_SSEED * N);
@@ -923,7 +965,7 @@ static int bg_chunk_limit(const bg_handle* h, bool* async_out) {
   const bool async = h->async_refill && ring >= 2 && gblocks >= 2;
   if (async) { ring /= 2; gblocks /= 2; }
   int max_chunk = 3 * ring;
-  int gchunk = (gblocks * BG_MT_N) / ((h->dev.flags & BG_FLAG_SCORER_JOKERS) ? 110 : 24);
+  int gchunk = bg_gsteps(h->dev.flags, gblocks);
   if (gchunk < max_chunk) max_chunk = gchunk;
   if (max_chunk < 1) max_chunk = 1;
   if (async_out) *async_out = async;
@@ -964,19 +1006,29 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   // workgroups (bg_engine.h: one SIMD per CU and ~5 KB of LDS are left to them) or, with nothing else running, several per SIMD.
   const int dense = h->refill_blocks;
   // the three kinds of work are independent once the lists exist: side by side on three streams, joined before the completion event
-  BG_HIP(hipEventRecord(h->ev_scan, s));
-  BG_HIP(hipStreamWaitEvent(h->side2, h->ev_scan, 0));
-  BG_HIP(hipStreamWaitEvent(h->side3, h->ev_scan, 0));
+  if (h->refill_order != 2) {
+    BG_HIP(hipEventRecord(h->ev_scan, s));
+    BG_HIP(hipStreamWaitEvent(h->side2, h->ev_scan, 0));
+    BG_HIP(hipStreamWaitEvent(h->side3, h->ev_scan, 0));
+  }
   const int skip = h->dev_skip_refill; // development: contention experiments only (breaks the rings)
   const int dense_shop = h->refill_blocks_shop > 0 ? h->refill_blocks_shop : dense;
-  if (!(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d);            // ALU-bound, lowest-priority stream
-  if (!(skip & 2)) hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side2, d);
-  if (!(skip & 4)) hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
-  if (!(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, h->side3, d);
-  BG_HIP(hipEventRecord(h->ev_deck, h->side2));
-  BG_HIP(hipEventRecord(h->ev_gblk, h->side3));
-  BG_HIP(hipStreamWaitEvent(s, h->ev_deck, 0));
-  BG_HIP(hipStreamWaitEvent(s, h->ev_gblk, 0));
+  // refill_order 0: the shop seeding (ALU-bound: 17 k waves of 64 registers, four fill the SIMD the engine leaves free) runs beside the
+  // latency-bound deck / seed-ring / block waves, which then wait for registers behind it; 1: it runs AFTER them; 2: all five kernels
+  // one after the other on `s` (a kernel's duration is then its own work, not its wait for a neighbour's registers)
+  const bool shop_last = h->refill_order >= 1, serial = h->refill_order == 2;
+  hipStream_t s_deck = serial ? s : h->side2, s_blk = serial ? s : h->side3;
+  if (!shop_last && !(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); // lowest-priority stream
+  if (!(skip & 2)) hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_deck, d);
+  if (!(skip & 4)) hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_blk, d);
+  if (!(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_blk, d);
+  if (!serial) {
+    BG_HIP(hipEventRecord(h->ev_deck, h->side2));
+    BG_HIP(hipEventRecord(h->ev_gblk, h->side3));
+    BG_HIP(hipStreamWaitEvent(s, h->ev_deck, 0));
+    BG_HIP(hipStreamWaitEvent(s, h->ev_gblk, 0));
+  }
+  if (shop_last && !(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d);
   bg_ev_end(h, h->ev_refill_t, s);
   BG_HIP(hipGetLastError());
   BG_HIP(hipEventRecord(h->ev_refill[h->refill_seq & 1], s));
@@ -1119,7 +1171,7 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
 static int bg_step_budget(const bg_handle* h) {
   const int ring = h->dev.KD < h->dev.KS - 1 ? h->dev.KD : h->dev.KS - 1;
   int lim = 3 * ring;
-  const int g = ((h->dev.KG - 1) * BG_MT_N) / ((h->dev.flags & BG_FLAG_SCORER_JOKERS) ? 110 : 24);
+  const int g = bg_gsteps(h->dev.flags, h->dev.KG - 1);
   if (g < lim) lim = g;
   return lim < 1 ? 1 : lim;
 }

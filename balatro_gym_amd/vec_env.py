@@ -461,6 +461,8 @@ class BalatroVecEnv:
         out["shop_slot_seeds"] = out["shop_slots"][:, nat.SHOP_SLOT_SEED_WORD]
         hot7 = out["hot"][7]
         out["shop_slot_current"] = int(hot7[1] & 0xff)
+        # words of the per-env global stream consumed since it was seeded (the block counter is a byte: modulo 256 blocks of 624 words)
+        out["global_words_consumed"] = int((out["hot"][6][3] >> 24) & 0xff) * 624 + int(hot7[0] & 0xffff)
         return out
 
     def set_profiling(self, enable: bool):

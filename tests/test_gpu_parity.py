@@ -200,8 +200,9 @@ def test_shop_stream_beyond_slot_vs_oracle():
     assert deepest >= 30, deepest  # visits of 30+ inventories (~300+ words) really happened
 
 
-def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_index0=0, t0=0, cards=None, consumables=None):
-    """SAME_STEP auto-reset rollout on the oracle; returns per-step obs/rewards/terminated and the stats dict."""
+def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_index0=0, t0=0, cards=None, consumables=None, action_fn=None):
+    """SAME_STEP auto-reset rollout on the oracle; returns per-step obs/rewards/terminated and the stats dict.  `action_fn(oracle_env, i, t)`
+    replaces the counter-hash policy."""
     orc = _oracle_envs(n, seeds, scorer, max_ante, jokers)
     if cards:
         for o, cs in zip(orc, cards):
@@ -216,7 +217,7 @@ def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_in
     for t in range(T):
         row = []
         for i, o in enumerate(orc):
-            a = o.policy_action(policy, pseed, env_index0 + i, t0 + t)
+            a = action_fn(o, i, t) if action_fn else o.policy_action(policy, pseed, env_index0 + i, t0 + t)
             ob, r, term, _, info = o.step(a)
             if term:
                 ob = o.reset()
@@ -308,6 +309,55 @@ def test_repeated_jokers_rollout_vs_oracle():
     for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
         assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
     assert got_stats["plays"] > 2000
+    env.close()
+
+
+def test_global_stream_budget_hungriest_policy(monkeypatch):
+    """The block ring of the per-env global stream is priced at 32 words per step (bg_lib.hip `bg_gwords`; rounds 1-2: 110).  The policy
+    that draws the most per step: five copies of a joker that draws per scoring card (8 Ball twice on an 8, Bloodstone), a play as soon as
+    c cards are toggled (c = 1..5 by env), smallest blind, straight out of the shop.  Run through bg_step_many with the SHALLOWEST ring
+    (BG_KG=5: four blocks ahead = a refill every 74 steps): no underflow (`check()`), bit-exact with the oracle, and the words every env
+    really consumed (from its state blob) stay under the bound."""
+    import torch
+    monkeypatch.setenv("BG_KG", "5")
+    n, T = 160, 296
+    seeds = [77_000 + SEED_OFFSET + 3 * i for i in range(n)]
+    jokers = [[26] * 5 if i % 2 else [117, 26, 117, 26, 27] for i in range(n)]
+
+    def hungry(o, i, t):
+        ob = o.obs()
+        m, sel = ob["action_mask"], ob["selected_cards"]
+        if int(ob["phase"]) == 0:
+            if m[0] and int(np.count_nonzero(sel)) >= 1 + i % 5:
+                return 0
+            for k in range(8):
+                kk = (k + i + t) % 8
+                if m[2 + kk] and not sel[kk]:
+                    return 2 + kk
+            return 0 if m[0] else int(np.flatnonzero(m)[0])
+        for a in (45, 31):
+            if m[a]:
+                return a
+        return int(np.flatnonzero(m)[0])
+
+    from balatro_gym_amd.vec_env import ObsBuffers
+    wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, T, 0, 0, True, 4, jokers, action_fn=hungry)
+    assert wstats["plays"] > 4000
+    env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4)
+    env.inject(jokers=jokers, apply_now=True)
+    ob = ObsBuffers(n, env.device, steps=T)
+    reward = torch.zeros((T, n), dtype=torch.float64, device=env.device)
+    term = torch.zeros((T, n), dtype=torch.uint8, device=env.device)
+    env.step_many(torch.from_numpy(wa).to(env.device), obs_buffers=ob, reward=reward, terminated=term)
+    env.check()
+    assert np.array_equal(reward.cpu().numpy().view(np.uint64), wr.view(np.uint64))
+    assert np.array_equal(term.cpu().numpy(), wt)
+    for k in OBS_KEYS:
+        assert np.array_equal(ob.tensors[k].cpu().numpy(), wobs[k]), f"obs[{k}] differs"
+    words = np.array([env.parse_state_blob(env.get_state(i))["global_words_consumed"] for i in range(n)])
+    print(f"global words per step: mean {words.mean() / T:.1f} max {words.max() / T:.1f}")
+    assert words.max() <= 32 * T + 128, words.max()
+    assert words.max() >= 8 * T, words.max()      # the policy really is hungry (a uniform policy draws 2-4 words per step)
     env.close()
 
 
