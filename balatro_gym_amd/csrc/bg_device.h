@@ -427,6 +427,13 @@ __device__ __forceinline__ uint32_t bg_gpeek(const BgDev& d, int env, const Env&
   if (e.g_valid < need) { atomicOr(d.err, BG_DEVERR_GSTREAM); return 0u; }
   return bg_temper(bg_gblock(d, env, blk)[idx]);
 }
+// one raw word `off` positions ahead, for its LINE (nobody looks at the value; 0 without a load when the ring does not hold it yet)
+__device__ __forceinline__ uint32_t bg_gtouch(const BgDev& d, int env, const Env& e, int off) {
+  int idx = e.g_idx + off, blk = e.g_cur, need = 1;
+  if (idx >= BG_MT_N) { idx -= BG_MT_N; blk = (blk + 1 == d.KG) ? 0 : blk + 1; need = 2; }
+  if (idx >= BG_MT_N) { idx -= BG_MT_N; blk = (blk + 1 == d.KG) ? 0 : blk + 1; need = 3; }
+  return e.g_valid >= need ? bg_gblock(d, env, blk)[idx] : 0u;
+}
 // the 12 tempered words `skip` positions ahead of the cursor, in three (unaligned) 16-byte loads: the spare words behind a
 // ring block mirror the head of the next one (bg_refill_gblk_kernel).  avail = which of them the ring already holds.
 struct __attribute__((packed, aligned(4))) BgU4 { uint32_t x, y, z, w; };

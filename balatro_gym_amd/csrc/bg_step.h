@@ -458,7 +458,16 @@ struct ChainIn {
 // The main phase's 12 candidate words, requested EARLY (bg_step_play_hand issues the loads before it gathers and classifies the
 // cards, so their HBM round trip runs beside ~5k cycles of LDS work instead of after it): valid when `skip` equals the number
 // of words the individual phase turns out to consume.
-struct ChainPeek { uint32_t mw[12]; uint32_t avail; int skip; bool ok; };
+// tl: LINE TOUCHES for the owners of an 8 Ball (the main phase's words then sit 2 words further per 8 played and per 8 Ball: known only after
+// the gather, but inside a span of <= 52 words) and of a Bloodstone (one word per Heart played, somewhere in the individual phase's words):
+// one dword per 128-byte line of the span, requested with the early words, so that the exact loads -- issued once the cards are known --
+// come from the L2 (~400 cycles beside the record stream) instead of HBM (~3 000: tools/micro/readlat.hip).  Only owners issue them: the
+// chip's random-line read rate is nearly spent, a touch of a line that is only probably needed costs every other load more than it saves.
+struct ChainPeek { uint32_t mw[12]; uint32_t avail; int skip; bool ok;
+#ifdef BG_CHAIN_TOUCH
+  uint32_t tl[5];
+#endif
+};
 // One joker's share of the individual phase: matching cards = sum of the histogram nibbles selected by the rank mask, or the
 // suit's count; (chips, mult) = count x the descriptor's constants; x2 per matching card for Triboulet.  sp = the descriptor's
 // "special" field (1 = 8 Ball, 2 = Bloodstone: settled card by card from the RNG words).
@@ -612,6 +621,9 @@ __device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, 
   uint32_t mw[12];
   uint32_t avail = 0; // main-phase words the ring already holds
   uint32_t mm = ((scnt >> 8) & 0xfu) ? mb : 0u; // Bloodstones with a Heart to look at
+#ifdef BG_CHAIN_TOUCH
+  if (pre) asm volatile("" ::"v"(pre->tl[0]), "v"(pre->tl[1]), "v"(pre->tl[2]), "v"(pre->tl[3]), "v"(pre->tl[4])); // the touched words are dead: the touches have landed
+#endif
 #pragma unroll 1
   while (mm) {
     const int jb = __ffs((int)mm) - 1;
@@ -671,6 +683,23 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
       bg_gpeek12_raw(d, env, e, pre.skip, pre.mw, pre.avail);
       pre.ok = true;
     }
+#ifdef BG_CHAIN_TOUCH
+    {
+      int nb8 = 0; bool blood = false;
+#pragma unroll
+      for (int j = 0; j < 5; j++) { const int id = j < e.njokers ? (int)bg_get8(e.jokers, j) : 0; nb8 += id == 26 ? 1 : 0; blood = blood || id == 117; }
+#pragma unroll
+      for (int m = 0; m < 5; m++) pre.tl[m] = 0u;
+      if (ball || blood) {
+        bg_gnorm(d, e);
+        const int cons_min = 2 * npre * e.njokers, cons_max = cons_min + 2 * (npre < 4 ? npre : 4) * nb8;
+        const int lo = blood ? 0 : cons_min, hi = ball ? cons_max + 11 : cons_min - 1; // (without an 8 Ball the main phase's words are `pre`)
+#pragma unroll
+        for (int m = 0; m < 4; m++) if (lo + 32 * m < hi) pre.tl[m] = bg_gtouch(d, env, e, lo + 32 * m);
+        if (hi >= lo) pre.tl[4] = bg_gtouch(d, env, e, hi);
+      }
+    }
+#endif
   }
   // A play that beats the blind generates a shop, whose inventory reads two lines of the next pre-seeded shop stream: touch
   // them now (two dword loads nobody waits for) so that they come from L2, not from HBM, if the play wins
