@@ -142,8 +142,8 @@ typedef struct bg_rollout_stats {
  * later.  Every entry point runs on the handle's device and leaves the caller's current device unchanged. */
 int bg_create(int n_envs, int device_id, uint32_t flags, int max_ante, bg_handle** out);
 /* bg_create with a memory hint: fused_steps_hint = the most steps the caller will ever ask ONE launch to fuse (bg_step users: 1;
- * an SB3-style collector: its n_steps; 0 = the default, 372-step launches).  The RNG look-ahead rings -- 0.66 MB per env at
- * full depth, 43 GB at 65 536 envs -- are sized for that: hint 16 -> 42 KB per env, hint 64 -> 0.13 MB (bg_state_bytes tells).
+ * an SB3-style collector: its n_steps; 0 = the default, 372-step launches).  The RNG look-ahead rings -- 0.2 MB per env at
+ * full depth, 12.8 GB at 65 536 envs -- are sized for that: hint 16 -> 26 KB per env, hint 64 -> 46 KB (bg_state_bytes tells).
  * bg_max_fused_steps reports what the rings allow; longer bg_rollout / bg_step_many calls are split into several launches. */
 int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fused_steps_hint, bg_handle** out);
 /* Replaces: `CurriculumBalatroEnv.current_max_ante` (train_balatro_agent.py:129-166: one wrapper, hence one cap, per env; the
