@@ -43,6 +43,9 @@
 #ifndef BG_ENG_OCC
 #define BG_ENG_OCC 2     // waves per SIMD the register budget is set for (2 = 256 VGPRs; 3 = 168: measured, spills)
 #endif
+#ifndef BG_ENG_IMG_PIECES
+#define BG_ENG_IMG_PIECES 22 // 16-byte pieces from one env's LDS record image to the next (22 = dense; 23: fewer bank conflicts)
+#endif
 #ifndef BG_ENG_NSV
 #define BG_ENG_NSV 4    // of them, how many own an RNG window and may run service batches
 #endif
@@ -83,11 +86,19 @@ __device__ __forceinline__ void bg_vm_drain() { asm volatile("s_waitcnt vmcnt(0)
 template <bool HASH, bool CARDS, bool INFO>
 __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_kernel(BgDev d, EngineArgs a) {
   constexpr int NE = BG_ENG_NE, NW = BG_ENG_NW, NSV = BG_ENG_NSV;
-  __shared__ bg_u32x4 s_img[NE][22];          // record images (88 KB)
+  // record images: 22 pieces of 16 bytes per env, IMGP pieces apart.  A row stride of 22 pieces = 88 dwords puts lane l's word k in bank
+  // (24 l + k) mod 32: four banks for the whole wave, a 16-way conflict on every per-lane field access of a cheap step; 23 pieces (92 dwords)
+  // spread the lanes over eight bank groups and make the image build's 16-byte stores conflict-free.
+  __shared__ bg_u32x4 s_img[NE][BG_ENG_IMG_PIECES];
   __shared__ uint4 s_c34[2][NE];              // hot chunks 3 and 4
   __shared__ uint32_t s_deck[16][NE];
   __shared__ unsigned long long s_mask[NE];
+#if BG_ENG_IMG_PIECES == 22
   __shared__ uint32_t s_t[NE], s_prod[NE];
+#else
+  __shared__ uint16_t s_t[NE];                // steps done in this launch (<= 372); 16 bits: the padded images leave the refill's deck waves their LDS
+  __shared__ uint32_t s_prod[NE];
+#endif
   __shared__ uint32_t s_q[3][NE];             // rings of items: env lane | generation of the ring position << 8 | action << 16 | VALID
   // queue control words, 32 bytes: [0..2] items ever queued per queue, [3] envs that have finished their T steps,
   // [4..6] items ever claimed per queue, [7] waves inside a batch -- a wave reads all eight with two 16-byte LDS loads
@@ -210,7 +221,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
         for (int j = 0; j < 3; j++) {
           const uint32_t pidx = (uint32_t)j * BG_BLOCK + (uint32_t)lane, rs = (pidx * 2731u) >> 16, c = pidx - 24u * rs;
           rsel[j] = rs; gl[j] = 16u * c;
-          mul[j] = c < 22u ? 352u : 0u;                                        // image byte address = l * mul + ib
+          mul[j] = c < 22u ? 16u * BG_ENG_IMG_PIECES : 0u;                     // image byte address = l * mul + ib
           ib[j] = c < 22u ? 16u * c : (uint32_t)((lds_cc*)&s_zero - imgb);
         }
         for (uint32_t g0 = 0; g0 < nb; g0 += 32u) {
@@ -296,7 +307,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   uint32_t polls = 0;
 #ifdef BG_TIMING4
   if (tid == 0 && d.dbg) { atomicAdd(&d.dbg[16], __builtin_readcyclecounter() - q_k0); atomicMax(&d.dbg[20], ~q_w0); }
-  unsigned long long q_batches[3] = {0, 0, 0}, q_items[3] = {0, 0, 0}, q_busy[3] = {0, 0, 0}, q_idle = 0, q_fail = 0, q_copy = 0, q_claim = 0, q_failt = 0, q_item = 0, q_cheap = 0, q_fin = 0, q_push = 0;
+  unsigned long long q_batches[3] = {0, 0, 0}, q_items[3] = {0, 0, 0}, q_busy[3] = {0, 0, 0}, q_idle = 0, q_fail = 0, q_copy = 0, q_claim = 0, q_failt = 0, q_item = 0, q_cheap = 0, q_fin = 0, q_push = 0, q_small[2] = {0, 0}, q_smallt[2] = {0, 0};
   const unsigned long long q_t0 = __builtin_readcyclecounter();
 #endif
   for (;;) {
@@ -583,6 +594,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     if (lane == 0) __hip_atomic_fetch_sub(&s_busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // after the pushes of this batch
 #ifdef BG_TIMING4
     q_batches[cls]++; q_items[cls] += nb; q_busy[cls] += __builtin_readcyclecounter() - q_b0;
+    if (nb <= 4u && cls != BG_Q_RUN) { q_small[cls - 1]++; q_smallt[cls - 1] += __builtin_readcyclecounter() - q_b0; } // the batches of a launch's tail
     if (cls == BG_Q_RUN) q_push += __builtin_readcyclecounter() - q_p0;
 #endif
   }
@@ -592,6 +604,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     for (int c = 0; c < 3; c++) { atomicAdd(&d.dbg[2 + 3 * c], q_batches[c]); atomicAdd(&d.dbg[3 + 3 * c], q_items[c]); atomicAdd(&d.dbg[4 + 3 * c], q_busy[c]); }
     atomicAdd(&d.dbg[11], q_idle); atomicAdd(&d.dbg[12], q_fail); atomicAdd(&d.dbg[13], q_copy); atomicAdd(&d.dbg[14], q_claim); atomicAdd(&d.dbg[15], q_failt);
     atomicAdd(&d.dbg[26], q_item); atomicAdd(&d.dbg[27], q_cheap); atomicAdd(&d.dbg[28], q_fin); atomicAdd(&d.dbg[29], q_push);
+    atomicAdd(&d.dbg[17], q_small[0]); atomicAdd(&d.dbg[18], q_smallt[0]); atomicAdd(&d.dbg[19], q_small[1]); atomicAdd(&d.dbg[30], q_smallt[1]);
   }
 #endif
   // ---------------------------------------------------------------- epilogue: chunks 3 / 4 -> HBM, statistics
