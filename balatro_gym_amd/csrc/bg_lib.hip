@@ -1056,8 +1056,8 @@ int bg_check(bg_handle* h, void* stream) {
   BG_HIP(hipMemcpyAsync(&w, h->dev.err, sizeof(w), hipMemcpyDeviceToHost, (hipStream_t)stream));
   BG_HIP(hipStreamSynchronize((hipStream_t)stream));
   if (w) {
-    char buf[160];
-    snprintf(buf, sizeof(buf), "device invariant violated: error word 0x%x (1 global-stream underflow, 2 shop block, 4 deck ring, 8 shop ring)", w);
+    char buf[256];
+    snprintf(buf, sizeof(buf), "device invariant violated: error word 0x%x (1 global-stream underflow, 2 shop block, 4 deck ring, 8 shop ring, 16 a bounded wait inside the step engine expired)", w);
     h->err = buf;
     return BG_E_INTERNAL;
   }
@@ -1156,6 +1156,10 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
   a.copier = a.obs.rows ? (uint32_t)h->eng_copiers : 0u;
   if (a.copier && a.n_waves > BG_ENG_NW - a.copier) a.n_waves = BG_ENG_NW - a.copier;
   if (a.n_waves < BG_ENG_NW && a.serve_mask == BG_ENG_SMASK_DEFAULT) // the last NSV of the workers (all of them when there are no more)
+    a.serve_mask = a.n_waves <= BG_ENG_NSV ? (1u << a.n_waves) - 1u : ((1u << BG_ENG_NSV) - 1u) << (a.n_waves - BG_ENG_NSV);
+  // a BG_ENG_SMASK that names no WORKER wave of this launch (fewer workers than the mask assumed: a short launch, copier waves) would leave the
+  // service queues without a taker: fall back to the last workers
+  if ((a.serve_mask & ((1u << a.n_waves) - 1u)) == 0u)
     a.serve_mask = a.n_waves <= BG_ENG_NSV ? (1u << a.n_waves) - 1u : ((1u << BG_ENG_NSV) - 1u) << (a.n_waves - BG_ENG_NSV);
   const dim3 g((h->dev.N + BG_ENG_NE - 1) / BG_ENG_NE), b(BG_ENG_NW * BG_BLOCK);
 #define BG_ENG(HASHV, CARDSV, INFOV) hipLaunchKernelGGL((bg_engine_kernel<HASHV, CARDSV, INFOV>), g, b, 0, st, dv, a)
