@@ -30,7 +30,11 @@
 #define BG_ITEM_VALID 0x80000000u
 #define BG_SPIN_LIMIT (1u << 24)
 #define BG_DEVERR_SPIN 16u
-#define BG_ENG_NE 256   // envs per workgroup (an item holds the env's lane in 8 bits)
+#ifndef BG_ENG_LNE
+#define BG_ENG_LNE 8     // log2 of the envs per workgroup.  Only 8 is supported: 7 (128 envs: twice the workgroups for a small job) passes the parity tests and
+                         // gives +9 % at 4 096 envs, 6 gives +15 % but trips a bounded wait (profiles/r03_small_workgroups_ab.txt)
+#endif
+#define BG_ENG_NE (1 << BG_ENG_LNE)   // envs per workgroup: 256 (an item holds the env's lane in 8 bits; rings have NE entries, an item's generation = position >> LNE)
 // Waves per workgroup.  SEVEN, not eight: a wave of this kernel needs 256 VGPRs, so eight fill the register file of all four SIMDs and
 // nothing can be placed beside the workgroup -- the RNG refill of the previous launch (~1 ms of one-wave workgroups) then waits for
 // the engine to retire and the next launch waits for the refill.  With seven, one SIMD per CU keeps 256 free registers (and the
@@ -194,7 +198,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       // this lane's entry (a producer bumps the tail first and writes the entry next: poll until the generation matches)
       uint2 ent = make_uint2(0u, 0u);
       if ((uint32_t)lane < nb) {
-        const uint32_t pos = head + (uint32_t)lane, want = BG_ITEM_VALID | (((pos >> 8) & 0x7fu) << 16);
+        const uint32_t pos = head + (uint32_t)lane, want = BG_ITEM_VALID | (((pos >> BG_ENG_LNE) & 0x7fu) << 16);
         lds_u32* ep = (lds_u32*)&s_cq[pos & (NE - 1)];
         uint32_t spin = 0, y = ep[1];
         while ((y & (BG_ITEM_VALID | 0x7f0000u)) != want && ++spin < BG_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); asm volatile("" ::: "memory"); y = ep[1]; }
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
         base = __builtin_amdgcn_readlane(base, __ffsll((long long)rm) - 1);
         if (valid && !through) {
           const uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(rm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)rm, 0u));
-          bg_lds_st(&s_q[BG_Q_RUN][slot & (NE - 1)], (ent.y & 0xffu) | (((slot >> 8) & 0xffu) << 8) | BG_ITEM_VALID);
+          bg_lds_st(&s_q[BG_Q_RUN][slot & (NE - 1)], (ent.y & 0xffu) | (((slot >> BG_ENG_LNE) & 0xffu) << 8) | BG_ITEM_VALID);
         }
       }
       if (dm && lane == 0) __hip_atomic_fetch_add(&s_done, (uint32_t)__popcll(dm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -391,7 +395,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     uint32_t t = 0;
     if ((uint32_t)lane < nb) {
       uint32_t spin = 0;
-      const uint32_t want = BG_ITEM_VALID | ((((head + (uint32_t)lane) >> 8) & 0xffu) << 8);
+      const uint32_t want = BG_ITEM_VALID | ((((head + (uint32_t)lane) >> BG_ENG_LNE) & 0xffu) << 8);
       while ((item & (BG_ITEM_VALID | 0xff00u)) != want && ++spin < BG_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); item = bg_lds_ld(slotp); }
       if ((item & (BG_ITEM_VALID | 0xff00u)) != want) atomicOr(d.err, BG_DEVERR_SPIN);
       else { active = true; l = (int)(item & 0xffu); env = env0 + l; t = s_t[l]; }
@@ -457,7 +461,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       else {
         const int q = (!terminal && phase == 0u && action == 0) ? BG_Q_PLAY : BG_Q_OTHER;
         const uint32_t slot = __hip_atomic_fetch_add(&s_tail[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        bg_lds_st(&s_q[q][slot & (NE - 1)], (uint32_t)l | (((slot >> 8) & 0xffu) << 8) | (((uint32_t)action & 0x7fffu) << 16) | BG_ITEM_VALID);
+        bg_lds_st(&s_q[q][slot & (NE - 1)], (uint32_t)l | (((slot >> BG_ENG_LNE) & 0xffu) << 8) | (((uint32_t)action & 0x7fffu) << 16) | BG_ITEM_VALID);
         active = false;                                                   // the env is the service queue's now
       }
       if (fin) {
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
           lds_u32* ep = (lds_u32*)&s_cq[pos & (NE - 1)];
           ep[0] = (uint32_t)row;
           asm volatile("" ::: "memory");
-          ep[1] = (uint32_t)l | (t >= (uint32_t)a.T ? 0x100u : 0u) | (((pos >> 8) & 0x7fu) << 16) | BG_ITEM_VALID;
+          ep[1] = (uint32_t)l | (t >= (uint32_t)a.T ? 0x100u : 0u) | (((pos >> BG_ENG_LNE) & 0x7fu) << 16) | BG_ITEM_VALID;
           asm volatile("" ::: "memory");
           active = false;
         }
@@ -589,7 +593,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     // ---- hand the remaining envs back to the run queue
     if (active) {
       const uint32_t slot = __hip_atomic_fetch_add(&s_tail[BG_Q_RUN], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-      bg_lds_st(&s_q[BG_Q_RUN][slot & (NE - 1)], (uint32_t)l | (((slot >> 8) & 0xffu) << 8) | BG_ITEM_VALID);
+      bg_lds_st(&s_q[BG_Q_RUN][slot & (NE - 1)], (uint32_t)l | (((slot >> BG_ENG_LNE) & 0xffu) << 8) | BG_ITEM_VALID);
     }
     if (lane == 0) __hip_atomic_fetch_sub(&s_busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // after the pushes of this batch
 #ifdef BG_TIMING4
