@@ -37,6 +37,20 @@
 #define BG_DEVERR_DECKRING 4u // pre-shuffled deck ring empty at reset
 #define BG_DEVERR_SHOPRING 8u // pre-seeded shop ring empty at shop generation
 
+// Agent-scope (sc1) accesses: they bypass the CU's vector L1, which another CU's stores never refresh (MI355X_MICROARCH.md, "inter-workgroup
+// visibility").  The two-kernel engine (bg_engine2.h) serves an env's steps on whichever CU of its XCD has a free service wave, so every
+// load of MUTABLE per-env state on the service path goes through these; stores are plain (they reach the XCD's L2, the one point all
+// accesses to that env share during a launch).
+typedef __attribute__((address_space(1))) unsigned long long g_u64;
+typedef __attribute__((address_space(1))) uint32_t g_u32;
+__device__ __forceinline__ unsigned long long bg_ld8a(const void* p) { return __hip_atomic_load((g_u64*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint32_t bg_ld4a(const void* p) { return __hip_atomic_load((g_u32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void bg_st8a(void* p, unsigned long long v) { __hip_atomic_store((g_u64*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ uint4 bg_ld16a(const void* p) { // two 8-byte agent-scope loads (global_load_dwordx2 sc1)
+  const unsigned long long a = bg_ld8a(p), b = bg_ld8a((const char*)p + 8);
+  return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
+}
+
 struct BgDev {
   int N;
   uint32_t flags;
@@ -293,8 +307,8 @@ __device__ __forceinline__ void bg_deck_set(DeckLds& dk, int k, uint4 c) {
 }
 __device__ __forceinline__ int bg_card(const BgDev& d, int env, const Deck0& k, int idx) {
   if (idx < 16) return (int)(((idx < 8 ? k.lo : k.hi) >> (8 * (idx & 7))) & 0xffull);
-  const uint8_t* p = (const uint8_t*)&d.deck[(size_t)(idx >> 4) * d.N + env];
-  return p[idx & 15];
+  const uint32_t* p = (const uint32_t*)&d.deck[(size_t)(idx >> 4) * d.N + env];   // (rare: past the L1, see bg_ld4a)
+  return (int)((bg_ld4a(p + ((idx & 15) >> 2)) >> (8 * (idx & 3))) & 0xffu);
 }
 // workgroup decks with the row stride as a parameter (bg_engine_kernel: 256 envs per workgroup)
 template <int S, bool C> struct DeckLdsS { lds_u32* col; static constexpr bool kCards = C; };
@@ -510,6 +524,8 @@ __device__ __forceinline__ void bg_shop_overflow(const BgDev& d, int env, Env& e
 }
 __device__ __forceinline__ const uint32_t* bg_sbase(const BgDev& d, int env, const Env& e, bool& full) {
   full = (e.bflags & BG_BF_SHOP_OVF) != 0;
+  // the overflow block may have been (re)written by another CU since this CU last cached its lines (two-kernel engine): rare path, one L1 invalidate
+  if (full) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   return full ? bg_sovf(d, env) : bg_sblock(d, env, e.s_cur);
 }
 // next output word of the shop stream; the window (w.lds) holds TEMPERED words

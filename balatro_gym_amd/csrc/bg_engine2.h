@@ -1,0 +1,527 @@
+// bg_engine2.h -- the step engine as TWO cooperating kernels (packed-record rollouts): OWNER waves and a chip-wide pool of SERVICE waves.
+//
+// Why two kernels.  The one-kernel engine (bg_engine.h) is bound by the latency of a step per env -- 256 envs per CU, each taking its T
+// steps one after the other -- and its 256 VGPRs per wave, set by the PLAY_HAND path, allow seven waves per CU: a card-select toggle (84 %
+// of a random policy's steps, ~150 instructions on ~40 registers) waits for one of five 256-register workers, and a play batch can only
+// draw on its own CU's 256 envs (26 of 64 lanes).  Here
+//   * bg_owner_kernel: lane = env for the whole launch (a workgroup = 256 envs = four waves of <= 128 VGPRs).  Every iteration a wave
+//     settles the CHEAP step of each of its ready envs on the env's record image in LDS (toggle / shop end / rejected action: exactly the
+//     run batch of bg_engine.h, but with chunks 3 / 4 and the action mask in registers and no queue, no claim, no hand-over), copies the
+//     finished records out (lane <-> 16-byte piece, whole 128-byte lines, non-temporal) and posts the other actions -- PLAY_HAND, DISCARD,
+//     blind select, shop buy / reroll / sell, consumables, terminal guards -- as REQUESTS to global-memory queues.  Nothing in the wave's
+//     loop touches another wave's LDS: there is no barrier and no LDS queue.
+//   * bg_service_kernel: one-wave workgroups of 256 VGPRs placed beside the owners (one per SIMD).  A service wave claims up to 64
+//     requests of one class from the queues of ITS XCD -- every CU of the XCD feeds them, so batches are full --, runs the step exactly as
+//     a service batch of bg_engine.h does (same device functions), writes the state back, writes the finished 352-byte record STRAIGHT TO
+//     ITS ROW (staged through LDS: whole lines) and answers.  The owner reads the record back from the row into its LDS image (the row IS
+//     the mailbox), so a service step's record is written once.
+// Hand-over (MI355X_MICROARCH.md, "inter-workgroup visibility"; cdna_hip_programming.md guideline 16): a CU's vector L1 is never refreshed
+// by another CU's stores and the eight XCD L2s are not coherent with each other.  A request is served on the XCD that posted it -- both
+// sides read HW_REG_XCC_ID, a fact about where the wave runs, not an assumption about dispatch order -- so every byte of an env's state
+// is written and read through ONE L2 for the length of a launch (kernel boundaries make it coherent between launches, as for any two
+// kernels).  Payload: plain stores (they stay in that L2), then `s_waitcnt vmcnt(0)` in the storing wave, then the flag / queue entry as an
+// agent-scope atomic; the reader polls with agent-scope loads and reads the payload with agent-scope (sc1) loads, which bypass its L1.
+// Every wait is bounded by the wall clock (sticky BG_DEVERR_SPIN instead of a hang).
+// Both kernels must be RESIDENT together: the host launches them on two streams (bg_engine2_launch); neither ever waits for a workgroup
+// that has not started (an owner that is not resident posts nothing; a service wave serves whoever posts).
+#pragma once
+
+#define BG_E2_NSUB 2                       // queues per (XCD, class): one returning atomic per owner wave, iteration and class; a word takes ~90 / us
+#define BG_E2_NQX (2 * BG_E2_NSUB)         // queues per XCD: [class][sub]
+#define BG_E2_NQ (8 * BG_E2_NQX)
+#define BG_E2_TIMEOUT 200000000ull         // 2 s of the 100 MHz wall clock: a wait that long is a bug (or a missing partner kernel)
+struct E2Queue { uint32_t tail; uint32_t pad0[31]; uint32_t head; uint32_t pad1[31]; }; // each word on its own 128-byte line
+struct E2Ctl {
+  uint32_t owners_done; uint32_t pad0[31];  // owner waves that have finished, ever (monotonic; a launch ends at E2Args.done_target)
+  uint32_t svc_seen[8]; uint32_t pad1[24];  // service waves started per XCD, ever (diagnostic)
+  unsigned long long svc_stat[8]; uint32_t pad2[16]; // [0] batches [1] requests [2] first owner wave started [3] last owner wave ended [4] first service wave started [5] last service wave ended (wall clock; development)
+  E2Queue q[BG_E2_NQ];
+  // development: per XCD -- service waves that have left, OR of the reasons (1 done, 2 idle time-out), the largest owners_done / smallest target a leaving
+  // wave saw, wall clock of the first / last leave, batches served
+  uint32_t x_exits[8], x_reason[8], x_done[8], x_target[8]; unsigned long long x_t0[8], x_t1[8], x_batches[8];
+  uint32_t x_migr[8];   // [0] owner waves / [1] service waves whose XCC id changed while they ran
+  uint32_t owners_started; uint32_t pad3[31];   // owner workgroups that have started, ever (the gate in front of the service kernel waits for it)
+};
+struct E2Args {
+  E2Ctl* ctl;
+  unsigned long long* ring;      // [BG_E2_NQ][1 << ring_log] entries: env | (action | valid << 8 | t << 9 | generation << 25 | 1 << 31) << 32
+  uint32_t ring_log;
+  uint4* ans;                    // [N] answers: {seq, mask_lo, seq, mask_hi}, seq = steps the env has completed in this launch
+  uint4* img;                    // [N][24] record images between launches (22 pieces used)
+  unsigned long long* imask;     // [N] action masks between launches
+  uint32_t done_target;          // ctl->owners_done at which this launch's service waves retire
+  uint32_t fill_wait;            // wall-clock ticks (10 ns) a service wave waits for a fuller batch once it has seen a request
+  uint32_t max_batch;            // <= 64
+  uint32_t start_target;         // ctl->owners_started at which the gate lets the service kernel start
+  uint32_t zero;                 // 0, as a run-time value: `fetch_add(p, zero)` stays a returning atomic (the compiler turns `fetch_add(p, 0)` into a load)
+};
+
+__device__ __forceinline__ uint32_t bg_xcc_id() { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x & 7u; }
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// images between launches: the packed record of every env + its action mask, rebuilt from the state whenever anything but the
+// two-kernel engine has touched it (bg_reset, bg_step, bg_inject, ...)
+// ------------------------------------------------------------------------------------------------------------------------------
+template <bool CARDS>
+__global__ __launch_bounds__(BG_BLOCK) void bg_e2_image_kernel(BgDev d, E2Args x) {
+  using DeckT = typename std::conditional<CARDS, Deck0C, Deck0>::type;
+  const int env = blockIdx.x * BG_BLOCK + threadIdx.x;
+  if (env >= d.N) return;
+  Env e;
+  bg_load_env(d, env, e);
+  DeckT dk; static_cast<Deck0&>(dk) = bg_load_deck0(d, env);
+  ShopRegs sr; sr.valid = false;
+  const uint64_t mask = bg_action_mask(d, env, e, sr);
+  ObsPtrs o; memset(&o, 0, sizeof(o));
+  o.rows = (uint8_t*)x.img; o.row_stride = 384u;
+  bg_write_obs<false>(d, env, (size_t)env, e, dk, o, mask, sr, RowExtra{0.0, 0, 0u});
+  x.imask[env] = mask;
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// owner kernel
+// ------------------------------------------------------------------------------------------------------------------------------
+#define BG_E2_OW 4                          // owner waves per workgroup (nothing is shared between them but the tables)
+#define BG_E2_IMG_BYTES (BG_E2_OW * BG_BLOCK * 22 * 16)
+#define BG_E2_LIST_BYTES (BG_E2_OW * BG_BLOCK * 8)
+#define BG_E2_OWNER_LDS (BG_E2_IMG_BYTES + BG_E2_LIST_BYTES + 16 + (int)sizeof(JTables))
+template <bool HASH>
+__global__ __launch_bounds__(BG_E2_OW * BG_BLOCK) void bg_owner_kernel(BgDev d, EngineArgs a, E2Args x) {
+  constexpr int NE = BG_E2_OW * BG_BLOCK;
+  // DYNAMIC LDS on purpose: with a static 97 KB the compiler knows that one workgroup fits a CU, derives "one wave per SIMD" from it and PADS the
+  // kernel's register allocation to 257 VGPRs so that no second wave of this kernel could ever share a SIMD -- which also locks out the 256-register
+  // service waves of the other kernel (found as "the service kernel starts when the owner kernel ends": tools/micro/corun2.hip, tools/e2_diag.py)
+  extern __shared__ __attribute__((aligned(16))) unsigned char e2_smem[];
+  typedef bg_u32x4 ImgRow[22];
+  typedef uint2 ListRow[BG_BLOCK];
+  ImgRow* const s_img = (ImgRow*)e2_smem;                                          // [NE][22] record images
+  ListRow* const s_list = (ListRow*)(e2_smem + BG_E2_IMG_BYTES);                   // [BG_E2_OW][64] copy-out list of a wave: .x = record row, .y = env lane of the workgroup
+  bg_u32x4& s_zero = *(bg_u32x4*)(e2_smem + BG_E2_IMG_BYTES + BG_E2_LIST_BYTES);
+  JTables& jt = *(JTables*)(e2_smem + BG_E2_IMG_BYTES + BG_E2_LIST_BYTES + 16);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int env0 = blockIdx.x * NE, env = env0 + tid;
+  const size_t N = (size_t)d.N;
+  const bool live = env < d.N;
+  const uint32_t xcc = bg_xcc_id();
+  if (tid == 0) { atomicMax(&x.ctl->svc_stat[7], ~wall_clock64()); __hip_atomic_fetch_add((g_u32*)&x.ctl->owners_started, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  typedef __attribute__((address_space(3))) const char lds_cc;
+  // ---- prologue: images (the workgroup's envs are one contiguous run of pieces), chunks 3 / 4, mask
+  if (tid == 0) s_zero = bg_u32x4{0u, 0u, 0u, 0u};
+  {
+    const int n_live = d.N - env0 < NE ? d.N - env0 : NE;
+    const bg_u32x4* src = (const bg_u32x4*)x.img + (size_t)env0 * 24;
+    for (int q = tid; q < n_live * 24; q += NE) {
+      const int e = (q * 2731) >> 16, p = q - 24 * e;   // q / 24 (exact below 8 000)
+      if (p < 22) s_img[e][p] = src[q];
+    }
+  }
+  uint4 c3 = make_uint4(0, 0, 0, 0), c4 = c3;
+  uint64_t mask = 0;
+  if (live) {
+    c3 = d.hot[3 * N + env]; c4 = d.hot[4 * N + env]; mask = x.imask[env];
+    bg_st8a(&x.ans[env], 0ull); bg_st8a((char*)&x.ans[env] + 8, 0ull);   // (the same flavour of store as the answers: drained before the first request)
+  }
+  bg_tables_load(&jt, d.jtab);   // (ends with the workgroup's only barrier)
+  const uint32_t T = (uint32_t)a.T;
+  const uint32_t bmod3 = (uint32_t)(a.env_index0 % 3ull);
+  const uint64_t gi = a.env_index0 + (uint64_t)env;
+  const uint64_t seed_env = a.policy_seed + 0x9E3779B97F4A7C15ull * (gi + 1);
+  const int blind = a.policy == 2 ? 45 + (int)((bmod3 + (uint32_t)env % 3u) % 3u) : 45;
+  lds_u32* const img32 = (lds_u32*)&s_img[tid][0];
+  lds_u8* const img8 = (lds_u8*)&s_img[tid][0];
+  lds_cc* const imgb = (lds_cc*)&s_img[0][0];
+  const bool whole = a.obs.row_stride == 384u;
+  // per-lane constants of the whole-line copy-out (bg_engine.h, copier): eight records = three rounds of the wave
+  uint32_t rsel[3], cmul[3], cib[3], cgl[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const uint32_t pidx = (uint32_t)j * BG_BLOCK + (uint32_t)lane, rs = (pidx * 2731u) >> 16, c = pidx - 24u * rs;
+    rsel[j] = rs; cgl[j] = 16u * c;
+    cmul[j] = c < 22u ? 16u * 22u : 0u;
+    cib[j] = c < 22u ? 16u * c : (uint32_t)((lds_cc*)&s_zero - imgb);
+  }
+  uint32_t t = 0;
+  bool waiting = false, migrated = false;
+  uint64_t n_steps = 0, rbits = 0, ohash = 0;
+  unsigned long long last_progress = wall_clock64();
+  if (lane == 0) atomicMax(&x.ctl->svc_stat[2], ~last_progress);   // (development: stored complemented so that the zeroed word means 'never')
+  __builtin_amdgcn_s_setprio(1);
+  for (;;) {
+    if (__ballot(live && (t < T || waiting)) == 0ull) break;
+    if (!migrated && bg_xcc_id() != xcc) { migrated = true; if (lane == 0) atomicAdd(&x.ctl->x_migr[0], 1u); }
+    const size_t row = (size_t)env + (a.obs_stride_steps ? (size_t)t * N : 0);
+    // ---- 1. answers
+    bool got = false;
+    if (waiting) {
+      const uint4 v = bg_ld16a(&x.ans[env]);
+      got = v.x == t + 1u && v.z == t + 1u;
+      if (got) { mask = (uint64_t)v.y | ((uint64_t)v.w << 32); waiting = false; }
+    }
+    unsigned long long gm = __ballot(got);
+    if (gm) {
+      // the service wave left chunks 3 / 4 in HBM and the finished record in its row: the record comes back lane <-> piece
+      if (got) { c3 = bg_ld16a(&d.hot[3 * N + env]); c4 = bg_ld16a(&d.hot[4 * N + env]); }
+      const uint32_t rlo = (uint32_t)row, rhi = (uint32_t)(row >> 32);
+      while (gm) {
+        int jj[4]; const uint8_t* src[4]; uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          jj[u] = gm ? __ffsll((long long)gm) - 1 : -1;
+          if (gm) gm &= gm - 1;
+          const int j = jj[u] < 0 ? 0 : jj[u];
+          const size_t rj = (size_t)__builtin_amdgcn_readlane(rlo, j) | ((size_t)__builtin_amdgcn_readlane(rhi, j) << 32);
+          src[u] = a.obs.rows + rj * (size_t)a.obs.row_stride + 16u * (uint32_t)lane;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (jj[u] >= 0 && lane < 22) v[u] = bg_ld16a(src[u]);
+#pragma unroll
+        for (int u = 0; u < 4; u++) if (jj[u] >= 0 && lane < 22) s_img[wave * BG_BLOCK + jj[u]][lane] = bg_u32x4{v[u].x, v[u].y, v[u].z, v[u].w};
+      }
+      BG_WAVE_SYNC();
+    }
+    // ---- 2. the cheap step of every ready env (bg_engine.h: cheap_step)
+    bool fin = false, post = false;
+    int action = 0, cls = 0;
+    uint32_t pvalid = 0;
+    double reward = 0.0;
+    if (live && !waiting && !got && t < T) {
+      const uint32_t ante = bg_b(c3.x, 0), phase = bg_b(c3.x, 2), discards_left = bg_b(c3.y, 0), nsel0 = bg_b(c3.y, 3);
+      {
+        Env pe; pe.phase = (int)phase; // the policy only looks at the phase and the mask
+        PolicyLane pl; pl.seed_env = seed_env; pl.blind = blind;
+        action = bg_policy_action_fast(pe, mask, a.policy, pl, seed_env + BG_POLICY_PSI * (a.t0 + (uint64_t)t + 1), (lds_JTables*)&jt);
+      }
+      const int64_t chips_scored = (int64_t)(((uint64_t)img32[33] << 32) | img32[32]);
+      const bool valid = action >= 0 && action < 60 && ((mask >> (action & 63)) & 1ull);
+      const bool terminal = ante > 100u || chips_scored > 1000000000ll;   // :619-623, settled by a service wave (it resets the env)
+      if (!terminal && valid && phase == 0u && action >= 2 && action < 10) {
+        // :1052-1058 toggle position `pos` in state.selected_cards (bg_toggle_select on chunk 4)
+        const int pos = action - 2;
+        Env te; te.sel = ((uint64_t)c4.w << 32) | c4.z; te.nsel = (int)nsel0;
+        bg_toggle_select(te, pos);
+        c4.z = (uint32_t)te.sel; c4.w = (uint32_t)(te.sel >> 32);
+        c3.y = (c3.y & 0x00ffffffu) | ((uint32_t)te.nsel << 24);
+        *(lds_u64*)&img32[2 * pos] = te.nsel > (int)nsel0 ? 1ull : 0ull;  // selected_cards[pos] (int64)
+        if ((te.nsel > 0) != (nsel0 > 0u)) {                             // PLAY_HAND / DISCARD availability (:1436-1441)
+          const uint32_t play = te.nsel > 0 ? 1u : 0u, disc = (te.nsel > 0 && discards_left > 0u) ? 1u : 0u;
+          mask = (mask & ~3ull) | play | ((uint64_t)disc << 1);
+          *(__attribute__((address_space(3))) uint16_t*)&img8[BG_ROW_ACTION_MASK] = (uint16_t)(play | (disc << 8));
+        }
+        fin = true;
+      } else if (!terminal && valid && phase == 1u && action == 31 && (int)(int8_t)bg_b(c3.y, 1) <= (int)bg_b(c3.y, 2)) {
+        // :1247-1251 leave the shop; the hand is full, so all that changes is the phase, the mask and the shop rows (:1534-1539)
+        const uint32_t nhand = bg_b(c3.y, 2), ncons = bg_b(c3.z, 1);
+        c3.x &= 0xff00ffffu;                                              // phase = PLAY
+        uint64_t m = (((1ull << (nhand < 8u ? nhand : 8u)) - 1ull) << 2) | (((1ull << ncons) - 1ull) << 10);
+        if (nsel0 > 0u) m |= 1ull | (discards_left > 0u ? 2ull : 0ull);
+        mask = m;
+#pragma unroll
+        for (int wq = 0; wq < 15; wq++) img32[44 + wq] = __umul24((uint32_t)(mask >> (4 * wq)) & 0xfu, 0x204081u) & 0x01010101u; // action_mask i8[60]
+#pragma unroll
+        for (int wq = 64; wq < 74; wq++) img32[wq] = 0u;                  // shop_items, shop_costs
+        img8[BG_ROW_PHASE] = 0;
+        fin = true;
+      } else if (!terminal && !valid) { reward = -1.0; fin = true; }    // :626-627 'Invalid action': nothing changes
+      else { post = true; cls = (!terminal && phase == 0u && action == 0) ? 0 : 1; pvalid = valid ? 1u : 0u; }
+      if (fin) {
+        *(__attribute__((address_space(3))) double*)&img32[34] = reward;  // BG_ROW_REWARD
+        img32[43] = (uint32_t)action;                                      // BG_ROW_ACTION
+        img8[BG_ROW_TERMINATED] = 0;
+      }
+    }
+    // ---- 3. requests: chunks 3 / 4 to HBM, one returning atomic per class on this wave's queue, the entries behind a drain
+    const unsigned long long pm = __ballot(post);
+    if (pm) {
+      if (post) { d.hot[3 * N + env] = c3; d.hot[4 * N + env] = c4; }
+      const unsigned long long m0 = __ballot(post && cls == 0), m1 = __ballot(post && cls == 1);
+      const uint32_t qb = xcc * BG_E2_NQX + ((uint32_t)wave & (BG_E2_NSUB - 1u));
+      uint32_t base = 0;
+      if (m0 && lane == (int)(__ffsll((long long)m0) - 1)) base = __hip_atomic_fetch_add((g_u32*)&x.ctl->q[qb].tail, (uint32_t)__popcll(m0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (m1 && lane == (int)(__ffsll((long long)m1) - 1)) base = __hip_atomic_fetch_add((g_u32*)&x.ctl->q[qb + BG_E2_NSUB].tail, (uint32_t)__popcll(m1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunks 3 / 4 are in the L2 before any entry is
+      const uint32_t b0 = m0 ? __builtin_amdgcn_readlane(base, __ffsll((long long)m0) - 1) : 0u;
+      const uint32_t b1 = m1 ? __builtin_amdgcn_readlane(base, __ffsll((long long)m1) - 1) : 0u;
+      if (post) {
+        const unsigned long long mm = cls ? m1 : m0;
+        const uint32_t pos = (cls ? b1 : b0) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+        const uint32_t q = qb + (cls ? BG_E2_NSUB : 0u);
+        const uint32_t hi = ((uint32_t)action & 0xffu) | (pvalid << 8) | ((t & 0xffffu) << 9) | (((pos >> x.ring_log) & 0x3fu) << 25) | 0x80000000u;
+        bg_st8a(&x.ring[((size_t)q << x.ring_log) + (pos & ((1u << x.ring_log) - 1u))], (unsigned long long)(uint32_t)env | ((unsigned long long)hi << 32));
+        waiting = true;
+      }
+    }
+    // ---- 4. accounting of the steps completed in this iteration (cheap: the image is patched; answered: the image is the service wave's)
+    if (fin || got) {
+      const uint64_t rb = ((uint64_t)img32[35] << 32) | img32[34];
+      if (HASH) ohash ^= bg_hash_image((const lds_u4*)&s_img[tid][0]) * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(a.t0 + t)) + gi;
+      n_steps++;
+      rbits ^= rb * (2 * (uint64_t)(a.t0 + t) + 1);
+      t++;
+    }
+    // ---- 5. copy-out of the cheap steps' records: lane <-> 16-byte piece, non-temporal (an answered step's record is in its row already)
+    const unsigned long long fm = __ballot(fin);
+    if (fm) {
+      const uint32_t nb = (uint32_t)__popcll(fm);
+      if (fin) s_list[wave][__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = make_uint2((uint32_t)row, (uint32_t)tid);
+      BG_WAVE_SYNC();
+      typedef uint32_t bg_u32x2 __attribute__((ext_vector_type(2)));
+      lds_cc* const lsb = (lds_cc*)&s_list[wave][0];
+      if (whole) {
+        for (uint32_t g0 = 0; g0 < nb; g0 += 16u) {
+          bg_u32x2 ce[2][3];
+          bg_u32x4 v[2][3];
+#pragma unroll
+          for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+              ce[u][j] = *(__attribute__((address_space(3))) const bg_u32x2*)(lsb + (((g0 + 8u * (uint32_t)u + rsel[j]) & 63u) << 3));
+#pragma unroll
+          for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+              v[u][j] = *(__attribute__((address_space(3))) const bg_u32x4*)(imgb + __umul24(ce[u][j].y & 0xffu, cmul[j]) + cib[j]);
+#pragma unroll
+          for (int u = 0; u < 2; u++)
+#pragma unroll
+            for (int j = 0; j < 3; j++)
+              if (g0 + 8u * (uint32_t)u + rsel[j] < nb)
+                __builtin_nontemporal_store(v[u][j], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)ce[u][j].x * 384u + cgl[j])));
+        }
+      } else {
+        const uint32_t total = 22u * nb;
+        for (uint32_t q0 = (uint32_t)lane; q0 < total; q0 += 4u * BG_BLOCK) {
+          bg_u32x2 ce[4]; uint32_t cpc[4]; bg_u32x4 v[4];
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const uint32_t q = q0 + (uint32_t)k * BG_BLOCK, r = (q * 2979u) >> 16;   // q / 22 (exact below 8 000)
+            cpc[k] = q - 22u * r;
+            ce[k] = *(__attribute__((address_space(3))) const bg_u32x2*)(lsb + ((r < nb ? r : 0u) << 3));
+          }
+#pragma unroll
+          for (int k = 0; k < 4; k++) v[k] = s_img[ce[k].y & 0xffu][cpc[k]];
+#pragma unroll
+          for (int k = 0; k < 4; k++)
+            if (q0 + (uint32_t)k * BG_BLOCK < total)
+              __builtin_nontemporal_store(v[k], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + (size_t)ce[k].x * (size_t)a.obs.row_stride + 16u * cpc[k]));
+        }
+      }
+      BG_WAVE_SYNC();   // the images have been read (a wave's LDS operations complete in order): the next iteration may patch them
+    }
+    // ---- 6. nothing moved: every env of the wave is with a service wave
+    if ((fm | pm | __ballot(got)) == 0ull) {
+      __builtin_amdgcn_s_sleep(16);
+      if (wall_clock64() - last_progress > BG_E2_TIMEOUT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN | 0x100u); break; }
+    } else last_progress = wall_clock64();
+  }
+  // ---- epilogue: chunks 3 / 4, images and masks back to HBM; statistics; this wave is done
+  if (live) { d.hot[3 * N + env] = c3; d.hot[4 * N + env] = c4; x.imask[env] = mask; }
+  {
+    // (each wave stores the images of its own 64 envs: no barrier needed)
+    const int w0 = wave * BG_BLOCK, n_w = d.N - (env0 + w0) < BG_BLOCK ? d.N - (env0 + w0) : BG_BLOCK;
+    bg_u32x4* dst = (bg_u32x4*)x.img + (size_t)(env0 + w0) * 24;
+    for (int q = lane; q < n_w * 24; q += BG_BLOCK) {
+      const int e = (q * 2731) >> 16, p = q - 24 * e;
+      if (p < 22) dst[q] = s_img[w0 + e][p];
+    }
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { n_steps += __shfl_down(n_steps, off); rbits ^= __shfl_down(rbits, off); ohash ^= __shfl_down(ohash, off); }
+    if (lane == 0) {
+      atomicAdd((unsigned long long*)&a.stats->steps, (unsigned long long)n_steps);
+      atomicXor((unsigned long long*)&a.stats->reward_bits, (unsigned long long)rbits);
+      atomicXor((unsigned long long*)&a.stats->obs_hash, (unsigned long long)ohash);
+    }
+  }
+  if (lane == 0) { atomicMax(&x.ctl->svc_stat[3], wall_clock64()); __hip_atomic_fetch_add((g_u32*)&x.ctl->owners_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+}
+
+// The GATE: one wave in front of the service kernel on its stream.  It ends when every owner workgroup that can be resident has started (or
+// after 0.5 ms: a timeout costs time, never correctness), so the service waves are always placed AFTER the owner workgroups.  Why: an owner
+// workgroup needs ONE CONTIGUOUS 97 KB of a CU's 160 KB of LDS; four service workgroups (13 KB each) that arrive first -- beside transient refill
+// workgroups -- are put wherever the allocator likes, and the 106 KB that remain may not contain 97 KB in one piece for as long as those
+// service waves live, which is until the owner they lock out has finished: found as launches that took the 2 s of a bounded wait.
+__global__ __launch_bounds__(BG_BLOCK) void bg_e2_gate_kernel(E2Args x) {
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    const uint32_t v = __builtin_amdgcn_readfirstlane(__hip_atomic_fetch_add((g_u32*)&x.ctl->owners_started, x.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    if ((int32_t)(v - x.start_target) >= 0 || wall_clock64() - t0 > 50000ull) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+}
+// development probe: a trivial one-wave kernel of the service kernel's register / LDS shape, launched in its place (BG_E2_PROBE)
+template <int VG, int LDSW>
+__global__ __launch_bounds__(BG_BLOCK) void bg_e2_probe_kernel(E2Args x) {
+  __shared__ uint32_t s[LDSW > 0 ? LDSW : 1];
+  if (LDSW > 0) s[threadIdx.x] = threadIdx.x;
+  if (VG == 256) asm volatile("v_mov_b32 v255, 0" ::: "v255");
+  if (threadIdx.x == 0) atomicMax(&x.ctl->svc_stat[6], ~wall_clock64());
+  if (LDSW > 0 && s[1] == 999u) x.ctl->svc_stat[0] = 1;
+}
+// ------------------------------------------------------------------------------------------------------------------------------
+// service kernel: one wave per workgroup, lane = request of the batch
+// ------------------------------------------------------------------------------------------------------------------------------
+// REGISTER ALLOCATION IS PART OF THE PROTOCOL.  The two kernels must be resident together whichever of them the dispatcher places first.  A
+// service wave allocates 256 VGPRs + 8 AGPRs = 264 of a SIMD's 512 registers, so a SIMD holds ONE service wave (never two) and always has 248
+// registers left for an owner wave (<= 136): at most four service waves per CU, exactly four when all 4 x 256 are resident, and an owner workgroup
+// (one wave per SIMD, 97 KB of the CU's 160 KB of LDS beside 4 x 13 KB) fits on every CU in either order.  With 256 registers per service wave the
+// dispatcher packed two per SIMD when the service kernel won the race: eight per CU on half the CUs, no owner workgroup could be placed there, and
+// the owners that did run waited for service waves of their own XCD that had no owner to serve -- found as "whole XCDs unserved from the start of a
+// launch" in one launch out of three (tools/e2_diag.py).
+template <bool CARDS>
+__global__ __launch_bounds__(BG_BLOCK) __attribute__((amdgpu_num_vgpr(256))) void bg_service_kernel(BgDev d, EngineArgs a, E2Args x) {
+  asm volatile("v_accvgpr_write_b32 a7, 0" ::: "a7");   // eight accumulation registers that nothing uses (see above)
+  __shared__ __attribute__((aligned(16))) uint32_t s_win[32][BG_BLOCK];   // the wave's RNG window (24 words per lane); at the end of a batch: record staging (64 x 8 pieces)
+  __shared__ unsigned long long s_addr[BG_BLOCK];
+  __shared__ JTables jt;
+  using DeckT = typename std::conditional<CARDS, Deck0C, Deck0>::type;
+  __builtin_amdgcn_s_setprio(3);
+  if (threadIdx.x == 0) atomicMax(&x.ctl->svc_stat[6], ~wall_clock64());   // (development: the first instruction of the first service wave)
+  bg_tables_load(&jt, d.jtab);
+  const int lane = threadIdx.x;
+  const size_t N = (size_t)d.N;
+  const uint32_t xcc = bg_xcc_id();
+  const uint32_t rmask = (1u << x.ring_log) - 1u;
+  if (lane == 0) __hip_atomic_fetch_add((g_u32*)&x.ctl->svc_seen[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  uint64_t n_eps = 0, n_plays = 0;
+  int64_t ssum = 0;
+  unsigned long long idle_since = wall_clock64(), first_seen = 0;
+  if (lane == 0) atomicMax(&x.ctl->svc_stat[4], ~idle_since);
+  unsigned long long q_batches = 0, q_reqs = 0;
+  uint32_t x_why = 0, x_dn = 0;
+  bool migrated = false;
+  bool seen = false;
+  const uint32_t maxb = x.max_batch < 1u ? 1u : (x.max_batch > BG_BLOCK ? BG_BLOCK : x.max_batch);
+  for (;;) {
+    // ---- the four queues of this XCD: heads (even lanes) and tails (odd lanes) with one load instruction
+    // (read with RETURNING ATOMICS, not loads: tails and heads only ever change through atomics, and an agent-scope load can be served a copy of the
+    //  line that the atomics never refreshed -- seen as every service wave of an XCD reading tail == head for two seconds while 2 700 requests waited)
+    uint32_t w = 0;
+    if (lane < 2 * BG_E2_NQX) { E2Queue* q = &x.ctl->q[xcc * BG_E2_NQX + ((uint32_t)lane >> 1)]; w = __hip_atomic_fetch_add((g_u32*)((lane & 1) ? &q->tail : &q->head), x.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    if (lane == 2 * BG_E2_NQX) w = __hip_atomic_fetch_add((g_u32*)&x.ctl->owners_done, x.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t done = __builtin_amdgcn_readlane(w, 2 * BG_E2_NQX);
+    uint32_t hq[BG_E2_NQX], nq[BG_E2_NQX], any = 0;
+#pragma unroll
+    for (int j = 0; j < BG_E2_NQX; j++) {
+      hq[j] = __builtin_amdgcn_readlane(w, 2 * j);
+      const uint32_t k = __builtin_amdgcn_readlane(w, 2 * j + 1) - hq[j];   // (a head newer than its tail reads as a huge number: nothing)
+      nq[j] = k <= rmask + 1u ? k : 0u;
+      any |= nq[j];
+    }
+    if (!migrated && bg_xcc_id() != xcc) { migrated = true; if (lane == 0) atomicAdd(&x.ctl->x_migr[1], 1u); }
+    if (!any) {
+      if ((int32_t)(__builtin_amdgcn_readfirstlane(done) - x.done_target) >= 0) { x_why = 1; x_dn = __builtin_amdgcn_readfirstlane(done); break; }   // every owner wave of this launch is through
+      seen = false;
+      __builtin_amdgcn_s_sleep(64);   // ~1.7 us between polls of an idle wave: 9 atomics per poll, a word takes ~90 per us
+      if (wall_clock64() - idle_since > BG_E2_TIMEOUT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN | 0x200u); x_why = 2; break; }
+      continue;
+    }
+    // plays first (the longest chains), the fuller sub-queue of a class first; a batch that is not full waits fill_wait ticks for more
+    int pick = -1;
+    {
+      const int s0 = (int)(blockIdx.x & (BG_E2_NSUB - 1));   // this wave's preferred sub-queue: the waves of an XCD do not all go for the same head
+      uint32_t best = 0;
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int k = 0; k < BG_E2_NSUB; k++) {
+          const int j = c * BG_E2_NSUB + ((s0 + k) & (BG_E2_NSUB - 1));
+          if (pick < 0 && nq[j] >= maxb) pick = j;
+        }
+      }
+      if (pick < 0) {
+        const unsigned long long now = wall_clock64();
+        if (!seen) { seen = true; first_seen = now; }
+        if (now - first_seen >= (unsigned long long)x.fill_wait) {
+#pragma unroll
+          for (int k = 0; k < BG_E2_NQX; k++) { const int j = (k & ~(BG_E2_NSUB - 1)) | ((s0 + k) & (BG_E2_NSUB - 1)); if (nq[j] > best) { best = nq[j]; pick = j; } }
+        }
+      }
+    }
+    if (pick < 0) { __builtin_amdgcn_s_sleep(4); continue; }
+    uint32_t head = 0, navail = 0;
+#pragma unroll
+    for (int j = 0; j < BG_E2_NQX; j++) if (j == pick) { head = hq[j]; navail = nq[j]; }
+    const uint32_t nb = navail > maxb ? maxb : navail;
+    const uint32_t qi = xcc * BG_E2_NQX + (uint32_t)pick;
+    {
+      uint32_t ok = 0;
+      if (lane == 0) { uint32_t exp = head; ok = __hip_atomic_compare_exchange_strong((g_u32*)&x.ctl->q[qi].head, &exp, head + nb, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u; }
+      if (__builtin_amdgcn_readfirstlane(ok) == 0u) continue;
+    }
+    seen = false;
+    // ---- the entries (a producer bumps the tail first and writes its entry behind a drain: poll until the generation matches)
+    bool active = false;
+    int env = 0, action = 0;
+    uint32_t t = 0, pvalid = 0;
+    if ((uint32_t)lane < nb) {
+      const uint32_t pos = head + (uint32_t)lane, want = 0x80000000u | (((pos >> x.ring_log) & 0x3fu) << 25);
+      const unsigned long long* ep = &x.ring[((size_t)qi << x.ring_log) + (pos & rmask)];
+      unsigned long long ent = bg_ld8a(ep);
+      const unsigned long long w0 = wall_clock64();
+      while (((uint32_t)(ent >> 32) & 0xfe000000u) != want) {
+        __builtin_amdgcn_s_sleep(2);
+        if (wall_clock64() - w0 > BG_E2_TIMEOUT) break;
+        ent = bg_ld8a(ep);
+      }
+      if (((uint32_t)(ent >> 32) & 0xfe000000u) != want) atomicOr(d.err, BG_DEVERR_SPIN | 0x400u);
+      else { active = true; env = (int)(uint32_t)ent; const uint32_t hi = (uint32_t)(ent >> 32); action = (int)(hi & 0xffu); pvalid = (hi >> 8) & 1u; t = (hi >> 9) & 0xffffu; }
+    }
+    if (active) {
+      BG_PROBE_BEGIN();
+      const size_t row = (size_t)env + (a.obs_stride_steps ? (size_t)t * N : 0);
+      uint4 c[BG_NHOT];
+#pragma unroll
+      for (int k = 0; k < BG_NHOT; k++) c[k] = bg_ld16a(&d.hot[(size_t)k * N + env]);
+      DeckT dk;
+      { const uint4 dc = bg_ld16a(&d.deck[env]); dk.lo = ((uint64_t)dc.y << 32) | dc.x; dk.hi = ((uint64_t)dc.w << 32) | dc.z; }
+      Env e;
+      bg_unpack(c, e);
+      bg_derive_ready(e, d.prod_view ? d.prod_view[env] : 0u);
+      ShopRegs sr; sr.valid = false;
+      RngWin w;
+      bg_win_init(w, &s_win[0][lane], &jt);
+      StepOut o;
+      bg_step_init(o);
+      o.bd_dst = nullptr;
+      // the owner has checked the action against the env's mask (pvalid); the terminal guards come first, as in the reference (:619-627)
+      if (bg_step_guards(e, pvalid ? ~0ull : 0ull, action, o)) bg_env_dispatch(d, env, e, w, sr, dk, action, o);
+      if (e.max_ante > 0 && e.ante > e.max_ante) { o.terminated = true; o.flags |= 256; }
+      if (o.terminated) n_eps++;
+      if (o.terminated && a.autoreset) bg_env_reset(d, env, e, dk);
+      const uint64_t mask = bg_action_mask(d, env, e, sr);
+      if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
+      bg_pack(e, c);
+#pragma unroll
+      for (int k = 0; k < BG_NHOT; k++) d.hot[(size_t)k * N + env] = c[k];
+      // the record, straight to its row: three slices of 8 / 7 / 7 pieces staged through LDS (lane <-> piece: runs of whole records)
+      ObsPtrs op = a.obs;
+      bg_write_obs_impl<false, 2>(d, env, row, e, dk, op, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u}, RowStage{(lds_u4*)&s_win[0][0], (lds_u64*)&s_addr[0]});
+      if (a.obs.row_stride == 384u) { // the two padding pieces of a whole-line record are zeros (bg_engine.h, copier)
+        __attribute__((address_space(1))) bg_u32x4* pad = (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + row * 384u + 352u);
+        pad[0] = bg_u32x4{0u, 0u, 0u, 0u}; pad[1] = bg_u32x4{0u, 0u, 0u, 0u};
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // state and record are in this XCD's L2 before the answer is
+      const unsigned long long seq = (unsigned long long)(t + 1u);
+      bg_st8a(&x.ans[env], seq | ((unsigned long long)(uint32_t)mask << 32));
+      bg_st8a((char*)&x.ans[env] + 8, seq | ((unsigned long long)(uint32_t)(mask >> 32) << 32));
+    }
+    idle_since = wall_clock64();
+    q_batches++; q_reqs += nb;
+  }
+  if (lane == 0) {
+    const unsigned long long now = wall_clock64();
+    atomicMax(&x.ctl->svc_stat[5], now); atomicAdd(&x.ctl->svc_stat[0], q_batches); atomicAdd(&x.ctl->svc_stat[1], q_reqs);
+    atomicAdd(&x.ctl->x_exits[xcc], 1u); atomicOr(&x.ctl->x_reason[xcc], x_why); atomicMax(&x.ctl->x_done[xcc], x_dn); atomicMax(&x.ctl->x_target[xcc], ~x.done_target);
+    atomicMax(&x.ctl->x_t0[xcc], ~now); atomicMax(&x.ctl->x_t1[xcc], now); atomicAdd(&x.ctl->x_batches[xcc], q_batches);
+  }
+  if (a.stats) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { n_eps += __shfl_down(n_eps, off); n_plays += __shfl_down(n_plays, off); ssum += __shfl_down(ssum, off); }
+    if (lane == 0 && (n_eps | n_plays)) {
+      atomicAdd((unsigned long long*)&a.stats->episodes, (unsigned long long)n_eps);
+      atomicAdd((unsigned long long*)&a.stats->plays, (unsigned long long)n_plays);
+      atomicAdd((unsigned long long*)&a.stats->score_sum, (unsigned long long)ssum);
+    }
+  }
+}

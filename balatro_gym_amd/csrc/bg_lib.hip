@@ -51,6 +51,7 @@ __device__ __forceinline__ void bg_emit_info(size_t row, const StepOut& o, uint8
 }
 
 #include "bg_engine.h" // the step engine: one kernel behind bg_step / bg_step_many / bg_rollout / bg_rollout_rows
+#include "bg_engine2.h" // the same engine as two cooperating kernels (owner waves + a chip-wide pool of service waves): packed-record rollouts
 
 template <bool CARDS>
 __global__ __launch_bounds__(BG_BLOCK) void bg_reset_kernel(BgDev d, const uint8_t* __restrict__ mask_in, ObsPtrs obs) {
@@ -680,6 +681,14 @@ struct bg_handle {
   // tunables read ONCE per handle in bg_create (environment variables)
   int refill_blocks, refill_blocks_shop, dev_skip_refill, refill_order;
   uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_smask; int eng_waves, eng_copiers; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
+  // the two-kernel engine (bg_engine2.h): queues / answers / images, the service kernel's stream, the pair of events that tie a launch's two kernels together
+  int engine;            // BG_ENGINE: 2 = owner + service kernels for packed-record rollouts (default), 1 = the one-kernel engine everywhere
+  E2Args e2;
+  bool e2_img_valid;     // the images in e2.img describe the state: false after anything but a two-kernel launch has touched it
+  hipStream_t svc;
+  hipEvent_t ev_e2a, ev_e2b;
+  int e2_svc_waves;      // service waves per launch (BG_E2_SVC; default 4 per CU)
+  long e2_launches;
 };
 
 static std::string g_create_err;
@@ -747,6 +756,15 @@ static double bg_ev_sum(bg_handle* h, std::vector<hipEvent_t>& v) {
 
 extern "C" {
 
+// development hook: the two-kernel engine's control block (queue tails / heads, arrival counters, wall-clock stamps) as 32-bit words
+int bg_debug_e2(bg_handle* h, unsigned int* out, int nwords) {
+  if (!h || !out || !h->e2.ctl) return BG_E_ARG;
+  BG_GUARD(h);
+  (void)hipDeviceSynchronize();
+  const size_t n = (size_t)nwords * 4 < sizeof(E2Ctl) ? (size_t)nwords * 4 : sizeof(E2Ctl);
+  BG_HIP(hipMemcpy(out, h->e2.ctl, n, hipMemcpyDeviceToHost));
+  return (int)(n / 4);
+}
 // development hook: copy (and clear) the 16 phase counters written by -DBG_TIMING builds
 int bg_debug_counters(bg_handle* h, unsigned long long* out16) {
   if (!h || !out16) return BG_E_ARG;
@@ -832,6 +850,11 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
     h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0); h->eng_copiers = geti("BG_ENG_COPIERS", 2); if (h->eng_copiers < 1 || h->eng_copiers > 3) h->eng_copiers = 2;
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
+    h->engine = geti("BG_ENGINE", 2); if (h->engine != 1) h->engine = 2;
+    memset(&h->e2, 0, sizeof(h->e2));
+    h->e2.fill_wait = (uint32_t)geti("BG_E2_FILL_WAIT", 100); h->e2.max_batch = (uint32_t)geti("BG_E2_MAX_BATCH", 64);
+    h->e2_svc_waves = geti("BG_E2_SVC", 0);
+    h->e2_img_valid = false; h->svc = nullptr; h->ev_e2a = h->ev_e2b = nullptr; h->e2_launches = 0;
   }
   h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->view_min = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
   h->ev_refill[0] = h->ev_refill[1] = nullptr; h->ev_rollout = nullptr;
@@ -906,6 +929,18 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
   if (e == hipSuccess) e = bg_alloc(h, &d.err, 4);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_seeds, N);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_mask, N);
+  if (e == hipSuccess && h->engine == 2) { // the two-kernel engine: request rings (one slot per env and queue: an env has at most one request in flight), answers, images
+    uint32_t lg = 6; while ((1ull << lg) < N) lg++;
+    h->e2.ring_log = lg;
+    e = bg_alloc(h, &h->e2.ctl, 1);
+    if (e == hipSuccess) e = bg_alloc(h, &h->e2.ring, (size_t)BG_E2_NQ << lg);
+    if (e == hipSuccess) e = bg_alloc(h, &h->e2.ans, N);
+    if (e == hipSuccess) e = bg_alloc(h, &h->e2.img, 24 * N);
+    if (e == hipSuccess) e = bg_alloc(h, &h->e2.imask, N);
+    if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->svc, hipStreamNonBlocking, prio_greatest);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_e2a, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_e2b, hipEventDisableTiming);
+  }
   if (e != hipSuccess) {
     g_create_err = std::string("bg_create: ") + hipGetErrorString(e);
     bg_destroy(h);
@@ -939,6 +974,10 @@ int bg_destroy(bg_handle* h) {
   if (h->ev_gblk) (void)hipEventDestroy(h->ev_gblk);
   for (int i = 0; i < 2; i++) if (h->ev_refill[i]) (void)hipEventDestroy(h->ev_refill[i]);
   if (h->ev_rollout) (void)hipEventDestroy(h->ev_rollout);
+  if (h->svc) (void)hipStreamDestroy(h->svc);
+  if (h->ev_e2a) (void)hipEventDestroy(h->ev_e2a);
+  if (h->ev_e2b) (void)hipEventDestroy(h->ev_e2b);
+  hipFree(h->e2.ctl); hipFree(h->e2.ring); hipFree(h->e2.ans); hipFree(h->e2.img); hipFree(h->e2.imask);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto* v : {&h->ev_rollout_t, &h->ev_refill_t, &h->ev_step_t}) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
   hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
@@ -1065,6 +1104,7 @@ int bg_check(bg_handle* h, void* stream) {
 }
 
 int bg_seed(bg_handle* h, const int64_t* seeds_host, const uint8_t* mask_host, int reseed_global, void* stream) {
+  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   if (!h || !seeds_host) return BG_E_ARG;
   BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;
@@ -1126,6 +1166,7 @@ static void bg_info_advance(InfoPtrs& p, size_t off) {
 }
 
 int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void* stream) {
+  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   int rc = bg_require_seeded(h);
   if (rc) return rc;
   BG_GUARD(h);
@@ -1147,9 +1188,62 @@ static int bg_engine_waves(const bg_handle* h, int T) {
   if (T <= 192) return BG_ENG_NW - 1;
   return BG_ENG_NW;
 }
+// Two kernels for one launch (bg_engine2.h): the owner kernel on the caller's stream, the service kernel on the handle's service stream,
+// both released by the same point of the caller's stream (so the service waves never spin while earlier work of the caller is still
+// running) and joined again behind the owner kernel.  Neither kernel waits for a workgroup that has not started, and every wait inside
+// them is bounded, so an unlucky placement costs time, never a hang.
+static bool bg_engine2_ok(const bg_handle* h, const EngineArgs& a, bool info) {
+  return h->engine == 2 && h->e2.ctl && a.obs.rows && !info && !h->dev.cstate && !a.actions_in && !a.reward && !a.term && !a.actions_out;
+}
+static int bg_engine2_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a, bool hash, hipStream_t st) {
+  const int n_wg = (h->dev.N + BG_E2_OW * BG_BLOCK - 1) / (BG_E2_OW * BG_BLOCK);
+  E2Args x = h->e2;
+  if (!h->e2_img_valid) { // something else has stepped / reset / injected since the last two-kernel launch: rebuild every image from the state
+    hipLaunchKernelGGL(bg_e2_image_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, x);
+    h->e2_img_valid = true;
+  }
+  // owner waves that will report: every wave of every workgroup (waves without a live env leave at once)
+  h->e2.done_target += (uint32_t)(n_wg * BG_E2_OW);
+  x.done_target = h->e2.done_target;
+  h->e2.start_target += (uint32_t)(n_wg < 256 ? n_wg : 256);   // (every workgroup starts eventually; the gate only waits for as many as can be resident)
+  x.start_target = h->e2.start_target;
+  if (n_wg > 256) h->e2.start_target += (uint32_t)(n_wg - 256);
+  // service waves: four per CU (one per SIMD beside an owner wave); small jobs get fewer (a wave per four envs, a multiple of the eight XCDs)
+  int nsvc = h->e2_svc_waves > 0 ? h->e2_svc_waves : 4 * 256;
+  if (h->e2_svc_waves <= 0 && h->dev.N < 4096) { nsvc = ((h->dev.N / 4 + 7) / 8) * 8; if (nsvc < 64) nsvc = 64; }
+  static const int nowait = getenv("BG_E2_NOWAIT") ? atoi(getenv("BG_E2_NOWAIT")) : 0;   // development
+  if (!nowait) {
+  BG_HIP(hipEventRecord(h->ev_e2a, st));
+  BG_HIP(hipStreamWaitEvent(h->svc, h->ev_e2a, 0));
+  }
+  static const int order = getenv("BG_E2_ORDER") ? atoi(getenv("BG_E2_ORDER")) : 0;   // development: 1 = the service kernel is launched first
+  if (order == 1) hipLaunchKernelGGL(bg_service_kernel<false>, dim3(nsvc), dim3(BG_BLOCK), 0, h->svc, dv, a, x);
+  static bool lds_attr = false;
+  if (!lds_attr) { // more than 64 KB of dynamic LDS needs the attribute (once per process and kernel)
+    BG_HIP(hipFuncSetAttribute((const void*)bg_owner_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BG_E2_OWNER_LDS));
+    BG_HIP(hipFuncSetAttribute((const void*)bg_owner_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BG_E2_OWNER_LDS));
+    lds_attr = true;
+  }
+  if (hash) hipLaunchKernelGGL(bg_owner_kernel<true>, dim3(n_wg), dim3(BG_E2_OW * BG_BLOCK), BG_E2_OWNER_LDS, st, dv, a, x);
+  else hipLaunchKernelGGL(bg_owner_kernel<false>, dim3(n_wg), dim3(BG_E2_OW * BG_BLOCK), BG_E2_OWNER_LDS, st, dv, a, x);
+  static const int probe = getenv("BG_E2_PROBE") ? atoi(getenv("BG_E2_PROBE")) : 0;   // development
+  if (probe == 1) hipLaunchKernelGGL((bg_e2_probe_kernel<0, 0>), dim3(nsvc), dim3(BG_BLOCK), 0, h->svc, x);
+  if (probe == 2) hipLaunchKernelGGL((bg_e2_probe_kernel<256, 0>), dim3(nsvc), dim3(BG_BLOCK), 0, h->svc, x);
+  if (probe == 3) hipLaunchKernelGGL((bg_e2_probe_kernel<256, 3344>), dim3(nsvc), dim3(BG_BLOCK), 0, h->svc, x);
+  if (probe == 4) hipLaunchKernelGGL((bg_e2_probe_kernel<0, 3344>), dim3(nsvc), dim3(BG_BLOCK), 0, h->svc, x);
+  static const int gate = getenv("BG_E2_GATE") ? atoi(getenv("BG_E2_GATE")) : 1;   // development: 0 = no gate in front of the service kernel
+  if (gate) hipLaunchKernelGGL(bg_e2_gate_kernel, dim3(1), dim3(BG_BLOCK), 0, h->svc, x);
+  if (order != 1) hipLaunchKernelGGL(bg_service_kernel<false>, dim3(nsvc), dim3(BG_BLOCK), 0, h->svc, dv, a, x);
+  BG_HIP(hipEventRecord(h->ev_e2b, h->svc));
+  BG_HIP(hipStreamWaitEvent(st, h->ev_e2b, 0));
+  h->e2_launches++;
+  return 0;
+}
 static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0, bool hash, bool info, hipStream_t st) {
   const bool cards = h->dev.cstate != nullptr;
   EngineArgs a = a0;
+  if (bg_engine2_ok(h, a, info)) { if (bg_engine2_launch(h, dv, a, hash, st) != 0) h->err = "two-kernel engine: " + h->err; return; }
+  h->e2_img_valid = false;
   a.n_waves = (uint32_t)bg_engine_waves(h, (int)a.T);
   // packed records: one more wave, the COPIER (bg_engine.h), takes the record copy-out off the workers; with the seven-wave shape that
   // leaves room for the refill beside the launch it is one of the seven
@@ -1375,6 +1469,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_inject_cards_kernel(BgDev d, cons
 
 int bg_inject_cards(bg_handle* h, const uint8_t* enh_host, const uint8_t* edition_host, const uint8_t* seal_host,
                     const uint8_t* mask_host, int apply_now, void* stream) {
+  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   if (!h) return BG_E_ARG;
   if (!h->dev.cstate) { h->err = "bg_inject_cards: the handle was created without BG_FLAG_CARD_STATES"; return BG_E_ARG; }
   BG_GUARD(h);
@@ -1401,6 +1496,7 @@ int bg_inject_cards(bg_handle* h, const uint8_t* enh_host, const uint8_t* editio
 
 int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_host, const int64_t* money_host,
               const int32_t* ante_host, const uint8_t* levels_host, const uint8_t* mask_host, int apply_now, void* stream) {
+  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   if (!h) return BG_E_ARG;
   BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;
@@ -1449,6 +1545,7 @@ int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_h
 
 int bg_inject_consumables(bg_handle* h, const int32_t* ids_host, const int32_t* n_host, const uint8_t* mask_host, int apply_now,
                           void* stream) {
+  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   if (!h || !ids_host || !n_host) return BG_E_ARG;
   BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;
@@ -1534,6 +1631,7 @@ int bg_get_state(bg_handle* h, int env_index, void* blob_host, uint64_t blob_byt
   return 0;
 }
 int bg_set_state(bg_handle* h, int env_index, const void* blob_host, uint64_t blob_bytes) {
+  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   int rc = bg_blob_args(h, "bg_set_state", env_index, blob_host, blob_bytes);
   if (rc) return rc;
   BG_GUARD(h);
@@ -1572,6 +1670,7 @@ int bg_set_state(bg_handle* h, int env_index, const void* blob_host, uint64_t bl
 
 // ---- harness injection of the LIVE deck order and of the curriculum cap ----
 int bg_inject_deck(bg_handle* h, const uint8_t* decks_host, const uint8_t* mask_host, void* stream) {
+  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   if (!h || !decks_host) return BG_E_ARG;
   BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;
@@ -1601,6 +1700,7 @@ int bg_inject_deck(bg_handle* h, const uint8_t* decks_host, const uint8_t* mask_
 }
 
 int bg_set_max_ante(bg_handle* h, int max_ante, const int32_t* per_env_host, const uint8_t* mask_host, void* stream) {
+  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   if (!h) return BG_E_ARG;
   BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;

@@ -28,7 +28,7 @@ struct ShopRegs { uint4 c3, c4, c5, c6; bool valid; };
 __device__ __forceinline__ void bg_shop_load(const BgDev& d, int env, ShopRegs& sr) {
   if (sr.valid) return;
   size_t N = d.N;
-  sr.c3 = d.cold[3 * N + env]; sr.c4 = d.cold[4 * N + env]; sr.c5 = d.cold[5 * N + env]; sr.c6 = d.cold[6 * N + env];
+  sr.c3 = bg_ld16a(&d.cold[3 * N + env]); sr.c4 = bg_ld16a(&d.cold[4 * N + env]); sr.c5 = bg_ld16a(&d.cold[5 * N + env]); sr.c6 = bg_ld16a(&d.cold[6 * N + env]); // (past the L1: bg_ld16a)
   sr.valid = true;
 }
 __device__ __forceinline__ void bg_shop_store(const BgDev& d, int env, const ShopRegs& sr) {
