@@ -32,7 +32,8 @@
 #define BG_E2_TIMEOUT 200000000ull         // 2 s of the 100 MHz wall clock: a wait that long is a bug (or a missing partner kernel)
 struct E2Queue { uint32_t tail; uint32_t pad0[31]; uint32_t head; uint32_t pad1[31]; }; // each word on its own 128-byte line
 struct E2Ctl {
-  uint32_t owners_done; uint32_t pad0[31];  // owner waves that have finished, ever (monotonic; a launch ends at E2Args.done_target)
+  uint32_t owners_done; uint32_t pad0[31];  // owner waves that have finished, ever (monotonic; only ever touched by atomics)
+  uint32_t done_flag; uint32_t padf[31];    // = E2Args.done_target once the last owner wave of a launch has finished: a STORE, which the service waves' loads see
   uint32_t svc_seen[8]; uint32_t pad1[24];  // service waves started per XCD, ever (diagnostic)
   unsigned long long svc_stat[8]; uint32_t pad2[16]; // [0] batches [1] requests [2] first owner wave started [3] last owner wave ended [4] first service wave started [5] last service wave ended (wall clock; development)
   E2Queue q[BG_E2_NQ];
@@ -40,13 +41,14 @@ struct E2Ctl {
   // wave saw, wall clock of the first / last leave, batches served
   uint32_t x_exits[8], x_reason[8], x_done[8], x_target[8]; unsigned long long x_t0[8], x_t1[8], x_batches[8];
   uint32_t x_migr[8];   // [0] owner waves / [1] service waves whose XCC id changed while they ran
-  uint32_t owners_started; uint32_t pad3[31];   // owner workgroups that have started, ever (the gate in front of the service kernel waits for it)
+  uint32_t owners_started; uint32_t pad3[31];
+  unsigned long long tm[32];   // development (-DBG_E2_TIMING): cycle sums, see tools/e2_diag.py   // owner workgroups that have started, ever (the gate in front of the service kernel waits for it)
 };
 struct E2Args {
   E2Ctl* ctl;
   unsigned long long* ring;      // [BG_E2_NQ][1 << ring_log] entries: env | (action | valid << 8 | t << 9 | generation << 25 | 1 << 31) << 32
   uint32_t ring_log;
-  uint4* ans;                    // [N] answers: {seq, mask_lo, seq, mask_hi}, seq = steps the env has completed in this launch
+  uint32_t* ansq;                // [N] answers: the number of steps the env has completed in this launch once its request has been served (the mask rides in the record)
   uint4* img;                    // [N][24] record images between launches (22 pieces used)
   unsigned long long* imask;     // [N] action masks between launches
   uint32_t done_target;          // ctl->owners_done at which this launch's service waves retire
@@ -58,6 +60,17 @@ struct E2Args {
 
 __device__ __forceinline__ uint32_t bg_xcc_id() { uint32_t x; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(x)); return x & 7u; }
 
+#ifdef BG_E2_TIMING
+#define E2T_DECL() unsigned long long e2t_[12] = {0,0,0,0,0,0,0,0,0,0,0,0}, e2t0_ = __builtin_readcyclecounter()
+#define E2T(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); e2t_[k] += n_ - e2t0_; e2t0_ = n_; } while (0)
+#define E2T_CNT(k, v) do { e2t_[k] += (v); } while (0)
+#define E2T_FLUSH(base) do { if ((threadIdx.x & 63) == 0) for (int k_ = 0; k_ < 12; k_++) atomicAdd(&x.ctl->tm[(base) + k_], e2t_[k_]); } while (0)
+#else
+#define E2T_DECL() do {} while (0)
+#define E2T(k) do {} while (0)
+#define E2T_CNT(k, v) do {} while (0)
+#define E2T_FLUSH(base) do {} while (0)
+#endif
 // ------------------------------------------------------------------------------------------------------------------------------
 // images between launches: the packed record of every env + its action mask, rebuilt from the state whenever anything but the
 // two-kernel engine has touched it (bg_reset, bg_step, bg_inject, ...)
@@ -119,7 +132,7 @@ __global__ __launch_bounds__(BG_E2_OW * BG_BLOCK) void bg_owner_kernel(BgDev d, 
   uint64_t mask = 0;
   if (live) {
     c3 = d.hot[3 * N + env]; c4 = d.hot[4 * N + env]; mask = x.imask[env];
-    bg_st8a(&x.ans[env], 0ull); bg_st8a((char*)&x.ans[env] + 8, 0ull);   // (the same flavour of store as the answers: drained before the first request)
+    __hip_atomic_store((g_u32*)&x.ansq[env], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (the same flavour of store as the answers; it lands before the first request's atomic returns)
   }
   bg_tables_load(&jt, d.jtab);   // (ends with the workgroup's only barrier)
   const uint32_t T = (uint32_t)a.T;
@@ -140,51 +153,41 @@ __global__ __launch_bounds__(BG_E2_OW * BG_BLOCK) void bg_owner_kernel(BgDev d, 
     cmul[j] = c < 22u ? 16u * 22u : 0u;
     cib[j] = c < 22u ? 16u * c : (uint32_t)((lds_cc*)&s_zero - imgb);
   }
-  uint32_t t = 0;
-  bool waiting = false, migrated = false;
+  // ---- the loop, software-pipelined: a hand-over hop costs 1.5 - 2.5 us under load (the price sits in memory, not in instructions), and a
+  // wave that waits for each hop in turn -- answer poll, then chunks 3 / 4 and the record, then the queue atomics -- spends 16 k cycles per
+  // iteration of which 2.5 k are work (tools/e2_diag.py, -DBG_E2_TIMING).  So every iteration
+  //   (1) ISSUES the answer polls of its waiting envs,
+  //   (2) settles the cheap steps of its ready envs (posting the others: chunks 3 / 4, then one returning atomic per class),
+  //   (3) copies the finished records out,
+  //   (4) only then looks at what came back: queue positions -> entries; answers -> the loads of chunks 3 / 4 and of the record are ISSUED
+  //       and fly over the whole next iteration; the loads issued one iteration ago -> image, registers, the step is complete.
+  // An env's state: 0 ready, 1 request posted (polling), 2 answered (its loads are in flight).
+  uint32_t t = 0, st = 0;
   uint64_t n_steps = 0, rbits = 0, ohash = 0;
   unsigned long long last_progress = wall_clock64();
   if (lane == 0) atomicMax(&x.ctl->svc_stat[2], ~last_progress);   // (development: stored complemented so that the zeroed word means 'never')
   __builtin_amdgcn_s_setprio(1);
+  // in flight from the previous iteration: chunks 3 / 4 of this lane's env (state 2) and, lane <-> piece, the records of up to four envs of the wave
+  bg_u32x4 ab_c3 = bg_u32x4{0u, 0u, 0u, 0u}, ab_c4 = ab_c3, ab_rec[4] = {ab_c3, ab_c3, ab_c3, ab_c3};
+  int ab_j[4] = {-1, -1, -1, -1};
+  E2T_DECL();
+#ifdef BG_E2_TIMING
+  unsigned long long e2_tpost = 0, e2_tans = 0, e2_l0 = 0, e2_l1 = 0, e2_ln = 0;
+#endif
   for (;;) {
-    if (__ballot(live && (t < T || waiting)) == 0ull) break;
-    if (!migrated && bg_xcc_id() != xcc) { migrated = true; if (lane == 0) atomicAdd(&x.ctl->x_migr[0], 1u); }
+    if (__ballot(live && (t < T || st != 0u)) == 0ull) break;
+    E2T_CNT(10, 1);
     const size_t row = (size_t)env + (a.obs_stride_steps ? (size_t)t * N : 0);
-    // ---- 1. answers
-    bool got = false;
-    if (waiting) {
-      const uint4 v = bg_ld16a(&x.ans[env]);
-      got = v.x == t + 1u && v.z == t + 1u;
-      if (got) { mask = (uint64_t)v.y | ((uint64_t)v.w << 32); waiting = false; }
-    }
-    unsigned long long gm = __ballot(got);
-    if (gm) {
-      // the service wave left chunks 3 / 4 in HBM and the finished record in its row: the record comes back lane <-> piece
-      if (got) { c3 = bg_ld16a(&d.hot[3 * N + env]); c4 = bg_ld16a(&d.hot[4 * N + env]); }
-      const uint32_t rlo = (uint32_t)row, rhi = (uint32_t)(row >> 32);
-      while (gm) {
-        int jj[4]; const uint8_t* src[4]; uint4 v[4];
-#pragma unroll
-        for (int u = 0; u < 4; u++) {
-          jj[u] = gm ? __ffsll((long long)gm) - 1 : -1;
-          if (gm) gm &= gm - 1;
-          const int j = jj[u] < 0 ? 0 : jj[u];
-          const size_t rj = (size_t)__builtin_amdgcn_readlane(rlo, j) | ((size_t)__builtin_amdgcn_readlane(rhi, j) << 32);
-          src[u] = a.obs.rows + rj * (size_t)a.obs.row_stride + 16u * (uint32_t)lane;
-        }
-#pragma unroll
-        for (int u = 0; u < 4; u++) if (jj[u] >= 0 && lane < 22) v[u] = bg_ld16a(src[u]);
-#pragma unroll
-        for (int u = 0; u < 4; u++) if (jj[u] >= 0 && lane < 22) s_img[wave * BG_BLOCK + jj[u]][lane] = bg_u32x4{v[u].x, v[u].y, v[u].z, v[u].w};
-      }
-      BG_WAVE_SYNC();
-    }
-    // ---- 2. the cheap step of every ready env (bg_engine.h: cheap_step)
+    // ---- (1) polls
+    uint32_t pollv = 0;
+    if (st == 1u) pollv = bg_ld4a(&x.ansq[env]);
+    E2T(0);
+    // ---- (2) the cheap step of every ready env (bg_engine.h: cheap_step)
     bool fin = false, post = false;
     int action = 0, cls = 0;
     uint32_t pvalid = 0;
     double reward = 0.0;
-    if (live && !waiting && !got && t < T) {
+    if (live && st == 0u && t < T) {
       const uint32_t ante = bg_b(c3.x, 0), phase = bg_b(c3.x, 2), discards_left = bg_b(c3.y, 0), nsel0 = bg_b(c3.y, 3);
       {
         Env pe; pe.phase = (int)phase; // the policy only looks at the phase and the mask
@@ -229,36 +232,27 @@ __global__ __launch_bounds__(BG_E2_OW * BG_BLOCK) void bg_owner_kernel(BgDev d, 
         img8[BG_ROW_TERMINATED] = 0;
       }
     }
-    // ---- 3. requests: chunks 3 / 4 to HBM, one returning atomic per class on this wave's queue, the entries behind a drain
+    E2T(1);
+    // requests: chunks 3 / 4 to HBM, then one returning atomic per class on this wave's queue (its result is looked at in (4): by then the
+    // stores before it have landed -- vector-memory operations complete in order)
     const unsigned long long pm = __ballot(post);
+    unsigned long long m0 = 0, m1 = 0;
+    uint32_t base = 0;
+    const uint32_t qb = xcc * BG_E2_NQX + ((uint32_t)wave & (BG_E2_NSUB - 1u));
     if (pm) {
       if (post) { d.hot[3 * N + env] = c3; d.hot[4 * N + env] = c4; }
-      const unsigned long long m0 = __ballot(post && cls == 0), m1 = __ballot(post && cls == 1);
-      const uint32_t qb = xcc * BG_E2_NQX + ((uint32_t)wave & (BG_E2_NSUB - 1u));
-      uint32_t base = 0;
+      m0 = __ballot(post && cls == 0); m1 = __ballot(post && cls == 1);
       if (m0 && lane == (int)(__ffsll((long long)m0) - 1)) base = __hip_atomic_fetch_add((g_u32*)&x.ctl->q[qb].tail, (uint32_t)__popcll(m0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (m1 && lane == (int)(__ffsll((long long)m1) - 1)) base = __hip_atomic_fetch_add((g_u32*)&x.ctl->q[qb + BG_E2_NSUB].tail, (uint32_t)__popcll(m1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // chunks 3 / 4 are in the L2 before any entry is
-      const uint32_t b0 = m0 ? __builtin_amdgcn_readlane(base, __ffsll((long long)m0) - 1) : 0u;
-      const uint32_t b1 = m1 ? __builtin_amdgcn_readlane(base, __ffsll((long long)m1) - 1) : 0u;
-      if (post) {
-        const unsigned long long mm = cls ? m1 : m0;
-        const uint32_t pos = (cls ? b1 : b0) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-        const uint32_t q = qb + (cls ? BG_E2_NSUB : 0u);
-        const uint32_t hi = ((uint32_t)action & 0xffu) | (pvalid << 8) | ((t & 0xffffu) << 9) | (((pos >> x.ring_log) & 0x3fu) << 25) | 0x80000000u;
-        bg_st8a(&x.ring[((size_t)q << x.ring_log) + (pos & ((1u << x.ring_log) - 1u))], (unsigned long long)(uint32_t)env | ((unsigned long long)hi << 32));
-        waiting = true;
-      }
     }
-    // ---- 4. accounting of the steps completed in this iteration (cheap: the image is patched; answered: the image is the service wave's)
-    if (fin || got) {
+    E2T(2);
+    // ---- (3) accounting and copy-out of the cheap steps' records: lane <-> 16-byte piece, non-temporal
+    if (fin) {
       const uint64_t rb = ((uint64_t)img32[35] << 32) | img32[34];
       if (HASH) ohash ^= bg_hash_image((const lds_u4*)&s_img[tid][0]) * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(a.t0 + t)) + gi;
       n_steps++;
       rbits ^= rb * (2 * (uint64_t)(a.t0 + t) + 1);
-      t++;
     }
-    // ---- 5. copy-out of the cheap steps' records: lane <-> 16-byte piece, non-temporal (an answered step's record is in its row already)
     const unsigned long long fm = __ballot(fin);
     if (fm) {
       const uint32_t nb = (uint32_t)__popcll(fm);
@@ -307,12 +301,88 @@ __global__ __launch_bounds__(BG_E2_OW * BG_BLOCK) void bg_owner_kernel(BgDev d, 
       }
       BG_WAVE_SYNC();   // the images have been read (a wave's LDS operations complete in order): the next iteration may patch them
     }
-    // ---- 6. nothing moved: every env of the wave is with a service wave
-    if ((fm | pm | __ballot(got)) == 0ull) {
-      __builtin_amdgcn_s_sleep(16);
+    if (fin) t++;
+    E2T(3);
+    // ---- (4a) the loads issued one iteration ago: the record into the image, chunks 3 / 4 and the mask into registers -- the step is complete
+    const unsigned long long am = __ballot(st == 2u);
+    if (am) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) if (ab_j[u] >= 0 && lane < 22) s_img[wave * BG_BLOCK + ab_j[u]][lane] = ab_rec[u];
+      BG_WAVE_SYNC();
+      if (st == 2u) {
+        c3 = make_uint4(ab_c3.x, ab_c3.y, ab_c3.z, ab_c3.w); c4 = make_uint4(ab_c4.x, ab_c4.y, ab_c4.z, ab_c4.w);
+        uint64_t m = 0;   // the action mask, from the record's action_mask i8[60]
+#pragma unroll
+        for (int wq = 0; wq < 15; wq++) { const uint32_t v = img32[44 + wq]; m |= (uint64_t)((v & 1u) | ((v >> 7) & 2u) | ((v >> 14) & 4u) | ((v >> 21) & 8u)) << (4 * wq); }
+        mask = m;
+        const uint64_t rb = ((uint64_t)img32[35] << 32) | img32[34];
+        if (HASH) ohash ^= bg_hash_image((const lds_u4*)&s_img[tid][0]) * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(a.t0 + t)) + gi;
+        n_steps++;
+        rbits ^= rb * (2 * (uint64_t)(a.t0 + t) + 1);
+        t++;
+        st = 0u;
+#ifdef BG_E2_TIMING
+        { const unsigned long long now = wall_clock64(); e2_l0 += e2_tans - e2_tpost; e2_l1 += now - e2_tans; e2_ln++; }
+#endif
+      }
+    }
+    E2T(4);
+    // ---- (4b) queue positions -> entries (8-byte agent-scope stores)
+    if (pm) {
+      const uint32_t b0 = m0 ? __builtin_amdgcn_readlane(base, __ffsll((long long)m0) - 1) : 0u;
+      const uint32_t b1 = m1 ? __builtin_amdgcn_readlane(base, __ffsll((long long)m1) - 1) : 0u;
+      if (post) {
+        const unsigned long long mm = cls ? m1 : m0;
+        const uint32_t pos = (cls ? b1 : b0) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+        const uint32_t q = qb + (cls ? BG_E2_NSUB : 0u);
+        // (t is still the index of the step in flight: a posted env's t moves when its answer has been absorbed)
+        const uint32_t hi = ((uint32_t)action & 0xffu) | (pvalid << 8) | ((t & 0xffffu) << 9) | (((pos >> x.ring_log) & 0x3fu) << 25) | 0x80000000u;
+        bg_st8a(&x.ring[((size_t)q << x.ring_log) + (pos & ((1u << x.ring_log) - 1u))], (unsigned long long)(uint32_t)env | ((unsigned long long)hi << 32));
+        st = 1u;
+#ifdef BG_E2_TIMING
+        e2_tpost = wall_clock64();
+#endif
+      }
+    }
+    // ---- (4c) answers -> issue the loads of chunks 3 / 4 and, lane <-> piece, of the records of up to four envs (the others poll again)
+    unsigned long long gm = __ballot(st == 1u && !post && pollv == t + 1u);
+    ab_j[0] = ab_j[1] = ab_j[2] = ab_j[3] = -1;
+    if (gm) {
+      const size_t arow = (size_t)env + (a.obs_stride_steps ? (size_t)t * N : 0);
+      const uint32_t rlo = (uint32_t)arow, rhi = (uint32_t)(arow >> 32);
+      unsigned long long take = 0;
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        if (gm) {
+          const int j = __ffsll((long long)gm) - 1;
+          gm &= gm - 1; take |= 1ull << j;
+          ab_j[u] = j;
+          const size_t rj = (size_t)__builtin_amdgcn_readlane(rlo, j) | ((size_t)__builtin_amdgcn_readlane(rhi, j) << 32);
+          if (lane < 22) ab_rec[u] = __builtin_nontemporal_load((const __attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + rj * (size_t)a.obs.row_stride + 16u * (uint32_t)lane));
+        }
+      }
+      if ((take >> lane) & 1ull) {
+        ab_c3 = __builtin_nontemporal_load((const __attribute__((address_space(1))) bg_u32x4*)&d.hot[3 * N + env]);
+        ab_c4 = __builtin_nontemporal_load((const __attribute__((address_space(1))) bg_u32x4*)&d.hot[4 * N + env]);
+        st = 2u;
+#ifdef BG_E2_TIMING
+        e2_tans = wall_clock64();
+#endif
+      }
+    }
+    E2T_CNT(11, __popcll(fm) + __popcll(am));
+    // ---- nothing moved: every env of the wave is with a service wave
+    if ((fm | pm | am | __ballot(st == 2u)) == 0ull) {
+      __builtin_amdgcn_s_sleep(8);
       if (wall_clock64() - last_progress > BG_E2_TIMEOUT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN | 0x100u); break; }
     } else last_progress = wall_clock64();
+    E2T(5);
   }
+  E2T_FLUSH(0);
+#ifdef BG_E2_TIMING
+  for (int off = 32; off > 0; off >>= 1) { e2_l0 += __shfl_down(e2_l0, off); e2_l1 += __shfl_down(e2_l1, off); e2_ln += __shfl_down(e2_ln, off); }
+  if (lane == 0) { atomicAdd(&x.ctl->tm[12], e2_l0); atomicAdd(&x.ctl->tm[13], e2_l1); atomicAdd(&x.ctl->tm[14], e2_ln); }
+#endif
   // ---- epilogue: chunks 3 / 4, images and masks back to HBM; statistics; this wave is done
   if (live) { d.hot[3 * N + env] = c3; d.hot[4 * N + env] = c4; x.imask[env] = mask; }
   {
@@ -333,7 +403,11 @@ __global__ __launch_bounds__(BG_E2_OW * BG_BLOCK) void bg_owner_kernel(BgDev d, 
       atomicXor((unsigned long long*)&a.stats->obs_hash, (unsigned long long)ohash);
     }
   }
-  if (lane == 0) { atomicMax(&x.ctl->svc_stat[3], wall_clock64()); __hip_atomic_fetch_add((g_u32*)&x.ctl->owners_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+  if (lane == 0) {
+    atomicMax(&x.ctl->svc_stat[3], wall_clock64());
+    const uint32_t old = __hip_atomic_fetch_add((g_u32*)&x.ctl->owners_done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1u == x.done_target) __hip_atomic_store((g_u32*)&x.ctl->done_flag, x.done_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // The GATE: one wave in front of the service kernel on its stream.  It ends when every owner workgroup that can be resident has started (or
@@ -385,99 +459,76 @@ __global__ __launch_bounds__(BG_BLOCK) __attribute__((amdgpu_num_vgpr(256))) voi
   if (lane == 0) __hip_atomic_fetch_add((g_u32*)&x.ctl->svc_seen[xcc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   uint64_t n_eps = 0, n_plays = 0;
   int64_t ssum = 0;
-  unsigned long long idle_since = wall_clock64(), first_seen = 0;
+  unsigned long long idle_since = wall_clock64();
   if (lane == 0) atomicMax(&x.ctl->svc_stat[4], ~idle_since);
   unsigned long long q_batches = 0, q_reqs = 0;
-  uint32_t x_why = 0, x_dn = 0;
-  bool migrated = false;
-  bool seen = false;
-  const uint32_t maxb = x.max_batch < 1u ? 1u : (x.max_batch > BG_BLOCK ? BG_BLOCK : x.max_batch);
+  uint32_t x_why = 0, x_dn = 0, empty_polls = 0;
+  // QUEUE PROTOCOL.  Words that atomics modify are never LOADED: an agent-scope load of such a word can be served a copy that the atomics have not
+  // refreshed for hundreds of microseconds (measured: 30 failed compare-and-swaps per claimed batch, requests waiting 150 us beside idle waves), while
+  // a word written by an agent-scope STORE is seen by the next load.  So a service wave RESERVES the next RS slots of a queue with one returning
+  // fetch_add on its head -- before anything is in them -- and then polls the slots themselves (entries are stores; a consumed slot is zeroed again).
+  // Producers reserve theirs with fetch_add on the tail.  Heads and tails start at 0 every launch (host memset); a slot's entry carries the generation
+  // of its position, so a lapped slot is a loud error, never a wrong env.  The launch's end is a store too (E2Ctl.done_flag).
+  const uint32_t RS = x.max_batch < 1u ? 1u : (x.max_batch > BG_BLOCK ? BG_BLOCK : x.max_batch);
+  const uint32_t qi0 = xcc * BG_E2_NQX + ((blockIdx.x >> 3) & (BG_E2_NSUB - 1u)), qi1 = qi0 + BG_E2_NSUB;   // this wave's play queue and other queue (workgroup b runs on XCD b % 8: the sub-queue comes from the bits above)
+  uint32_t cur0, end0, cur1, end1;
+  {
+    uint32_t b = 0;
+    if (lane < 2) b = __hip_atomic_fetch_add((g_u32*)&x.ctl->q[lane ? qi1 : qi0].head, RS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    cur0 = __builtin_amdgcn_readlane(b, 0); cur1 = __builtin_amdgcn_readlane(b, 1);
+    end0 = cur0 + RS; end1 = cur1 + RS;
+  }
+  E2T_DECL();
   for (;;) {
-    // ---- the four queues of this XCD: heads (even lanes) and tails (odd lanes) with one load instruction
-    // (read with RETURNING ATOMICS, not loads: tails and heads only ever change through atomics, and an agent-scope load can be served a copy of the
-    //  line that the atomics never refreshed -- seen as every service wave of an XCD reading tail == head for two seconds while 2 700 requests waited)
-    uint32_t w = 0;
-    if (lane < 2 * BG_E2_NQX) { E2Queue* q = &x.ctl->q[xcc * BG_E2_NQX + ((uint32_t)lane >> 1)]; w = __hip_atomic_fetch_add((g_u32*)((lane & 1) ? &q->tail : &q->head), x.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    if (lane == 2 * BG_E2_NQX) w = __hip_atomic_fetch_add((g_u32*)&x.ctl->owners_done, x.zero, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t done = __builtin_amdgcn_readlane(w, 2 * BG_E2_NQX);
-    uint32_t hq[BG_E2_NQX], nq[BG_E2_NQX], any = 0;
-#pragma unroll
-    for (int j = 0; j < BG_E2_NQX; j++) {
-      hq[j] = __builtin_amdgcn_readlane(w, 2 * j);
-      const uint32_t k = __builtin_amdgcn_readlane(w, 2 * j + 1) - hq[j];   // (a head newer than its tail reads as a huge number: nothing)
-      nq[j] = k <= rmask + 1u ? k : 0u;
-      any |= nq[j];
-    }
-    if (!migrated && bg_xcc_id() != xcc) { migrated = true; if (lane == 0) atomicAdd(&x.ctl->x_migr[1], 1u); }
-    if (!any) {
-      if ((int32_t)(__builtin_amdgcn_readfirstlane(done) - x.done_target) >= 0) { x_why = 1; x_dn = __builtin_amdgcn_readfirstlane(done); break; }   // every owner wave of this launch is through
-      seen = false;
-      __builtin_amdgcn_s_sleep(64);   // ~1.7 us between polls of an idle wave: 9 atomics per poll, a word takes ~90 per us
+    // ---- the slots this wave holds, and the launch's end
+    unsigned long long e0 = 0, e1 = 0;
+    if ((uint32_t)lane < end0 - cur0) e0 = bg_ld8a(&x.ring[((size_t)qi0 << x.ring_log) + ((cur0 + (uint32_t)lane) & rmask)]);
+    if ((uint32_t)lane < end1 - cur1) e1 = bg_ld8a(&x.ring[((size_t)qi1 << x.ring_log) + ((cur1 + (uint32_t)lane) & rmask)]);
+    const uint32_t dflag = bg_ld4a(&x.ctl->done_flag);
+    // entries are written in position order only roughly (each producer wave writes its own a moment after reserving them): serve the valid PREFIX
+    const unsigned long long v0 = __ballot((uint32_t)(e0 >> 63) != 0u), v1 = __ballot((uint32_t)(e1 >> 63) != 0u);
+    const uint32_t k0 = v0 == ~0ull ? 64u : (uint32_t)(__ffsll((long long)~v0) - 1), k1 = v1 == ~0ull ? 64u : (uint32_t)(__ffsll((long long)~v1) - 1);
+    if ((k0 | k1) == 0u) {
+      if (__builtin_amdgcn_readfirstlane(dflag) == x.done_target) { x_why = 1; x_dn = x.done_target; break; }   // every owner wave of this launch is through
+      __builtin_amdgcn_s_sleep(8);
+      if (++empty_polls > 16u) __builtin_amdgcn_s_sleep(40);   // an idle wave backs off to ~1.5 us between polls
       if (wall_clock64() - idle_since > BG_E2_TIMEOUT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN | 0x200u); x_why = 2; break; }
       continue;
     }
-    // plays first (the longest chains), the fuller sub-queue of a class first; a batch that is not full waits fill_wait ticks for more
-    int pick = -1;
-    {
-      const int s0 = (int)(blockIdx.x & (BG_E2_NSUB - 1));   // this wave's preferred sub-queue: the waves of an XCD do not all go for the same head
-      uint32_t best = 0;
-#pragma unroll
-      for (int c = 0; c < 2; c++) {
-#pragma unroll
-        for (int k = 0; k < BG_E2_NSUB; k++) {
-          const int j = c * BG_E2_NSUB + ((s0 + k) & (BG_E2_NSUB - 1));
-          if (pick < 0 && nq[j] >= maxb) pick = j;
-        }
-      }
-      if (pick < 0) {
-        const unsigned long long now = wall_clock64();
-        if (!seen) { seen = true; first_seen = now; }
-        if (now - first_seen >= (unsigned long long)x.fill_wait) {
-#pragma unroll
-          for (int k = 0; k < BG_E2_NQX; k++) { const int j = (k & ~(BG_E2_NSUB - 1)) | ((s0 + k) & (BG_E2_NSUB - 1)); if (nq[j] > best) { best = nq[j]; pick = j; } }
-        }
-      }
-    }
-    if (pick < 0) { __builtin_amdgcn_s_sleep(4); continue; }
-    uint32_t head = 0, navail = 0;
-#pragma unroll
-    for (int j = 0; j < BG_E2_NQX; j++) if (j == pick) { head = hq[j]; navail = nq[j]; }
-    const uint32_t nb = navail > maxb ? maxb : navail;
-    const uint32_t qi = xcc * BG_E2_NQX + (uint32_t)pick;
-    {
-      uint32_t ok = 0;
-      if (lane == 0) { uint32_t exp = head; ok = __hip_atomic_compare_exchange_strong((g_u32*)&x.ctl->q[qi].head, &exp, head + nb, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u; }
-      if (__builtin_amdgcn_readfirstlane(ok) == 0u) continue;
-    }
-    seen = false;
-    // ---- the entries (a producer bumps the tail first and writes its entry behind a drain: poll until the generation matches)
+    empty_polls = 0;
+    const bool cls1 = k0 == 0u;                         // plays first (the longest chains)
+    const uint32_t nb = cls1 ? k1 : k0, head = cls1 ? cur1 : cur0, qi = cls1 ? qi1 : qi0;
+    const unsigned long long ent = cls1 ? e1 : e0;
+    E2T(0);
+    E2T_CNT(10, 1); E2T_CNT(11, nb);
+    // the next reservation is requested now and looked at after the batch
+    const bool renew = head + nb == (cls1 ? end1 : end0);
+    uint32_t nbase = 0;
+    if (renew && lane == 0) nbase = __hip_atomic_fetch_add((g_u32*)&x.ctl->q[qi].head, RS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool active = false;
     int env = 0, action = 0;
     uint32_t t = 0, pvalid = 0;
     if ((uint32_t)lane < nb) {
-      const uint32_t pos = head + (uint32_t)lane, want = 0x80000000u | (((pos >> x.ring_log) & 0x3fu) << 25);
-      const unsigned long long* ep = &x.ring[((size_t)qi << x.ring_log) + (pos & rmask)];
-      unsigned long long ent = bg_ld8a(ep);
-      const unsigned long long w0 = wall_clock64();
-      while (((uint32_t)(ent >> 32) & 0xfe000000u) != want) {
-        __builtin_amdgcn_s_sleep(2);
-        if (wall_clock64() - w0 > BG_E2_TIMEOUT) break;
-        ent = bg_ld8a(ep);
-      }
-      if (((uint32_t)(ent >> 32) & 0xfe000000u) != want) atomicOr(d.err, BG_DEVERR_SPIN | 0x400u);
-      else { active = true; env = (int)(uint32_t)ent; const uint32_t hi = (uint32_t)(ent >> 32); action = (int)(hi & 0xffu); pvalid = (hi >> 8) & 1u; t = (hi >> 9) & 0xffffu; }
+      const uint32_t pos = head + (uint32_t)lane, hi = (uint32_t)(ent >> 32);
+      if (((hi >> 25) & 0x3fu) != ((pos >> x.ring_log) & 0x3fu)) atomicOr(d.err, BG_DEVERR_SPIN | 0x400u);   // the ring was lapped
+      else { active = true; env = (int)(uint32_t)ent; action = (int)(hi & 0xffu); pvalid = (hi >> 8) & 1u; t = (hi >> 9) & 0xffffu; }
+      bg_st8a(&x.ring[((size_t)qi << x.ring_log) + (pos & rmask)], 0ull);   // the slot is free again
     }
+    E2T(1);
     if (active) {
       BG_PROBE_BEGIN();
       const size_t row = (size_t)env + (a.obs_stride_steps ? (size_t)t * N : 0);
+      // state: 16-byte NON-TEMPORAL loads -- they bypass the CU's L1 (which may hold the line from a neighbour env's earlier service step here,
+      // with this env's chunk as it was then) and are served by the XCD's L2, where the last writer's plain stores are
       uint4 c[BG_NHOT];
 #pragma unroll
-      for (int k = 0; k < BG_NHOT; k++) c[k] = bg_ld16a(&d.hot[(size_t)k * N + env]);
+      for (int k = 0; k < BG_NHOT; k++) { const bg_u32x4 v = __builtin_nontemporal_load((const __attribute__((address_space(1))) bg_u32x4*)&d.hot[(size_t)k * N + env]); c[k] = make_uint4(v.x, v.y, v.z, v.w); }
       DeckT dk;
-      { const uint4 dc = bg_ld16a(&d.deck[env]); dk.lo = ((uint64_t)dc.y << 32) | dc.x; dk.hi = ((uint64_t)dc.w << 32) | dc.z; }
+      { const bg_u32x4 dc = __builtin_nontemporal_load((const __attribute__((address_space(1))) bg_u32x4*)&d.deck[env]); dk.lo = ((uint64_t)dc.y << 32) | dc.x; dk.hi = ((uint64_t)dc.w << 32) | dc.z; }
       Env e;
       bg_unpack(c, e);
       bg_derive_ready(e, d.prod_view ? d.prod_view[env] : 0u);
+      E2T(2);
       ShopRegs sr; sr.valid = false;
       RngWin w;
       bg_win_init(w, &s_win[0][lane], &jt);
@@ -486,29 +537,41 @@ __global__ __launch_bounds__(BG_BLOCK) __attribute__((amdgpu_num_vgpr(256))) voi
       o.bd_dst = nullptr;
       // the owner has checked the action against the env's mask (pvalid); the terminal guards come first, as in the reference (:619-627)
       if (bg_step_guards(e, pvalid ? ~0ull : 0ull, action, o)) bg_env_dispatch(d, env, e, w, sr, dk, action, o);
+      E2T(3);
       if (e.max_ante > 0 && e.ante > e.max_ante) { o.terminated = true; o.flags |= 256; }
       if (o.terminated) n_eps++;
       if (o.terminated && a.autoreset) bg_env_reset(d, env, e, dk);
+      E2T(4);
       const uint64_t mask = bg_action_mask(d, env, e, sr);
       if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
       bg_pack(e, c);
 #pragma unroll
       for (int k = 0; k < BG_NHOT; k++) d.hot[(size_t)k * N + env] = c[k];
+      E2T(5);
       // the record, straight to its row: three slices of 8 / 7 / 7 pieces staged through LDS (lane <-> piece: runs of whole records)
       ObsPtrs op = a.obs;
+#ifndef BG_E2_DIRECT_RECORD
       bg_write_obs_impl<false, 2>(d, env, row, e, dk, op, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u}, RowStage{(lds_u4*)&s_win[0][0], (lds_u64*)&s_addr[0]});
+#else
+      // every lane stores its own 22 pieces: plain stores, the XCD's L2 puts the lines together (the owner reads them back from there)
+      bg_write_obs_impl<false, 0>(d, env, row, e, dk, op, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u}, RowStage{nullptr, nullptr});
+#endif
       if (a.obs.row_stride == 384u) { // the two padding pieces of a whole-line record are zeros (bg_engine.h, copier)
         __attribute__((address_space(1))) bg_u32x4* pad = (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + row * 384u + 352u);
         pad[0] = bg_u32x4{0u, 0u, 0u, 0u}; pad[1] = bg_u32x4{0u, 0u, 0u, 0u};
       }
+      E2T(6);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // state and record are in this XCD's L2 before the answer is
-      const unsigned long long seq = (unsigned long long)(t + 1u);
-      bg_st8a(&x.ans[env], seq | ((unsigned long long)(uint32_t)mask << 32));
-      bg_st8a((char*)&x.ans[env] + 8, seq | ((unsigned long long)(uint32_t)(mask >> 32) << 32));
+      E2T(7);
+      __hip_atomic_store((g_u32*)&x.ansq[env], t + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     idle_since = wall_clock64();
     q_batches++; q_reqs += nb;
+    if (cls1) { cur1 += nb; if (renew) { cur1 = __builtin_amdgcn_readfirstlane(nbase); end1 = cur1 + RS; } }
+    else { cur0 += nb; if (renew) { cur0 = __builtin_amdgcn_readfirstlane(nbase); end0 = cur0 + RS; } }
+    E2T(8);
   }
+  E2T_FLUSH(16);
   if (lane == 0) {
     const unsigned long long now = wall_clock64();
     atomicMax(&x.ctl->svc_stat[5], now); atomicAdd(&x.ctl->svc_stat[0], q_batches); atomicAdd(&x.ctl->svc_stat[1], q_reqs);

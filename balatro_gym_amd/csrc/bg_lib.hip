@@ -931,10 +931,11 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
   if (e == hipSuccess) e = bg_alloc(h, &h->d_mask, N);
   if (e == hipSuccess && h->engine == 2) { // the two-kernel engine: request rings (one slot per env and queue: an env has at most one request in flight), answers, images
     uint32_t lg = 6; while ((1ull << lg) < N) lg++;
+    lg++;   // twice the envs: an env has one request in flight, but a slot is only free again once its reader has been there (a lapped slot is a loud error)
     h->e2.ring_log = lg;
     e = bg_alloc(h, &h->e2.ctl, 1);
     if (e == hipSuccess) e = bg_alloc(h, &h->e2.ring, (size_t)BG_E2_NQ << lg);
-    if (e == hipSuccess) e = bg_alloc(h, &h->e2.ans, N);
+    if (e == hipSuccess) e = bg_alloc(h, &h->e2.ansq, N);
     if (e == hipSuccess) e = bg_alloc(h, &h->e2.img, 24 * N);
     if (e == hipSuccess) e = bg_alloc(h, &h->e2.imask, N);
     if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->svc, hipStreamNonBlocking, prio_greatest);
@@ -977,7 +978,7 @@ int bg_destroy(bg_handle* h) {
   if (h->svc) (void)hipStreamDestroy(h->svc);
   if (h->ev_e2a) (void)hipEventDestroy(h->ev_e2a);
   if (h->ev_e2b) (void)hipEventDestroy(h->ev_e2b);
-  hipFree(h->e2.ctl); hipFree(h->e2.ring); hipFree(h->e2.ans); hipFree(h->e2.img); hipFree(h->e2.imask);
+  hipFree(h->e2.ctl); hipFree(h->e2.ring); hipFree(h->e2.ansq); hipFree(h->e2.img); hipFree(h->e2.imask);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto* v : {&h->ev_rollout_t, &h->ev_refill_t, &h->ev_step_t}) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
   hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
@@ -1211,6 +1212,8 @@ static int bg_engine2_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a,
   // service waves: four per CU (one per SIMD beside an owner wave); small jobs get fewer (a wave per four envs, a multiple of the eight XCDs)
   int nsvc = h->e2_svc_waves > 0 ? h->e2_svc_waves : 4 * 256;
   if (h->e2_svc_waves <= 0 && h->dev.N < 4096) { nsvc = ((h->dev.N / 4 + 7) / 8) * 8; if (nsvc < 64) nsvc = 64; }
+  // heads and tails start at 0 every launch: a service wave RESERVES slots ahead of the requests, and what it held when the launch ended is nobody's
+  BG_HIP(hipMemsetAsync((char*)h->e2.ctl + offsetof(E2Ctl, q), 0, sizeof(((E2Ctl*)0)->q), st));
   static const int nowait = getenv("BG_E2_NOWAIT") ? atoi(getenv("BG_E2_NOWAIT")) : 0;   // development
   if (!nowait) {
   BG_HIP(hipEventRecord(h->ev_e2a, st));
