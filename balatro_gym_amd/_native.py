@@ -92,11 +92,26 @@ def lib_path() -> str:
 
 
 def device_code_signature(path: str | None = None) -> str:
-    """sha256 (first 16 hex digits) of the `.hip_fatbin` section of the library: identifies the DEVICE code that runs.  bench.py
-    only quotes a committed PMC traffic measurement (profiles/*_hbm_traffic.json) taken on exactly this device code."""
+    """Identifies the DEVICE code that runs, reproducibly: the signature the library was built with (`bg_build_signature`: sha256
+    prefix over sources + flags + compiler, `build.source_signature()`), which any rebuild of unchanged sources repeats -- the bytes
+    of the code object do not (three rebuilds of unchanged sources gave three .hip_fatbin hashes).  bench.py only quotes a committed
+    PMC traffic measurement (profiles/*_hbm_traffic.json) taken on exactly this signature.  Ad-hoc builds ("unsigned", e.g.
+    tools/build_variant.sh) fall back to the sha256 of their .hip_fatbin section."""
+    path = path or lib_path()
+    try:
+        L = C.CDLL(path) if (_lib is None or path != lib_path()) else _lib
+        L.bg_build_signature.restype = C.c_char_p
+        sig = L.bg_build_signature().decode()
+        if sig and sig != "unsigned":
+            return sig
+    except (OSError, AttributeError):
+        pass
+    return fatbin_sha(path)
+
+
+def fatbin_sha(path: str) -> str:
     import hashlib
     import struct
-    path = path or lib_path()
     with open(path, "rb") as f:
         data = f.read()
     if data[:4] != b"\x7fELF" or data[4] != 2:

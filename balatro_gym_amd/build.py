@@ -25,20 +25,43 @@ def hipcc_path() -> str:
     return p
 
 
+FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value"]
+
+
+def source_signature() -> str:
+    """What identifies the DEVICE CODE of a build, reproducibly: sha256 (first 16 hex digits) over every source the library is
+    compiled from, the compiler flags and the compiler's version.  Two builds of unchanged sources with the same hipcc carry the
+    same signature (the bytes of the code object do not: rebuilding unchanged sources gave three different .hip_fatbin hashes), so a
+    committed PMC traffic measurement (profiles/*_hbm_traffic.json) stays attached to the code it was taken on across rebuilds."""
+    import hashlib
+    h = hashlib.sha256()
+    for d in DEPS:
+        h.update(os.path.basename(d).encode() + b"\0")
+        with open(d, "rb") as f:
+            h.update(f.read())
+        h.update(b"\0")
+    h.update(" ".join(FLAGS).encode())
+    try:
+        ver = subprocess.run([hipcc_path(), "--version"], capture_output=True, text=True, timeout=60).stdout
+        h.update("\n".join(l for l in ver.splitlines() if "version" in l.lower()).encode())
+    except Exception:
+        h.update(b"hipcc-unknown")
+    return h.hexdigest()[:16]
+
+
 def needs_build() -> bool:
     return not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, out: str | None = None) -> str:
+    if not force and not out and not needs_build():
         return LIB
-    cmd = [hipcc_path(), "-O3", f"--offload-arch={ARCH}", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared",
-           "-Wno-unused-value", "-o", LIB, SRC]
+    cmd = [hipcc_path()] + FLAGS + [f'-DBG_BUILD_SIGNATURE="{source_signature()}"', "-o", out or LIB, SRC]
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return out or LIB
 
 
 if __name__ == "__main__":

@@ -94,6 +94,9 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_e2_image_kernel(BgDev d, E2Args x
 // ------------------------------------------------------------------------------------------------------------------------------
 // owner kernel
 // ------------------------------------------------------------------------------------------------------------------------------
+#ifndef BG_E2_AB
+#define BG_E2_AB 4                          // answered envs a wave absorbs per iteration (their records come back lane <-> piece, one register each)
+#endif
 #define BG_E2_OW 4                          // owner waves per workgroup (nothing is shared between them but the tables)
 #define BG_E2_IMG_BYTES (BG_E2_OW * BG_BLOCK * 22 * 16)
 #define BG_E2_LIST_BYTES (BG_E2_OW * BG_BLOCK * 8)
@@ -168,8 +171,13 @@ __global__ __launch_bounds__(BG_E2_OW * BG_BLOCK) void bg_owner_kernel(BgDev d, 
   if (lane == 0) atomicMax(&x.ctl->svc_stat[2], ~last_progress);   // (development: stored complemented so that the zeroed word means 'never')
   __builtin_amdgcn_s_setprio(1);
   // in flight from the previous iteration: chunks 3 / 4 of this lane's env (state 2) and, lane <-> piece, the records of up to four envs of the wave
-  bg_u32x4 ab_c3 = bg_u32x4{0u, 0u, 0u, 0u}, ab_c4 = ab_c3, ab_rec[4] = {ab_c3, ab_c3, ab_c3, ab_c3};
-  int ab_j[4] = {-1, -1, -1, -1};
+  bg_u32x4 ab_c3 = bg_u32x4{0u, 0u, 0u, 0u}, ab_c4 = ab_c3, ab_rec[BG_E2_AB];
+  int ab_j[BG_E2_AB];
+#pragma unroll
+  for (int u = 0; u < BG_E2_AB; u++) { ab_rec[u] = ab_c3; ab_j[u] = -1; }
+  // a request whose queue position (a returning atomic) is in flight: state 3; its entry is written at the top of the next iteration
+  unsigned long long pq_m0 = 0, pq_m1 = 0;
+  uint32_t pq_base = 0, pq_hi = 0;
   E2T_DECL();
 #ifdef BG_E2_TIMING
   unsigned long long e2_tpost = 0, e2_tans = 0, e2_l0 = 0, e2_l1 = 0, e2_ln = 0;
@@ -178,6 +186,28 @@ __global__ __launch_bounds__(BG_E2_OW * BG_BLOCK) void bg_owner_kernel(BgDev d, 
     if (__ballot(live && (t < T || st != 0u)) == 0ull) break;
     E2T_CNT(10, 1);
     const size_t row = (size_t)env + (a.obs_stride_steps ? (size_t)t * N : 0);
+    // ---- (0) the queue positions asked for in the previous iteration -> entries (8-byte agent-scope stores).  The atomic has had the whole
+    // copy-out and absorb phase to come back, and the stores of chunks 3 / 4 before it have landed (vector-memory operations complete in order)
+    if (pq_m0 | pq_m1) {
+      const uint32_t b0 = pq_m0 ? __builtin_amdgcn_readlane(pq_base, __ffsll((long long)pq_m0) - 1) : 0u;
+      const uint32_t b1 = pq_m1 ? __builtin_amdgcn_readlane(pq_base, __ffsll((long long)pq_m1) - 1) : 0u;
+      if (st == 3u) {
+        const bool c1 = ((pq_m1 >> lane) & 1ull) != 0ull;
+        const unsigned long long mm = c1 ? pq_m1 : pq_m0;
+        const uint32_t pos = (c1 ? b1 : b0) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
+        const uint32_t q = xcc * BG_E2_NQX + ((uint32_t)wave & (BG_E2_NSUB - 1u)) + (c1 ? BG_E2_NSUB : 0u);
+        #ifdef BG_E2_TIMING   // (development: bits 24..31 of the env word carry the time of the store in 0.64 us units)
+        bg_st8a(&x.ring[((size_t)q << x.ring_log) + (pos & ((1u << x.ring_log) - 1u))], (unsigned long long)((uint32_t)env | ((uint32_t)((wall_clock64() >> 6) & 0xffu) << 24)) | ((unsigned long long)(pq_hi | (((pos >> x.ring_log) & 0x3fu) << 25)) << 32));
+#else
+        bg_st8a(&x.ring[((size_t)q << x.ring_log) + (pos & ((1u << x.ring_log) - 1u))], (unsigned long long)(uint32_t)env | ((unsigned long long)(pq_hi | (((pos >> x.ring_log) & 0x3fu) << 25)) << 32));
+#endif
+        st = 1u;
+#ifdef BG_E2_TIMING
+        e2_tpost = wall_clock64();
+#endif
+      }
+      pq_m0 = 0; pq_m1 = 0;
+    }
     // ---- (1) polls
     uint32_t pollv = 0;
     if (st == 1u) pollv = bg_ld4a(&x.ansq[env]);
@@ -244,6 +274,11 @@ __global__ __launch_bounds__(BG_E2_OW * BG_BLOCK) void bg_owner_kernel(BgDev d, 
       m0 = __ballot(post && cls == 0); m1 = __ballot(post && cls == 1);
       if (m0 && lane == (int)(__ffsll((long long)m0) - 1)) base = __hip_atomic_fetch_add((g_u32*)&x.ctl->q[qb].tail, (uint32_t)__popcll(m0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       if (m1 && lane == (int)(__ffsll((long long)m1) - 1)) base = __hip_atomic_fetch_add((g_u32*)&x.ctl->q[qb + BG_E2_NSUB].tail, (uint32_t)__popcll(m1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      pq_m0 = m0; pq_m1 = m1; pq_base = base;
+      if (post) { // (t is still the index of the step in flight: a posted env's t moves when its answer has been absorbed)
+        pq_hi = ((uint32_t)action & 0xffu) | (pvalid << 8) | ((t & 0xffffu) << 9) | 0x80000000u;
+        st = 3u;
+      }
     }
     E2T(2);
     // ---- (3) accounting and copy-out of the cheap steps' records: lane <-> 16-byte piece, non-temporal
@@ -307,7 +342,7 @@ __global__ __launch_bounds__(BG_E2_OW * BG_BLOCK) void bg_owner_kernel(BgDev d, 
     const unsigned long long am = __ballot(st == 2u);
     if (am) {
 #pragma unroll
-      for (int u = 0; u < 4; u++) if (ab_j[u] >= 0 && lane < 22) s_img[wave * BG_BLOCK + ab_j[u]][lane] = ab_rec[u];
+      for (int u = 0; u < BG_E2_AB; u++) if (ab_j[u] >= 0 && lane < 22) s_img[wave * BG_BLOCK + ab_j[u]][lane] = ab_rec[u];
       BG_WAVE_SYNC();
       if (st == 2u) {
         c3 = make_uint4(ab_c3.x, ab_c3.y, ab_c3.z, ab_c3.w); c4 = make_uint4(ab_c4.x, ab_c4.y, ab_c4.z, ab_c4.w);
@@ -327,32 +362,16 @@ __global__ __launch_bounds__(BG_E2_OW * BG_BLOCK) void bg_owner_kernel(BgDev d, 
       }
     }
     E2T(4);
-    // ---- (4b) queue positions -> entries (8-byte agent-scope stores)
-    if (pm) {
-      const uint32_t b0 = m0 ? __builtin_amdgcn_readlane(base, __ffsll((long long)m0) - 1) : 0u;
-      const uint32_t b1 = m1 ? __builtin_amdgcn_readlane(base, __ffsll((long long)m1) - 1) : 0u;
-      if (post) {
-        const unsigned long long mm = cls ? m1 : m0;
-        const uint32_t pos = (cls ? b1 : b0) + __builtin_amdgcn_mbcnt_hi((uint32_t)(mm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mm, 0u));
-        const uint32_t q = qb + (cls ? BG_E2_NSUB : 0u);
-        // (t is still the index of the step in flight: a posted env's t moves when its answer has been absorbed)
-        const uint32_t hi = ((uint32_t)action & 0xffu) | (pvalid << 8) | ((t & 0xffffu) << 9) | (((pos >> x.ring_log) & 0x3fu) << 25) | 0x80000000u;
-        bg_st8a(&x.ring[((size_t)q << x.ring_log) + (pos & ((1u << x.ring_log) - 1u))], (unsigned long long)(uint32_t)env | ((unsigned long long)hi << 32));
-        st = 1u;
-#ifdef BG_E2_TIMING
-        e2_tpost = wall_clock64();
-#endif
-      }
-    }
     // ---- (4c) answers -> issue the loads of chunks 3 / 4 and, lane <-> piece, of the records of up to four envs (the others poll again)
-    unsigned long long gm = __ballot(st == 1u && !post && pollv == t + 1u);
-    ab_j[0] = ab_j[1] = ab_j[2] = ab_j[3] = -1;
+    unsigned long long gm = __ballot(st == 1u && pollv == t + 1u);
+#pragma unroll
+    for (int u = 0; u < BG_E2_AB; u++) ab_j[u] = -1;
     if (gm) {
       const size_t arow = (size_t)env + (a.obs_stride_steps ? (size_t)t * N : 0);
       const uint32_t rlo = (uint32_t)arow, rhi = (uint32_t)(arow >> 32);
       unsigned long long take = 0;
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+      for (int u = 0; u < BG_E2_AB; u++) {
         if (gm) {
           const int j = __ffsll((long long)gm) - 1;
           gm &= gm - 1; take |= 1ull << j;
@@ -372,7 +391,7 @@ __global__ __launch_bounds__(BG_E2_OW * BG_BLOCK) void bg_owner_kernel(BgDev d, 
     }
     E2T_CNT(11, __popcll(fm) + __popcll(am));
     // ---- nothing moved: every env of the wave is with a service wave
-    if ((fm | pm | am | __ballot(st == 2u)) == 0ull) {
+    if ((fm | pm | am | __ballot(st >= 2u)) == 0ull) {
       __builtin_amdgcn_s_sleep(8);
       if (wall_clock64() - last_progress > BG_E2_TIMEOUT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN | 0x100u); break; }
     } else last_progress = wall_clock64();
@@ -463,6 +482,11 @@ __global__ __launch_bounds__(BG_BLOCK) __attribute__((amdgpu_num_vgpr(256))) voi
   if (lane == 0) atomicMax(&x.ctl->svc_stat[4], ~idle_since);
   unsigned long long q_batches = 0, q_reqs = 0;
   uint32_t x_why = 0, x_dn = 0, empty_polls = 0;
+  bool seen = false;
+  unsigned long long first_seen = 0;
+#ifdef BG_E2_TIMING
+  unsigned long long e2_wait = 0, e2_waitn = 0;
+#endif
   // QUEUE PROTOCOL.  Words that atomics modify are never LOADED: an agent-scope load of such a word can be served a copy that the atomics have not
   // refreshed for hundreds of microseconds (measured: 30 failed compare-and-swaps per claimed batch, requests waiting 150 us beside idle waves), while
   // a word written by an agent-scope STORE is seen by the next load.  So a service wave RESERVES the next RS slots of a queue with one returning
@@ -471,23 +495,26 @@ __global__ __launch_bounds__(BG_BLOCK) __attribute__((amdgpu_num_vgpr(256))) voi
   // of its position, so a lapped slot is a loud error, never a wrong env.  The launch's end is a store too (E2Ctl.done_flag).
   const uint32_t RS = x.max_batch < 1u ? 1u : (x.max_batch > BG_BLOCK ? BG_BLOCK : x.max_batch);
   const uint32_t qi0 = xcc * BG_E2_NQX + ((blockIdx.x >> 3) & (BG_E2_NSUB - 1u)), qi1 = qi0 + BG_E2_NSUB;   // this wave's play queue and other queue (workgroup b runs on XCD b % 8: the sub-queue comes from the bits above)
-  uint32_t cur0, end0, cur1, end1;
+  // a wave holds one range of RS slots per class: `base` and the set of slots it has served already (entries arrive in any order: each producer
+  // wave writes its own an iteration after reserving them, and waiting for the slowest one first -- serving only the valid PREFIX -- made a request
+  // wait 35 us on average beside idle waves)
+  uint32_t base0, base1;
+  unsigned long long served0 = 0, served1 = 0;
+  const unsigned long long full = RS >= 64u ? ~0ull : ((1ull << RS) - 1ull);
   {
     uint32_t b = 0;
     if (lane < 2) b = __hip_atomic_fetch_add((g_u32*)&x.ctl->q[lane ? qi1 : qi0].head, RS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    cur0 = __builtin_amdgcn_readlane(b, 0); cur1 = __builtin_amdgcn_readlane(b, 1);
-    end0 = cur0 + RS; end1 = cur1 + RS;
+    base0 = __builtin_amdgcn_readlane(b, 0); base1 = __builtin_amdgcn_readlane(b, 1);
   }
   E2T_DECL();
   for (;;) {
     // ---- the slots this wave holds, and the launch's end
     unsigned long long e0 = 0, e1 = 0;
-    if ((uint32_t)lane < end0 - cur0) e0 = bg_ld8a(&x.ring[((size_t)qi0 << x.ring_log) + ((cur0 + (uint32_t)lane) & rmask)]);
-    if ((uint32_t)lane < end1 - cur1) e1 = bg_ld8a(&x.ring[((size_t)qi1 << x.ring_log) + ((cur1 + (uint32_t)lane) & rmask)]);
+    if ((uint32_t)lane < RS && !((served0 >> lane) & 1ull)) e0 = bg_ld8a(&x.ring[((size_t)qi0 << x.ring_log) + ((base0 + (uint32_t)lane) & rmask)]);
+    if ((uint32_t)lane < RS && !((served1 >> lane) & 1ull)) e1 = bg_ld8a(&x.ring[((size_t)qi1 << x.ring_log) + ((base1 + (uint32_t)lane) & rmask)]);
     const uint32_t dflag = bg_ld4a(&x.ctl->done_flag);
-    // entries are written in position order only roughly (each producer wave writes its own a moment after reserving them): serve the valid PREFIX
     const unsigned long long v0 = __ballot((uint32_t)(e0 >> 63) != 0u), v1 = __ballot((uint32_t)(e1 >> 63) != 0u);
-    const uint32_t k0 = v0 == ~0ull ? 64u : (uint32_t)(__ffsll((long long)~v0) - 1), k1 = v1 == ~0ull ? 64u : (uint32_t)(__ffsll((long long)~v1) - 1);
+    const uint32_t k0 = (uint32_t)__popcll(v0), k1 = (uint32_t)__popcll(v1);
     if ((k0 | k1) == 0u) {
       if (__builtin_amdgcn_readfirstlane(dflag) == x.done_target) { x_why = 1; x_dn = x.done_target; break; }   // every owner wave of this launch is through
       __builtin_amdgcn_s_sleep(8);
@@ -496,22 +523,33 @@ __global__ __launch_bounds__(BG_BLOCK) __attribute__((amdgpu_num_vgpr(256))) voi
       continue;
     }
     empty_polls = 0;
-    const bool cls1 = k0 == 0u;                         // plays first (the longest chains)
-    const uint32_t nb = cls1 ? k1 : k0, head = cls1 ? cur1 : cur0, qi = cls1 ? qi1 : qi0;
+    // a range that is filling is given fill_wait ticks to fill up: the rest of it would otherwise wait for this wave's batch to end
+    if ((served0 | v0) != full && (served1 | v1) != full && x.fill_wait) {
+      const unsigned long long now = wall_clock64();
+      if (!seen) { seen = true; first_seen = now; }
+      if (now - first_seen < (unsigned long long)x.fill_wait) { __builtin_amdgcn_s_sleep(2); continue; }
+    }
+    seen = false;
+    const bool cls1 = k1 > k0;   // the class with more requests waiting (plays on a tie: the longer chains)
+    const unsigned long long vm = cls1 ? v1 : v0;
+    const uint32_t nb = cls1 ? k1 : k0, head = cls1 ? base1 : base0, qi = cls1 ? qi1 : qi0;
     const unsigned long long ent = cls1 ? e1 : e0;
     E2T(0);
     E2T_CNT(10, 1); E2T_CNT(11, nb);
-    // the next reservation is requested now and looked at after the batch
-    const bool renew = head + nb == (cls1 ? end1 : end0);
+    // when this batch exhausts the range the next reservation is requested now and looked at after the batch
+    const bool renew = ((cls1 ? served1 : served0) | vm) == full;
     uint32_t nbase = 0;
     if (renew && lane == 0) nbase = __hip_atomic_fetch_add((g_u32*)&x.ctl->q[qi].head, RS, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool active = false;
     int env = 0, action = 0;
     uint32_t t = 0, pvalid = 0;
-    if ((uint32_t)lane < nb) {
+    if ((vm >> lane) & 1ull) {
       const uint32_t pos = head + (uint32_t)lane, hi = (uint32_t)(ent >> 32);
       if (((hi >> 25) & 0x3fu) != ((pos >> x.ring_log) & 0x3fu)) atomicOr(d.err, BG_DEVERR_SPIN | 0x400u);   // the ring was lapped
-      else { active = true; env = (int)(uint32_t)ent; action = (int)(hi & 0xffu); pvalid = (hi >> 8) & 1u; t = (hi >> 9) & 0xffffu; }
+      else { active = true; env = (int)((uint32_t)ent & 0xffffffu); action = (int)(hi & 0xffu); pvalid = (hi >> 8) & 1u; t = (hi >> 9) & 0xffffu; }
+#ifdef BG_E2_TIMING
+      e2_wait += (uint32_t)(((wall_clock64() >> 6) - ((uint32_t)ent >> 24)) & 0xffu); e2_waitn++;
+#endif
       bg_st8a(&x.ring[((size_t)qi << x.ring_log) + (pos & rmask)], 0ull);   // the slot is free again
     }
     E2T(1);
@@ -567,11 +605,15 @@ __global__ __launch_bounds__(BG_BLOCK) __attribute__((amdgpu_num_vgpr(256))) voi
     }
     idle_since = wall_clock64();
     q_batches++; q_reqs += nb;
-    if (cls1) { cur1 += nb; if (renew) { cur1 = __builtin_amdgcn_readfirstlane(nbase); end1 = cur1 + RS; } }
-    else { cur0 += nb; if (renew) { cur0 = __builtin_amdgcn_readfirstlane(nbase); end0 = cur0 + RS; } }
+    if (cls1) { served1 |= vm; if (renew) { base1 = __builtin_amdgcn_readfirstlane(nbase); served1 = 0; } }
+    else { served0 |= vm; if (renew) { base0 = __builtin_amdgcn_readfirstlane(nbase); served0 = 0; } }
     E2T(8);
   }
   E2T_FLUSH(16);
+#ifdef BG_E2_TIMING
+  for (int off = 32; off > 0; off >>= 1) { e2_wait += __shfl_down(e2_wait, off); e2_waitn += __shfl_down(e2_waitn, off); }
+  if (lane == 0) { atomicAdd(&x.ctl->tm[28], e2_wait); atomicAdd(&x.ctl->tm[29], e2_waitn); }
+#endif
   if (lane == 0) {
     const unsigned long long now = wall_clock64();
     atomicMax(&x.ctl->svc_stat[5], now); atomicAdd(&x.ctl->svc_stat[0], q_batches); atomicAdd(&x.ctl->svc_stat[1], q_reqs);

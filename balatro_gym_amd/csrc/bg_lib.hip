@@ -754,7 +754,14 @@ static double bg_ev_sum(bg_handle* h, std::vector<hipEvent_t>& v) {
   return ms;
 }
 
+#ifndef BG_BUILD_SIGNATURE
+#define BG_BUILD_SIGNATURE "unsigned"
+#endif
+
 extern "C" {
+
+// sha256 prefix of the sources + flags + compiler this library was built from (balatro_gym_amd/build.py source_signature()); "unsigned" for ad-hoc builds
+const char* bg_build_signature(void) { return BG_BUILD_SIGNATURE; }
 
 // development hook: the two-kernel engine's control block (queue tails / heads, arrival counters, wall-clock stamps) as 32-bit words
 int bg_debug_e2(bg_handle* h, unsigned int* out, int nwords) {
@@ -852,7 +859,7 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
     h->engine = geti("BG_ENGINE", 2); if (h->engine != 1) h->engine = 2;
     memset(&h->e2, 0, sizeof(h->e2));
-    h->e2.fill_wait = (uint32_t)geti("BG_E2_FILL_WAIT", 100); h->e2.max_batch = (uint32_t)geti("BG_E2_MAX_BATCH", 64);
+    h->e2.fill_wait = (uint32_t)geti("BG_E2_FILL_WAIT", 200); h->e2.max_batch = (uint32_t)geti("BG_E2_MAX_BATCH", 64);
     h->e2_svc_waves = geti("BG_E2_SVC", 0);
     h->e2_img_valid = false; h->svc = nullptr; h->ev_e2a = h->ev_e2b = nullptr; h->e2_launches = 0;
   }
@@ -930,8 +937,9 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
   if (e == hipSuccess) e = bg_alloc(h, &h->d_seeds, N);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_mask, N);
   if (e == hipSuccess && h->engine == 2) { // the two-kernel engine: request rings (one slot per env and queue: an env has at most one request in flight), answers, images
-    uint32_t lg = 6; while ((1ull << lg) < N) lg++;
-    lg++;   // twice the envs: an env has one request in flight, but a slot is only free again once its reader has been there (a lapped slot is a loud error)
+    // ring entries per queue: the service waves of a queue RESERVE slots ahead of the requests (64 waves x 64 slots at most), and behind them an
+    // env has one request in flight -- twice that, as a power of two (a lapped slot is a loud error, never a wrong env)
+    uint32_t lg = 6; while ((1ull << lg) < 2 * (N + 64 * 64)) lg++;
     h->e2.ring_log = lg;
     e = bg_alloc(h, &h->e2.ctl, 1);
     if (e == hipSuccess) e = bg_alloc(h, &h->e2.ring, (size_t)BG_E2_NQ << lg);

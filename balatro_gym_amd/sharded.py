@@ -56,6 +56,7 @@ class ShardedBalatroVecEnv:
             local_env_factory = BalatroVecEnv
         self.local = local_env_factory(self.hi - self.lo, list(seeds[self.lo:self.hi]), **env_kwargs)
         self._gathered = None
+        self._pad_bytes = None
 
     @property
     def env_index0(self) -> int:
@@ -74,10 +75,15 @@ class ShardedBalatroVecEnv:
     def gather_obs(self) -> torch.Tensor:
         """all_gather of the flat observation buffer -> uint8 [world, shard_bytes] (smaller shards are zero padded)."""
         flat = self.local.obs_flat
-        nbytes = torch.tensor([flat.numel()], dtype=torch.int64, device=flat.device)
-        if self.total_envs % self.world:
-            dist.all_reduce(nbytes, op=dist.ReduceOp.MAX, group=self.group)
-        n = int(nbytes.item())
+        # the padded shard size is a function of the split alone (the first total % world ranks own one env more, and every env has the
+        # same number of observation bytes): computed on the host, once -- a MAX all-reduce + `.item()` here was a host sync per call
+        if self._pad_bytes is None:
+            biggest = max(shard_range(self.total_envs, self.world, r)[1] - shard_range(self.total_envs, self.world, r)[0] for r in range(self.world))
+            flat_bytes = getattr(self.local, "obs_flat_bytes", None)   # (a stand-in env of the CPU tests may size its buffer itself)
+            if flat_bytes is None:
+                from .vec_env import obs_flat_bytes as flat_bytes
+            self._pad_bytes = max(int(flat_bytes(biggest)), flat.numel())
+        n = self._pad_bytes
         if flat.numel() != n:
             buf = torch.zeros(n, dtype=torch.uint8, device=flat.device)
             buf[:flat.numel()] = flat

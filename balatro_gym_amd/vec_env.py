@@ -24,6 +24,15 @@ def _align(n: int, a: int = 256) -> int:
     return (n + a - 1) // a * a
 
 
+def obs_flat_bytes(n: int, steps: int = 1) -> int:
+    """Bytes of the flat observation buffer of `n` envs (every key's array, each aligned like `ObsBuffers` lays them out)."""
+    off = 0
+    for k in nat.OBS_KEYS:
+        dt, shape = nat.OBS_SPEC[k]
+        off = _align(off + n * steps * int(np.prod(shape, dtype=np.int64)) * np.dtype(dt).itemsize)
+    return off
+
+
 class ObsBuffers:
     """The 31 observation arrays as views into ONE flat device byte buffer (one collective gathers all keys)."""
 

@@ -137,6 +137,11 @@ typedef struct bg_rollout_stats {
   uint64_t obs_hash;     /* XOR over (env,t) of a 64-bit hash of each observation row (only with BG_POLICY_HASH_OBS) */
 } bg_rollout_stats;
 
+/* Identity of the device code: sha256 prefix over the sources, compiler flags and compiler version the library was built from
+ * ("unsigned" for ad-hoc builds).  Reproducible across rebuilds of unchanged sources -- the bytes of the code object are not --, so
+ * profiles/*_hbm_traffic.json measurements are keyed on it (bench.py roofline.traffic).  No reference counterpart. */
+const char* bg_build_signature(void);
+
 /* Replaces: constructing n_envs `BalatroEnv` objects (balatro_env_2.py:359-384) + SB3 SubprocVecEnv (hpc_train.py:60-65).
  * max_ante > 0 applies the CurriculumBalatroEnv cap (train_balatro_agent.py:146-152) to every env; bg_set_max_ante changes it
  * later.  Every entry point runs on the handle's device and leaves the caller's current device unchanged. */

@@ -34,6 +34,7 @@ def dump(env, label):
         o, sv = tm[:12].astype(np.float64), tm[16:28].astype(np.float64)
         print(f"   OWNER per iteration (cycles; {o[10]:.0f} iterations, {o[11] / max(o[10], 1):.1f} steps finished per iteration): issue polls {o[0] / o[10]:.0f} cheap {o[1] / o[10]:.0f} post {o[2] / o[10]:.0f} account+copy {o[3] / o[10]:.0f} absorb (wait) {o[4] / o[10]:.0f} entries+issue loads {o[5] / o[10]:.0f}")
         print(f"   OWNER-side service step: entry written -> answer seen {tm[12] / max(tm[14], 1) / 100:.1f} us, answer seen -> absorbed {tm[13] / max(tm[14], 1) / 100:.1f} us ({tm[14]} service steps)")
+        print(f"   SERVICE-side: entry written -> batch started {tm[28] / max(tm[29], 1) * 0.64:.1f} us")
         print(f"   SERVICE per batch (cycles; {sv[10]:.0f} batches of {sv[11] / max(sv[10], 1):.1f}): poll+claim {sv[0] / sv[10]:.0f} entries {sv[1] / sv[10]:.0f} state {sv[2] / sv[10]:.0f} dispatch {sv[3] / sv[10]:.0f} cap+reset {sv[4] / sv[10]:.0f} mask+pack+stores {sv[5] / sv[10]:.0f} record {sv[6] / sv[10]:.0f} drain {sv[7] / sv[10]:.0f} answer {sv[8] / sv[10]:.0f}; FAILED CLAIMS per batch {sv[9] / sv[10]:.2f}")
     print("   MIGRATED waves (owner, service):", w[b + 80:b + 82].tolist())
     print("   per xcc: exits", ex.tolist(), "reasons", why.tolist(), "done seen", dn.tolist(), "min target", tg.tolist())
@@ -42,7 +43,7 @@ def dump(env, label):
 
 def main():
     sizes = [int(a) for a in sys.argv[1:]] or [1024, 4096, 16384, 65536]
-    T = 24
+    T = int(__import__("os").environ.get("T", "24"))
     for n in sizes:
         from tests.test_gpu_parity import _vec
         env = _vec(n, [1000 + i for i in range(n)], autoreset=True, fused_steps=T)
