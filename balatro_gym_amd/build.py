@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bg_lib.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("bg_device.h", "bg_step.h", "bg_tables.h", "bg_ops.h", "bg_sim.h", "bg_engine.h", "bg_engine2.h")] + [
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("bg_device.h", "bg_step.h", "bg_tables.h", "bg_ops.h", "bg_sim.h", "bg_engine.h", "bg_engine2.h", "bg_engine3.h")] + [
     os.path.join(os.path.dirname(HERE), "include", "balatro_mi355x.h")]
 LIB = os.path.join(HERE, "libbalatro_mi355x.so")
 ARCH = "gfx950"

@@ -1,0 +1,330 @@
+// bg_engine3.h -- the step engine with OWNER waves inside the workgroup (packed-record rollouts).
+//
+// What rounds 2-4 measured, put together:
+//   * bg_engine.h (round 2/3): every wave is a worker that pulls batches from LDS queues.  A cheap step (card-select toggle: 84 % of a random
+//     policy's steps) costs an env ~9 k cycles, of which ~4 k are the batch and the rest is waiting for one of five workers and for a copier.
+//   * bg_engine2.h (round 4): cheap steps by OWNER waves (lane = env for the whole launch, no queue, no claim) and service steps by a chip-wide
+//     pool of service waves in a second kernel.  The owner loop is what it should be -- ~2 k cycles of work per iteration for ~13 steps -- but every
+//     hand-over hop between two CUs goes through the L2 / memory at 1.5 - 2.5 us under load, a service step needs eight of them in series
+//     (queue position, entry, state, record, answer, chunks 3 / 4 ...), and the pipeline that hides them adds four owner iterations: 4.5 G
+//     env-steps/s against 6.8 G (profiles/r04_two_kernel_*.txt).
+// This kernel keeps the owner waves and puts the service waves back INTO the workgroup: four owner waves (lane = env: cheap step on the env's LDS
+// image, copy-out of every finished record as whole lines) + three service waves that pull PLAY_HAND / other requests from two LDS queues exactly
+// as bg_engine.h's workers do (same device functions, same queue protocol) and answer through an LDS word per env.  Hand-over = LDS (~100 cycles a
+// hop); the state of an env in HBM is only ever touched from this CU (the memory model of bg_engine.h).
+#pragma once
+
+#ifndef BG_E3_NSV
+#define BG_E3_NSV 3                       // service waves (each owns an RNG window); 4 owners + 3 = seven waves: one SIMD keeps 256 registers for the refill
+#endif
+#define BG_E3_NW (4 + BG_E3_NSV)
+
+template <bool HASH, bool CARDS>
+__global__ __launch_bounds__(BG_E3_NW * BG_BLOCK, 2) void bg_engine3_kernel(BgDev d, EngineArgs a) {
+  constexpr int NE = 256, NSV = BG_E3_NSV, LNE = 8;
+  __shared__ bg_u32x4 s_img[NE][22];
+  __shared__ uint4 s_c34[2][NE];              // hot chunks 3 and 4
+  __shared__ uint32_t s_deck[16][NE];
+  __shared__ unsigned long long s_mask[NE];
+  __shared__ uint32_t s_prod[NE];
+  __shared__ uint32_t s_ans[NE];              // service steps completed for this env in this launch (the owner counts its requests)
+  __shared__ uint32_t s_q[2][NE];             // request rings: env lane | generation of the ring position << 8 | action << 16 | VALID
+  __shared__ __attribute__((aligned(16))) uint32_t s_ctl[8];   // [0..1] requests ever queued per class, [4..5] ever claimed
+  __shared__ uint32_t s_win[NSV][BG_WIN][BG_BLOCK];
+  __shared__ uint2 s_list[4][BG_BLOCK];       // copy-out list of an owner wave: .x = record row, .y = env lane
+  __shared__ bg_u32x4 s_zero;
+  __shared__ uint32_t s_owners_left;
+  __shared__ JTables jt;
+  __builtin_amdgcn_s_setprio(2);
+  bg_tables_load(&jt, d.jtab);
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int env0 = blockIdx.x * NE;
+  const int n_live = d.N - env0 < NE ? d.N - env0 : NE;
+  using DeckT = DeckLdsS<NE, CARDS>;
+  const size_t N = (size_t)d.N;
+  typedef __attribute__((address_space(3))) const char lds_cc;
+  // ---------------------------------------------------------------- prologue: HBM -> LDS, images built, lane = env (bg_engine.h)
+  if (tid < 8) s_ctl[tid] = 0;
+  if (tid == 0) { s_zero = bg_u32x4{0u, 0u, 0u, 0u}; s_owners_left = 4; }
+  if (tid < NE) {
+    const int l = tid, env = env0 + l;
+    s_q[0][l] = 0; s_q[1][l] = 0; s_ans[l] = 0;
+    if (l < n_live) {
+      uint4 c[BG_NHOT];
+#pragma unroll
+      for (int k = 0; k < BG_NHOT; k++) c[k] = d.hot[(size_t)k * N + env];
+      s_c34[0][l] = c[3]; s_c34[1][l] = c[4];
+      DeckT dk; dk.col = (lds_u32*)&s_deck[0][l];
+#pragma unroll
+      for (int k = 0; k < BG_NDECK; k++) bg_deck_set(dk, k, d.deck[(size_t)k * N + env]);
+      const uint32_t prod = d.prod_view ? d.prod_view[env] : 0u;
+      s_prod[l] = prod;
+      Env e;
+      bg_unpack(c, e);
+      bg_derive_ready(e, prod);
+      ShopRegs sr; sr.valid = false;
+      const uint64_t mask = bg_action_mask(d, env, e, sr);
+      s_mask[l] = mask;
+      const ObsPtrs none{};
+      bg_write_obs_impl<false, 3>(d, env, 0, e, dk, none, mask, sr, RowExtra{0.0, 0, 0u}, RowStage{(lds_u4*)&s_img[l][0], nullptr});
+    }
+  }
+  __syncthreads();
+  const uint32_t T = (uint32_t)a.T;
+  if (wave < 4) {
+    // ============================================================== OWNER wave: lane = env for the whole launch
+    const int l = tid, env = env0 + l;
+    const bool live = l < n_live;
+    const uint32_t bmod3 = (uint32_t)(a.env_index0 % 3ull);
+    const uint64_t gi = a.env_index0 + (uint64_t)env;
+    const uint64_t seed_env = a.policy_seed + 0x9E3779B97F4A7C15ull * (gi + 1);
+    const int blind = a.policy == 2 ? 45 + (int)((bmod3 + (uint32_t)env % 3u) % 3u) : 45;
+    lds_u32* const img32 = (lds_u32*)&s_img[l][0];
+    lds_u8* const img8 = (lds_u8*)&s_img[l][0];
+    lds_cc* const imgb = (lds_cc*)&s_img[0][0];
+    const bool whole = a.obs.row_stride == 384u;
+    // per-lane constants of the whole-line copy-out (bg_engine.h, copier): eight records = three rounds of the wave
+    uint32_t rsel[3], cmul[3], cib[3], cgl[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const uint32_t pidx = (uint32_t)j * BG_BLOCK + (uint32_t)lane, rs = (pidx * 2731u) >> 16, c = pidx - 24u * rs;
+      rsel[j] = rs; cgl[j] = 16u * c;
+      cmul[j] = c < 22u ? 16u * 22u : 0u;
+      cib[j] = c < 22u ? 16u * c : (uint32_t)((lds_cc*)&s_zero - imgb);
+    }
+    uint32_t t = 0, nreq = 0;   // steps done; requests posted (the service wave counts them in s_ans)
+    bool waiting = false;
+    uint64_t n_steps = 0, rbits = 0, ohash = 0;
+    uint32_t idle = 0;
+    for (;;) {
+      if (__ballot(live && (t < T || waiting)) == 0ull) break;
+      const size_t row = (size_t)env + (a.obs_stride_steps ? (size_t)t * N : 0);
+      // ---- answers: the service wave has left the finished image, chunks 3 / 4 and the mask in LDS
+      bool fin = false;
+      if (waiting && bg_lds_ld(&s_ans[l]) == nreq) { waiting = false; fin = true; }
+      // ---- the cheap step of every ready env (bg_engine.h: cheap_step)
+      else if (live && !waiting && t < T) {
+        uint64_t mask = s_mask[l];
+        const uint4 c3 = s_c34[0][l];
+        const uint32_t ante = bg_b(c3.x, 0), phase = bg_b(c3.x, 2), discards_left = bg_b(c3.y, 0), nsel0 = bg_b(c3.y, 3);
+        int action;
+        {
+          Env pe; pe.phase = (int)phase; // the policy only looks at the phase and the mask
+          PolicyLane pl; pl.seed_env = seed_env; pl.blind = blind;
+          action = bg_policy_action_fast(pe, mask, a.policy, pl, seed_env + BG_POLICY_PSI * (a.t0 + (uint64_t)t + 1), (lds_JTables*)&jt);
+        }
+        double reward = 0.0;
+        const int64_t chips_scored = (int64_t)(((uint64_t)img32[33] << 32) | img32[32]);
+        const bool valid = action >= 0 && action < 60 && ((mask >> (action & 63)) & 1ull);
+        const bool terminal = ante > 100u || chips_scored > 1000000000ll;   // :619-623, settled by a service wave (it resets the env)
+        if (!terminal && valid && phase == 0u && action >= 2 && action < 10) {
+          // :1052-1058 toggle position `pos` in state.selected_cards (bg_toggle_select on chunk 4)
+          const int pos = action - 2;
+          uint4 c4 = s_c34[1][l];
+          Env te; te.sel = ((uint64_t)c4.w << 32) | c4.z; te.nsel = (int)nsel0;
+          bg_toggle_select(te, pos);
+          c4.z = (uint32_t)te.sel; c4.w = (uint32_t)(te.sel >> 32);
+          s_c34[1][l] = c4;
+          ((lds_u8*)&s_c34[0][l])[7] = (uint8_t)te.nsel;                   // chunk 3, word y, byte 3
+          *(lds_u64*)&img32[2 * pos] = te.nsel > (int)nsel0 ? 1ull : 0ull;  // selected_cards[pos] (int64)
+          if ((te.nsel > 0) != (nsel0 > 0u)) {                             // PLAY_HAND / DISCARD availability (:1436-1441)
+            const uint32_t play = te.nsel > 0 ? 1u : 0u, disc = (te.nsel > 0 && discards_left > 0u) ? 1u : 0u;
+            mask = (mask & ~3ull) | play | ((uint64_t)disc << 1);
+            s_mask[l] = mask;
+            *(__attribute__((address_space(3))) uint16_t*)&img8[BG_ROW_ACTION_MASK] = (uint16_t)(play | (disc << 8));
+          }
+          fin = true;
+        } else if (!terminal && valid && phase == 1u && action == 31 && (int)(int8_t)bg_b(c3.y, 1) <= (int)bg_b(c3.y, 2)) {
+          // :1247-1251 leave the shop; the hand is full, so all that changes is the phase, the mask and the shop rows (:1534-1539)
+          const uint32_t nhand = bg_b(c3.y, 2), ncons = bg_b(c3.z, 1);
+          ((lds_u8*)&s_c34[0][l])[2] = 0;                                   // chunk 3, word x, byte 2: phase = PLAY
+          uint64_t m = (((1ull << (nhand < 8u ? nhand : 8u)) - 1ull) << 2) | (((1ull << ncons) - 1ull) << 10);
+          if (nsel0 > 0u) m |= 1ull | (discards_left > 0u ? 2ull : 0ull);
+          mask = m;
+          s_mask[l] = mask;
+#pragma unroll
+          for (int wq = 0; wq < 15; wq++) img32[44 + wq] = __umul24((uint32_t)(mask >> (4 * wq)) & 0xfu, 0x204081u) & 0x01010101u; // action_mask i8[60]
+#pragma unroll
+          for (int wq = 64; wq < 74; wq++) img32[wq] = 0u;                  // shop_items, shop_costs
+          img8[BG_ROW_PHASE] = 0;
+          fin = true;
+        } else if (!terminal && !valid) { reward = -1.0; fin = true; }    // :626-627 'Invalid action': nothing changes
+        else {
+          // a request: one LDS word (the state is untouched); the service waves poll the tails
+          const int q = (!terminal && phase == 0u && action == 0) ? 0 : 1;
+          const uint32_t slot = __hip_atomic_fetch_add(&s_ctl[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          bg_lds_st(&s_q[q][slot & (NE - 1)], (uint32_t)l | (((slot >> LNE) & 0xffu) << 8) | (((uint32_t)action & 0x7fffu) << 16) | BG_ITEM_VALID);
+          nreq++;
+          waiting = true;
+        }
+        if (fin) {
+          *(__attribute__((address_space(3))) double*)&img32[34] = reward;  // BG_ROW_REWARD
+          img32[43] = (uint32_t)action;                                      // BG_ROW_ACTION
+          img8[BG_ROW_TERMINATED] = 0;
+        }
+      }
+      // ---- accounting + copy-out of every record finished in this iteration (cheap or served): lane <-> 16-byte piece, non-temporal
+      if (fin) {
+        const uint64_t rb = ((uint64_t)img32[35] << 32) | img32[34];
+        if (HASH) ohash ^= bg_hash_image((const lds_u4*)&s_img[l][0]) * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(a.t0 + t)) + gi;
+        n_steps++;
+        rbits ^= rb * (2 * (uint64_t)(a.t0 + t) + 1);
+        t++;
+      }
+      const unsigned long long fm = __ballot(fin);
+      if (fm) {
+        idle = 0;
+        const uint32_t nb = (uint32_t)__popcll(fm);
+        if (fin) s_list[wave][__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = make_uint2((uint32_t)row, (uint32_t)l);
+        BG_WAVE_SYNC();
+        typedef uint32_t bg_u32x2 __attribute__((ext_vector_type(2)));
+        lds_cc* const lsb = (lds_cc*)&s_list[wave][0];
+        if (whole) {
+          for (uint32_t g0 = 0; g0 < nb; g0 += 16u) {
+            bg_u32x2 ce[2][3];
+            bg_u32x4 v[2][3];
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+              for (int j = 0; j < 3; j++)
+                ce[u][j] = *(__attribute__((address_space(3))) const bg_u32x2*)(lsb + (((g0 + 8u * (uint32_t)u + rsel[j]) & 63u) << 3));
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+              for (int j = 0; j < 3; j++)
+                v[u][j] = *(__attribute__((address_space(3))) const bg_u32x4*)(imgb + __umul24(ce[u][j].y & 0xffu, cmul[j]) + cib[j]);
+#pragma unroll
+            for (int u = 0; u < 2; u++)
+#pragma unroll
+              for (int j = 0; j < 3; j++)
+                if (g0 + 8u * (uint32_t)u + rsel[j] < nb)
+                  __builtin_nontemporal_store(v[u][j], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)ce[u][j].x * 384u + cgl[j])));
+          }
+        } else {
+          const uint32_t total = 22u * nb;
+          for (uint32_t q0 = (uint32_t)lane; q0 < total; q0 += 4u * BG_BLOCK) {
+            bg_u32x2 ce[4]; uint32_t cpc[4]; bg_u32x4 v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+              const uint32_t q = q0 + (uint32_t)k * BG_BLOCK, r = (q * 2979u) >> 16;   // q / 22 (exact below 8 000)
+              cpc[k] = q - 22u * r;
+              ce[k] = *(__attribute__((address_space(3))) const bg_u32x2*)(lsb + ((r < nb ? r : 0u) << 3));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = s_img[ce[k].y & 0xffu][cpc[k]];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+              if (q0 + (uint32_t)k * BG_BLOCK < total)
+                __builtin_nontemporal_store(v[k], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + (size_t)ce[k].x * (size_t)a.obs.row_stride + 16u * cpc[k]));
+          }
+        }
+        BG_WAVE_SYNC();   // the images have been read (a wave's LDS operations complete in order): the next iteration may patch them
+      } else {
+        __builtin_amdgcn_s_sleep(2);   // every env of the wave is with a service wave
+        if (++idle > BG_SPIN_LIMIT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
+      }
+    }
+    if (lane == 0) __hip_atomic_fetch_sub(&s_owners_left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (a.stats) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { n_steps += __shfl_down(n_steps, off); rbits ^= __shfl_down(rbits, off); ohash ^= __shfl_down(ohash, off); }
+      if (lane == 0) {
+        atomicAdd((unsigned long long*)&a.stats->steps, (unsigned long long)n_steps);
+        atomicXor((unsigned long long*)&a.stats->reward_bits, (unsigned long long)rbits);
+        atomicXor((unsigned long long*)&a.stats->obs_hash, (unsigned long long)ohash);
+      }
+    }
+  } else {
+    // ============================================================== SERVICE wave: batches from the two request queues (bg_engine.h's service batch)
+    __builtin_amdgcn_s_setprio(3);
+    const int sidx = wave - 4;
+    uint64_t n_eps = 0, n_plays = 0;
+    int64_t ssum = 0;
+    uint32_t polls = 0;
+    for (;;) {
+      // heads first, then tails (bg_engine.h: a tail older than its head reads as four billion items)
+      asm volatile("" ::: "memory");
+      const bg_u32x4 ch = *(volatile __attribute__((address_space(3))) bg_u32x4*)&s_ctl[4];
+      asm volatile("" ::: "memory");
+      const bg_u32x4 ct = *(volatile __attribute__((address_space(3))) bg_u32x4*)&s_ctl[0];
+      asm volatile("" ::: "memory");
+      const uint32_t hp = __builtin_amdgcn_readfirstlane(ch.x), ho = __builtin_amdgcn_readfirstlane(ch.y);
+      auto queued = [&](uint32_t tail, uint32_t head) -> uint32_t { const uint32_t k = tail - head; return k <= (uint32_t)NE ? k : 0u; };
+      const uint32_t np = queued(__builtin_amdgcn_readfirstlane(ct.x), hp), no = queued(__builtin_amdgcn_readfirstlane(ct.y), ho);
+      if ((np | no) == 0u) {
+        if (__builtin_amdgcn_readfirstlane(bg_lds_ld(&s_owners_left)) == 0u) break;   // every owner wave is through: nothing can arrive any more
+        __builtin_amdgcn_s_sleep(2);
+        if (++polls > BG_SPIN_LIMIT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
+        continue;
+      }
+      const int cls = np >= no ? 0 : 1;   // the fuller queue (plays on a tie: the longer chains)
+      const uint32_t head = cls ? ho : hp, navail = cls ? no : np;
+      const uint32_t nb = navail > BG_BLOCK ? BG_BLOCK : navail;
+      uint32_t item = 0;
+      uint32_t* const slotp = &s_q[cls][(head + (uint32_t)lane) & (NE - 1)];
+      {
+        uint32_t got = 0;
+        if ((uint32_t)lane < nb) item = bg_lds_ld(slotp);
+        if (lane == 0) got = atomicCAS(&s_ctl[4 + cls], head, head + nb) == head ? 1u : 0u;
+        if (__builtin_amdgcn_readfirstlane(got) == 0u) continue;
+      }
+      polls = 0;
+      if ((uint32_t)lane < nb) {
+        uint32_t spin = 0;
+        const uint32_t want = BG_ITEM_VALID | ((((head + (uint32_t)lane) >> LNE) & 0xffu) << 8);
+        while ((item & (BG_ITEM_VALID | 0xff00u)) != want && ++spin < BG_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); item = bg_lds_ld(slotp); }
+        if ((item & (BG_ITEM_VALID | 0xff00u)) != want) atomicOr(d.err, BG_DEVERR_SPIN);
+        else {
+          const int l = (int)(item & 0xffu), env = env0 + l;
+          const int action = (int)((item >> 16) & 0x7fffu);
+          uint64_t mask = s_mask[l];
+          BG_PROBE_BEGIN();
+          uint4 c[BG_NHOT];
+#pragma unroll
+          for (int k = 0; k < BG_NHOT; k++) if (k != 3 && k != 4) c[k] = d.hot[(size_t)k * N + env];
+          c[3] = s_c34[0][l]; c[4] = s_c34[1][l];
+          Env e;
+          bg_unpack(c, e);
+          bg_derive_ready(e, s_prod[l]);
+          DeckT dk; dk.col = (lds_u32*)&s_deck[0][l];
+          ShopRegs sr; sr.valid = false;
+          RngWin w;
+          bg_win_init(w, &s_win[sidx][0][lane], &jt);
+          StepOut o;
+          bg_step_init(o);
+          o.bd_dst = nullptr;
+          if (bg_step_guards(e, mask, action, o)) bg_env_dispatch(d, env, e, w, sr, dk, action, o);
+          if (e.max_ante > 0 && e.ante > e.max_ante) { o.terminated = true; o.flags |= 256; }
+          if (o.terminated) n_eps++;
+          if (o.terminated && a.autoreset) bg_env_reset(d, env, e, dk);
+          if constexpr (CARDS) bg_vm_drain(); // card states / lazy streams in HBM are edited from any service wave: let the stores land
+          mask = bg_action_mask(d, env, e, sr);
+          bg_write_obs_impl<false, 3>(d, env, 0, e, dk, a.obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u}, RowStage{(lds_u4*)&s_img[l][0], nullptr});
+          bg_pack(e, c);
+#pragma unroll
+          for (int k = 0; k < BG_NHOT; k++) if (k != 3 && k != 4) d.hot[(size_t)k * N + env] = c[k];
+          s_c34[0][l] = c[3]; s_c34[1][l] = c[4];
+          s_mask[l] = mask;
+          if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
+          // the answer, behind everything above (one wave's LDS operations execute in program order)
+          bg_lds_st(&s_ans[l], bg_lds_ld(&s_ans[l]) + 1u);
+        }
+      }
+    }
+    if (a.stats) {
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) { n_eps += __shfl_down(n_eps, off); n_plays += __shfl_down(n_plays, off); ssum += __shfl_down(ssum, off); }
+      if (lane == 0 && (n_eps | n_plays)) {
+        atomicAdd((unsigned long long*)&a.stats->episodes, (unsigned long long)n_eps);
+        atomicAdd((unsigned long long*)&a.stats->plays, (unsigned long long)n_plays);
+        atomicAdd((unsigned long long*)&a.stats->score_sum, (unsigned long long)ssum);
+      }
+    }
+  }
+  // ---------------------------------------------------------------- epilogue: chunks 3 / 4 -> HBM
+  __syncthreads();
+  if (tid < n_live) {
+    d.hot[(size_t)3 * N + env0 + tid] = s_c34[0][tid];
+    d.hot[(size_t)4 * N + env0 + tid] = s_c34[1][tid];
+  }
+}

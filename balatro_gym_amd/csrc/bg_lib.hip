@@ -51,6 +51,7 @@ __device__ __forceinline__ void bg_emit_info(size_t row, const StepOut& o, uint8
 }
 
 #include "bg_engine.h" // the step engine: one kernel behind bg_step / bg_step_many / bg_rollout / bg_rollout_rows
+#include "bg_engine3.h" // owner waves + service waves in ONE workgroup (packed-record rollouts)
 #include "bg_engine2.h" // the same engine as two cooperating kernels (owner waves + a chip-wide pool of service waves): packed-record rollouts
 
 template <bool CARDS>
@@ -857,7 +858,7 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
     h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0); h->eng_copiers = geti("BG_ENG_COPIERS", 2); if (h->eng_copiers < 1 || h->eng_copiers > 3) h->eng_copiers = 2;
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
-    h->engine = geti("BG_ENGINE", 2); if (h->engine != 1) h->engine = 2;
+    h->engine = geti("BG_ENGINE", 3); if (h->engine < 1 || h->engine > 3) h->engine = 3;
     memset(&h->e2, 0, sizeof(h->e2));
     h->e2.fill_wait = (uint32_t)geti("BG_E2_FILL_WAIT", 200); h->e2.max_batch = (uint32_t)geti("BG_E2_MAX_BATCH", 64);
     h->e2_svc_waves = geti("BG_E2_SVC", 0);
@@ -1254,6 +1255,15 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
   const bool cards = h->dev.cstate != nullptr;
   EngineArgs a = a0;
   if (bg_engine2_ok(h, a, info)) { if (bg_engine2_launch(h, dv, a, hash, st) != 0) h->err = "two-kernel engine: " + h->err; return; }
+  if (h->engine == 3 && a.obs.rows && !info && !a.actions_in && !a.reward && !a.term && !a.actions_out) { // packed-record rollouts: owner waves + service waves (bg_engine3.h)
+    h->e2_img_valid = false;
+    const dim3 g3((h->dev.N + 255) / 256), b3(BG_E3_NW * BG_BLOCK);
+    if (hash && cards) hipLaunchKernelGGL((bg_engine3_kernel<true, true>), g3, b3, 0, st, dv, a);
+    else if (hash) hipLaunchKernelGGL((bg_engine3_kernel<true, false>), g3, b3, 0, st, dv, a);
+    else if (cards) hipLaunchKernelGGL((bg_engine3_kernel<false, true>), g3, b3, 0, st, dv, a);
+    else hipLaunchKernelGGL((bg_engine3_kernel<false, false>), g3, b3, 0, st, dv, a);
+    return;
+  }
   h->e2_img_valid = false;
   a.n_waves = (uint32_t)bg_engine_waves(h, (int)a.T);
   // packed records: one more wave, the COPIER (bg_engine.h), takes the record copy-out off the workers; with the seven-wave shape that
