@@ -14,24 +14,32 @@
 // hop); the state of an env in HBM is only ever touched from this CU (the memory model of bg_engine.h).
 #pragma once
 
-#ifndef BG_E3_NSV
-#define BG_E3_NSV 3                       // service waves (each owns an RNG window); 4 owners + 3 = seven waves: one SIMD keeps 256 registers for the refill
+#ifdef BG_E3_TIMING   // development: cycle sums into d.dbg (tools/e3_timing.py)
+#define E3T_DECL() unsigned long long e3t_[8] = {0,0,0,0,0,0,0,0}, e3t0_ = __builtin_readcyclecounter()
+#define E3T(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); e3t_[k] += n_ - e3t0_; e3t0_ = n_; } while (0)
+#define E3T_CNT(k, v) do { e3t_[k] += (v); } while (0)
+#define E3T_FLUSH(base) do { if (lane == 0 && d.dbg) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&d.dbg[(base) + k_], e3t_[k_]); } while (0)
+#else
+#define E3T_DECL() do {} while (0)
+#define E3T(k) do {} while (0)
+#define E3T_CNT(k, v) do {} while (0)
+#define E3T_FLUSH(base) do {} while (0)
 #endif
-#define BG_E3_NW (4 + BG_E3_NSV)
 
-template <bool HASH, bool CARDS>
-__global__ __launch_bounds__(BG_E3_NW * BG_BLOCK, 2) void bg_engine3_kernel(BgDev d, EngineArgs a) {
-  constexpr int NE = 256, NSV = BG_E3_NSV, LNE = 8;
+// NOW owner waves (each owns 256 / NOW envs: 4 / NOW slices of 64, lane = env of a slice) + NSV service waves.
+template <bool HASH, bool CARDS, int NOW, int NSV>
+__global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(BgDev d, EngineArgs a) {
+  constexpr int NE = 256, LNE = 8, KS = 4 / NOW;
+  static_assert(NOW == 1 || NOW == 2 || NOW == 4, "owner waves");
   __shared__ bg_u32x4 s_img[NE][22];
   __shared__ uint4 s_c34[2][NE];              // hot chunks 3 and 4
-  __shared__ uint32_t s_deck[16][NE];
   __shared__ unsigned long long s_mask[NE];
   __shared__ uint32_t s_prod[NE];
   __shared__ uint32_t s_ans[NE];              // service steps completed for this env in this launch (the owner counts its requests)
   __shared__ uint32_t s_q[2][NE];             // request rings: env lane | generation of the ring position << 8 | action << 16 | VALID
   __shared__ __attribute__((aligned(16))) uint32_t s_ctl[8];   // [0..1] requests ever queued per class, [4..5] ever claimed
   __shared__ uint32_t s_win[NSV][BG_WIN][BG_BLOCK];
-  __shared__ uint2 s_list[4][BG_BLOCK];       // copy-out list of an owner wave: .x = record row, .y = env lane
+  __shared__ uint2 s_list[NOW][KS * BG_BLOCK]; // copy-out list of an owner wave: .x = record row, .y = env lane
   __shared__ bg_u32x4 s_zero;
   __shared__ uint32_t s_owners_left;
   __shared__ JTables jt;
@@ -40,23 +48,22 @@ __global__ __launch_bounds__(BG_E3_NW * BG_BLOCK, 2) void bg_engine3_kernel(BgDe
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int env0 = blockIdx.x * NE;
   const int n_live = d.N - env0 < NE ? d.N - env0 : NE;
-  using DeckT = DeckLdsS<NE, CARDS>;
+  // (decks stay in HBM: the first 16 cards -- every index a hand normally holds -- ride in two registers of the service lane, bg_device.h Deck0)
+  using DeckT = typename std::conditional<CARDS, Deck0C, Deck0>::type;
   const size_t N = (size_t)d.N;
   typedef __attribute__((address_space(3))) const char lds_cc;
   // ---------------------------------------------------------------- prologue: HBM -> LDS, images built, lane = env (bg_engine.h)
   if (tid < 8) s_ctl[tid] = 0;
-  if (tid == 0) { s_zero = bg_u32x4{0u, 0u, 0u, 0u}; s_owners_left = 4; }
-  if (tid < NE) {
-    const int l = tid, env = env0 + l;
+  if (tid == 0) { s_zero = bg_u32x4{0u, 0u, 0u, 0u}; s_owners_left = NOW; }
+  for (int l = tid; l < NE; l += (NOW + NSV) * BG_BLOCK) {
+    const int env = env0 + l;
     s_q[0][l] = 0; s_q[1][l] = 0; s_ans[l] = 0;
     if (l < n_live) {
       uint4 c[BG_NHOT];
 #pragma unroll
       for (int k = 0; k < BG_NHOT; k++) c[k] = d.hot[(size_t)k * N + env];
       s_c34[0][l] = c[3]; s_c34[1][l] = c[4];
-      DeckT dk; dk.col = (lds_u32*)&s_deck[0][l];
-#pragma unroll
-      for (int k = 0; k < BG_NDECK; k++) bg_deck_set(dk, k, d.deck[(size_t)k * N + env]);
+      DeckT dk; static_cast<Deck0&>(dk) = bg_load_deck0(d, env);
       const uint32_t prod = d.prod_view ? d.prod_view[env] : 0u;
       s_prod[l] = prod;
       Env e;
@@ -71,16 +78,12 @@ __global__ __launch_bounds__(BG_E3_NW * BG_BLOCK, 2) void bg_engine3_kernel(BgDe
   }
   __syncthreads();
   const uint32_t T = (uint32_t)a.T;
-  if (wave < 4) {
-    // ============================================================== OWNER wave: lane = env for the whole launch
-    const int l = tid, env = env0 + l;
-    const bool live = l < n_live;
+  if (wave < NOW) {
+    // ============================================================== OWNER wave: lane = env of each of its KS slices, for the whole launch
+#ifdef BG_E3_OPRIO
+    __builtin_amdgcn_s_setprio(BG_E3_OPRIO);
+#endif
     const uint32_t bmod3 = (uint32_t)(a.env_index0 % 3ull);
-    const uint64_t gi = a.env_index0 + (uint64_t)env;
-    const uint64_t seed_env = a.policy_seed + 0x9E3779B97F4A7C15ull * (gi + 1);
-    const int blind = a.policy == 2 ? 45 + (int)((bmod3 + (uint32_t)env % 3u) % 3u) : 45;
-    lds_u32* const img32 = (lds_u32*)&s_img[l][0];
-    lds_u8* const img8 = (lds_u8*)&s_img[l][0];
     lds_cc* const imgb = (lds_cc*)&s_img[0][0];
     const bool whole = a.obs.row_stride == 384u;
     // per-lane constants of the whole-line copy-out (bg_engine.h, copier): eight records = three rounds of the wave
@@ -92,109 +95,128 @@ __global__ __launch_bounds__(BG_E3_NW * BG_BLOCK, 2) void bg_engine3_kernel(BgDe
       cmul[j] = c < 22u ? 16u * 22u : 0u;
       cib[j] = c < 22u ? 16u * c : (uint32_t)((lds_cc*)&s_zero - imgb);
     }
-    uint32_t t = 0, nreq = 0;   // steps done; requests posted (the service wave counts them in s_ans)
-    bool waiting = false;
+    uint32_t t[KS], nreq[KS];   // per slice: steps done; requests posted (the service wave counts them in s_ans)
+    bool waiting[KS];
+#pragma unroll
+    for (int s = 0; s < KS; s++) { t[s] = 0; nreq[s] = 0; waiting[s] = false; }
     uint64_t n_steps = 0, rbits = 0, ohash = 0;
     uint32_t idle = 0;
+    E3T_DECL();
     for (;;) {
-      if (__ballot(live && (t < T || waiting)) == 0ull) break;
-      const size_t row = (size_t)env + (a.obs_stride_steps ? (size_t)t * N : 0);
-      // ---- answers: the service wave has left the finished image, chunks 3 / 4 and the mask in LDS
-      bool fin = false;
-      if (waiting && bg_lds_ld(&s_ans[l]) == nreq) { waiting = false; fin = true; }
-      // ---- the cheap step of every ready env (bg_engine.h: cheap_step)
-      else if (live && !waiting && t < T) {
-        uint64_t mask = s_mask[l];
-        const uint4 c3 = s_c34[0][l];
-        const uint32_t ante = bg_b(c3.x, 0), phase = bg_b(c3.x, 2), discards_left = bg_b(c3.y, 0), nsel0 = bg_b(c3.y, 3);
-        int action;
-        {
-          Env pe; pe.phase = (int)phase; // the policy only looks at the phase and the mask
-          PolicyLane pl; pl.seed_env = seed_env; pl.blind = blind;
-          action = bg_policy_action_fast(pe, mask, a.policy, pl, seed_env + BG_POLICY_PSI * (a.t0 + (uint64_t)t + 1), (lds_JTables*)&jt);
-        }
-        double reward = 0.0;
-        const int64_t chips_scored = (int64_t)(((uint64_t)img32[33] << 32) | img32[32]);
-        const bool valid = action >= 0 && action < 60 && ((mask >> (action & 63)) & 1ull);
-        const bool terminal = ante > 100u || chips_scored > 1000000000ll;   // :619-623, settled by a service wave (it resets the env)
-        if (!terminal && valid && phase == 0u && action >= 2 && action < 10) {
-          // :1052-1058 toggle position `pos` in state.selected_cards (bg_toggle_select on chunk 4)
-          const int pos = action - 2;
-          uint4 c4 = s_c34[1][l];
-          Env te; te.sel = ((uint64_t)c4.w << 32) | c4.z; te.nsel = (int)nsel0;
-          bg_toggle_select(te, pos);
-          c4.z = (uint32_t)te.sel; c4.w = (uint32_t)(te.sel >> 32);
-          s_c34[1][l] = c4;
-          ((lds_u8*)&s_c34[0][l])[7] = (uint8_t)te.nsel;                   // chunk 3, word y, byte 3
-          *(lds_u64*)&img32[2 * pos] = te.nsel > (int)nsel0 ? 1ull : 0ull;  // selected_cards[pos] (int64)
-          if ((te.nsel > 0) != (nsel0 > 0u)) {                             // PLAY_HAND / DISCARD availability (:1436-1441)
-            const uint32_t play = te.nsel > 0 ? 1u : 0u, disc = (te.nsel > 0 && discards_left > 0u) ? 1u : 0u;
-            mask = (mask & ~3ull) | play | ((uint64_t)disc << 1);
-            s_mask[l] = mask;
-            *(__attribute__((address_space(3))) uint16_t*)&img8[BG_ROW_ACTION_MASK] = (uint16_t)(play | (disc << 8));
+      bool busy = false;
+#pragma unroll
+      for (int s = 0; s < KS; s++) busy = busy || ((wave * KS + s) * BG_BLOCK + lane < n_live && (t[s] < T || waiting[s]));
+      if (__ballot(busy) == 0ull) break;
+      E3T_CNT(4, 1);
+      uint32_t nb = 0;   // records finished in this iteration (all slices): the copy-out list
+#pragma unroll
+      for (int s = 0; s < KS; s++) {
+        const int l = (wave * KS + s) * BG_BLOCK + lane, env = env0 + l;
+        const bool live = l < n_live;
+        lds_u32* const img32 = (lds_u32*)&s_img[l][0];
+        lds_u8* const img8 = (lds_u8*)&s_img[l][0];
+        const size_t row = (size_t)env + (a.obs_stride_steps ? (size_t)t[s] * N : 0);
+        // ---- answers: the service wave has left the finished image, chunks 3 / 4 and the mask in LDS
+        bool fin = false;
+        if (waiting[s] && bg_lds_ld(&s_ans[l]) == nreq[s]) { waiting[s] = false; fin = true; }
+        // ---- the cheap step of every ready env (bg_engine.h: cheap_step)
+        else if (live && !waiting[s] && t[s] < T) {
+          uint64_t mask = s_mask[l];
+          const uint4 c3 = s_c34[0][l];
+          const uint32_t ante = bg_b(c3.x, 0), phase = bg_b(c3.x, 2), discards_left = bg_b(c3.y, 0), nsel0 = bg_b(c3.y, 3);
+          int action;
+          {
+            const uint64_t gi0 = a.env_index0 + (uint64_t)env;
+            Env pe; pe.phase = (int)phase; // the policy only looks at the phase and the mask
+            PolicyLane pl; pl.seed_env = a.policy_seed + 0x9E3779B97F4A7C15ull * (gi0 + 1);
+            pl.blind = a.policy == 2 ? 45 + (int)((bmod3 + (uint32_t)env % 3u) % 3u) : 45;
+            action = bg_policy_action_fast(pe, mask, a.policy, pl, pl.seed_env + BG_POLICY_PSI * (a.t0 + (uint64_t)t[s] + 1), (lds_JTables*)&jt);
           }
-          fin = true;
-        } else if (!terminal && valid && phase == 1u && action == 31 && (int)(int8_t)bg_b(c3.y, 1) <= (int)bg_b(c3.y, 2)) {
-          // :1247-1251 leave the shop; the hand is full, so all that changes is the phase, the mask and the shop rows (:1534-1539)
-          const uint32_t nhand = bg_b(c3.y, 2), ncons = bg_b(c3.z, 1);
-          ((lds_u8*)&s_c34[0][l])[2] = 0;                                   // chunk 3, word x, byte 2: phase = PLAY
-          uint64_t m = (((1ull << (nhand < 8u ? nhand : 8u)) - 1ull) << 2) | (((1ull << ncons) - 1ull) << 10);
-          if (nsel0 > 0u) m |= 1ull | (discards_left > 0u ? 2ull : 0ull);
-          mask = m;
-          s_mask[l] = mask;
+          double reward = 0.0;
+          const int64_t chips_scored = (int64_t)(((uint64_t)img32[33] << 32) | img32[32]);
+          const bool valid = action >= 0 && action < 60 && ((mask >> (action & 63)) & 1ull);
+          const bool terminal = ante > 100u || chips_scored > 1000000000ll;   // :619-623, settled by a service wave (it resets the env)
+          if (!terminal && valid && phase == 0u && action >= 2 && action < 10) {
+            // :1052-1058 toggle position `pos` in state.selected_cards (bg_toggle_select on chunk 4)
+            const int pos = action - 2;
+            uint4 c4 = s_c34[1][l];
+            Env te; te.sel = ((uint64_t)c4.w << 32) | c4.z; te.nsel = (int)nsel0;
+            bg_toggle_select(te, pos);
+            c4.z = (uint32_t)te.sel; c4.w = (uint32_t)(te.sel >> 32);
+            s_c34[1][l] = c4;
+            ((lds_u8*)&s_c34[0][l])[7] = (uint8_t)te.nsel;                   // chunk 3, word y, byte 3
+            *(lds_u64*)&img32[2 * pos] = te.nsel > (int)nsel0 ? 1ull : 0ull;  // selected_cards[pos] (int64)
+            if ((te.nsel > 0) != (nsel0 > 0u)) {                             // PLAY_HAND / DISCARD availability (:1436-1441)
+              const uint32_t play = te.nsel > 0 ? 1u : 0u, disc = (te.nsel > 0 && discards_left > 0u) ? 1u : 0u;
+              mask = (mask & ~3ull) | play | ((uint64_t)disc << 1);
+              s_mask[l] = mask;
+              *(__attribute__((address_space(3))) uint16_t*)&img8[BG_ROW_ACTION_MASK] = (uint16_t)(play | (disc << 8));
+            }
+            fin = true;
+          } else if (!terminal && valid && phase == 1u && action == 31 && (int)(int8_t)bg_b(c3.y, 1) <= (int)bg_b(c3.y, 2)) {
+            // :1247-1251 leave the shop; the hand is full, so all that changes is the phase, the mask and the shop rows (:1534-1539)
+            const uint32_t nhand = bg_b(c3.y, 2), ncons = bg_b(c3.z, 1);
+            ((lds_u8*)&s_c34[0][l])[2] = 0;                                   // chunk 3, word x, byte 2: phase = PLAY
+            uint64_t m = (((1ull << (nhand < 8u ? nhand : 8u)) - 1ull) << 2) | (((1ull << ncons) - 1ull) << 10);
+            if (nsel0 > 0u) m |= 1ull | (discards_left > 0u ? 2ull : 0ull);
+            mask = m;
+            s_mask[l] = mask;
 #pragma unroll
-          for (int wq = 0; wq < 15; wq++) img32[44 + wq] = __umul24((uint32_t)(mask >> (4 * wq)) & 0xfu, 0x204081u) & 0x01010101u; // action_mask i8[60]
+            for (int wq = 0; wq < 15; wq++) img32[44 + wq] = __umul24((uint32_t)(mask >> (4 * wq)) & 0xfu, 0x204081u) & 0x01010101u; // action_mask i8[60]
 #pragma unroll
-          for (int wq = 64; wq < 74; wq++) img32[wq] = 0u;                  // shop_items, shop_costs
-          img8[BG_ROW_PHASE] = 0;
-          fin = true;
-        } else if (!terminal && !valid) { reward = -1.0; fin = true; }    // :626-627 'Invalid action': nothing changes
-        else {
-          // a request: one LDS word (the state is untouched); the service waves poll the tails
-          const int q = (!terminal && phase == 0u && action == 0) ? 0 : 1;
-          const uint32_t slot = __hip_atomic_fetch_add(&s_ctl[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-          bg_lds_st(&s_q[q][slot & (NE - 1)], (uint32_t)l | (((slot >> LNE) & 0xffu) << 8) | (((uint32_t)action & 0x7fffu) << 16) | BG_ITEM_VALID);
-          nreq++;
-          waiting = true;
+            for (int wq = 64; wq < 74; wq++) img32[wq] = 0u;                  // shop_items, shop_costs
+            img8[BG_ROW_PHASE] = 0;
+            fin = true;
+          } else if (!terminal && !valid) { reward = -1.0; fin = true; }    // :626-627 'Invalid action': nothing changes
+          else {
+            // a request: one LDS word (the state is untouched); the service waves poll the tails
+            const int q = (!terminal && phase == 0u && action == 0) ? 0 : 1;
+            const uint32_t slot = __hip_atomic_fetch_add(&s_ctl[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            bg_lds_st(&s_q[q][slot & (NE - 1)], (uint32_t)l | (((slot >> LNE) & 0xffu) << 8) | (((uint32_t)action & 0x7fffu) << 16) | BG_ITEM_VALID);
+            nreq[s]++;
+            waiting[s] = true;
+          }
+          if (fin) {
+            *(__attribute__((address_space(3))) double*)&img32[34] = reward;  // BG_ROW_REWARD
+            img32[43] = (uint32_t)action;                                      // BG_ROW_ACTION
+            img8[BG_ROW_TERMINATED] = 0;
+          }
         }
+        // ---- accounting of every record finished in this iteration (cheap or served), and its place in the copy-out list
         if (fin) {
-          *(__attribute__((address_space(3))) double*)&img32[34] = reward;  // BG_ROW_REWARD
-          img32[43] = (uint32_t)action;                                      // BG_ROW_ACTION
-          img8[BG_ROW_TERMINATED] = 0;
+          const uint64_t rb = ((uint64_t)img32[35] << 32) | img32[34];
+          if (HASH) ohash ^= bg_hash_image((const lds_u4*)&s_img[l][0]) * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(a.t0 + t[s])) + (a.env_index0 + (uint64_t)env);
+          n_steps++;
+          rbits ^= rb * (2 * (uint64_t)(a.t0 + t[s]) + 1);
+          t[s]++;
         }
+        const unsigned long long fms = __ballot(fin);
+        if (fin) s_list[wave][nb + __builtin_amdgcn_mbcnt_hi((uint32_t)(fms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fms, 0u))] = make_uint2((uint32_t)row, (uint32_t)l);
+        nb += (uint32_t)__popcll(fms);
       }
-      // ---- accounting + copy-out of every record finished in this iteration (cheap or served): lane <-> 16-byte piece, non-temporal
-      if (fin) {
-        const uint64_t rb = ((uint64_t)img32[35] << 32) | img32[34];
-        if (HASH) ohash ^= bg_hash_image((const lds_u4*)&s_img[l][0]) * (0x9E3779B97F4A7C15ull + 2 * (uint64_t)(a.t0 + t)) + gi;
-        n_steps++;
-        rbits ^= rb * (2 * (uint64_t)(a.t0 + t) + 1);
-        t++;
-      }
-      const unsigned long long fm = __ballot(fin);
-      if (fm) {
+      E3T(0);
+      // ---- copy-out: lane <-> 16-byte piece, non-temporal (32 records per round of loads: the LDS round trips overlap)
+      if (nb) {
         idle = 0;
-        const uint32_t nb = (uint32_t)__popcll(fm);
-        if (fin) s_list[wave][__builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0u))] = make_uint2((uint32_t)row, (uint32_t)l);
         BG_WAVE_SYNC();
         typedef uint32_t bg_u32x2 __attribute__((ext_vector_type(2)));
         lds_cc* const lsb = (lds_cc*)&s_list[wave][0];
         if (whole) {
-          for (uint32_t g0 = 0; g0 < nb; g0 += 16u) {
-            bg_u32x2 ce[2][3];
-            bg_u32x4 v[2][3];
+          for (uint32_t g0 = 0; g0 < nb; g0 += 32u) {
+            bg_u32x2 ce[4][3];
+            bg_u32x4 v[4][3];
 #pragma unroll
-            for (int u = 0; u < 2; u++)
+            for (int u = 0; u < 4; u++)
 #pragma unroll
               for (int j = 0; j < 3; j++)
-                ce[u][j] = *(__attribute__((address_space(3))) const bg_u32x2*)(lsb + (((g0 + 8u * (uint32_t)u + rsel[j]) & 63u) << 3));
+                ce[u][j] = *(__attribute__((address_space(3))) const bg_u32x2*)(lsb + (((g0 + 8u * (uint32_t)u + rsel[j]) & (KS * BG_BLOCK - 1u)) << 3));
 #pragma unroll
-            for (int u = 0; u < 2; u++)
+            for (int u = 0; u < 4; u++)
 #pragma unroll
               for (int j = 0; j < 3; j++)
                 v[u][j] = *(__attribute__((address_space(3))) const bg_u32x4*)(imgb + __umul24(ce[u][j].y & 0xffu, cmul[j]) + cib[j]);
 #pragma unroll
-            for (int u = 0; u < 2; u++)
+            for (int u = 0; u < 4; u++)
 #pragma unroll
               for (int j = 0; j < 3; j++)
                 if (g0 + 8u * (uint32_t)u + rsel[j] < nb)
@@ -219,11 +241,14 @@ __global__ __launch_bounds__(BG_E3_NW * BG_BLOCK, 2) void bg_engine3_kernel(BgDe
           }
         }
         BG_WAVE_SYNC();   // the images have been read (a wave's LDS operations complete in order): the next iteration may patch them
+        E3T(1); E3T_CNT(5, nb);
       } else {
         __builtin_amdgcn_s_sleep(2);   // every env of the wave is with a service wave
         if (++idle > BG_SPIN_LIMIT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
+        E3T(2);
       }
     }
+    E3T_FLUSH(0);
     if (lane == 0) __hip_atomic_fetch_sub(&s_owners_left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (a.stats) {
 #pragma unroll
@@ -237,10 +262,13 @@ __global__ __launch_bounds__(BG_E3_NW * BG_BLOCK, 2) void bg_engine3_kernel(BgDe
   } else {
     // ============================================================== SERVICE wave: batches from the two request queues (bg_engine.h's service batch)
     __builtin_amdgcn_s_setprio(3);
-    const int sidx = wave - 4;
+    const int sidx = wave - NOW;
     uint64_t n_eps = 0, n_plays = 0;
     int64_t ssum = 0;
     uint32_t polls = 0;
+    bool seen = false;
+    unsigned long long t_seen = 0;
+    E3T_DECL();
     for (;;) {
       // heads first, then tails (bg_engine.h: a tail older than its head reads as four billion items)
       asm volatile("" ::: "memory");
@@ -257,7 +285,18 @@ __global__ __launch_bounds__(BG_E3_NW * BG_BLOCK, 2) void bg_engine3_kernel(BgDe
         if (++polls > BG_SPIN_LIMIT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
         continue;
       }
-      const int cls = np >= no ? 0 : 1;   // the fuller queue (plays on a tie: the longer chains)
+      // A batch costs its instruction stream whatever its lane count, and with the cheap steps on the owner waves the service waves are what a long
+      // launch is bound by: a queue is served once it holds th_play / th_other requests, or once the wave has looked at a shorter one for th_more ticks
+      int cls;
+      if (np >= a.th_play) cls = 0;
+      else if (no >= a.th_other) cls = 1;
+      else {
+        const unsigned long long now = wall_clock64();
+        if (!seen) { seen = true; t_seen = now; }
+        if (now - t_seen < (unsigned long long)a.th_more) { __builtin_amdgcn_s_sleep(1); continue; }
+        cls = np >= no ? 0 : 1;   // the fuller queue (plays on a tie: the longer chains)
+      }
+      seen = false;
       const uint32_t head = cls ? ho : hp, navail = cls ? no : np;
       const uint32_t nb = navail > BG_BLOCK ? BG_BLOCK : navail;
       uint32_t item = 0;
@@ -269,6 +308,7 @@ __global__ __launch_bounds__(BG_E3_NW * BG_BLOCK, 2) void bg_engine3_kernel(BgDe
         if (__builtin_amdgcn_readfirstlane(got) == 0u) continue;
       }
       polls = 0;
+      E3T(0);
       if ((uint32_t)lane < nb) {
         uint32_t spin = 0;
         const uint32_t want = BG_ITEM_VALID | ((((head + (uint32_t)lane) >> LNE) & 0xffu) << 8);
@@ -286,7 +326,7 @@ __global__ __launch_bounds__(BG_E3_NW * BG_BLOCK, 2) void bg_engine3_kernel(BgDe
           Env e;
           bg_unpack(c, e);
           bg_derive_ready(e, s_prod[l]);
-          DeckT dk; dk.col = (lds_u32*)&s_deck[0][l];
+          DeckT dk; static_cast<Deck0&>(dk) = bg_load_deck0(d, env);
           ShopRegs sr; sr.valid = false;
           RngWin w;
           bg_win_init(w, &s_win[sidx][0][lane], &jt);
@@ -310,7 +350,9 @@ __global__ __launch_bounds__(BG_E3_NW * BG_BLOCK, 2) void bg_engine3_kernel(BgDe
           bg_lds_st(&s_ans[l], bg_lds_ld(&s_ans[l]) + 1u);
         }
       }
+      E3T(1 + cls); E3T_CNT(4 + cls, 1); E3T_CNT(6 + cls, nb);
     }
+    E3T_FLUSH(8);
     if (a.stats) {
 #pragma unroll
       for (int off = 32; off > 0; off >>= 1) { n_eps += __shfl_down(n_eps, off); n_plays += __shfl_down(n_plays, off); ssum += __shfl_down(ssum, off); }
@@ -323,8 +365,8 @@ __global__ __launch_bounds__(BG_E3_NW * BG_BLOCK, 2) void bg_engine3_kernel(BgDe
   }
   // ---------------------------------------------------------------- epilogue: chunks 3 / 4 -> HBM
   __syncthreads();
-  if (tid < n_live) {
-    d.hot[(size_t)3 * N + env0 + tid] = s_c34[0][tid];
-    d.hot[(size_t)4 * N + env0 + tid] = s_c34[1][tid];
+  for (int l = tid; l < n_live; l += (NOW + NSV) * BG_BLOCK) {
+    d.hot[(size_t)3 * N + env0 + l] = s_c34[0][l];
+    d.hot[(size_t)4 * N + env0 + l] = s_c34[1][l];
   }
 }

@@ -1257,11 +1257,23 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
   if (bg_engine2_ok(h, a, info)) { if (bg_engine2_launch(h, dv, a, hash, st) != 0) h->err = "two-kernel engine: " + h->err; return; }
   if (h->engine == 3 && a.obs.rows && !info && !a.actions_in && !a.reward && !a.term && !a.actions_out) { // packed-record rollouts: owner waves + service waves (bg_engine3.h)
     h->e2_img_valid = false;
-    const dim3 g3((h->dev.N + 255) / 256), b3(BG_E3_NW * BG_BLOCK);
-    if (hash && cards) hipLaunchKernelGGL((bg_engine3_kernel<true, true>), g3, b3, 0, st, dv, a);
-    else if (hash) hipLaunchKernelGGL((bg_engine3_kernel<true, false>), g3, b3, 0, st, dv, a);
-    else if (cards) hipLaunchKernelGGL((bg_engine3_kernel<false, true>), g3, b3, 0, st, dv, a);
-    else hipLaunchKernelGGL((bg_engine3_kernel<false, false>), g3, b3, 0, st, dv, a);
+    { // batch thresholds of the service waves: BG_E3_TH requests, or after BG_E3_WAIT ticks of 10 ns.  Default: never by threshold and no waiting --
+      // a free service wave takes the FULLER of the two queues at once (measured at 372 steps: thresholds 32 / 48 / 64 with waits of 3 - 20 us all lose
+      // 1 - 8 %, and serving plays as soon as one is queued -- batches of a few lanes -- loses a third: profiles/r04_engine3/thresholds_ab.txt)
+      static const int th = getenv("BG_E3_TH") ? atoi(getenv("BG_E3_TH")) : 0x7fffffff, wt = getenv("BG_E3_WAIT") ? atoi(getenv("BG_E3_WAIT")) : 0;
+      a.th_play = a.th_other = (uint32_t)th; a.th_more = (uint32_t)wt;
+    }
+    const dim3 g3((h->dev.N + 255) / 256);
+    // owner waves x service waves of a workgroup (BG_E3_CFG = 10 * owners + service waves; seven waves leave the refill its SIMD)
+    static const int cfg_env = getenv("BG_E3_CFG") ? atoi(getenv("BG_E3_CFG")) : 0;
+    const int cfg = cfg_env ? cfg_env : 43;
+#define BG_E3(NOWV, NSVV) do { const dim3 b3((NOWV + NSVV) * BG_BLOCK); \
+      if (hash && cards) hipLaunchKernelGGL((bg_engine3_kernel<true, true, NOWV, NSVV>), g3, b3, 0, st, dv, a); \
+      else if (hash) hipLaunchKernelGGL((bg_engine3_kernel<true, false, NOWV, NSVV>), g3, b3, 0, st, dv, a); \
+      else if (cards) hipLaunchKernelGGL((bg_engine3_kernel<false, true, NOWV, NSVV>), g3, b3, 0, st, dv, a); \
+      else hipLaunchKernelGGL((bg_engine3_kernel<false, false, NOWV, NSVV>), g3, b3, 0, st, dv, a); } while (0)
+    if (cfg == 25) BG_E3(2, 5); else if (cfg == 24) BG_E3(2, 4); else if (cfg == 44) BG_E3(4, 4); else if (cfg == 16) BG_E3(1, 6); else if (cfg == 26) BG_E3(2, 6); else BG_E3(4, 3);
+#undef BG_E3
     return;
   }
   h->e2_img_valid = false;
