@@ -34,6 +34,7 @@
 #define BG_ENG_LNE 8     // log2 of the envs per workgroup.  Only 8 is supported: 7 (128 envs: twice the workgroups for a small job) passes the parity tests and
                          // gives +9 % at 4 096 envs, 6 gives +15 % but trips a bounded wait (profiles/r03_small_workgroups_ab.txt)
 #endif
+static_assert(BG_ENG_LNE == 8, "only 256 envs per workgroup are supported: items carry the env lane in 8 bits, copy-queue generations in 7, and the epilogue assumes NE = 256");
 #define BG_ENG_NE (1 << BG_ENG_LNE)   // envs per workgroup: 256 (an item holds the env's lane in 8 bits; rings have NE entries, an item's generation = position >> LNE)
 // Waves per workgroup.  SEVEN, not eight: a wave of this kernel needs 256 VGPRs, so eight fill the register file of all four SIMDs and
 // nothing can be placed beside the workgroup -- the RNG refill of the previous launch (~1 ms of one-wave workgroups) then waits for
@@ -202,9 +203,9 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
         lds_u32* ep = (lds_u32*)&s_cq[pos & (NE - 1)];
         uint32_t spin = 0, y = ep[1];
         while ((y & (BG_ITEM_VALID | 0x7f0000u)) != want && ++spin < BG_SPIN_LIMIT) { __builtin_amdgcn_s_sleep(1); asm volatile("" ::: "memory"); y = ep[1]; }
-        if ((y & (BG_ITEM_VALID | 0x7f0000u)) != want) atomicOr(d.err, BG_DEVERR_SPIN);
         asm volatile("" ::: "memory");
-        ent = make_uint2(ep[0], y);
+        if ((y & (BG_ITEM_VALID | 0x7f0000u)) != want) atomicOr(d.err, BG_DEVERR_SPIN);   // (the launch is lost: sticky error; this lane's entry stays 0 = through-less, row 0)
+        else ent = make_uint2(ep[0], y);
       }
       BG_WAVE_SYNC();
       // WHOLE LINES.  The HBM takes scattered 352-byte records (22 pieces: two partial 128-byte lines each) at 2.6 TB/s, and scattered

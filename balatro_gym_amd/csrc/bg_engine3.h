@@ -26,24 +26,35 @@
 #define E3T_FLUSH(base) do {} while (0)
 #endif
 
-// NOW owner waves (each owns 256 / NOW envs: 4 / NOW slices of 64, lane = env of a slice) + NSV service waves.
-template <bool HASH, bool CARDS, int NOW, int NSV>
+template <int NOW, int KS, int NSV>
+struct E3Lds {
+  static constexpr int NE = NOW * KS * BG_BLOCK;
+  bg_u32x4 s_img[NE][22];
+  uint4 s_c34[2][NE];              // hot chunks 3 and 4
+  unsigned long long s_mask[NE];
+  uint32_t s_prod[NE];
+  uint32_t s_ans[NE];              // service steps completed for this env in this launch (the owner counts its requests)
+  uint32_t s_q[2][NE];             // request rings: env lane | generation of the ring position << 8 | action << 16 | VALID
+  __attribute__((aligned(16))) uint32_t s_ctl[8];   // [0..1] requests ever queued per class, [4..5] ever claimed
+  uint32_t s_win[NSV][BG_WIN][BG_BLOCK];
+  uint2 s_list[NOW][KS * BG_BLOCK]; // copy-out list of an owner wave: .x = record row, .y = env lane
+  bg_u32x4 s_zero;
+  uint32_t s_owners_left;
+  JTables jt;
+};
+// A workgroup = NE = 64 * NOW * KS envs: NOW owner waves (each owns KS slices of 64 envs, lane = env of a slice) + NSV service waves.  256 envs per
+// workgroup fill the chip at 65 536 envs; a small job takes 64 or 128 per workgroup and spreads over four or two times as many CUs.
+template <bool HASH, bool CARDS, int NOW, int KS, int NSV>
 __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(BgDev d, EngineArgs a) {
-  constexpr int NE = 256, LNE = 8, KS = 4 / NOW;
-  static_assert(NOW == 1 || NOW == 2 || NOW == 4, "owner waves");
-  __shared__ bg_u32x4 s_img[NE][22];
-  __shared__ uint4 s_c34[2][NE];              // hot chunks 3 and 4
-  __shared__ unsigned long long s_mask[NE];
-  __shared__ uint32_t s_prod[NE];
-  __shared__ uint32_t s_ans[NE];              // service steps completed for this env in this launch (the owner counts its requests)
-  __shared__ uint32_t s_q[2][NE];             // request rings: env lane | generation of the ring position << 8 | action << 16 | VALID
-  __shared__ __attribute__((aligned(16))) uint32_t s_ctl[8];   // [0..1] requests ever queued per class, [4..5] ever claimed
-  __shared__ uint32_t s_win[NSV][BG_WIN][BG_BLOCK];
-  __shared__ uint2 s_list[NOW][KS * BG_BLOCK]; // copy-out list of an owner wave: .x = record row, .y = env lane
-  __shared__ bg_u32x4 s_zero;
-  __shared__ uint32_t s_owners_left;
-  __shared__ JTables jt;
+  constexpr int NE = NOW * KS * BG_BLOCK, LNE = NE == 256 ? 8 : (NE == 128 ? 7 : 6);
+  static_assert(NE == 64 || NE == 128 || NE == 256, "envs per workgroup (a request carries the env's lane in 8 bits)");
+  // (static LDS: the compiler then pads the register allocation to the 256 VGPRs that two waves per SIMD leave each -- which this kernel needs
+  //  anyway: with dynamic LDS and the same cap it compiles to 256 VGPRs plus a spilled one)
+  __shared__ E3Lds<NOW, KS, NSV> L;
+  auto& s_img = L.s_img; auto& s_c34 = L.s_c34; auto& s_mask = L.s_mask; auto& s_prod = L.s_prod; auto& s_ans = L.s_ans; auto& s_q = L.s_q;
+  auto& s_ctl = L.s_ctl; auto& s_win = L.s_win; auto& s_list = L.s_list; auto& s_zero = L.s_zero; auto& s_owners_left = L.s_owners_left; auto& jt = L.jt;
   __builtin_amdgcn_s_setprio(2);
+  BG_PROBE_INIT();
   bg_tables_load(&jt, d.jtab);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int env0 = blockIdx.x * NE;
@@ -96,9 +107,19 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
       cib[j] = c < 22u ? 16u * c : (uint32_t)((lds_cc*)&s_zero - imgb);
     }
     uint32_t t[KS], nreq[KS];   // per slice: steps done; requests posted (the service wave counts them in s_ans)
-    bool waiting[KS];
+    bool waiting[KS], terminal[KS];
+    // chunks 3 / 4 and the action mask of the lane's env live in REGISTERS between two service steps (a toggle is then LDS writes only -- the image --,
+    // no LDS read: the step phase of an iteration was five dependent LDS round trips); they go to LDS with a request and come back with its answer
+    uint4 rc3[KS], rc4[KS];
+    uint64_t rmask[KS];
 #pragma unroll
-    for (int s = 0; s < KS; s++) { t[s] = 0; nreq[s] = 0; waiting[s] = false; }
+    for (int s = 0; s < KS; s++) {
+      t[s] = 0; nreq[s] = 0; waiting[s] = false;
+      const int l = (wave * KS + s) * BG_BLOCK + lane;
+      rc3[s] = s_c34[0][l]; rc4[s] = s_c34[1][l]; rmask[s] = s_mask[l];
+      const lds_u32* im = (const lds_u32*)&s_img[l][0];
+      terminal[s] = bg_b(rc3[s].x, 0) > 100u || (int64_t)(((uint64_t)im[33] << 32) | im[32]) > 1000000000ll;   // :619-623
+    }
     uint64_t n_steps = 0, rbits = 0, ohash = 0;
     uint32_t idle = 0;
     E3T_DECL();
@@ -118,12 +139,16 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
         const size_t row = (size_t)env + (a.obs_stride_steps ? (size_t)t[s] * N : 0);
         // ---- answers: the service wave has left the finished image, chunks 3 / 4 and the mask in LDS
         bool fin = false;
-        if (waiting[s] && bg_lds_ld(&s_ans[l]) == nreq[s]) { waiting[s] = false; fin = true; }
+        if (waiting[s] && bg_lds_ld(&s_ans[l]) == nreq[s]) {
+          waiting[s] = false; fin = true;
+          rc3[s] = s_c34[0][l]; rc4[s] = s_c34[1][l]; rmask[s] = s_mask[l];
+          terminal[s] = bg_b(rc3[s].x, 0) > 100u || (int64_t)(((uint64_t)img32[33] << 32) | img32[32]) > 1000000000ll;
+        }
         // ---- the cheap step of every ready env (bg_engine.h: cheap_step)
         else if (live && !waiting[s] && t[s] < T) {
-          uint64_t mask = s_mask[l];
-          const uint4 c3 = s_c34[0][l];
-          const uint32_t ante = bg_b(c3.x, 0), phase = bg_b(c3.x, 2), discards_left = bg_b(c3.y, 0), nsel0 = bg_b(c3.y, 3);
+          uint64_t mask = rmask[s];
+          const uint4 c3 = rc3[s];
+          const uint32_t phase = bg_b(c3.x, 2), discards_left = bg_b(c3.y, 0), nsel0 = bg_b(c3.y, 3);
           int action;
           {
             const uint64_t gi0 = a.env_index0 + (uint64_t)env;
@@ -133,44 +158,42 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
             action = bg_policy_action_fast(pe, mask, a.policy, pl, pl.seed_env + BG_POLICY_PSI * (a.t0 + (uint64_t)t[s] + 1), (lds_JTables*)&jt);
           }
           double reward = 0.0;
-          const int64_t chips_scored = (int64_t)(((uint64_t)img32[33] << 32) | img32[32]);
           const bool valid = action >= 0 && action < 60 && ((mask >> (action & 63)) & 1ull);
-          const bool terminal = ante > 100u || chips_scored > 1000000000ll;   // :619-623, settled by a service wave (it resets the env)
-          if (!terminal && valid && phase == 0u && action >= 2 && action < 10) {
+          const bool term = terminal[s];   // :619-623, settled by a service wave (it resets the env)
+          if (!term && valid && phase == 0u && action >= 2 && action < 10) {
             // :1052-1058 toggle position `pos` in state.selected_cards (bg_toggle_select on chunk 4)
             const int pos = action - 2;
-            uint4 c4 = s_c34[1][l];
-            Env te; te.sel = ((uint64_t)c4.w << 32) | c4.z; te.nsel = (int)nsel0;
+            Env te; te.sel = ((uint64_t)rc4[s].w << 32) | rc4[s].z; te.nsel = (int)nsel0;
             bg_toggle_select(te, pos);
-            c4.z = (uint32_t)te.sel; c4.w = (uint32_t)(te.sel >> 32);
-            s_c34[1][l] = c4;
-            ((lds_u8*)&s_c34[0][l])[7] = (uint8_t)te.nsel;                   // chunk 3, word y, byte 3
+            rc4[s].z = (uint32_t)te.sel; rc4[s].w = (uint32_t)(te.sel >> 32);
+            rc3[s].y = (rc3[s].y & 0x00ffffffu) | ((uint32_t)te.nsel << 24);   // chunk 3, word y, byte 3
             *(lds_u64*)&img32[2 * pos] = te.nsel > (int)nsel0 ? 1ull : 0ull;  // selected_cards[pos] (int64)
             if ((te.nsel > 0) != (nsel0 > 0u)) {                             // PLAY_HAND / DISCARD availability (:1436-1441)
               const uint32_t play = te.nsel > 0 ? 1u : 0u, disc = (te.nsel > 0 && discards_left > 0u) ? 1u : 0u;
               mask = (mask & ~3ull) | play | ((uint64_t)disc << 1);
-              s_mask[l] = mask;
+              rmask[s] = mask;
               *(__attribute__((address_space(3))) uint16_t*)&img8[BG_ROW_ACTION_MASK] = (uint16_t)(play | (disc << 8));
             }
             fin = true;
-          } else if (!terminal && valid && phase == 1u && action == 31 && (int)(int8_t)bg_b(c3.y, 1) <= (int)bg_b(c3.y, 2)) {
+          } else if (!term && valid && phase == 1u && action == 31 && (int)(int8_t)bg_b(c3.y, 1) <= (int)bg_b(c3.y, 2)) {
             // :1247-1251 leave the shop; the hand is full, so all that changes is the phase, the mask and the shop rows (:1534-1539)
             const uint32_t nhand = bg_b(c3.y, 2), ncons = bg_b(c3.z, 1);
-            ((lds_u8*)&s_c34[0][l])[2] = 0;                                   // chunk 3, word x, byte 2: phase = PLAY
+            rc3[s].x &= 0xff00ffffu;                                          // chunk 3, word x, byte 2: phase = PLAY
             uint64_t m = (((1ull << (nhand < 8u ? nhand : 8u)) - 1ull) << 2) | (((1ull << ncons) - 1ull) << 10);
             if (nsel0 > 0u) m |= 1ull | (discards_left > 0u ? 2ull : 0ull);
             mask = m;
-            s_mask[l] = mask;
+            rmask[s] = mask;
 #pragma unroll
             for (int wq = 0; wq < 15; wq++) img32[44 + wq] = __umul24((uint32_t)(mask >> (4 * wq)) & 0xfu, 0x204081u) & 0x01010101u; // action_mask i8[60]
 #pragma unroll
             for (int wq = 64; wq < 74; wq++) img32[wq] = 0u;                  // shop_items, shop_costs
             img8[BG_ROW_PHASE] = 0;
             fin = true;
-          } else if (!terminal && !valid) { reward = -1.0; fin = true; }    // :626-627 'Invalid action': nothing changes
+          } else if (!term && !valid) { reward = -1.0; fin = true; }    // :626-627 'Invalid action': nothing changes
           else {
-            // a request: one LDS word (the state is untouched); the service waves poll the tails
-            const int q = (!terminal && phase == 0u && action == 0) ? 0 : 1;
+            // a request: chunks 3 / 4 and the mask to LDS, then one queue word (the service waves poll the tails)
+            s_c34[0][l] = rc3[s]; s_c34[1][l] = rc4[s]; s_mask[l] = mask;
+            const int q = (!term && phase == 0u && action == 0) ? 0 : 1;
             const uint32_t slot = __hip_atomic_fetch_add(&s_ctl[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             bg_lds_st(&s_q[q][slot & (NE - 1)], (uint32_t)l | (((slot >> LNE) & 0xffu) << 8) | (((uint32_t)action & 0x7fffu) << 16) | BG_ITEM_VALID);
             nreq[s]++;
@@ -249,6 +272,8 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
       }
     }
     E3T_FLUSH(0);
+#pragma unroll
+    for (int s = 0; s < KS; s++) { const int l = (wave * KS + s) * BG_BLOCK + lane; s_c34[0][l] = rc3[s]; s_c34[1][l] = rc4[s]; }   // (the epilogue stores them)
     if (lane == 0) __hip_atomic_fetch_sub(&s_owners_left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     if (a.stats) {
 #pragma unroll
@@ -323,10 +348,11 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
 #pragma unroll
           for (int k = 0; k < BG_NHOT; k++) if (k != 3 && k != 4) c[k] = d.hot[(size_t)k * N + env];
           c[3] = s_c34[0][l]; c[4] = s_c34[1][l];
+          DeckT dk; static_cast<Deck0&>(dk) = bg_load_deck0(d, env);
           Env e;
           bg_unpack(c, e);
+          BG_PROBE(23);
           bg_derive_ready(e, s_prod[l]);
-          DeckT dk; static_cast<Deck0&>(dk) = bg_load_deck0(d, env);
           ShopRegs sr; sr.valid = false;
           RngWin w;
           bg_win_init(w, &s_win[sidx][0][lane], &jt);
@@ -334,12 +360,16 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
           bg_step_init(o);
           o.bd_dst = nullptr;
           if (bg_step_guards(e, mask, action, o)) bg_env_dispatch(d, env, e, w, sr, dk, action, o);
+          BG_PROBE(cls == 0 ? 20 : 21);
           if (e.max_ante > 0 && e.ante > e.max_ante) { o.terminated = true; o.flags |= 256; }
           if (o.terminated) n_eps++;
           if (o.terminated && a.autoreset) bg_env_reset(d, env, e, dk);
           if constexpr (CARDS) bg_vm_drain(); // card states / lazy streams in HBM are edited from any service wave: let the stores land
+          BG_PROBE(24);
           mask = bg_action_mask(d, env, e, sr);
+          BG_PROBE(25);
           bg_write_obs_impl<false, 3>(d, env, 0, e, dk, a.obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u}, RowStage{(lds_u4*)&s_img[l][0], nullptr});
+          BG_PROBE(26);
           bg_pack(e, c);
 #pragma unroll
           for (int k = 0; k < BG_NHOT; k++) if (k != 3 && k != 4) d.hot[(size_t)k * N + env] = c[k];
@@ -348,6 +378,7 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
           if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
           // the answer, behind everything above (one wave's LDS operations execute in program order)
           bg_lds_st(&s_ans[l], bg_lds_ld(&s_ans[l]) + 1u);
+          BG_PROBE(27);
         }
       }
       E3T(1 + cls); E3T_CNT(4 + cls, 1); E3T_CNT(6 + cls, nb);
@@ -364,6 +395,7 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
     }
   }
   // ---------------------------------------------------------------- epilogue: chunks 3 / 4 -> HBM
+  BG_PROBE_FLUSH(d);
   __syncthreads();
   for (int l = tid; l < n_live; l += (NOW + NSV) * BG_BLOCK) {
     d.hot[(size_t)3 * N + env0 + l] = s_c34[0][l];

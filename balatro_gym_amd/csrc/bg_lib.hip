@@ -856,7 +856,7 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0);
     h->refill_order = geti("BG_REFILL_ORDER", 2);
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
-    h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0); h->eng_copiers = geti("BG_ENG_COPIERS", 2); if (h->eng_copiers < 1 || h->eng_copiers > 3) h->eng_copiers = 2;
+    h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0); h->eng_copiers = geti("BG_ENG_COPIERS", 1); if (h->eng_copiers < 1 || h->eng_copiers > 3) h->eng_copiers = 1;
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
     h->engine = geti("BG_ENGINE", 3); if (h->engine < 1 || h->engine > 3) h->engine = 3;
     memset(&h->e2, 0, sizeof(h->e2));
@@ -1263,23 +1263,35 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
       static const int th = getenv("BG_E3_TH") ? atoi(getenv("BG_E3_TH")) : 0x7fffffff, wt = getenv("BG_E3_WAIT") ? atoi(getenv("BG_E3_WAIT")) : 0;
       a.th_play = a.th_other = (uint32_t)th; a.th_more = (uint32_t)wt;
     }
-    const dim3 g3((h->dev.N + 255) / 256);
-    // owner waves x service waves of a workgroup (BG_E3_CFG = 10 * owners + service waves; seven waves leave the refill its SIMD)
+    // Shape of a workgroup: owner waves x slices of 64 envs x service waves.  BG_E3_CFG = 100 * owners + 10 * slices + service waves overrides.
+    // 65 536 envs: 4 x 1 x 3 = 256 envs on seven waves per CU (the refill keeps its SIMD).  A small job spreads over more CUs: 64 envs per
+    // workgroup up to 8 192 envs, 128 up to 32 768 (profiles/r04_engine3/small_jobs.txt).
     static const int cfg_env = getenv("BG_E3_CFG") ? atoi(getenv("BG_E3_CFG")) : 0;
-    const int cfg = cfg_env ? cfg_env : 43;
-#define BG_E3(NOWV, NSVV) do { const dim3 b3((NOWV + NSVV) * BG_BLOCK); \
-      if (hash && cards) hipLaunchKernelGGL((bg_engine3_kernel<true, true, NOWV, NSVV>), g3, b3, 0, st, dv, a); \
-      else if (hash) hipLaunchKernelGGL((bg_engine3_kernel<true, false, NOWV, NSVV>), g3, b3, 0, st, dv, a); \
-      else if (cards) hipLaunchKernelGGL((bg_engine3_kernel<false, true, NOWV, NSVV>), g3, b3, 0, st, dv, a); \
-      else hipLaunchKernelGGL((bg_engine3_kernel<false, false, NOWV, NSVV>), g3, b3, 0, st, dv, a); } while (0)
-    if (cfg == 25) BG_E3(2, 5); else if (cfg == 24) BG_E3(2, 4); else if (cfg == 44) BG_E3(4, 4); else if (cfg == 16) BG_E3(1, 6); else if (cfg == 26) BG_E3(2, 6); else BG_E3(4, 3);
+    const int cfg = cfg_env ? cfg_env : (h->dev.N <= 8192 ? 113 : (h->dev.N <= 32768 ? 213 : 413));
+#define BG_E3K(HV, CV, NOWV, KSV, NSVV) hipLaunchKernelGGL((bg_engine3_kernel<HV, CV, NOWV, KSV, NSVV>), dim3((h->dev.N + NOWV * KSV * 64 - 1) / (NOWV * KSV * 64)), dim3((NOWV + NSVV) * BG_BLOCK), 0, st, dv, a)
+#define BG_E3(NOWV, KSV, NSVV) do { \
+      if (hash && cards) BG_E3K(true, true, NOWV, KSV, NSVV); else if (hash) BG_E3K(true, false, NOWV, KSV, NSVV); \
+      else if (cards) BG_E3K(false, true, NOWV, KSV, NSVV); else BG_E3K(false, false, NOWV, KSV, NSVV); } while (0)
+    switch (cfg) {
+      case 113: BG_E3(1, 1, 3); break;
+      case 112: BG_E3(1, 1, 2); break;
+      case 213: BG_E3(2, 1, 3); break;
+      case 414: BG_E3(4, 1, 4); break;
+      case 225: BG_E3(2, 2, 5); break;
+      default: BG_E3(4, 1, 3); break;
+    }
 #undef BG_E3
+#undef BG_E3K
     return;
   }
   h->e2_img_valid = false;
   a.n_waves = (uint32_t)bg_engine_waves(h, (int)a.T);
   // packed records: one more wave, the COPIER (bg_engine.h), takes the record copy-out off the workers; with the seven-wave shape that
   // leaves room for the refill beside the launch it is one of the seven
+  // ONE copier unless BG_ENG_COPIERS asks for more: a single copier drains the copy queue in order, so "one outstanding entry per env" bounds
+  // tail - head by the ring size; with two or three dealing the ring out in blocks, a worker can lap a block a lagging copier has not read yet
+  // (nothing publishes the copiers' heads).  Packed-record ROLLOUTS no longer come this way (bg_engine3.h); what does is bg_step_rows, a
+  // one-step launch, where a second copier buys nothing.
   a.copier = a.obs.rows ? (uint32_t)h->eng_copiers : 0u;
   if (a.copier && a.n_waves > BG_ENG_NW - a.copier) a.n_waves = BG_ENG_NW - a.copier;
   if (a.n_waves < BG_ENG_NW && a.serve_mask == BG_ENG_SMASK_DEFAULT) // the last NSV of the workers (all of them when there are no more)

@@ -120,9 +120,6 @@ def measured_copy_gbps(dev):
 
 
 HBM_PEAK_GUIDE_GBPS = 6290.0                     # MI355X_MICROARCH.md: 6.29 TB/s measured for a float4 copy
-# what the HBM takes for THIS kernel's output pattern -- 352-byte records scattered over a buffer, written as three whole 128-byte lines
-# each (tools/micro/recwrite.hip, profiles/r03_recwrite.txt: 4.5 TB/s of payload; 2.6 TB/s when a record ends in partial lines)
-HBM_PEAK_SCATTERED_RECORDS_GBPS = 4500.0
 
 
 def matching_traffic(kernel: str, n: int, fused: float):
@@ -189,6 +186,7 @@ def main():
     ap.add_argument("--row-stride", type=int, default=384,
                     help="bytes between packed records: 384 = every record as three whole 128-byte lines (the fast layout), 352 = dense")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-small-n", action="store_true", help="skip the 4 096-env sub-record")
     ap.add_argument("--no-step-path", action="store_true", help="skip the bg_step / bg_step_many sample")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the RCCL all_gather of the current observation out")
     ap.add_argument("--force-gather", action="store_true", help="N = 1: run the gather path anyway (a one-rank RCCL group; exercises the N > 1 code on a one-GPU box)")
@@ -360,7 +358,8 @@ def main():
 
     if rank == 0:
         value = env_steps / elapsed
-        kernel = "bg_engine_kernel"
+        # the kernel behind packed-record rollouts: bg_engine3.h (owner waves + service waves) unless BG_ENGINE says otherwise; per-key output: bg_engine.h
+        kernel = {"1": "bg_engine_kernel", "2": "bg_owner_kernel", "3": "bg_engine3_kernel"}.get(os.environ.get("BG_ENGINE", "3"), "bg_engine3_kernel") if args.obs_layout == "rows" else "bg_engine_kernel"
         # roofline of the dominant kernel: algorithmic bytes per launch / mean launch duration (HIP events on the launch stream)
         launches = max(1, prof["rollout_launches"])
         fused = prof["rollout_fused_steps"] / launches           # mean fused steps T per launch
@@ -400,9 +399,6 @@ def main():
                          "traffic_frac_of_measured": traffic[0] / mean_launch_s / 1e9 / peak_measured if (traffic and mean_launch_s > 0 and peak_measured) else None,
                          "peak_measured": peak_measured, "frac_of_measured": achieved / peak_measured if peak_measured else None,
                          "peak_guide": HBM_PEAK_GUIDE_GBPS, "frac_of_guide": achieved / HBM_PEAK_GUIDE_GBPS,
-                         # a microbenchmark constant, not measured in this run: the ceiling of the output pattern (records scattered over the buffer)
-                         "peak_scattered_records": HBM_PEAK_SCATTERED_RECORDS_GBPS if (args.obs_layout == "rows" and args.row_stride == 384) else None,
-                         "frac_of_scattered_records": achieved / HBM_PEAK_SCATTERED_RECORDS_GBPS if (args.obs_layout == "rows" and args.row_stride == 384) else None,
                          # stores only: the records + the state written back, against a plain fill kernel on this GPU
                          "write_gbps": write_gbps, "peak_measured_write": peak_write, "write_frac_of_measured": write_gbps / peak_write if peak_write else None,
                          "kernel": kernel, "algorithmic_bytes_per_env_step": a_step,
@@ -434,6 +430,32 @@ def main():
                              "bytes_per_gpu_per_launch": (gather_bytes_timed // max(1, launches)) if do_gather else 0}
     env.close()
     del ob, bufs
+
+    if rank == 0 and world == 1 and not args.no_small_n:
+        # ---- BASELINE configs[1]'s size: 4 096 envs on one GPU (what the reference's own users run is smaller still), same workload and launch shape
+        sn = 4096
+        es = BalatroVecEnv(sn, [1000 + g for g in range(sn)], device=local_rank, scorer_jokers=True, autoreset=True, max_ante=MAX_ANTE)
+        es.inject(jokers=[jokers_for(g) for g in range(sn)], apply_now=True)
+        cs = min(372, es.max_fused_steps)
+        rbs = RowBuffers(sn, dev, steps=cs, row_stride=args.row_stride)
+        for i in range(4):
+            es.rollout(cs, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, t0=i * cs, obs_buffers=rbs, zero_stats=False)
+        torch.cuda.synchronize(dev)
+        es.set_profiling(True)
+        t0s = time.perf_counter()
+        for i in range(8):
+            es.rollout(cs, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, t0=(4 + i) * cs, obs_buffers=rbs, zero_stats=False)
+        torch.cuda.synchronize(dev)
+        dts = time.perf_counter() - t0s
+        ps = es.get_profile()
+        es.check()
+        es.close()
+        a_s = OBS_BYTES + IO_BYTES + 2 * STATE_BYTES / cs
+        out["small_n"] = {"envs": sn, "value": sn * cs * 8 / dts, "unit": "env-steps/s", "fused_steps_per_launch": cs,
+                          "mean_launch_us": ps["rollout_ms"] / max(1, ps["rollout_launches"]) * 1e3,
+                          "roofline_frac": sn * cs * a_s / (ps["rollout_ms"] / max(1, ps["rollout_launches"]) * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                          "what": "BASELINE configs[1]'s env count with the workload of the headline line: 8 launches back to back"}
+        del rbs
 
     if rank == 0 and world == 1 and not args.no_step_path:
         # ---- the Gymnasium-surface path: bg_step with actions from a device tensor (recorded from a fused rollout of a twin

@@ -9,7 +9,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from balatro_gym_amd import _native as nat
 
 
-KERNELS = ("bg_engine_kernel",)  # the step engine
+KERNELS = ("bg_engine3_kernel", "bg_engine_kernel")  # the step engine (packed-record rollouts: bg_engine3.h)
 # bench.py only quotes a measurement taken on the device code it runs: the sha256 of the library's .hip_fatbin section (run this script
 # with the same BALATRO_MI355X_LIB / product library the profiled command used)
 

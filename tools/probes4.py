@@ -10,7 +10,7 @@ n, T = 65536, int(os.environ.get("T", "372"))
 env = BalatroVecEnv(n, [1000 + g for g in range(n)], device=0, scorer_jokers=True, autoreset=True, max_ante=4)
 env.inject(jokers=[jokers_for(g) for g in range(n)], apply_now=True)
 WARM = int(os.environ.get("WARM", str(T)))
-rb = RowBuffers(n, env.device, steps=max(T, WARM))
+rb = RowBuffers(n, env.device, steps=max(T, WARM), row_stride=384)
 for i in range(2):
     env.rollout(WARM, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, t0=i * WARM, obs_buffers=rb, zero_stats=False)
 torch.cuda.synchronize()
