@@ -1272,12 +1272,9 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
 #define BG_E3(NOWV, KSV, NSVV) do { \
       if (hash && cards) BG_E3K(true, true, NOWV, KSV, NSVV); else if (hash) BG_E3K(true, false, NOWV, KSV, NSVV); \
       else if (cards) BG_E3K(false, true, NOWV, KSV, NSVV); else BG_E3K(false, false, NOWV, KSV, NSVV); } while (0)
-    switch (cfg) {
+    switch (cfg) {   // (other shapes were measured and dropped: profiles/r04_engine3/wave_split_ab.txt, small_jobs.txt)
       case 113: BG_E3(1, 1, 3); break;
-      case 112: BG_E3(1, 1, 2); break;
       case 213: BG_E3(2, 1, 3); break;
-      case 414: BG_E3(4, 1, 4); break;
-      case 225: BG_E3(2, 2, 5); break;
       default: BG_E3(4, 1, 3); break;
     }
 #undef BG_E3

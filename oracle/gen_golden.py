@@ -519,6 +519,15 @@ def gen_traces():
           ante_fn=lambda i: [1, 3, 4, 6][i % 4])
 
 
+def gen_trace_seeds():
+    """Q12 and the corners of `DeterministicRNG(master_seed)` (balatro_env_2.py:88,105): seed 0 (falsy: the master seed is drawn from the
+    env's global stream, `random.randint(0, 2**32 - 1)`), negative seeds (truthy; stream i is seeded `(seed + 1000 i) % 2**32`, Python's
+    non-negative modulo), seeds at and beyond 2**32, and the same seed twice (two envs must play the same game)."""
+    seeds = [0, 0, -5, -5, -1000, -16000, -(2 ** 33) - 7, 2 ** 32, 2 ** 32 + 5, 2 ** 32 - 16000, 2 ** 40 + 3, -(2 ** 62), 2 ** 62 + 12345, 16000, 1, -1]
+    trace("seeds_special", seeds, 160, rh.POLICY_UNIFORM, scorer=True, max_ante=20,
+          jokers_fn=lambda i: random.Random(2100 + i).sample(IMPLEMENTED, 3))
+
+
 def gen_trace_consumables():
     """Tarot / spectral / planet consumables: two injected per episode, all 52 ids (Immolate and Cryptid change
     the deck length; Blue Joker among the jokers sees it); purple seals create more tarots on discards."""
@@ -619,6 +628,8 @@ def main():
         gen_traces()
     if "consumables" in which:
         gen_trace_consumables()
+    if "traces" in which or "seeds" in which:
+        gen_trace_seeds()
     if "boss" in which:
         gen_boss()
     if "kat" in which:

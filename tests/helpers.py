@@ -16,7 +16,7 @@ OBS_KEYS = [
     "boss_blind_active", "boss_blind_type", "face_down_cards",
 ]
 
-TRACES = ["c1_small_only", "c2_cycle3", "c3_jokers", "c5_uniform", "c5_uniform_rich", "cards_levels", "consumables",
+TRACES = ["c1_small_only", "c2_cycle3", "c3_jokers", "c5_uniform", "c5_uniform_rich", "cards_levels", "seeds_special", "consumables",
           "consumables_scorer", "boss_forced", "boss_forced_scorer"]
 POLICY_SCRIPTED = 255   # the trace's actions come from its generator (oracle/gen_golden.py boss_policy), not from a counter-hash policy
 BG_INFO_BEAT_BLIND, BG_INFO_FAILED = 1, 2

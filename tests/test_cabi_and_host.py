@@ -193,3 +193,19 @@ def test_operator_wrappers_validate_every_tensor():
     src = open(os.path.join(ROOT, "balatro_gym_amd", "vec_env.py")).read()
     assert "n.device != cards.device" in src and "tuple(n.shape) != (cards.shape[0],)" in src
     assert "n.to(device=hands.device, dtype=torch.int32)" in src and "flags.to(device=hands.device, dtype=torch.int32)" in src
+
+
+def test_build_signature_is_reproducible(tmp_path):
+    """The identity of the device code (`bg_build_signature`, what profiles/*_hbm_traffic.json are keyed on) must survive a rebuild of
+    unchanged sources: the library reports the sha256 prefix of sources + flags + compiler it was built from, and a second build -- whose
+    code-object bytes differ -- reports the same."""
+    import ctypes as C
+    from balatro_gym_amd import _native as nat, build
+    want = build.source_signature()
+    assert want == build.source_signature() and len(want) == 16
+    assert nat.device_code_signature() == want, "the in-tree library was not built from the sources in the tree (python -m balatro_gym_amd.build --force)"
+    other = build.build(force=True, out=str(tmp_path / "rebuilt.so"))
+    L = C.CDLL(other)
+    L.bg_build_signature.restype = C.c_char_p
+    assert L.bg_build_signature().decode() == want
+    assert nat.device_code_signature(other) == want

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 # BG_TEST_SEED_OFFSET=<k> moves every oracle-compared test below to other games (a soak runs the suite under several offsets)
 SEED_OFFSET = int(os.environ.get("BG_TEST_SEED_OFFSET", "0"))
 
-GPU_TRACES = ["c1_small_only", "c2_cycle3", "c3_jokers", "c5_uniform", "c5_uniform_rich", "cards_levels", "consumables",
+GPU_TRACES = ["c1_small_only", "c2_cycle3", "c3_jokers", "c5_uniform", "c5_uniform_rich", "cards_levels", "seeds_special", "consumables",
               "consumables_scorer", "boss_forced", "boss_forced_scorer"]
 TERMS = 8
 
@@ -452,6 +452,65 @@ def test_packed_record_rollout_vs_oracle(policy, scorer, n):
     for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
         assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
     env.close()
+
+
+@pytest.mark.parametrize("engine,cfg", [(1, None), (2, None), (3, "413"), (3, "113"), (3, "213")])
+@pytest.mark.parametrize("stride", [352, 384])
+def test_packed_record_rollout_every_engine(engine, cfg, stride, monkeypatch):
+    """The three step engines behind bg_rollout_rows -- bg_engine.h (workers + copiers), bg_engine2.h (owner kernel + service kernel)
+    and bg_engine3.h (owner waves + service waves in one workgroup, in its workgroup shapes of 64 / 128 / 256 envs) -- against the oracle:
+    every record byte of a fused rollout over several launches (the handle reads BG_ENGINE / BG_E3_CFG when it is created)."""
+    from balatro_gym_amd.vec_env import RowBuffers
+    from oracle.gen_golden import IMPLEMENTED
+    monkeypatch.setenv("BG_ENGINE", str(engine))
+    if cfg:
+        monkeypatch.setenv("BG_E3_CFG", cfg)
+    n, T, chunks = 333, 64, 3
+    seeds = [88_000 + SEED_OFFSET + 3 * i for i in range(n)]
+    jokers = [random.Random(2600 + i).sample(IMPLEMENTED, 5) for i in range(n)]
+    env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4)
+    env.inject(jokers=jokers, apply_now=True)
+    rb = RowBuffers(n, env.device, steps=T * chunks, row_stride=stride)
+    rbc = [RowBuffers(n, env.device, steps=T, row_stride=stride) for _ in range(chunks)]
+    for c in range(chunks):   # several launches: hand-overs, images and queue positions carry over from one to the next
+        env.rollout(T, policy=0, policy_seed=5, env_index0=1, t0=c * T, obs_buffers=rbc[c], zero_stats=(c == 0))
+    env.check()
+    got_stats = env.stats()
+    wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, T * chunks, 0, 5, True, 4, jokers, env_index0=1, t0=0)
+    for c in range(chunks):
+        sl = slice(c * T, (c + 1) * T)
+        assert np.array_equal(rbc[c].action.cpu().numpy(), wa[sl])
+        assert np.array_equal(rbc[c].terminated.cpu().numpy(), wt[sl])
+        assert np.array_equal(rbc[c].reward.contiguous().cpu().numpy().view(np.uint64), wr[sl].view(np.uint64))
+        for k in OBS_KEYS:
+            assert np.array_equal(rbc[c].tensors[k].contiguous().cpu().numpy(), wobs[k][sl]), f"launch {c}: record key {k} differs"
+    for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
+        assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
+    env.close()
+    del rb
+
+
+def test_engines_agree_full_size(monkeypatch):
+    """65 536 envs, configs[2]: the checksums of a fused rollout (every observation row hashed on the device, reward bits, episodes, plays,
+    scores) must be the same whichever engine ran it."""
+    from balatro_gym_amd.vec_env import RowBuffers
+    from oracle.gen_golden import IMPLEMENTED
+    n, T = 65536, 40
+    seeds = [1000 + SEED_OFFSET + i for i in range(n)]
+    jokers = [random.Random(i).sample(IMPLEMENTED, 5) for i in range(n)]
+    res = []
+    for engine in (1, 2, 3):
+        monkeypatch.setenv("BG_ENGINE", str(engine))
+        env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4, fused_steps=T)
+        env.inject(jokers=jokers, apply_now=True)
+        rb = RowBuffers(n, env.device, steps=T, row_stride=384)
+        for c in range(3):
+            env.rollout(T, policy=2 | 0x100, policy_seed=7, t0=c * T, obs_buffers=rb, zero_stats=(c == 0))
+        env.check()
+        res.append(env.stats())
+        env.close()
+        del rb
+    assert res[0] == res[1] == res[2], res
 
 
 def test_packed_records_same_content_full_size():

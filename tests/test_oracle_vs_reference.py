@@ -192,3 +192,44 @@ def test_reseed_reproduces_first_shuffle():
     for e in (r, o):
         e.step(45)
     assert r.obs()["hand"].tolist() == first and o.obs()["hand"].tolist() == first
+
+
+def test_consumable_deck_fence_placement():
+    """WHERE the `BG_ERR_CONSUMABLE_DECK` fence stands relative to the reference (two corners are fenced, not followed).
+    Immolate (consumables.py:519-531) removes five sampled cards from the live deck list.  The restatement follows it while 24 or more real
+    cards are left -- six uses in one episode, 52 -> 22 cards, in lockstep with the reference -- and REFUSES the seventh (reward -1.0, error 12,
+    state untouched).  The reference itself accepts it and every later one (reward 7.0: $20 / 10 + 5 destroyed cards), plays on with a deck
+    of 17, 12, 7, 2 cards, and raises IndexError on the first step after the deck is empty (eleven uses).  So the fence is a documented
+    deviation that starts at the seventh Immolate of ONE episode (an episode is injected two consumables; The Fool can copy one more), not
+    the point where the reference breaks.  Cryptid (:581-591): the fence stands at 60 foreign copies (deck_size is an int8 observation)."""
+    r = rh.RefEnv(4242, scorer_jokers=False, max_ante=20)
+    o = po.OracleEnv(4242, scorer_jokers=False, max_ante=20)
+    for e in (r, o):
+        e.step(45)
+    uses_followed = 0
+    for it in range(7):
+        for e in (r, o):
+            e.set_consumables([59])   # Immolate
+        for act in (2, 3, 10):
+            obs_r, rr, tr, _, ir = r.step(act)
+            obs_o, ro, to, _, io = o.step(act)
+            if act != 10:
+                assert_obs_equal(obs_o, obs_r, f"use {it} action {act}")
+                continue
+            if it < 6:
+                assert_obs_equal(obs_o, obs_r, f"Immolate {it}")
+                assert ro == rr == 7.0 and int(obs_r["deck_size"]) == 47 - 5 * it
+                uses_followed += 1
+            else:   # the fence: the reference goes on, the restatement refuses
+                assert rr == 7.0 and len(r.env.state.deck) == 17
+                assert ro == -1.0 and io.error == 12 and int(obs_o["deck_size"]) == 22
+    assert uses_followed == 6
+    # ... and the reference alone: down to an empty deck, then IndexError on the next play
+    for it in range(4):
+        r.set_consumables([59])
+        for act in (2, 3, 10):
+            r.step(act)
+    assert len(r.env.state.deck) == 0
+    with pytest.raises(IndexError):
+        for act in (2, 3, 0):
+            r.step(act)
