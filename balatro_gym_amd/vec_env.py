@@ -101,7 +101,7 @@ class BalatroVecEnv:
                  card_states: bool = False, fused_steps: int = 0, obs_layout: str = "keys"):
         """obs_layout: "keys" -- one contiguous tensor per observation key (bg_step / bg_observe, the reference's dict of arrays);
         "rows" -- ONE packed 384-byte record per env (bg_step_rows / bg_observe_rows): `obs[key]` are strided, correctly typed views of it
-        (`obs_rows` is the [N, 384] byte tensor, what a policy network would concatenate anyway) and `step()` is a third shorter."""
+        (`obs_rows` is the [N, 384] byte tensor, what a policy network would concatenate anyway) and `step()` is ~10 % shorter (bench.py `step_path`)."""
         if obs_layout not in ("keys", "rows"):
             raise ValueError("obs_layout must be 'keys' or 'rows'")
         self.obs_layout = obs_layout

@@ -193,7 +193,7 @@ int bg_observe(bg_handle* h, const bg_obs_ptrs* obs, void* stream);
 /* bg_step / bg_observe with the observation as ONE packed record per env (the BG_ROW_* layout of bg_rollout_rows below: every key a
  * strided view of a [N, row_stride_bytes] byte tensor, plus the step's reward / action / terminated) instead of 31 arrays: what a
  * policy network reads after `obs_as_tensor` + concatenation anyway.  A cheap step then patches the record image and the copier waves
- * write it (a step that emits 31 arrays spends most of its instructions on address arithmetic): the one-step launch is a third shorter.
+ * write it (a step that emits 31 arrays spends most of its instructions on address arithmetic): the one-step launch is ~10 % shorter (19.5 against 21.6 us of kernel time at 65 536 envs: bench.py step_path).
  * Same step semantics, same reward / terminated / truncated / info arrays as bg_step (balatro_env_2.py:616-637, :1473-1541);
  * bg_observe_rows (bytes 352.. of a record untouched) after bg_reset(h, mask, NULL, stream) gives the records of a reset.
  * rows_dev: 16-byte aligned, row_stride_bytes a multiple of 16, >= BG_ROW_BYTES; BG_RECORD_STRIDE_LINES on a 128-byte aligned buffer is the fast layout. */
