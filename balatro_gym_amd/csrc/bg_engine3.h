@@ -38,6 +38,12 @@ struct E3Lds {
   __attribute__((aligned(16))) uint32_t s_ctl[8];   // [0..1] requests ever queued per class, [4..5] ever claimed
   uint32_t s_win[NSV][BG_WIN][BG_BLOCK];
   uint2 s_list[NOW][KS * BG_BLOCK]; // copy-out list of an owner wave: .x = record row, .y = env lane
+  // The NEXT pre-shuffled deck of every env (the ring slot a reset will consume) and its state: 0 = not here (the reset reads the ring itself), 1 = here,
+  // 2 | slot << 8 = consumed, the owner is to fetch ring slot `slot`.  A reset's copy ring -> deck is a dependent HBM round trip in the middle of a
+  // service batch that nearly always holds a lane whose episode ends (5.9 k of the 56 k service cycles per workgroup-step, profiles/r04_engine3/probes.txt);
+  // the owner waves have the time to fetch the deck ahead (their lanes are mostly waiting).
+  uint4 s_nd[BG_NDECK][NE];
+  uint32_t s_ndst[NE];
   bg_u32x4 s_zero;
   uint32_t s_owners_left;
   JTables jt;
@@ -53,6 +59,7 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
   __shared__ E3Lds<NOW, KS, NSV> L;
   auto& s_img = L.s_img; auto& s_c34 = L.s_c34; auto& s_mask = L.s_mask; auto& s_prod = L.s_prod; auto& s_ans = L.s_ans; auto& s_q = L.s_q;
   auto& s_ctl = L.s_ctl; auto& s_win = L.s_win; auto& s_list = L.s_list; auto& s_zero = L.s_zero; auto& s_owners_left = L.s_owners_left; auto& jt = L.jt;
+  auto& s_nd = L.s_nd; auto& s_ndst = L.s_ndst;
   __builtin_amdgcn_s_setprio(2);
   BG_PROBE_INIT();
   bg_tables_load(&jt, d.jtab);
@@ -68,7 +75,7 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
   if (tid == 0) { s_zero = bg_u32x4{0u, 0u, 0u, 0u}; s_owners_left = NOW; }
   for (int l = tid; l < NE; l += (NOW + NSV) * BG_BLOCK) {
     const int env = env0 + l;
-    s_q[0][l] = 0; s_q[1][l] = 0; s_ans[l] = 0;
+    s_q[0][l] = 0; s_q[1][l] = 0; s_ans[l] = 0; s_ndst[l] = 0;
     if (l < n_live) {
       uint4 c[BG_NHOT];
 #pragma unroll
@@ -80,6 +87,11 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
       Env e;
       bg_unpack(c, e);
       bg_derive_ready(e, prod);
+      s_ndst[l] = e.d_ready > 0 ? 1u : 0u;
+      if (e.d_ready > 0) {
+#pragma unroll
+        for (int k = 0; k < BG_NDECK; k++) s_nd[k][l] = d.ndeck[((size_t)e.d_head * BG_NDECK + k) * N + env];
+      }
       ShopRegs sr; sr.valid = false;
       const uint64_t mask = bg_action_mask(d, env, e, sr);
       s_mask[l] = mask;
@@ -122,8 +134,14 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
     }
     uint64_t n_steps = 0, rbits = 0, ohash = 0;
     uint32_t idle = 0;
+    // a ring deck on its way into LDS (requested when the answer of a step that reset the env is seen, stored at the end of the iteration,
+    // behind the copy-out: the round trip runs beside it): per slice
     E3T_DECL();
     for (;;) {
+      bg_u32x4 ndv[KS][BG_NDECK];
+      bool ndp[KS];
+#pragma unroll
+      for (int s = 0; s < KS; s++) ndp[s] = false;
       bool busy = false;
 #pragma unroll
       for (int s = 0; s < KS; s++) busy = busy || ((wave * KS + s) * BG_BLOCK + lane < n_live && (t[s] < T || waiting[s]));
@@ -141,6 +159,13 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
         bool fin = false;
         if (waiting[s] && bg_lds_ld(&s_ans[l]) == nreq[s]) {
           waiting[s] = false; fin = true;
+          const uint32_t nds = bg_lds_ld(&s_ndst[l]);
+          if ((nds & 0xffu) == 2u) {   // the step reset the env and consumed its LDS deck: fetch the next ring slot
+#pragma unroll
+            for (int k = 0; k < BG_NDECK; k++) ndv[s][k] = *(const __attribute__((address_space(1))) bg_u32x4*)&d.ndeck[((size_t)(nds >> 8) * BG_NDECK + k) * N + env];
+            bg_lds_st(&s_ndst[l], 0u);   // (not here until it has landed: a reset in between reads the ring itself)
+            ndp[s] = true;
+          }
           rc3[s] = s_c34[0][l]; rc4[s] = s_c34[1][l]; rmask[s] = s_mask[l];
           terminal[s] = bg_b(rc3[s].x, 0) > 100u || (int64_t)(((uint64_t)img32[33] << 32) | img32[32]) > 1000000000ll;
         }
@@ -264,6 +289,16 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
           }
         }
         BG_WAVE_SYNC();   // the images have been read (a wave's LDS operations complete in order): the next iteration may patch them
+#pragma unroll
+        for (int s = 0; s < KS; s++) {
+          if (ndp[s]) {
+            const int l = (wave * KS + s) * BG_BLOCK + lane;
+#pragma unroll
+            for (int k = 0; k < BG_NDECK; k++) *(__attribute__((address_space(3))) bg_u32x4*)&s_nd[k][l] = ndv[s][k];
+            bg_lds_st(&s_ndst[l], 1u);
+            ndp[s] = false;
+          }
+        }
         E3T(1); E3T_CNT(5, nb);
       } else {
         __builtin_amdgcn_s_sleep(2);   // every env of the wave is with a service wave
@@ -363,7 +398,12 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
           BG_PROBE(cls == 0 ? 20 : 21);
           if (e.max_ante > 0 && e.ante > e.max_ante) { o.terminated = true; o.flags |= 256; }
           if (o.terminated) n_eps++;
-          if (o.terminated && a.autoreset) bg_env_reset(d, env, e, dk);
+          if (o.terminated && a.autoreset) {
+            const bool have = bg_lds_ld(&s_ndst[l]) == 1u;
+            bg_env_reset(d, env, e, dk, nullptr, have ? (lds_cu4*)&s_nd[0][l] : (lds_cu4*)nullptr, NE);
+            // the slot after it, if the ring (as this launch may see it) holds one: the env's owner fetches it
+            bg_lds_st(&s_ndst[l], e.d_ready > 0 ? (2u | ((uint32_t)e.d_head << 8)) : 0u);
+          }
           if constexpr (CARDS) bg_vm_drain(); // card states / lazy streams in HBM are edited from any service wave: let the stores land
           BG_PROBE(24);
           mask = bg_action_mask(d, env, e, sr);

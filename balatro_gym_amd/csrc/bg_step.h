@@ -81,9 +81,12 @@ __device__ __forceinline__ uint64_t bg_action_mask(const BgDev& d, int env, cons
 // reset (balatro_env_2.py:505-558).  The shuffled deck comes from the look-ahead ring filled by the refill kernel
 // (`rng.shuffle('deck_shuffle', deck)` :525 depends on nothing but stream 0).
 // ---------------------------------------------------------------------------------------------------------
-// `pre`: the four 16-byte chunks of the ring's next deck, loaded ahead of time by the caller (nullptr = load them here)
+// `pre`: the four 16-byte chunks of the ring's next deck, loaded ahead of time by the caller (nullptr = load them here);
+// `pv`: the same in LDS (bg_engine3.h keeps the next deck of every env there), chunk k at pv[k * pv_stride]
+typedef uint32_t bg_pv_u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) const bg_pv_u32x4 lds_cu4;
 template <class DK>
-__device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, DK& dk, const uint4* pre = nullptr) {
+__device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, DK& dk, const uint4* pre = nullptr, lds_cu4* pv = nullptr, int pv_stride = 0) {
   e.ante = 1; e.round = 1; e.phase = 2; e.chips_needed = 300; e.chips_scored = 0; e.round_chips = 0; e.money = 4;
   e.hand = 0; e.nhand = 0; e.sel = 0; e.nsel = 0; e.hands_left = 4; e.discards_left = 3; e.hand_size = 8;
   e.njokers = 0; e.jokers = 0; e.ncons = 0; e.cons0 = 0; e.cons1 = 0; e.n_magic = 0; e.n_minim = 0;
@@ -102,7 +105,9 @@ __device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, DK
   else {
 #pragma unroll
     for (int k = 0; k < BG_NDECK; k++) {
-      uint4 c = pre ? pre[k] : d.ndeck[((size_t)e.d_head * BG_NDECK + k) * d.N + env];
+      uint4 c;
+      if (pv) { const bg_pv_u32x4 v = pv[k * pv_stride]; c = make_uint4(v.x, v.y, v.z, v.w); }   // (bg_engine3.h: the env's next deck waits in LDS; chunk by chunk, so that only one is in registers at a time)
+      else c = pre ? pre[k] : d.ndeck[((size_t)e.d_head * BG_NDECK + k) * d.N + env];
       d.deck[(size_t)k * d.N + env] = c;
       bg_deck_set(dk, k, c);
     }
