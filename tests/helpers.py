@@ -113,3 +113,38 @@ def forced_hand_script(k, rr, blind=45):
     order = list(range(k))
     rr.shuffle(order)
     return [blind] + [2 + p for p in order] + [0]
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Workloads of the sharded (N > 1) tests, by GLOBAL env index: a shard injects its own slice and must reproduce the bytes
+# the one-process run holds for those envs.
+#   "configs2": BASELINE configs[2] -- scorer-level joker chain, Antes 1-4 cap (the bench workload)
+#   "configs3": BASELINE configs[3] style -- card states (enhancement / edition / seal on half the deck), jokers by id and
+#               two consumables per episode out of all tarots / planets / spectrals
+# ---------------------------------------------------------------------------------------------------------
+CONSUMABLE_POOL = list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68))
+
+
+def sharded_workload(kind, total, seed0=6000):
+    import random
+    seeds = [seed0 + i for i in range(total)]
+    if kind == "configs2":
+        return dict(seeds=seeds, env_kwargs=dict(autoreset=True, scorer_jokers=True, max_ante=4), jokers=None, cards=None, consumables=None)
+    assert kind == "configs3", kind
+    jokers = [random.Random(seed0 + i).sample(range(1, 151), i % 6) for i in range(total)]
+    cards = []
+    for i in range(total):
+        rr = random.Random(seed0 * 7 + i)
+        cards.append([(d, rr.choice([0, 1, 4, 5, 6, 7, 8]), rr.choice([0, 0, 1, 2]), rr.choice([0, 0, 1, 2, 3, 4])) for d in rr.sample(range(52), 26)])
+    cons = [random.Random(seed0 * 13 + i).sample(CONSUMABLE_POOL, 1 + (i % 5 != 0)) for i in range(total)]
+    return dict(seeds=seeds, env_kwargs=dict(autoreset=True, scorer_jokers=True, max_ante=4, card_states=True), jokers=jokers, cards=cards, consumables=cons)
+
+
+def apply_sharded_workload(env, wl, lo, hi):
+    """env: the BalatroVecEnv of envs [lo, hi) of the workload."""
+    if wl["jokers"] is not None:
+        env.inject(jokers=wl["jokers"][lo:hi], apply_now=True)
+    if wl["cards"] is not None:
+        env.inject_cards(wl["cards"][lo:hi], apply_now=True)
+    if wl["consumables"] is not None:
+        env.inject_consumables(wl["consumables"][lo:hi], apply_now=True)

@@ -1,5 +1,5 @@
 """World-size-2 GPU test (NCCL = RCCL) of the multi-GPU path over the REAL engine: ShardedBalatroVecEnv around BalatroVecEnv, one
-process per GPU.  Skipped unless two GPUs are visible (the build pool's boxes have one; the driver's 8-GPU node runs it)."""
+process per GPU, for the bench workload (BASELINE configs[2]) and a configs[3]-style one (card states + jokers + consumables).  Skipped unless two GPUs are visible (the build pool's boxes have one; the driver's 8-GPU node runs it)."""
 import os
 import socket
 import sys
@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, total, T, q):
+def _worker(rank, world, port, total, T, kind, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -22,8 +22,10 @@ def _worker(rank, world, port, total, T, q):
     dist.init_process_group("nccl", rank=rank, world_size=world)
     from balatro_gym_amd.sharded import ShardedBalatroVecEnv
     from balatro_gym_amd.vec_env import RowBuffers
-    seeds = [6000 + i for i in range(total)]
-    env = ShardedBalatroVecEnv(total, seeds, device=rank, autoreset=True)
+    from tests.helpers import apply_sharded_workload, sharded_workload
+    wl = sharded_workload(kind, total)
+    env = ShardedBalatroVecEnv(total, wl["seeds"], device=rank, **wl["env_kwargs"])
+    apply_sharded_workload(env.local, wl, env.lo, env.hi)
     rb = RowBuffers(env.hi - env.lo, env.local.device, steps=T)
     env.rollout(T, policy=2, policy_seed=5, obs_buffers=rb)
     rec = env.gather_records(rb.rows[T - 1])
@@ -36,20 +38,22 @@ def _worker(rank, world, port, total, T, q):
     dist.destroy_process_group()
 
 
-def test_two_gpu_sharding_matches_one_gpu():
+@pytest.mark.parametrize("kind", ["configs2", "configs3"])
+def test_two_gpu_sharding_matches_one_gpu(kind):
     import torch
     if torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
     import torch.multiprocessing as mp
     from balatro_gym_amd import BalatroVecEnv
     from balatro_gym_amd.vec_env import RowBuffers
+    from tests.helpers import apply_sharded_workload, sharded_workload
     total, world, T = 512, 2, 64
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, T, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, T, kind, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=600) for _ in range(world)]
@@ -57,7 +61,9 @@ def test_two_gpu_sharding_matches_one_gpu():
         p.join(timeout=120)
         assert p.exitcode == 0
     # the same envs on ONE GPU
-    env = BalatroVecEnv(total, [6000 + i for i in range(total)], device=0, autoreset=True)
+    wl = sharded_workload(kind, total)
+    env = BalatroVecEnv(total, wl["seeds"], device=0, **wl["env_kwargs"])
+    apply_sharded_workload(env, wl, 0, total)
     rb = RowBuffers(total, env.device, steps=T)
     env.rollout(T, policy=2, policy_seed=5, obs_buffers=rb)
     want = rb.rows[T - 1].cpu().numpy()

@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
-def _worker(rank, world, port, total, T, q):
+def _worker(rank, world, port, total, T, kind, q):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -25,8 +25,10 @@ def _worker(rank, world, port, total, T, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from balatro_gym_amd.sharded import ShardedBalatroVecEnv
     from balatro_gym_amd.vec_env import RowBuffers
-    seeds = [6000 + i for i in range(total)]
-    env = ShardedBalatroVecEnv(total, seeds, device=0, autoreset=True, scorer_jokers=True, max_ante=4)
+    from tests.helpers import apply_sharded_workload, sharded_workload
+    wl = sharded_workload(kind, total)
+    env = ShardedBalatroVecEnv(total, wl["seeds"], device=0, **wl["env_kwargs"])
+    apply_sharded_workload(env.local, wl, env.lo, env.hi)
     rb = RowBuffers(env.hi - env.lo, env.local.device, steps=T)
     env.rollout(T, policy=2, policy_seed=5, obs_buffers=rb)
     rec = env.gather_records(rb.rows[T - 1])
@@ -39,36 +41,45 @@ def _worker(rank, world, port, total, T, q):
     dist.destroy_process_group()
 
 
-def test_two_ranks_one_gpu_match_one_process():
+@pytest.mark.parametrize("kind", ["configs2", "configs3"])
+def test_two_ranks_one_gpu_match_one_process(kind):
     import torch.multiprocessing as mp
     from balatro_gym_amd import BalatroVecEnv
     from balatro_gym_amd.vec_env import RowBuffers
+    from tests.helpers import apply_sharded_workload, sharded_workload
     total, world, T = 1024, 2, 96
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, T, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, total, T, kind, q)) for r in range(world)]
     for p in procs:
         p.start()
     results = [q.get(timeout=900) for _ in range(world)]
     for p in procs:
         p.join(timeout=120)
         assert p.exitcode == 0
-    env = BalatroVecEnv(total, [6000 + i for i in range(total)], device=0, autoreset=True, scorer_jokers=True, max_ante=4)
+    wl = sharded_workload(kind, total)
+    env = BalatroVecEnv(total, wl["seeds"], device=0, **wl["env_kwargs"])
+    apply_sharded_workload(env, wl, 0, total)
     rb = RowBuffers(total, env.device, steps=T)
     env.rollout(T, policy=2, policy_seed=5, obs_buffers=rb)
     want = rb.rows[T - 1].cpu().numpy()
     env.observe()
     want_flat = env.obs_flat.cpu().numpy()
     st1 = env.stats()
+    env.check()
     env.close()
     half = total // world
     for rank, rec, flat, st in results:
         assert rec.shape == (world, half, 352)
         assert np.array_equal(rec.reshape(total, 352), want), rank   # every rank holds every env's current record
         assert flat.shape[0] == world
+    if kind == "configs3":
+        from balatro_gym_amd import _native as nat
+        o = nat.ROW_OFFSETS["consumable_count"]
+        assert st1["episodes"] > 0 and want[:, o].max() > 0   # (consumables are held: the workload is the one meant)
     # the gathered per-key buffers hold each shard's keys back to back: compare shard 0's keys with the first half of every key of the
     # one-process run through the vec env's own layout
     for k in ("steps", "episodes", "plays", "score_sum"):
