@@ -63,7 +63,8 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
   __builtin_amdgcn_s_setprio(2);
   BG_PROBE_INIT();
   bg_tables_load(&jt, d.jtab);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = tid >> 6;
   const int env0 = blockIdx.x * NE;
   const int n_live = d.N - env0 < NE ? d.N - env0 : NE;
   // (decks stay in HBM: the first 16 cards -- every index a hand normally holds -- ride in two registers of the service lane, bg_device.h Deck0)
@@ -100,6 +101,11 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
     }
   }
   __syncthreads();
+#ifdef BG_E3_TIMING
+  if (lane == 0) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); atomicOr(&s_ctl[2], ((hw >> 4) & 3u) << (2 * wave)); }   // (word 2: nobody's)
+  const unsigned long long e3_w0 = wall_clock64();
+  __syncthreads();
+#endif
   const uint32_t T = (uint32_t)a.T;
   if (wave < NOW) {
     // ============================================================== OWNER wave: lane = env of each of its KS slices, for the whole launch
@@ -307,6 +313,21 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
       }
     }
     E3T_FLUSH(0);
+#ifdef BG_E3_TIMING
+    // (does the owner wave that shares its SIMD with the refill's waves instead of a service wave lag?)  by the number of engine waves on this wave's SIMD:
+    // dbg[16 + 4 k ..] = sum of end times (100 MHz ticks since the workgroup started), iterations, waves, steps done
+    if (lane == 0 && d.dbg) {
+      uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      const uint32_t my = (hw >> 4) & 3u;
+      int same = 0;
+      const uint32_t simds = bg_lds_ld(&s_ctl[2]);   // (posted behind the prologue's barrier)
+      for (int k = 0; k < NOW + NSV; k++) same += (((simds >> (2 * k)) & 3u) == my) ? 1 : 0;
+      const int key = same >= 3 ? 3 : same;
+      atomicAdd(&d.dbg[16 + 4 * (key - 1) + 0], wall_clock64() - e3_w0);
+      atomicAdd(&d.dbg[16 + 4 * (key - 1) + 1], e3t_[4]);
+      atomicAdd(&d.dbg[16 + 4 * (key - 1) + 2], 1ull);
+    }
+#endif
 #pragma unroll
     for (int s = 0; s < KS; s++) { const int l = (wave * KS + s) * BG_BLOCK + lane; s_c34[0][l] = rc3[s]; s_c34[1][l] = rc4[s]; }   // (the epilogue stores them)
     if (lane == 0) __hip_atomic_fetch_sub(&s_owners_left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);

@@ -33,3 +33,7 @@ for c, name in ((0, "play"), (1, "other")):
     b = max(o[12 + c], 1)
     print(f"SERVICE {name}: {b / wgs / T:.2f} batches per workgroup-step of {o[14 + c] / b:.1f} envs, {o[9 + c] / b:.0f} cycles each")
 print(f"SERVICE waves: polling / claiming {o[8] / max(o[8] + o[9] + o[10], 1):.2f} of their time")
+for k in range(3):
+    c = o[16 + 4 * k + 2]
+    if c:
+        print(f"OWNER waves with {k + 1} engine wave(s) on their SIMD: {c / wgs:.2f} per workgroup, end {o[16 + 4 * k] / c / 100:.0f} us after the workgroup's start, {o[16 + 4 * k + 1] / c:.0f} iterations")
