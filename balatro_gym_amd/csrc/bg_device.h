@@ -441,6 +441,15 @@ __device__ __forceinline__ uint32_t bg_gpeek(const BgDev& d, int env, const Env&
   if (e.g_valid < need) { atomicOr(d.err, BG_DEVERR_GSTREAM); return 0u; }
   return bg_temper(bg_gblock(d, env, blk)[idx]);
 }
+// ADDRESS of the raw word `off` positions ahead (ok = the ring holds it; otherwise a harmless address): for loads that are issued side by side and
+// looked at together -- bg_gpeek's tempering, inside a divergent branch, makes every call wait for its own HBM round trip
+__device__ __forceinline__ const uint32_t* bg_gpeek_addr(const BgDev& d, int env, const Env& e, int off, bool& ok) {
+  int idx = e.g_idx + off, blk = e.g_cur, need = 1;
+  if (idx >= BG_MT_N) { idx -= BG_MT_N; blk = (blk + 1 == d.KG) ? 0 : blk + 1; need = 2; }
+  if (idx >= BG_MT_N) { idx -= BG_MT_N; blk = (blk + 1 == d.KG) ? 0 : blk + 1; need = 3; }
+  ok = e.g_valid >= need;
+  return bg_gblock(d, env, ok ? blk : e.g_cur) + (ok ? idx : 0);
+}
 // one raw word `off` positions ahead, for its LINE (nobody looks at the value; 0 without a load when the ring does not hold it yet)
 __device__ __forceinline__ uint32_t bg_gtouch(const BgDev& d, int env, const Env& e, int off) {
   int idx = e.g_idx + off, blk = e.g_cur, need = 1;

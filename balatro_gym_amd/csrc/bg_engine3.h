@@ -26,6 +26,18 @@
 #define E3T_FLUSH(base) do {} while (0)
 #endif
 
+// the record stores of the whole-line copy-out: non-temporal (development: -DBG_E3_STORE=1 sc1, 2 sc0 sc1, 3 plain, 4 sc1 nt)
+#ifndef BG_E3_STORE
+#define BG_E3_REC_STORE(v, p) __builtin_nontemporal_store(v, p)
+#elif BG_E3_STORE == 1
+#define BG_E3_REC_STORE(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory")
+#elif BG_E3_STORE == 2
+#define BG_E3_REC_STORE(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory")
+#elif BG_E3_STORE == 3
+#define BG_E3_REC_STORE(v, p) (*(p) = (v))
+#else
+#define BG_E3_REC_STORE(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory")
+#endif
 template <int NOW, int KS, int NSV>
 struct E3Lds {
   static constexpr int NE = NOW * KS * BG_BLOCK;
@@ -250,6 +262,9 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
       }
       E3T(0);
       // ---- copy-out: lane <-> 16-byte piece, non-temporal (32 records per round of loads: the LDS round trips overlap)
+#ifdef BG_E3_NOCOPY   // development (sensitivity only, records are NOT written): what the launch would take with the copy-out for free
+      if (nb) { idle = 0; E3T(1); E3T_CNT(5, nb); } else
+#endif
       if (nb) {
         idle = 0;
         BG_WAVE_SYNC();
@@ -273,8 +288,16 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
             for (int u = 0; u < 4; u++)
 #pragma unroll
               for (int j = 0; j < 3; j++)
+#ifndef BG_E3_NOSTORE   // development (sensitivity only)
                 if (g0 + 8u * (uint32_t)u + rsel[j] < nb)
-                  __builtin_nontemporal_store(v[u][j], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)ce[u][j].x * 384u + cgl[j])));
+#else
+                if (g0 + 8u * (uint32_t)u + rsel[j] < nb && a.T == 0x7fffffff)
+#endif
+#ifdef BG_E3_STORE_L2   // development (sensitivity only): every record into the first 64 rows -- the same instructions, no HBM write stream
+                  BG_E3_REC_STORE(v[u][j], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)(ce[u][j].x & 63u) * 384u + cgl[j])));
+#else
+                  BG_E3_REC_STORE(v[u][j], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)ce[u][j].x * 384u + cgl[j])));
+#endif
           }
         } else {
           const uint32_t total = 22u * nb;

@@ -626,6 +626,15 @@ __device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, 
   uint32_t mw[12];
   uint32_t avail = 0; // main-phase words the ring already holds
   uint32_t mm = ((scnt >> 8) & 0xfu) ? mb : 0u; // Bloodstones with a Heart to look at
+  // An 8 Ball owner's main-phase words could not be requested early (their place depends on the 8s played): request them NOW, raw, before the
+  // Bloodstone words below are waited for -- a batch nearly always holds an owner of each, and the two HBM round trips then run side by side
+  // instead of one after the other (2.9 k + 2.8 k cycles per workgroup-step, probes 2 / 3)
+  const bool pre_ok = pre && pre->ok && pre->skip == consumed;
+  if (pre_ok) {
+#pragma unroll
+    for (int i = 0; i < 12; i++) mw[i] = pre->mw[i];
+    avail = pre->avail;
+  } else bg_gpeek12_raw(d, env, e, consumed, mw, avail);
 #ifdef BG_CHAIN_TOUCH
   if (pre) asm volatile("" ::"v"(pre->tl[0]), "v"(pre->tl[1]), "v"(pre->tl[2]), "v"(pre->tl[3]), "v"(pre->tl[4])); // the touched words are dead: the touches have landed
 #endif
@@ -643,18 +652,29 @@ __device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, 
       boff[c] = bg_chain_blood_off(c, code, st, n, nj, jb, m8, nb8, true, eights);
       if (c < n && nb8 && !st && rk == 8) eights++;
     }
+    // eight loads side by side (unconditional, from a harmless address where there is no word), looked at together: as eight `if (...) bg_gpeek()`
+    // every Heart was a branch region with its own wait -- up to five HBM round trips in a row inside a play batch
     uint32_t ra[8];
+    uint32_t vm = 0;
+    bool bad = false;
 #pragma unroll
-    for (int c = 0; c < 8; c++) { ra[c] = 0x80000000u; if (boff[c] >= 0) ra[c] = bg_gpeek(d, env, e, boff[c]); }
+    for (int c = 0; c < 8; c++) {
+      const bool v = boff[c] >= 0;
+      bool okc;
+      const uint32_t* p = bg_gpeek_addr(d, env, e, v ? boff[c] : 0, okc);
+      ra[c] = *p;
+      bad = bad || (v && !okc);
+      vm |= (v && okc ? 1u : 0u) << c;
+    }
+    if (bad) atomicOr(d.err, BG_DEVERR_GSTREAM);
 #pragma unroll
-    for (int c = 0; c < 8; c++) xexp += (int)((ra[c] >> 31) ^ 1u);
+    for (int c = 0; c < 8; c++) xexp += (int)(((vm >> c) & 1u) & ((bg_temper(ra[c]) >> 31) ^ 1u));
   }
-  if (pre && pre->ok && pre->skip == consumed) {
+  BG_PROBE(2);
 #pragma unroll
-    for (int i = 0; i < 12; i++) mw[i] = bg_temper(pre->mw[i]); // requested raw (the first use of a loaded value is the wait)
-    avail = pre->avail;
-  } else bg_gpeek12(d, env, e, consumed, mw, avail);
+  for (int i = 0; i < 12; i++) mw[i] = bg_temper(mw[i]); // requested raw (the first use of a loaded value is the wait)
   bg_gskip(d, e, consumed);
+  BG_PROBE(3);
   chips += ic; mult += im;
   x_mult *= (double)(1ull << xexp);
   bg_chain_main<GENERAL, DK>(d, env, e, w, in, dms, mw, avail, chips, mult, x_mult);
@@ -788,6 +808,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   bg_hand_base(ht, level, bchips, bmult);
   int64_t chips = bchips + chip_sum, mult = bmult;
   double x_mult = 1.0;
+  BG_PROBE(1);
   if ((d.flags & 1u) && e.njokers > 0) { // scorer-level joker names (BG_FLAG_SCORER_JOKERS); dict jokers are inert (Q6)
     ChainIn in;
     in.phist = phist; in.pcodes = pcodes; in.scnt = scnt; in.stone = stone; in.n = n; in.ht = ht; in.kings = kings; in.queens = queens;

@@ -24,7 +24,7 @@ st = env.stats()
 L.bg_debug_counters(env._h, out)
 o = list(out)
 wgs = n / 256
-names = {5: "gather selected cards", 6: "classify", 7: "chain: individual", 8: "chain: peeks", 13: "chain: -", 14: "chain: main", 15: "hand base + joker chain (whole call)", 16: "final score + card-state effects", 17: "boss scoring ratio", 18: "shop: stream window (loads + twist)", 10: "progress, counters, boss bookkeeping",
+names = {1: "boss checks + hand base (since classify)", 2: "chain: Bloodstone words (since chain: individual)", 3: "chain: main-phase words ready + skip", 5: "gather selected cards", 6: "classify", 7: "chain: individual", 8: "chain: peeks", 13: "chain: -", 14: "chain: main", 15: "hand base + joker chain (whole call)", 16: "final score + card-state effects", 17: "boss scoring ratio", 18: "shop: stream window (loads + twist)", 10: "progress, counters, boss bookkeeping",
          11: "reward shaping", 12: "outcome (advance round / draw / boss)", 20: "play dispatch total", 21: "other dispatch total", 22: "shop inventory",
          28: "reset: cold stores", 29: "reset: ring deck copy", 30: "reset: template loads + apply", 23: "service: state load + unpack", 24: "service: cap + reset", 25: "service: mask", 26: "service: image build", 27: "service: pack + state store"}
 print(f"T {T}: cycles per workgroup-step (first active lane of each batch)")
