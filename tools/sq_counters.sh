@@ -10,6 +10,6 @@ for set in "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAVES" "SQ_ACTIVE_INST_ANY SQ_WAIT_
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU" "SQ_INSTS_VMEM_WR SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM_WR SQ_INSTS_SMEM" \
            "SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS" "SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES" "SQ_IFETCH SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_WAVE32_LDS"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$out/sq_$i" -o runc -- python3 bench.py --no-cpu-baseline --no-step-path --steps 1488 --warmup 744 > "$out/sq_$i.json" 2> "$out/sq_$i.err"
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d "$out/sq_$i" -o runc -- python3 bench.py --no-cpu-baseline --no-step-path --no-small-n --steps 1488 --warmup 744 > "$out/sq_$i.json" 2> "$out/sq_$i.err"
 done
 ls $out/sq_*/runc_counter_collection.csv
