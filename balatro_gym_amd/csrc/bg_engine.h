@@ -118,6 +118,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   __shared__ uint2 s_cq[NE];
   __shared__ uint32_t s_cqt;                  // entries ever queued
   __shared__ bg_u32x4 s_zero;                 // the two padding pieces of a 384-byte record are read from here
+  __shared__ unsigned long long s_stats[6];   // the workgroup's share of bg_rollout_stats (bg_step.h bg_stats_wave / bg_stats_flush)
   __shared__ JTables jt;
   __builtin_amdgcn_s_setprio(3);
 #ifdef BG_TIMING4
@@ -140,6 +141,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   // ---------------------------------------------------------------- prologue: HBM -> LDS, images built, lane = env
   if (tid < 3) { s_tail[tid] = tid == BG_Q_RUN ? (uint32_t)n_live : 0u; s_head[tid] = 0; }
   if (tid == 0) { s_done = 0; s_busy = 0; s_cqt = 0; s_zero = bg_u32x4{0u, 0u, 0u, 0u}; }
+  if (tid < 6) s_stats[tid] = 0ull;
   if (tid < NE) {
     const int l = tid, env = env0 + l;
     s_q[BG_Q_PLAY][l] = 0; s_q[BG_Q_OTHER][l] = 0; s_cq[l] = make_uint2(0u, 0u);
@@ -619,19 +621,9 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     d.hot[(size_t)3 * N + env0 + tid] = s_c34[0][tid];
     d.hot[(size_t)4 * N + env0 + tid] = s_c34[1][tid];
   }
-  if (a.stats) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      n_steps += __shfl_down(n_steps, off); n_eps += __shfl_down(n_eps, off); n_plays += __shfl_down(n_plays, off);
-      ssum += __shfl_down(ssum, off); rbits ^= __shfl_down(rbits, off); ohash ^= __shfl_down(ohash, off);
-    }
-    if (lane == 0) {
-      atomicAdd((unsigned long long*)&a.stats->steps, (unsigned long long)n_steps);
-      atomicAdd((unsigned long long*)&a.stats->episodes, (unsigned long long)n_eps);
-      atomicAdd((unsigned long long*)&a.stats->plays, (unsigned long long)n_plays);
-      atomicAdd((unsigned long long*)&a.stats->score_sum, (unsigned long long)ssum);
-      atomicXor((unsigned long long*)&a.stats->reward_bits, (unsigned long long)rbits);
-      atomicXor((unsigned long long*)&a.stats->obs_hash, (unsigned long long)ohash);
-    }
+  if (a.stats) {   // (bg_step.h: one set of global atomics per workgroup, not per wave)
+    bg_stats_wave(s_stats, n_steps, n_eps, n_plays, ssum, rbits, ohash);
+    __syncthreads();
+    bg_stats_flush(a.stats, s_stats, tid);
   }
 }

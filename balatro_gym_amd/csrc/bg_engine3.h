@@ -57,6 +57,7 @@ struct E3Lds {
   uint4 s_nd[BG_NDECK][NE];
   uint32_t s_ndst[NE];
   bg_u32x4 s_zero;
+  unsigned long long s_stats[6];   // the workgroup's share of bg_rollout_stats (bg_stats_wave / bg_stats_flush)
   uint32_t s_owners_left;
   JTables jt;
 };
@@ -73,6 +74,9 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
   auto& s_ctl = L.s_ctl; auto& s_win = L.s_win; auto& s_list = L.s_list; auto& s_zero = L.s_zero; auto& s_owners_left = L.s_owners_left; auto& jt = L.jt;
   auto& s_nd = L.s_nd; auto& s_ndst = L.s_ndst;
   __builtin_amdgcn_s_setprio(2);
+#if defined(BG_E3_TIMING) || defined(BG_E3_TL)
+  const unsigned long long e3_k0 = wall_clock64();
+#endif
   BG_PROBE_INIT();
   bg_tables_load(&jt, d.jtab);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -86,6 +90,7 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
   // ---------------------------------------------------------------- prologue: HBM -> LDS, images built, lane = env (bg_engine.h)
   if (tid < 8) s_ctl[tid] = 0;
   if (tid == 0) { s_zero = bg_u32x4{0u, 0u, 0u, 0u}; s_owners_left = NOW; }
+  if (tid < 6) L.s_stats[tid] = 0ull;
   for (int l = tid; l < NE; l += (NOW + NSV) * BG_BLOCK) {
     const int env = env0 + l;
     s_q[0][l] = 0; s_q[1][l] = 0; s_ans[l] = 0; s_ndst[l] = 0;
@@ -115,7 +120,10 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
   __syncthreads();
 #ifdef BG_E3_TIMING
   if (lane == 0) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); atomicOr(&s_ctl[2], ((hw >> 4) & 3u) << (2 * wave)); }   // (word 2: nobody's)
+#endif
+#if defined(BG_E3_TIMING) || defined(BG_E3_TL)
   const unsigned long long e3_w0 = wall_clock64();
+  if (tid == 0 && d.dbg) atomicAdd(&d.dbg[28], e3_w0 - e3_k0);   // prologue (100 MHz ticks, summed over workgroups)
   __syncthreads();
 #endif
   const uint32_t T = (uint32_t)a.T;
@@ -351,18 +359,13 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
       atomicAdd(&d.dbg[16 + 4 * (key - 1) + 2], 1ull);
     }
 #endif
+#if defined(BG_E3_TIMING) || defined(BG_E3_TL)
+    if (lane == 0 && d.dbg) atomicAdd(&d.dbg[29], wall_clock64() - e3_k0);   // owner loop end, summed over owner waves
+#endif
 #pragma unroll
     for (int s = 0; s < KS; s++) { const int l = (wave * KS + s) * BG_BLOCK + lane; s_c34[0][l] = rc3[s]; s_c34[1][l] = rc4[s]; }   // (the epilogue stores them)
     if (lane == 0) __hip_atomic_fetch_sub(&s_owners_left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (a.stats) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) { n_steps += __shfl_down(n_steps, off); rbits ^= __shfl_down(rbits, off); ohash ^= __shfl_down(ohash, off); }
-      if (lane == 0) {
-        atomicAdd((unsigned long long*)&a.stats->steps, (unsigned long long)n_steps);
-        atomicXor((unsigned long long*)&a.stats->reward_bits, (unsigned long long)rbits);
-        atomicXor((unsigned long long*)&a.stats->obs_hash, (unsigned long long)ohash);
-      }
-    }
+    if (a.stats) bg_stats_wave(L.s_stats, n_steps, 0, 0, 0, rbits, ohash);
   } else {
     // ============================================================== SERVICE wave: batches from the two request queues (bg_engine.h's service batch)
     __builtin_amdgcn_s_setprio(3);
@@ -468,15 +471,10 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
       E3T(1 + cls); E3T_CNT(4 + cls, 1); E3T_CNT(6 + cls, nb);
     }
     E3T_FLUSH(8);
-    if (a.stats) {
-#pragma unroll
-      for (int off = 32; off > 0; off >>= 1) { n_eps += __shfl_down(n_eps, off); n_plays += __shfl_down(n_plays, off); ssum += __shfl_down(ssum, off); }
-      if (lane == 0 && (n_eps | n_plays)) {
-        atomicAdd((unsigned long long*)&a.stats->episodes, (unsigned long long)n_eps);
-        atomicAdd((unsigned long long*)&a.stats->plays, (unsigned long long)n_plays);
-        atomicAdd((unsigned long long*)&a.stats->score_sum, (unsigned long long)ssum);
-      }
-    }
+#if defined(BG_E3_TIMING) || defined(BG_E3_TL)
+    if (lane == 0 && d.dbg) atomicAdd(&d.dbg[30], wall_clock64() - e3_k0);   // service loop end, summed over service waves
+#endif
+    if (a.stats) bg_stats_wave(L.s_stats, 0, n_eps, n_plays, ssum, 0, 0);
   }
   // ---------------------------------------------------------------- epilogue: chunks 3 / 4 -> HBM
   BG_PROBE_FLUSH(d);
@@ -485,4 +483,8 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
     d.hot[(size_t)3 * N + env0 + l] = s_c34[0][l];
     d.hot[(size_t)4 * N + env0 + l] = s_c34[1][l];
   }
+  if (a.stats) bg_stats_flush(a.stats, L.s_stats, tid);
+#if defined(BG_E3_TIMING) || defined(BG_E3_TL)
+  if (tid == 0 && d.dbg) atomicAdd(&d.dbg[31], wall_clock64() - e3_k0);   // workgroup end
+#endif
 }

@@ -1467,6 +1467,37 @@ struct RowStage { lds_u4* stage; lds_u64* addr; };
 #define BG_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif // reward / action / terminated ride in the record
 
+// Statistics of a launch (bg_rollout_stats).  A wave folds its lanes with shuffles and adds the result to six LDS words of its workgroup; behind the
+// workgroup's last barrier six lanes add those to the caller's struct.  One global atomic per wave and field -- 5 376 (engine 3) / 10 752 (bg_engine.h)
+// read-modify-writes of ONE 48-byte line per launch of 65 536 envs, which the memory side serialises at ~11 ns apiece -- kept every launch ~58 us longer
+// than its last workgroup (a fifth of a 20-step launch; tools/short_launches.py).
+typedef __attribute__((address_space(3))) unsigned long long lds_stat;
+__device__ __forceinline__ void bg_stats_wave(unsigned long long* st, uint64_t n_steps, uint64_t n_eps, uint64_t n_plays, int64_t ssum, uint64_t rbits, uint64_t ohash) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    n_steps += __shfl_down(n_steps, off); n_eps += __shfl_down(n_eps, off); n_plays += __shfl_down(n_plays, off);
+    ssum += __shfl_down(ssum, off); rbits ^= __shfl_down(rbits, off); ohash ^= __shfl_down(ohash, off);
+  }
+  if ((threadIdx.x & 63u) == 0u) {
+    lds_stat* s = (lds_stat*)st;
+    if (n_steps) __hip_atomic_fetch_add(&s[0], (unsigned long long)n_steps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (n_eps) __hip_atomic_fetch_add(&s[1], (unsigned long long)n_eps, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (n_plays) __hip_atomic_fetch_add(&s[2], (unsigned long long)n_plays, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (ssum) __hip_atomic_fetch_add(&s[3], (unsigned long long)ssum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (rbits) __hip_atomic_fetch_xor(&s[4], (unsigned long long)rbits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (ohash) __hip_atomic_fetch_xor(&s[5], (unsigned long long)ohash, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  }
+}
+// behind a __syncthreads() that follows every wave's bg_stats_wave
+__device__ __forceinline__ void bg_stats_flush(bg_rollout_stats* out, const unsigned long long* st, int tid) {
+  if (tid < 6) {
+    const unsigned long long v = ((const lds_stat*)st)[tid];
+    unsigned long long* dst = (unsigned long long*)out + tid;   // steps, episodes, plays, score_sum, reward_bits, obs_hash
+    if (v) { if (tid < 4) atomicAdd(dst, v); else atomicXor(dst, v); }
+  }
+}
+static_assert(sizeof(bg_rollout_stats) == 48, "six 64-bit fields, in the order bg_stats_flush assumes");
+
 // `row` = env + t * N for [T, N, ...] rollout buffers.  Returns a 64-bit hash of the row (rollout checksum; the same
 // value for both output layouts).
 //

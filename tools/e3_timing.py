@@ -37,3 +37,4 @@ for k in range(3):
     c = o[16 + 4 * k + 2]
     if c:
         print(f"OWNER waves with {k + 1} engine wave(s) on their SIMD: {c / wgs:.2f} per workgroup, end {o[16 + 4 * k] / c / 100:.0f} us after the workgroup's start, {o[16 + 4 * k + 1] / c:.0f} iterations")
+print(f"WORKGROUP timeline (mean, us after its first instruction): prologue done {o[28] / wgs / 100:.1f}, owner loops end {o[29] / (4 * wgs) / 100:.1f}, service loops end {o[30] / (3 * wgs) / 100:.1f}, workgroup end {o[31] / wgs / 100:.1f}")
