@@ -19,7 +19,7 @@ L = nat.load()
 L.bg_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
 env.set_profiling(True)
 wgs = (n + 255) // 256
-for T in (1, 2, 5, 10, 20, 40):
+for T in [int(x) for x in os.environ.get("TS", "1,2,5,10,20,40").split(",")]:
     a = (C.c_ulonglong * 32)(); b = (C.c_ulonglong * 32)()
     reps = 8
     L.bg_debug_counters(env._h, a)
