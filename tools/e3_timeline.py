@@ -28,7 +28,7 @@ for T in [int(x) for x in os.environ.get("TS", "1,2,5,10,20,40").split(",")]:
         env.rollout(T, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, t0=t0, obs_buffers=rb, zero_stats=False); t0 += T
         torch.cuda.synchronize(); us.append(env.get_profile()["rollout_ms"] * 1e3)
     L.bg_debug_counters(env._h, b)
-    o = [(float(b[i]) - float(a[i])) / reps for i in range(32)]
+    o = [float(b[i]) / reps for i in range(32)]   # (bg_debug_counters reads AND clears)
     us.sort()
     print(f"T {T:3d}: launch {us[len(us) // 2]:6.1f} us | mean over workgroups, us after the workgroup's first instruction: prologue done {o[28] / wgs / 100:5.1f}, "
           f"owner loops end {o[29] / (4 * wgs) / 100:6.1f}, service loops end {o[30] / (3 * wgs) / 100:6.1f}, workgroup end {o[31] / wgs / 100:6.1f}", flush=True)
