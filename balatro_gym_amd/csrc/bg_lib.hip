@@ -1192,9 +1192,10 @@ int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void
 // worker waves for a launch of T fused steps (BG_ENG_WAVES overrides)
 static int bg_engine_waves(const bg_handle* h, int T) {
   if (h->eng_waves >= 4 && h->eng_waves <= BG_ENG_NW) return h->eng_waves;
-  // measured (tools/ab_waves.sh, us per launch at 4 / 5 / 6 / 7 waves): T = 4: 157 / 182 / 203 / 226; 20: 312 / 326 / 347 / 380; 40: 589 / 572 /
-  // 532 / 615; 160: 1 714 / 1 611 / 1 562 / 1 660; 372: 3 790 / 3 628 / 3 671 / 3 506
-  if (T <= 24) return 4;
+  // measured (tools/ab_waves.sh with BG_ENGINE=1, us per launch at 4 / 5 / 6 / 7 waves): T = 4: 80 / 79 / 80 / 78; 10: 150 / 149 / 145 / 146; 20: 260 / 254 /
+  // 249 / 249; 40: 507 / 490 / 489 / 481; 80: 925 / 920 / 928 / 926; 160: 1 847 / 1 770 / 1 831 / 1 835; 372: 4 010 / 3 805 / 3 674 / 3 632.
+  // (Rounds 2-3 ran short launches on FOUR waves: their measurements -- T = 20: 312 / 326 / 347 / 380 -- had six statistics atomics per WAVE in them,
+  //  an end-of-launch tail that grew with the wave count; bg_step.h bg_stats_wave.)
   if (T <= 192) return BG_ENG_NW - 1;
   return BG_ENG_NW;
 }
