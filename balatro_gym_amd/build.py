@@ -12,7 +12,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "csrc", "bg_lib.hip")
-DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("bg_device.h", "bg_step.h", "bg_tables.h", "bg_ops.h", "bg_sim.h", "bg_engine.h", "bg_engine2.h", "bg_engine3.h")] + [
+DEPS = [SRC] + [os.path.join(HERE, "csrc", f) for f in ("bg_device.h", "bg_step.h", "bg_tables.h", "bg_ops.h", "bg_sim.h", "bg_engine.h", "bg_engine3.h")] + [
     os.path.join(os.path.dirname(HERE), "include", "balatro_mi355x.h")]
 LIB = os.path.join(HERE, "libbalatro_mi355x.so")
 ARCH = "gfx950"
@@ -29,10 +29,12 @@ FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-ffp-contract=off", "-f
 
 
 def source_signature() -> str:
-    """What identifies the DEVICE CODE of a build, reproducibly: sha256 (first 16 hex digits) over every source the library is
-    compiled from, the compiler flags and the compiler's version.  Two builds of unchanged sources with the same hipcc carry the
-    same signature (the bytes of the code object do not: rebuilding unchanged sources gave three different .hip_fatbin hashes), so a
-    committed PMC traffic measurement (profiles/*_hbm_traffic.json) stays attached to the code it was taken on across rebuilds."""
+    """What identifies the DEVICE CODE of a build, reproducibly: 16 hex digits = sha256 prefix (12) over every source the library is
+    compiled from and the compiler flags, then sha256 prefix (4) of the compiler's version line.  Two builds of unchanged sources with the
+    same hipcc carry the same signature (the bytes of the code object do not: rebuilding unchanged sources gave three different .hip_fatbin
+    hashes), so a committed PMC traffic measurement (profiles/*_hbm_traffic.json) stays attached to the code it was taken on across
+    rebuilds.  The first 12 digits do not depend on the box (`sources_part`): a library that travelled to a box with another ROCm still
+    says which sources it was built from."""
     import hashlib
     h = hashlib.sha256()
     for d in DEPS:
@@ -41,12 +43,18 @@ def source_signature() -> str:
             h.update(f.read())
         h.update(b"\0")
     h.update(" ".join(FLAGS).encode())
+    c = hashlib.sha256()
     try:
         ver = subprocess.run([hipcc_path(), "--version"], capture_output=True, text=True, timeout=60).stdout
-        h.update("\n".join(l for l in ver.splitlines() if "version" in l.lower()).encode())
+        c.update("\n".join(l for l in ver.splitlines() if "version" in l.lower()).encode())
     except Exception:
-        h.update(b"hipcc-unknown")
-    return h.hexdigest()[:16]
+        c.update(b"hipcc-unknown")
+    return h.hexdigest()[:12] + c.hexdigest()[:4]
+
+
+def sources_part(signature: str) -> str:
+    """The compiler-independent part of a build signature."""
+    return signature[:12]
 
 
 def needs_build() -> bool:

@@ -52,7 +52,6 @@ __device__ __forceinline__ void bg_emit_info(size_t row, const StepOut& o, uint8
 
 #include "bg_engine.h" // the step engine: one kernel behind bg_step / bg_step_many / bg_rollout / bg_rollout_rows
 #include "bg_engine3.h" // owner waves + service waves in ONE workgroup (packed-record rollouts)
-#include "bg_engine2.h" // the same engine as two cooperating kernels (owner waves + a chip-wide pool of service waves): packed-record rollouts
 
 template <bool CARDS>
 __global__ __launch_bounds__(BG_BLOCK) void bg_reset_kernel(BgDev d, const uint8_t* __restrict__ mask_in, ObsPtrs obs) {
@@ -682,14 +681,10 @@ struct bg_handle {
   // tunables read ONCE per handle in bg_create (environment variables)
   int refill_blocks, refill_blocks_shop, dev_skip_refill, refill_order;
   uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_smask; int eng_waves, eng_copiers; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
-  // the two-kernel engine (bg_engine2.h): queues / answers / images, the service kernel's stream, the pair of events that tie a launch's two kernels together
-  int engine;            // BG_ENGINE: 2 = owner + service kernels for packed-record rollouts (default), 1 = the one-kernel engine everywhere
-  E2Args e2;
-  bool e2_img_valid;     // the images in e2.img describe the state: false after anything but a two-kernel launch has touched it
-  hipStream_t svc;
-  hipEvent_t ev_e2a, ev_e2b;
-  int e2_svc_waves;      // service waves per launch (BG_E2_SVC; default 4 per CU)
-  long e2_launches;
+  int engine;            // BG_ENGINE: 3 = bg_engine3.h (owner + service waves in one workgroup) for packed-record rollouts (default), 1 = bg_engine.h everywhere
+  // bg_engine3.h: workgroup shape (BG_E3_CFG = 100 * owner waves + 10 * slices + service waves; 0 = by env count) and the service waves' batch
+  // thresholds (BG_E3_TH requests, or after BG_E3_WAIT ticks of 10 ns)
+  int e3_cfg; uint32_t e3_th, e3_wait;
 };
 
 static std::string g_create_err;
@@ -764,15 +759,6 @@ extern "C" {
 // sha256 prefix of the sources + flags + compiler this library was built from (balatro_gym_amd/build.py source_signature()); "unsigned" for ad-hoc builds
 const char* bg_build_signature(void) { return BG_BUILD_SIGNATURE; }
 
-// development hook: the two-kernel engine's control block (queue tails / heads, arrival counters, wall-clock stamps) as 32-bit words
-int bg_debug_e2(bg_handle* h, unsigned int* out, int nwords) {
-  if (!h || !out || !h->e2.ctl) return BG_E_ARG;
-  BG_GUARD(h);
-  (void)hipDeviceSynchronize();
-  const size_t n = (size_t)nwords * 4 < sizeof(E2Ctl) ? (size_t)nwords * 4 : sizeof(E2Ctl);
-  BG_HIP(hipMemcpy(out, h->e2.ctl, n, hipMemcpyDeviceToHost));
-  return (int)(n / 4);
-}
 // development hook: copy (and clear) the 16 phase counters written by -DBG_TIMING builds
 int bg_debug_counters(bg_handle* h, unsigned long long* out16) {
   if (!h || !out16) return BG_E_ARG;
@@ -858,11 +844,11 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
     h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0); h->eng_copiers = geti("BG_ENG_COPIERS", 0); if (h->eng_copiers < 0 || h->eng_copiers > 3) h->eng_copiers = 0;   // 0 = by launch length (bg_engine_launch)
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
-    h->engine = geti("BG_ENGINE", 3); if (h->engine < 1 || h->engine > 3) h->engine = 3;
-    memset(&h->e2, 0, sizeof(h->e2));
-    h->e2.fill_wait = (uint32_t)geti("BG_E2_FILL_WAIT", 200); h->e2.max_batch = (uint32_t)geti("BG_E2_MAX_BATCH", 64);
-    h->e2_svc_waves = geti("BG_E2_SVC", 0);
-    h->e2_img_valid = false; h->svc = nullptr; h->ev_e2a = h->ev_e2b = nullptr; h->e2_launches = 0;
+    h->engine = geti("BG_ENGINE", 3);
+    if (h->engine != 1 && h->engine != 3) { delete h; g_create_err = "bg_create: BG_ENGINE must be 3 (bg_engine3.h, the default) or 1 (bg_engine.h); the two-kernel engine 2 was retired in round 5"; return BG_E_ARG; }
+    h->e3_cfg = geti("BG_E3_CFG", 0);
+    if (h->e3_cfg != 0 && h->e3_cfg != 113 && h->e3_cfg != 213 && h->e3_cfg != 413 && h->e3_cfg != 414) { delete h; g_create_err = "bg_create: BG_E3_CFG must be 113, 213, 413 or 414 (100 x owner waves + 10 x slices + service waves)"; return BG_E_ARG; }
+    h->e3_th = (uint32_t)geti("BG_E3_TH", 0x7fffffff); h->e3_wait = (uint32_t)geti("BG_E3_WAIT", 0);
   }
   h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->view_min = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
   h->ev_refill[0] = h->ev_refill[1] = nullptr; h->ev_rollout = nullptr;
@@ -937,20 +923,6 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
   if (e == hipSuccess) e = bg_alloc(h, &d.err, 4);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_seeds, N);
   if (e == hipSuccess) e = bg_alloc(h, &h->d_mask, N);
-  if (e == hipSuccess && h->engine == 2) { // the two-kernel engine: request rings (one slot per env and queue: an env has at most one request in flight), answers, images
-    // ring entries per queue: the service waves of a queue RESERVE slots ahead of the requests (64 waves x 64 slots at most), and behind them an
-    // env has one request in flight -- twice that, as a power of two (a lapped slot is a loud error, never a wrong env)
-    uint32_t lg = 6; while ((1ull << lg) < 2 * (N + 64 * 64)) lg++;
-    h->e2.ring_log = lg;
-    e = bg_alloc(h, &h->e2.ctl, 1);
-    if (e == hipSuccess) e = bg_alloc(h, &h->e2.ring, (size_t)BG_E2_NQ << lg);
-    if (e == hipSuccess) e = bg_alloc(h, &h->e2.ansq, N);
-    if (e == hipSuccess) e = bg_alloc(h, &h->e2.img, 24 * N);
-    if (e == hipSuccess) e = bg_alloc(h, &h->e2.imask, N);
-    if (e == hipSuccess) e = hipStreamCreateWithPriority(&h->svc, hipStreamNonBlocking, prio_greatest);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_e2a, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&h->ev_e2b, hipEventDisableTiming);
-  }
   if (e != hipSuccess) {
     g_create_err = std::string("bg_create: ") + hipGetErrorString(e);
     bg_destroy(h);
@@ -984,10 +956,6 @@ int bg_destroy(bg_handle* h) {
   if (h->ev_gblk) (void)hipEventDestroy(h->ev_gblk);
   for (int i = 0; i < 2; i++) if (h->ev_refill[i]) (void)hipEventDestroy(h->ev_refill[i]);
   if (h->ev_rollout) (void)hipEventDestroy(h->ev_rollout);
-  if (h->svc) (void)hipStreamDestroy(h->svc);
-  if (h->ev_e2a) (void)hipEventDestroy(h->ev_e2a);
-  if (h->ev_e2b) (void)hipEventDestroy(h->ev_e2b);
-  hipFree(h->e2.ctl); hipFree(h->e2.ring); hipFree(h->e2.ansq); hipFree(h->e2.img); hipFree(h->e2.imask);
   for (hipEvent_t e : h->ev_pool) (void)hipEventDestroy(e);
   for (auto* v : {&h->ev_rollout_t, &h->ev_refill_t, &h->ev_step_t}) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
   hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
@@ -1114,7 +1082,6 @@ int bg_check(bg_handle* h, void* stream) {
 }
 
 int bg_seed(bg_handle* h, const int64_t* seeds_host, const uint8_t* mask_host, int reseed_global, void* stream) {
-  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   if (!h || !seeds_host) return BG_E_ARG;
   BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;
@@ -1176,7 +1143,6 @@ static void bg_info_advance(InfoPtrs& p, size_t off) {
 }
 
 int bg_reset(bg_handle* h, const uint8_t* mask_dev, const bg_obs_ptrs* obs, void* stream) {
-  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   int rc = bg_require_seeded(h);
   if (rc) return rc;
   BG_GUARD(h);
@@ -1199,76 +1165,20 @@ static int bg_engine_waves(const bg_handle* h, int T) {
   if (T <= 192) return BG_ENG_NW - 1;
   return BG_ENG_NW;
 }
-// Two kernels for one launch (bg_engine2.h): the owner kernel on the caller's stream, the service kernel on the handle's service stream,
-// both released by the same point of the caller's stream (so the service waves never spin while earlier work of the caller is still
-// running) and joined again behind the owner kernel.  Neither kernel waits for a workgroup that has not started, and every wait inside
-// them is bounded, so an unlucky placement costs time, never a hang.
-static bool bg_engine2_ok(const bg_handle* h, const EngineArgs& a, bool info) {
-  return h->engine == 2 && h->e2.ctl && a.obs.rows && !info && !h->dev.cstate && !a.actions_in && !a.reward && !a.term && !a.actions_out;
-}
-static int bg_engine2_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a, bool hash, hipStream_t st) {
-  const int n_wg = (h->dev.N + BG_E2_OW * BG_BLOCK - 1) / (BG_E2_OW * BG_BLOCK);
-  E2Args x = h->e2;
-  if (!h->e2_img_valid) { // something else has stepped / reset / injected since the last two-kernel launch: rebuild every image from the state
-    hipLaunchKernelGGL(bg_e2_image_kernel<false>, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, st, dv, x);
-    h->e2_img_valid = true;
-  }
-  // owner waves that will report: every wave of every workgroup (waves without a live env leave at once)
-  h->e2.done_target += (uint32_t)(n_wg * BG_E2_OW);
-  x.done_target = h->e2.done_target;
-  h->e2.start_target += (uint32_t)(n_wg < 256 ? n_wg : 256);   // (every workgroup starts eventually; the gate only waits for as many as can be resident)
-  x.start_target = h->e2.start_target;
-  if (n_wg > 256) h->e2.start_target += (uint32_t)(n_wg - 256);
-  // service waves: four per CU (one per SIMD beside an owner wave); small jobs get fewer (a wave per four envs, a multiple of the eight XCDs)
-  int nsvc = h->e2_svc_waves > 0 ? h->e2_svc_waves : 4 * 256;
-  if (h->e2_svc_waves <= 0 && h->dev.N < 4096) { nsvc = ((h->dev.N / 4 + 7) / 8) * 8; if (nsvc < 64) nsvc = 64; }
-  // heads and tails start at 0 every launch: a service wave RESERVES slots ahead of the requests, and what it held when the launch ended is nobody's
-  BG_HIP(hipMemsetAsync((char*)h->e2.ctl + offsetof(E2Ctl, q), 0, sizeof(((E2Ctl*)0)->q), st));
-  static const int nowait = getenv("BG_E2_NOWAIT") ? atoi(getenv("BG_E2_NOWAIT")) : 0;   // development
-  if (!nowait) {
-  BG_HIP(hipEventRecord(h->ev_e2a, st));
-  BG_HIP(hipStreamWaitEvent(h->svc, h->ev_e2a, 0));
-  }
-  static const int order = getenv("BG_E2_ORDER") ? atoi(getenv("BG_E2_ORDER")) : 0;   // development: 1 = the service kernel is launched first
-  if (order == 1) hipLaunchKernelGGL(bg_service_kernel<false>, dim3(nsvc), dim3(BG_BLOCK), 0, h->svc, dv, a, x);
-  static bool lds_attr = false;
-  if (!lds_attr) { // more than 64 KB of dynamic LDS needs the attribute (once per process and kernel)
-    BG_HIP(hipFuncSetAttribute((const void*)bg_owner_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, BG_E2_OWNER_LDS));
-    BG_HIP(hipFuncSetAttribute((const void*)bg_owner_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, BG_E2_OWNER_LDS));
-    lds_attr = true;
-  }
-  if (hash) hipLaunchKernelGGL(bg_owner_kernel<true>, dim3(n_wg), dim3(BG_E2_OW * BG_BLOCK), BG_E2_OWNER_LDS, st, dv, a, x);
-  else hipLaunchKernelGGL(bg_owner_kernel<false>, dim3(n_wg), dim3(BG_E2_OW * BG_BLOCK), BG_E2_OWNER_LDS, st, dv, a, x);
-  static const int probe = getenv("BG_E2_PROBE") ? atoi(getenv("BG_E2_PROBE")) : 0;   // development
-  if (probe == 1) hipLaunchKernelGGL((bg_e2_probe_kernel<0, 0>), dim3(nsvc), dim3(BG_BLOCK), 0, h->svc, x);
-  if (probe == 2) hipLaunchKernelGGL((bg_e2_probe_kernel<256, 0>), dim3(nsvc), dim3(BG_BLOCK), 0, h->svc, x);
-  if (probe == 3) hipLaunchKernelGGL((bg_e2_probe_kernel<256, 3344>), dim3(nsvc), dim3(BG_BLOCK), 0, h->svc, x);
-  if (probe == 4) hipLaunchKernelGGL((bg_e2_probe_kernel<0, 3344>), dim3(nsvc), dim3(BG_BLOCK), 0, h->svc, x);
-  static const int gate = getenv("BG_E2_GATE") ? atoi(getenv("BG_E2_GATE")) : 1;   // development: 0 = no gate in front of the service kernel
-  if (gate) hipLaunchKernelGGL(bg_e2_gate_kernel, dim3(1), dim3(BG_BLOCK), 0, h->svc, x);
-  if (order != 1) hipLaunchKernelGGL(bg_service_kernel<false>, dim3(nsvc), dim3(BG_BLOCK), 0, h->svc, dv, a, x);
-  BG_HIP(hipEventRecord(h->ev_e2b, h->svc));
-  BG_HIP(hipStreamWaitEvent(st, h->ev_e2b, 0));
-  h->e2_launches++;
-  return 0;
-}
 static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0, bool hash, bool info, hipStream_t st) {
   const bool cards = h->dev.cstate != nullptr;
   EngineArgs a = a0;
-  if (bg_engine2_ok(h, a, info)) { if (bg_engine2_launch(h, dv, a, hash, st) != 0) h->err = "two-kernel engine: " + h->err; return; }
   if (h->engine == 3 && a.obs.rows && !info && !a.actions_in && !a.reward && !a.term && !a.actions_out) { // packed-record rollouts: owner waves + service waves (bg_engine3.h)
-    h->e2_img_valid = false;
     { // batch thresholds of the service waves: BG_E3_TH requests, or after BG_E3_WAIT ticks of 10 ns.  Default: never by threshold and no waiting --
       // a free service wave takes the FULLER of the two queues at once (measured at 372 steps: thresholds 32 / 48 / 64 with waits of 3 - 20 us all lose
       // 1 - 8 %, and serving plays as soon as one is queued -- batches of a few lanes -- loses a third: profiles/r04_engine3/thresholds_ab.txt)
-      static const int th = getenv("BG_E3_TH") ? atoi(getenv("BG_E3_TH")) : 0x7fffffff, wt = getenv("BG_E3_WAIT") ? atoi(getenv("BG_E3_WAIT")) : 0;
-      a.th_play = a.th_other = (uint32_t)th; a.th_more = (uint32_t)wt;
+      a.th_play = a.th_other = h->e3_th; a.th_more = h->e3_wait;   // (read once per handle in bg_create_ex, like every tunable)
     }
     // Shape of a workgroup: owner waves x slices of 64 envs x service waves.  BG_E3_CFG = 100 * owners + 10 * slices + service waves overrides.
     // 65 536 envs: 4 x 1 x 3 = 256 envs on seven waves per CU (the refill keeps its SIMD).  A small job spreads over more CUs: 64 envs per
-    // workgroup up to 8 192 envs, 128 up to 32 768 (profiles/r04_engine3/small_jobs.txt).
-    static const int cfg_env = getenv("BG_E3_CFG") ? atoi(getenv("BG_E3_CFG")) : 0;
-    const int cfg = cfg_env ? cfg_env : (h->dev.N <= 8192 ? 113 : (h->dev.N <= 32768 ? 213 : 413));
+    // workgroup up to 16 384 envs (256 workgroups = one per CU: 2.89 G env-steps/s against 2.59 G at 128 per workgroup), 128 up to 32 768
+    // (profiles/r04_engine3/small_jobs.txt).  Unknown shapes are refused by bg_create_ex.
+    const int cfg = h->e3_cfg ? h->e3_cfg : (h->dev.N <= 16384 ? 113 : (h->dev.N <= 32768 ? 213 : 413));
 #define BG_E3K(HV, CV, NOWV, KSV, NSVV) hipLaunchKernelGGL((bg_engine3_kernel<HV, CV, NOWV, KSV, NSVV>), dim3((h->dev.N + NOWV * KSV * 64 - 1) / (NOWV * KSV * 64)), dim3((NOWV + NSVV) * BG_BLOCK), 0, st, dv, a)
 #define BG_E3(NOWV, KSV, NSVV) do { \
       if (hash && cards) BG_E3K(true, true, NOWV, KSV, NSVV); else if (hash) BG_E3K(true, false, NOWV, KSV, NSVV); \
@@ -1276,13 +1186,13 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
     switch (cfg) {   // (other shapes were measured and dropped: profiles/r04_engine3/wave_split_ab.txt, small_jobs.txt)
       case 113: BG_E3(1, 1, 3); break;
       case 213: BG_E3(2, 1, 3); break;
+      case 414: BG_E3(4, 1, 4); break;   // eight waves: no room for the refill beside the launch (it then runs when the workgroups retire)
       default: BG_E3(4, 1, 3); break;
     }
 #undef BG_E3
 #undef BG_E3K
     return;
   }
-  h->e2_img_valid = false;
   a.n_waves = (uint32_t)bg_engine_waves(h, (int)a.T);
   // packed records: one more wave, the COPIER (bg_engine.h), takes the record copy-out off the workers; with the seven-wave shape that
   // leaves room for the refill beside the launch it is one of the seven
@@ -1514,7 +1424,6 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_inject_cards_kernel(BgDev d, cons
 
 int bg_inject_cards(bg_handle* h, const uint8_t* enh_host, const uint8_t* edition_host, const uint8_t* seal_host,
                     const uint8_t* mask_host, int apply_now, void* stream) {
-  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   if (!h) return BG_E_ARG;
   if (!h->dev.cstate) { h->err = "bg_inject_cards: the handle was created without BG_FLAG_CARD_STATES"; return BG_E_ARG; }
   BG_GUARD(h);
@@ -1541,7 +1450,6 @@ int bg_inject_cards(bg_handle* h, const uint8_t* enh_host, const uint8_t* editio
 
 int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_host, const int64_t* money_host,
               const int32_t* ante_host, const uint8_t* levels_host, const uint8_t* mask_host, int apply_now, void* stream) {
-  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   if (!h) return BG_E_ARG;
   BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;
@@ -1590,7 +1498,6 @@ int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_h
 
 int bg_inject_consumables(bg_handle* h, const int32_t* ids_host, const int32_t* n_host, const uint8_t* mask_host, int apply_now,
                           void* stream) {
-  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   if (!h || !ids_host || !n_host) return BG_E_ARG;
   BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;
@@ -1676,7 +1583,6 @@ int bg_get_state(bg_handle* h, int env_index, void* blob_host, uint64_t blob_byt
   return 0;
 }
 int bg_set_state(bg_handle* h, int env_index, const void* blob_host, uint64_t blob_bytes) {
-  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   int rc = bg_blob_args(h, "bg_set_state", env_index, blob_host, blob_bytes);
   if (rc) return rc;
   BG_GUARD(h);
@@ -1715,7 +1621,6 @@ int bg_set_state(bg_handle* h, int env_index, const void* blob_host, uint64_t bl
 
 // ---- harness injection of the LIVE deck order and of the curriculum cap ----
 int bg_inject_deck(bg_handle* h, const uint8_t* decks_host, const uint8_t* mask_host, void* stream) {
-  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   if (!h || !decks_host) return BG_E_ARG;
   BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;
@@ -1745,7 +1650,6 @@ int bg_inject_deck(bg_handle* h, const uint8_t* decks_host, const uint8_t* mask_
 }
 
 int bg_set_max_ante(bg_handle* h, int max_ante, const int32_t* per_env_host, const uint8_t* mask_host, void* stream) {
-  if (h) h->e2_img_valid = false; // (the two-kernel engine rebuilds its record images from the state)
   if (!h) return BG_E_ARG;
   BG_GUARD(h);
   hipStream_t s = (hipStream_t)stream;

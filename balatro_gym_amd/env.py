@@ -70,7 +70,24 @@ _ERRORS = {1: "Invalid action", 2: "Must play exactly 5 cards", 6: "Insufficient
 _TERMS = ["progress", "milestone", "score", "hand_quality", "efficiency", "synergy", "strategy", "ante_bonus"]
 
 
+# The 20 keys balatro_env_2.py:439-468 DECLARES and `_get_observation` (:1473-1541) never produces: (low, high, shape, dtype).
+# They are part of the space -- the reference's own wrapper iterates `env.observation_space.spaces.items()` (train_balatro_fixed.py:31)
+# and zero-fills what is missing from an observation -- but never of an observation.
+_DECLARED_ONLY = {
+    "hand_one_hot": (0, 1, (8, 52), np.float32), "hand_suits": (0, 4, (8,), np.int8), "hand_ranks": (0, 13, (8,), np.int8),
+    "rank_counts": (0, 4, (13,), np.int8), "suit_counts": (0, 8, (4,), np.int8), "straight_potential": (0, 1, (), np.float32),
+    "flush_potential": (0, 1, (), np.float32), "avg_score_per_hand": (0, 10000, (), np.float32), "hands_until_shop": (0, 20, (), np.int8),
+    "rounds_until_boss": (0, 3, (), np.int8), "has_mult_jokers": (0, 1, (), np.int8), "has_chip_jokers": (0, 1, (), np.int8),
+    "has_xmult_jokers": (0, 1, (), np.int8), "has_economy_jokers": (0, 1, (), np.int8),
+    "hand_potential_scores": (0, 10000, (12,), np.int32), "joker_synergy_score": (0, 10, (), np.float32),
+    "risk_level": (0, 1, (), np.float32), "economy_health": (0, 1, (), np.float32), "blind_difficulty": (0, 1, (), np.float32),
+    "win_probability": (0, 1, (), np.float32),
+}
+
+
 def make_observation_space():
+    """The reference's `_create_observation_space` (balatro_env_2.py:386-470): all 51 declared keys in declaration order -- the 31
+    `_get_observation` fills, then the 20 it never does."""
     d = {}
     for k in nat.OBS_KEYS:
         dt, shape = nat.OBS_SPEC[k]
@@ -81,6 +98,8 @@ def make_observation_space():
         else:
             lo, hi = _BOUNDS[k]
             d[k] = _spaces.Box(lo, hi, shape, dtype=np.dtype(dt).type)
+    for k, (lo, hi, shape, dt) in _DECLARED_ONLY.items():
+        d[k] = _spaces.Box(lo, hi, shape, dtype=dt)
     return _spaces.Dict(d)
 
 

@@ -79,10 +79,14 @@ class ShardedBalatroVecEnv:
         # same number of observation bytes): computed on the host, once -- a MAX all-reduce + `.item()` here was a host sync per call
         if self._pad_bytes is None:
             biggest = max(shard_range(self.total_envs, self.world, r)[1] - shard_range(self.total_envs, self.world, r)[0] for r in range(self.world))
-            flat_bytes = getattr(self.local, "obs_flat_bytes", None)   # (a stand-in env of the CPU tests may size its buffer itself)
+            # the LOCAL env says how many bytes `biggest` envs take in ITS layout (per-key arrays, or 384-byte records with obs_layout="rows"):
+            # every rank then pads to the same size whatever the layout -- a per-key formula here gave uneven "rows" shards different sizes
+            flat_bytes = getattr(self.local, "obs_flat_bytes", None)
             if flat_bytes is None:
-                from .vec_env import obs_flat_bytes as flat_bytes
-            self._pad_bytes = max(int(flat_bytes(biggest)), flat.numel())
+                raise TypeError("the local env must expose obs_flat_bytes(n): bytes of the flat observation buffer of n envs in its layout")
+            self._pad_bytes = int(flat_bytes(biggest))
+            if flat.numel() > self._pad_bytes:
+                raise ValueError(f"local observation buffer ({flat.numel()} bytes) exceeds obs_flat_bytes({biggest}) = {self._pad_bytes}")
         n = self._pad_bytes
         if flat.numel() != n:
             buf = torch.zeros(n, dtype=torch.uint8, device=flat.device)

@@ -168,6 +168,11 @@ class BalatroVecEnv:
     def obs_flat(self) -> torch.Tensor:
         return self._rowbuf.rows[0].reshape(-1) if self._rowbuf is not None else self._obs.flat
 
+    def obs_flat_bytes(self, n: int) -> int:
+        """Bytes `obs_flat` takes for `n` envs in THIS env's layout: n records of `row_stride` bytes with obs_layout "rows", else the per-key
+        arrays as `ObsBuffers` lays them out (what a sharded gather pads every rank's buffer to)."""
+        return int(n) * self._rowbuf.row_stride if self._rowbuf is not None else obs_flat_bytes(int(n))
+
     def state_bytes(self) -> int:
         return int(self._L.bg_state_bytes(self._h))
 

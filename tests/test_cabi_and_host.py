@@ -124,6 +124,61 @@ def test_sb3_fixed_space_matches_reference_fixture():
         assert FIXED_SPEC[k][0] == dt and FIXED_SPEC[k][1] == want_shape, (k, FIXED_SPEC[k], dt, want_shape)
 
 
+def test_drop_in_observation_space_declares_all_51_keys():
+    """`BalatroEnv.observation_space` is the reference's `_create_observation_space` (balatro_env_2.py:386-470): 51 keys -- the 31 that
+    `_get_observation` fills followed by the 20 it never does -- so that the reference's own wrapper, which walks
+    `self.env.observation_space.spaces.items()` (train_balatro_fixed.py:31-75), builds the SAME fixed space over this drop-in as over
+    the reference env.  The wrapper's rule is applied here to `make_observation_space()` and compared, key by key, with the space the
+    reference's `BalatroEnvFixed(BalatroEnv)` built (tests/golden/sb3_fixed.npz)."""
+    from balatro_gym_amd import _native as nat
+    from balatro_gym_amd.env import make_observation_space, _DECLARED_ONLY, _spaces
+    from tests.helpers import GOLD
+    space = make_observation_space()
+    assert len(space.spaces) == 51 and list(space.spaces)[:31] == nat.OBS_KEYS and list(space.spaces)[31:] == list(_DECLARED_ONLY)
+    upgrade = {"chips_scored", "round_chips_scored", "chips_needed", "shop_costs", "shop_items", "joker_ids", "shop_rerolls",
+               "hand_potential_scores", "best_hand_this_ante", "money", "hands_played", "ante", "round_chips_scored_rank"}
+    fixed = {}
+    for k, sp in space.spaces.items():                      # train_balatro_fixed.py:31-100
+        if isinstance(sp, _spaces.MultiBinary):
+            fixed[k] = ("int8", (int(sp.n),))               # MultiBinary -> Box(int8)
+        else:
+            dt, shape = np.dtype(sp.dtype), tuple(sp.shape)
+            if shape == ():
+                fixed[k] = (dt.name, (1,))                  # scalar -> (1,), dtype kept
+            elif dt in (np.dtype(np.int16), np.dtype(np.int8)) and k in upgrade:
+                fixed[k] = ("int32", shape)                 # int upgrade of the array keys on the list
+            else:
+                fixed[k] = (dt.name, shape)
+    with np.load(os.path.join(GOLD, "sb3_fixed.npz")) as z:
+        keys, dtypes, shapes = [str(k) for k in z["keys"]], [str(d) for d in z["dtypes"]], [str(x) for x in z["shapes"]]
+    assert list(fixed) == keys
+    for k, dt, sh in zip(keys, dtypes, shapes):
+        assert fixed[k] == (dt, tuple(int(x) for x in sh.split(",") if x)), (k, fixed[k], dt, sh)
+    # bounds of the declared-only keys as the reference states them (:439-468)
+    assert space.spaces["hand_one_hot"].shape == (8, 52) and np.dtype(space.spaces["hand_one_hot"].dtype) == np.float32
+    assert space.spaces["hand_potential_scores"].shape == (12,) and np.dtype(space.spaces["hand_potential_scores"].dtype) == np.int32
+    assert float(np.max(space.spaces["avg_score_per_hand"].high)) == 10000.0 and float(np.max(space.spaces["suit_counts"].high)) == 8.0
+
+
+def test_integration_snippet_structs_match_the_header():
+    """INTEGRATION.md's reference-side ctypes binding declares `InfoPtrs` / `ObsPtrs` with exactly the members of the header's
+    `bg_info_ptrs` / `bg_obs_ptrs`, in order (a struct that is one pointer short hands the library a garbage last member)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hdr = open(os.path.join(root, "include", "balatro_mi355x.h")).read()
+    doc = open(os.path.join(root, "INTEGRATION.md")).read()
+
+    def members(struct):
+        body = re.search(r"typedef struct %s \{(.*?)\} %s;" % (struct, struct), hdr, re.S).group(1)
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        return re.findall(r"\*\s*(\w+)\s*;", body)
+
+    info_doc = re.search(r"class InfoPtrs\(C\.Structure\).*?\[(\"final_score\".*?)\]\]", doc, re.S).group(1)
+    assert re.findall(r'"(\w+)"', info_doc) == members("bg_info_ptrs")
+    obs_doc = re.search(r"OBS_KEYS = \[(.*?)\]", doc, re.S).group(1)
+    assert re.findall(r'"(\w+)"', obs_doc) == members("bg_obs_ptrs")
+
+
 def test_packed_record_layout_matches_header():
     """The record offsets the Python views use are the BG_ROW_* constants of include/balatro_mi355x.h, every key is
     naturally aligned and no two fields overlap."""
@@ -197,13 +252,18 @@ def test_operator_wrappers_validate_every_tensor():
 
 def test_build_signature_is_reproducible(tmp_path):
     """The identity of the device code (`bg_build_signature`, what profiles/*_hbm_traffic.json are keyed on) must survive a rebuild of
-    unchanged sources: the library reports the sha256 prefix of sources + flags + compiler it was built from, and a second build -- whose
-    code-object bytes differ -- reports the same."""
+    unchanged sources: the library reports the sha256 prefix of sources + flags (12 digits) and compiler (4 digits) it was built from, and
+    a second build -- whose code-object bytes differ -- reports the same.  The in-tree library is only held to the compiler-independent
+    part (it may have been built on a box with another ROCm); without hipcc there is nothing to rebuild."""
     import ctypes as C
+    import shutil
     from balatro_gym_amd import _native as nat, build
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available: nothing to rebuild")
     want = build.source_signature()
     assert want == build.source_signature() and len(want) == 16
-    assert nat.device_code_signature() == want, "the in-tree library was not built from the sources in the tree (python -m balatro_gym_amd.build --force)"
+    assert build.sources_part(nat.device_code_signature()) == build.sources_part(want), \
+        "the in-tree library was not built from the sources in the tree (python -m balatro_gym_amd.build --force)"
     other = build.build(force=True, out=str(tmp_path / "rebuilt.so"))
     L = C.CDLL(other)
     L.bg_build_signature.restype = C.c_char_p

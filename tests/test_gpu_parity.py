@@ -200,9 +200,10 @@ def test_shop_stream_beyond_slot_vs_oracle():
     assert deepest >= 30, deepest  # visits of 30+ inventories (~300+ words) really happened
 
 
-def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_index0=0, t0=0, cards=None, consumables=None, action_fn=None):
+def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_index0=0, t0=0, cards=None, consumables=None, action_fn=None,
+                    env_indexes=None):
     """SAME_STEP auto-reset rollout on the oracle; returns per-step obs/rewards/terminated and the stats dict.  `action_fn(oracle_env, i, t)`
-    replaces the counter-hash policy."""
+    replaces the counter-hash policy; `env_indexes[i]` = the GLOBAL index env i has in the job it is a slice of (default env_index0 + i)."""
     orc = _oracle_envs(n, seeds, scorer, max_ante, jokers)
     if cards:
         for o, cs in zip(orc, cards):
@@ -217,7 +218,7 @@ def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_in
     for t in range(T):
         row = []
         for i, o in enumerate(orc):
-            a = action_fn(o, i, t) if action_fn else o.policy_action(policy, pseed, env_index0 + i, t0 + t)
+            a = action_fn(o, i, t) if action_fn else o.policy_action(policy, pseed, env_indexes[i] if env_indexes is not None else env_index0 + i, t0 + t)
             ob, r, term, _, info = o.step(a)
             if term:
                 ob = o.reset()
@@ -454,12 +455,13 @@ def test_packed_record_rollout_vs_oracle(policy, scorer, n):
     env.close()
 
 
-@pytest.mark.parametrize("engine,cfg", [(1, None), (2, None), (3, "413"), (3, "113"), (3, "213")])
+@pytest.mark.parametrize("engine,cfg", [(1, None), (3, "413"), (3, "113"), (3, "213"), (3, "414")])
 @pytest.mark.parametrize("stride", [352, 384])
 def test_packed_record_rollout_every_engine(engine, cfg, stride, monkeypatch):
-    """The three step engines behind bg_rollout_rows -- bg_engine.h (workers + copiers), bg_engine2.h (owner kernel + service kernel)
-    and bg_engine3.h (owner waves + service waves in one workgroup, in its workgroup shapes of 64 / 128 / 256 envs) -- against the oracle:
-    every record byte of a fused rollout over several launches (the handle reads BG_ENGINE / BG_E3_CFG when it is created)."""
+    """The step engines behind bg_rollout_rows -- bg_engine.h (workers + copiers) and bg_engine3.h (owner waves + service waves in one
+    workgroup, in its workgroup shapes of 64 / 128 / 256 envs and with four service waves) -- against the oracle: every record byte of a fused
+    rollout over several launches.  The handle reads BG_ENGINE / BG_E3_CFG when it is created (bg_create_ex), so each parameter really runs
+    its shape; n = 333 leaves every shape a partial last workgroup (333 = 5 x 64 + 13 = 2 x 128 + 77 = 256 + 77)."""
     from balatro_gym_amd.vec_env import RowBuffers
     from oracle.gen_golden import IMPLEMENTED
     monkeypatch.setenv("BG_ENGINE", str(engine))
@@ -490,17 +492,124 @@ def test_packed_record_rollout_every_engine(engine, cfg, stride, monkeypatch):
     del rb
 
 
+def test_engine_env_vars_are_per_handle_and_validated(monkeypatch):
+    """BG_ENGINE / BG_E3_CFG are read by bg_create_ex, once per handle (they used to latch process-wide at the first launch, so a test
+    that set them later silently ran the default shape), and an unknown value is refused instead of falling through to a default."""
+    from balatro_gym_amd import _native as nat
+    monkeypatch.setenv("BG_E3_CFG", "112")
+    with pytest.raises(nat.NativeError, match="BG_E3_CFG"):
+        _vec(64, [1 + i for i in range(64)])
+    monkeypatch.delenv("BG_E3_CFG")
+    monkeypatch.setenv("BG_ENGINE", "2")
+    with pytest.raises(nat.NativeError, match="BG_ENGINE"):
+        _vec(64, [1 + i for i in range(64)])
+
+
+@pytest.mark.parametrize("cfg,n", [("213", 333), ("413", 333), ("414", 300), (None, 16385 + 63)])
+def test_card_states_every_workgroup_shape_vs_oracle(cfg, n, monkeypatch):
+    """The CARDS instantiation of bg_engine3_kernel in the shapes the small tests never reached (they all ran 64 envs per workgroup): 128 and
+    256 envs per workgroup with a partial last workgroup, and the shape bg_lib.hip picks by itself above 16 384 envs (128 per workgroup) -- card states on
+    half of every deck, two consumables per env and episode, every record byte of two launches against the oracle."""
+    from balatro_gym_amd.vec_env import RowBuffers
+    if cfg:
+        monkeypatch.setenv("BG_E3_CFG", cfg)
+    big = n > 4096
+    T, chunks = (6, 2) if big else (48, 2)
+    seeds = [93_000 + SEED_OFFSET + 5 * i for i in range(n)]
+    jokers = [random.Random(5200 + i).sample(range(1, 151), 5) for i in range(n)]
+    cons_ids = list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68))
+    cons = [[cons_ids[(3 * i) % 52], cons_ids[(11 * i + 5) % 52]] for i in range(n)]
+    cards = []
+    for i in range(n):
+        rr = random.Random(6000 + i)
+        cards.append([(d, rr.choice([0, 1, 4, 5, 6, 7, 8]), rr.choice([0, 0, 1]), rr.choice([0, 0, 1, 2, 3, 4])) for d in rr.sample(range(52), 26)])
+    env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=6, card_states=True)
+    env.inject(jokers=jokers, apply_now=True)
+    env.inject_cards(cards, apply_now=True)
+    env.inject_consumables(cons, apply_now=True)
+    rbc = [RowBuffers(n, env.device, steps=T, row_stride=384) for _ in range(chunks)]
+    for c in range(chunks):
+        env.rollout(T, policy=0, policy_seed=13, env_index0=2, t0=c * T, obs_buffers=rbc[c], zero_stats=(c == 0))
+    env.check()
+    got_stats = env.stats()
+    wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, T * chunks, 0, 13, True, 6, jokers, env_index0=2, cards=cards, consumables=cons)
+    for c in range(chunks):
+        sl = slice(c * T, (c + 1) * T)
+        assert np.array_equal(rbc[c].action.cpu().numpy(), wa[sl])
+        assert np.array_equal(rbc[c].reward.contiguous().cpu().numpy().view(np.uint64), wr[sl].view(np.uint64))
+        for k in OBS_KEYS:
+            assert np.array_equal(rbc[c].tensors[k].contiguous().cpu().numpy(), wobs[k][sl]), f"launch {c}: record key {k} differs"
+    for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
+        assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
+    env.close()
+
+
+@pytest.mark.parametrize("config", ["configs2_jokers_antes_1_4", "configs3_share_consumables_all_jokers_antes_1_8"])
+def test_full_size_slice_vs_oracle(config):
+    """BASELINE.json's full size, compared with the ORACLE (not with itself): 65 536 envs on the benchmark's path -- 256 envs per workgroup,
+    packed records 384 bytes apart, three launches of 20 fused steps (the driver's launch shape) -- and every record byte, reward bit
+    pattern, action and terminated flag of 2 048 of them, spread over all 256 workgroups (eight per workgroup, a different lane and owner
+    wave in each), against the oracle run on just those envs with their GLOBAL indexes.  configs[2]: 5 implemented jokers, Antes 1-4,
+    blind by env index; configs[3]'s single-GPU share: 5 of all 150 joker ids, card states, two consumables per env and episode, Antes
+    1-8, uniform policy."""
+    import torch
+    from balatro_gym_amd.vec_env import RowBuffers
+    from oracle.gen_golden import IMPLEMENTED
+    n, T, chunks = 65536, 20, 3
+    cons3 = config.startswith("configs3")
+    seeds = [1000 + SEED_OFFSET + i for i in range(n)]
+    pool = list(range(1, 151)) if cons3 else IMPLEMENTED
+    jokers = [random.Random(i).sample(pool, 5) for i in range(n)]
+    cons_ids = list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68))
+    cons = [[cons_ids[i % 52], cons_ids[(7 * i + 3) % 52]] for i in range(n)] if cons3 else None
+    cards = [[(d, [0, 1, 4, 6, 8][(i + d) % 5], [0, 1, 3][d % 3], [0, 1, 2, 3, 4][(i // 3 + d) % 5]) for d in range(16)] if i % 3 == 0 else []
+             for i in range(n)] if cons3 else None
+    policy, max_ante = (0, 8) if cons3 else (2, 4)
+    env = _vec(n, seeds, autoreset=True, scorer_jokers=True, max_ante=max_ante, card_states=cons3)
+    if cons3:
+        env.inject_cards(cards, apply_now=True)
+    env.inject(jokers=jokers, apply_now=True)
+    if cons3:
+        env.inject_consumables(cons, apply_now=True)
+    pick = np.array([32 * j + (5 * j + j // 8) % 32 for j in range(2048)], dtype=np.int64)   # 8 per 256-env workgroup, lanes and waves vary
+    assert len(set(pick.tolist())) == 2048 and pick.max() < n
+    pick_t = torch.from_numpy(pick).to(env.device)
+    rb = RowBuffers(n, env.device, steps=T, row_stride=384)
+    got = []
+    for c in range(chunks):
+        env.rollout(T, policy=policy, policy_seed=21, env_index0=0, t0=c * T, obs_buffers=rb, zero_stats=(c == 0))
+        got.append(rb.rows[:, pick_t, :].cpu().numpy().copy())   # [T, 2048, 384]
+    env.check()
+    st = env.stats()
+    env.close()
+    del rb
+    assert st["steps"] == n * T * chunks and st["plays"] > 0 and st["episodes"] > 0
+    rows = np.concatenate(got, axis=0)
+    sub = RowBuffers(len(pick), torch.device("cpu"), steps=T * chunks, row_stride=384)   # the same record layout over the slice
+    sub.rows.copy_(torch.from_numpy(rows))
+    wobs, wr, wt, wa, _ = _oracle_rollout(len(pick), [seeds[i] for i in pick], T * chunks, policy, 21, True, max_ante, [jokers[i] for i in pick],
+                                          cards=[cards[i] for i in pick] if cons3 else None, consumables=[cons[i] for i in pick] if cons3 else None,
+                                          env_indexes=pick.tolist())
+    assert np.array_equal(sub.action.numpy(), wa)
+    assert np.array_equal(sub.terminated.numpy(), wt)
+    assert np.array_equal(sub.reward.contiguous().numpy().view(np.uint64), wr.view(np.uint64))
+    for k in OBS_KEYS:
+        assert np.array_equal(sub.tensors[k].contiguous().numpy(), wobs[k]), f"record key {k} differs"
+    assert not rows[:, :, 343:].any()   # padding and the two zero pieces of the whole-line layout
+
+
 def test_engines_agree_full_size(monkeypatch):
     """65 536 envs, configs[2]: the checksums of a fused rollout (every observation row hashed on the device, reward bits, episodes, plays,
-    scores) must be the same whichever engine ran it."""
+    scores) must be the same whichever engine (and, for bg_engine3.h, service-wave count) ran it."""
     from balatro_gym_amd.vec_env import RowBuffers
     from oracle.gen_golden import IMPLEMENTED
     n, T = 65536, 40
     seeds = [1000 + SEED_OFFSET + i for i in range(n)]
     jokers = [random.Random(i).sample(IMPLEMENTED, 5) for i in range(n)]
     res = []
-    for engine in (1, 2, 3):
+    for engine, cfg in ((1, "413"), (3, "413"), (3, "414")):
         monkeypatch.setenv("BG_ENGINE", str(engine))
+        monkeypatch.setenv("BG_E3_CFG", cfg)
         env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4, fused_steps=T)
         env.inject(jokers=jokers, apply_now=True)
         rb = RowBuffers(n, env.device, steps=T, row_stride=384)

@@ -233,3 +233,45 @@ def test_consumable_deck_fence_placement():
     with pytest.raises(IndexError):
         for act in (2, 3, 0):
             r.step(act)
+
+
+def test_reference_wrapper_over_the_drop_in_space():
+    """The reference's own `BalatroEnvFixed.__init__` (train_balatro_fixed.py:20-124) run over the DROP-IN's observation space instead
+    of the reference env's: it walks `self.env.observation_space.spaces.items()`, so it must come out with the same 51-key fixed
+    space it builds over `balatro_env_2.BalatroEnv` (the space recorded in tests/golden/sb3_fixed.npz) -- key order, dtypes, shapes and
+    the bounds of every Box it keeps as is.  No GPU: a stand-in env class that carries only the two spaces takes the drop-in's place."""
+    import contextlib
+    import importlib
+    import io
+    import os
+    tbf = rh.load_fixed_wrappers()          # (installs the gymnasium stand-in the reference is imported with)
+    import balatro_gym_amd.env as envmod
+    envmod = importlib.reload(envmod)        # the drop-in builds its space from whatever `gymnasium` is importable: now the stand-in
+    space = envmod.make_observation_space()
+
+    class SpacesOnly:
+        def __init__(self, seed=None):
+            self.observation_space = space
+            self.action_space = envmod._spaces.Discrete(60)
+
+    ref_cls = tbf.OriginalBalatroEnv
+    try:
+        tbf.OriginalBalatroEnv = SpacesOnly
+        with contextlib.redirect_stdout(io.StringIO()):
+            over_drop_in = tbf.BalatroEnvFixed(seed=1)
+        tbf.OriginalBalatroEnv = ref_cls
+        with contextlib.redirect_stdout(io.StringIO()):
+            over_reference = tbf.BalatroEnvFixed(seed=1)
+    finally:
+        tbf.OriginalBalatroEnv = ref_cls
+    a, b = over_drop_in.observation_space.spaces, over_reference.observation_space.spaces
+    assert list(a) == list(b) and len(a) == 51
+    assert over_drop_in.space_transforms == over_reference.space_transforms
+    for k in a:
+        assert a[k].dtype == b[k].dtype and tuple(a[k].shape) == tuple(b[k].shape), k
+        assert np.array_equal(np.asarray(a[k].low, dtype=np.float64), np.asarray(b[k].low, dtype=np.float64)), k
+        assert np.array_equal(np.asarray(a[k].high, dtype=np.float64), np.asarray(b[k].high, dtype=np.float64)), k
+    from tests.helpers import GOLD
+    with np.load(os.path.join(GOLD, "sb3_fixed.npz")) as z:
+        assert [str(x) for x in z["keys"]] == list(a)
+        assert [str(x) for x in z["dtypes"]] == [a[k].dtype.name for k in a]

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development: cycle counters of engine 3 (build with tools/build_variant.sh e3t -DBG_E3_TIMING, then
-BALATRO_MI355X_LIB=balatro_gym_amd/variants/e3t.so python tools/e3_timing.py)."""
+BALATRO_MI355X_LIB=build/variants/e3t.so python tools/e3_timing.py)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development aid: cycle counters of the step engine kernel (build with -DBG_TIMING4: tools/build_variant.sh t4 -DBG_TIMING4,
-then BALATRO_MI355X_LIB=balatro_gym_amd/variants/t4.so python tools/timing4.py)."""
+then BALATRO_MI355X_LIB=build/variants/t4.so python tools/timing4.py)."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

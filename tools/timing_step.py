@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Development aid: cycle counters of the step engine behind bg_step (one launch per step, caller's actions, per-key output, info arrays).
-Build with tools/build_variant.sh t4 -DBG_TIMING4 and run with BALATRO_MI355X_LIB=balatro_gym_amd/variants/t4.so."""
+Build with tools/build_variant.sh t4 -DBG_TIMING4 and run with BALATRO_MI355X_LIB=build/variants/t4.so."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
