@@ -679,7 +679,7 @@ struct bg_handle {
   std::vector<hipEvent_t> ev_rollout_t, ev_refill_t, ev_step_t; // start/stop pairs
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
   // tunables read ONCE per handle in bg_create (environment variables)
-  int refill_blocks, refill_blocks_shop, dev_skip_refill, refill_order;
+  int refill_blocks, refill_blocks_shop, dev_skip_refill, refill_order, refill_min;
   uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_smask; int eng_waves, eng_copiers; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
   int engine;            // BG_ENGINE: 3 = bg_engine3.h (owner + service waves in one workgroup) for packed-record rollouts (default), 1 = bg_engine.h everywhere
   // bg_engine3.h: workgroup shape (BG_E3_CFG = 100 * owner waves + 10 * slices + service waves; 0 = by env count) and the service waves' batch
@@ -841,6 +841,7 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->refill_blocks = geti("BG_REFILL_BLOCKS", 4096); h->refill_blocks_shop = geti("BG_REFILL_BLOCKS_SHOP", 0);
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0);
     h->refill_order = geti("BG_REFILL_ORDER", 2);
+    h->refill_min = geti("BG_REFILL_MIN", 16);   // a rollout launch of at least this many steps (since the last refill) takes a refill beside it; 0 = only when the rings demand one
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
     h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0); h->eng_copiers = geti("BG_ENG_COPIERS", 0); if (h->eng_copiers < 0 || h->eng_copiers > 3) h->eng_copiers = 0;   // 0 = by launch length (bg_engine_launch)
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
@@ -1009,7 +1010,8 @@ static int bg_wait_refill(bg_handle* h, hipStream_t s, int back) {
   return 0;
 }
 
-static int bg_refill_on(bg_handle* h, hipStream_t s) {
+// steps_hint: env steps launched since the previous refill plus those of the chunk this one runs beside (< 0: unknown, size the grids for a full-depth refill)
+static int bg_refill_on(bg_handle* h, hipStream_t s, int steps_hint = -1) {
   BgDev d = h->dev;
   d.prod_in = bg_prod_latest(h);
   d.prod_out = h->d_prod[h->refill_seq & 1];
@@ -1021,7 +1023,10 @@ static int bg_refill_on(bg_handle* h, hipStream_t s) {
   hipLaunchKernelGGL(bg_refill_scan_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, d);
   // Grids of ONE-WAVE workgroups, grid-stride over the compacted work lists: they are placed beside the resident step-engine
   // workgroups (bg_engine.h: one SIMD per CU and ~5 KB of LDS are left to them) or, with nothing else running, several per SIMD.
-  const int dense = h->refill_blocks;
+  // (a refill behind a short launch finds short work lists: a grid sized for 372 steps' worth would be thousands of one-wave workgroups that are
+  //  placed beside the engine only to find nothing to do)
+  int dense = h->refill_blocks;
+  if (steps_hint >= 0 && steps_hint < 372) { dense = (int)((long)dense * (steps_hint + 24) / 372); if (dense < 512) dense = 512; if (dense > h->refill_blocks) dense = h->refill_blocks; }
   // the three kinds of work are independent once the lists exist: side by side on three streams, joined before the completion event
   if (h->refill_order != 2) {
     BG_HIP(hipEventRecord(h->ev_scan, s));
@@ -1344,14 +1349,24 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
     if (rows_dev) { o.rows = rows_dev + off * row_stride; o.row_stride = (uint32_t)row_stride; }
     if (off) bg_obs_advance(o, off);
     if (h->profiling) h->rollout_steps.push_back(chunk);
-    const bool need = h->steps_since_refill + chunk > max_chunk;
-    if (need && async) { // R beside this chunk: after everything on the stream so far (the previous launches) and after the latest refill
-      BG_HIP(hipEventRecord(h->ev_rollout, (hipStream_t)stream));
-      BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));
-      rc = bg_wait_refill(h, h->side, 0);
-      if (rc) return rc;
-      rc = bg_refill_on(h, h->side); // (sets steps_since_refill = 0)
-      if (rc) return rc;
+    // ... and EAGER where that is free: a launch of >= refill_min steps (BG_REFILL_MIN, default 16) takes its own share of the refill beside it --
+    // every launch the same small refill instead of a full-depth one beside every 18th (which made that launch, and a caller who synchronises
+    // behind it, wait ~0.7 ms: bench.py's `samples.min` was a quarter of its median).
+    const bool must = h->steps_since_refill + chunk > max_chunk;
+    const bool need = must || (async && h->refill_min > 0 && h->steps_since_refill + chunk >= h->refill_min);
+    const long s0 = h->refill_seq;
+    // Overlapped and the chunk reads the view of the refill BEFORE this one (the usual case): the engine is launched FIRST, the refill's six small
+    // kernels are queued on the side stream behind it -- their host-side issue time (~30 us) is then not in front of a 220 us launch.
+    const bool refill_after = need && async && s0 >= 1 && s0 - 1 >= h->view_min;
+    if (need && async) {
+      BG_HIP(hipEventRecord(h->ev_rollout, (hipStream_t)stream));   // everything the stream has done so far (the previous launches)
+      if (!refill_after) { // R beside this chunk, queued before it (the chunk reads R's own view: right behind a synchronous refill)
+        BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));
+        rc = bg_wait_refill(h, h->side, 0);
+        if (rc) return rc;
+        rc = bg_refill_on(h, h->side, h->steps_since_refill + chunk); // (sets steps_since_refill = 0)
+        if (rc) return rc;
+      }
     } else if (need) {
       rc = bg_refill(h, stream);
       if (rc) return rc;
@@ -1361,7 +1376,8 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
     // (steps between the two refills <= B) + u + chunk <= 2 B.  Never one older than the last SYNCHRONOUS refill (bg_reset, bg_step,
     // ...: the steps before those are not bounded by B).  Synchronous: the latest.
     long vi = h->refill_seq - 1;
-    if (async && vi - 1 >= h->view_min) vi--;
+    if (refill_after) vi = s0 - 1;   // (R, queued below, will be refill s0: the one before it)
+    else if (async && vi - 1 >= h->view_min) vi--;
     if (vi >= 0) BG_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_refill[vi & 1], 0));
     const uint32_t* view = vi >= 0 ? h->d_prod[vi & 1] : bg_prod_latest(h);
     bg_ev_begin(h, h->ev_rollout_t, (hipStream_t)stream); // after the waits: the events bracket the kernel, not the stream's wait for the refill
@@ -1383,6 +1399,13 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
     }
     bg_ev_end(h, h->ev_rollout_t, (hipStream_t)stream);
     BG_HIP(hipGetLastError());
+    if (refill_after) { // R beside this chunk: after everything the stream had done BEFORE the chunk (ev_rollout) and after the latest refill
+      BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));
+      rc = bg_wait_refill(h, h->side, 0);
+      if (rc) return rc;
+      rc = bg_refill_on(h, h->side, h->steps_since_refill + chunk); // (sets steps_since_refill = 0: the chunk beside it counts below)
+      if (rc) return rc;
+    }
     h->steps_since_refill += chunk;
     done += chunk;
   }

@@ -934,8 +934,10 @@ def test_single_env_gym_surface():
     si = 0
     env = BalatroEnv(seed=int(tr["seeds"][si]))
     assert env.action_space.n == 60
-    assert set(env.observation_space.spaces.keys()) == set(OBS_KEYS)
+    # the space DECLARES the reference's 51 keys (balatro_env_2.py:386-470); an observation holds the 31 `_get_observation` fills (Q14)
+    assert list(env.observation_space.spaces.keys())[:31] == list(OBS_KEYS) and len(env.observation_space.spaces) == 51
     obs = env._np_obs()
+    assert set(obs) == set(OBS_KEYS)
     for k in OBS_KEYS:
         assert np.array_equal(obs[k], tr["obs0_" + k][si]) and np.asarray(obs[k]).dtype == tr["obs0_" + k].dtype, k
     for t in range(200):
