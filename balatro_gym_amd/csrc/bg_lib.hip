@@ -841,7 +841,10 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->refill_blocks = geti("BG_REFILL_BLOCKS", 4096); h->refill_blocks_shop = geti("BG_REFILL_BLOCKS_SHOP", 0);
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0);
     h->refill_order = geti("BG_REFILL_ORDER", 2);
-    h->refill_min = geti("BG_REFILL_MIN", 16);   // a rollout launch of at least this many steps (since the last refill) takes a refill beside it; 0 = only when the rings demand one
+    // BG_REFILL_MIN = m > 0: a rollout launch of >= m steps (since the last refill) takes a refill beside it.  Default 0 = only when the rings demand one:
+    // 20 steps' worth of refill is ~320 us of five small latency-bound kernels against 129 us per 20 steps in bulk (profiles/r05/refill_policy_ab.txt:
+    // a refill beside every 20-step launch costs 21 % of the sustained rate)
+    h->refill_min = geti("BG_REFILL_MIN", 0);
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
     h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0); h->eng_copiers = geti("BG_ENG_COPIERS", 0); if (h->eng_copiers < 0 || h->eng_copiers > 3) h->eng_copiers = 0;   // 0 = by launch length (bg_engine_launch)
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
@@ -1349,9 +1352,7 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
     if (rows_dev) { o.rows = rows_dev + off * row_stride; o.row_stride = (uint32_t)row_stride; }
     if (off) bg_obs_advance(o, off);
     if (h->profiling) h->rollout_steps.push_back(chunk);
-    // ... and EAGER where that is free: a launch of >= refill_min steps (BG_REFILL_MIN, default 16) takes its own share of the refill beside it --
-    // every launch the same small refill instead of a full-depth one beside every 18th (which made that launch, and a caller who synchronises
-    // behind it, wait ~0.7 ms: bench.py's `samples.min` was a quarter of its median).
+    // (BG_REFILL_MIN = m > 0 makes them eager: a launch of >= m steps takes its own small refill beside it -- measured, not the default: bg_create_ex.)
     const bool must = h->steps_since_refill + chunk > max_chunk;
     const bool need = must || (async && h->refill_min > 0 && h->steps_since_refill + chunk >= h->refill_min);
     const long s0 = h->refill_seq;

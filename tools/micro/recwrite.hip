@@ -42,6 +42,27 @@ __global__ __launch_bounds__(64) void rec_k(unsigned char* base, size_t nrows, i
     }
   }
 }
+// LANE = RECORD (round 5): every active lane writes the P pieces of ITS OWN record with P back-to-back stores -- one instruction = one 16-byte piece
+// of up to 64 different rows (what an owner wave that kept its env's record in REGISTERS would issue).  `active` of the 64 lanes write per batch (the
+// engine finishes ~19 records per owner iteration); rows: a random row of the wave's 256-row window (win90k) or of the whole buffer.
+template <int PATTERN, int STORE, int P>
+__global__ __launch_bounds__(64) void rec_lane_k(unsigned char* base, size_t nrows, int stride, int batches, size_t n_windows, int active) {
+  const int lane = threadIdx.x;
+  const size_t w = blockIdx.x;
+  for (int b = 0; b < batches; b++) {
+    const size_t win = (w + (size_t)b * gridDim.x) % n_windows;
+    const bool on = (int)((mix(w * 131 + b * 7 + 1) + (unsigned)lane * 0x9E3779B9u) % 64u) < active;   // a changing subset of ~active lanes
+    if (on) {
+      const size_t row = PATTERN == 1 ? win * 256 + (mix(w * 7919 + b * 104729 + lane) & 255) : mix(w * 7919 + (size_t)b * 104729 + lane) % nrows;
+      u32x4* dst = (u32x4*)(base + row * (size_t)stride);
+#pragma unroll
+      for (int pc = 0; pc < P; pc++) {
+        u32x4 v = {(unsigned)pc, (unsigned)b, (unsigned)w, (unsigned)row};
+        if (STORE == 1) __builtin_nontemporal_store(v, dst + pc); else dst[pc] = v;
+      }
+    }
+  }
+}
 template <typename F> static double time_it(F launch) {
   hipEvent_t a, b; CK(hipEventCreate(&a)); CK(hipEventCreate(&b));
   launch();
@@ -86,6 +107,19 @@ int main() {
     nrows = bytes / 256; n_windows = nrows / 256;
     a = time_it([&] { hipLaunchKernelGGL((rec_k<1, true, 16>), dim3(waves), dim3(64), 0, 0, buf, nrows, 256, batches, n_windows); });
     printf("256-byte records (16 pieces): nt win90k %7.1f GB/s raw\n", (double)waves * batches * 32 * 256 / a / 1e9);
+  }
+  // lane = record: P = 24 pieces (384-byte whole-line records), 64 / 32 / 19 active lanes per batch; the same number of records per wave as above
+  {
+    const size_t nrows = bytes / 384, n_windows = nrows / 256;
+    for (int active : {64, 32, 19}) {
+      const int nb = batches * 32 / active;   // batches so that every wave writes ~ the same number of records
+      const double payload = (double)waves * nb * active * 352;
+      double a = time_it([&] { hipLaunchKernelGGL((rec_lane_k<1, 1, 24>), dim3(waves), dim3(64), 0, 0, buf, nrows, 384, nb, n_windows, active); });
+      double b = time_it([&] { hipLaunchKernelGGL((rec_lane_k<3, 1, 24>), dim3(waves), dim3(64), 0, 0, buf, nrows, 384, nb, n_windows, active); });
+      double c = time_it([&] { hipLaunchKernelGGL((rec_lane_k<1, 0, 24>), dim3(waves), dim3(64), 0, 0, buf, nrows, 384, nb, n_windows, active); });
+      printf("LANE = RECORD, 24 pieces per lane back to back, %2d of 64 lanes active: nt win90k %7.1f  nt random %7.1f  plain win90k %7.1f GB/s of 352-byte payload\n",
+             active, payload / a / 1e9, payload / b / 1e9, payload / c / 1e9);
+    }
   }
   return 0;
 }
