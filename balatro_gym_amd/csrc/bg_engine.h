@@ -73,6 +73,7 @@ struct EngineArgs {
   uint32_t th_more;            // further cheap steps an env may take inside the batch that has it
   uint32_t autoreset;          // SAME_STEP auto-reset of terminated envs
   uint32_t copier;             // packed records: wave `n_waves` is the COPIER (it writes the records and hands the envs back), the workers never copy
+  uint32_t epw;                // bg_engine3.h, the 64-env workgroup shape only: envs per workgroup that are LIVE (8 .. 64; 0 = all 64) -- a small job spreads over more CUs
 };
 
 __device__ __forceinline__ uint32_t bg_lds_ld(uint32_t* p) {

@@ -63,8 +63,13 @@ struct E3Lds {
 };
 // A workgroup = NE = 64 * NOW * KS envs: NOW owner waves (each owns KS slices of 64 envs, lane = env of a slice) + NSV service waves.  256 envs per
 // workgroup fill the chip at 65 536 envs; a small job takes 64 or 128 per workgroup and spreads over four or two times as many CUs.
+#ifdef BG_E3_NUM_VGPR   // development: cap the kernel's registers below the 256 that two waves per SIMD leave each (what does a fourth service wave AND the refill beside it cost in spills?)
+#define BG_E3_VGPR_ATTR __attribute__((amdgpu_num_vgpr(BG_E3_NUM_VGPR)))
+#else
+#define BG_E3_VGPR_ATTR
+#endif
 template <bool HASH, bool CARDS, int NOW, int KS, int NSV>
-__global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(BgDev d, EngineArgs a) {
+__global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_engine3_kernel(BgDev d, EngineArgs a) {
   constexpr int NE = NOW * KS * BG_BLOCK, LNE = NE == 256 ? 8 : (NE == 128 ? 7 : 6);
   static_assert(NE == 64 || NE == 128 || NE == 256, "envs per workgroup (a request carries the env's lane in 8 bits)");
   // (static LDS: the compiler then pads the register allocation to the 256 VGPRs that two waves per SIMD leave each -- which this kernel needs
@@ -81,8 +86,11 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
   bg_tables_load(&jt, d.jtab);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = tid >> 6;
-  const int env0 = blockIdx.x * NE;
-  const int n_live = d.N - env0 < NE ? d.N - env0 : NE;
+  // (64-env shape: a small job may ask for fewer LIVE envs per workgroup -- a.epw of the 64 lanes of the one owner wave -- and so for more workgroups:
+  //  4 096 envs as 512 workgroups of 8 instead of 64 of 64 fill the chip, and an env's service step no longer queues behind 63 neighbours)
+  const int epw = (NE == 64 && a.epw >= 1u && a.epw < 64u) ? (int)a.epw : NE;
+  const int env0 = blockIdx.x * epw;
+  const int n_live = d.N - env0 < epw ? d.N - env0 : epw;
   // (decks stay in HBM: the first 16 cards -- every index a hand normally holds -- ride in two registers of the service lane, bg_device.h Deck0)
   using DeckT = typename std::conditional<CARDS, Deck0C, Deck0>::type;
   const size_t N = (size_t)d.N;

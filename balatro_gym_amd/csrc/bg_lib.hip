@@ -202,6 +202,101 @@ __device__ __forceinline__ void bg_mt_seed_impl(uint32_t* p, uint32_t key) {
 __device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) { bg_mt_seed_impl<false>(p, key); }
 __device__ void bg_mt_seed_slot(uint32_t* __restrict__ p, uint32_t key) { bg_mt_seed_impl<true>(p, key); }
 
+// The slot seeding for NS streams per lane, interleaved step by step (the measurement VERDICT r4 #9 asked for: does instruction-level parallelism
+// across streams shorten the quarter-rate multiply chains?  BG_SHOP_ILP=2 selects it; profiles/r05/shop_seeding_ilp.txt).  Same arithmetic as
+// bg_mt_seed_impl<true>, every per-stream scalar an array of NS.
+template <int NS>
+__device__ __forceinline__ void bg_mt_seed_slot_n(uint32_t* const (&p)[NS], const uint32_t (&key)[NS]) {
+  constexpr int NB = BG_MT_N / 16;
+  uint32_t a[NS], a1[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) { a[s] = BG_GENRAND.blk[0].v[0]; a1[s] = 0; }
+  {
+    BgG16 cur = BG_GENRAND.blk[0];
+#pragma unroll 1
+    for (int b = 0; b < NB; b++) {
+      const BgG16 nxt = BG_GENRAND.blk[b + 1 < NB ? b + 1 : NB - 1];
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+        if (b > 0 || c >= 1) {
+#pragma unroll
+          for (int s = 0; s < NS; s++) {
+            a[s] = (cur.v[c] ^ ((a[s] ^ (a[s] >> 30)) * 1664525u)) + key[s];
+            if (b == 0 && c == 1) a1[s] = a[s];
+          }
+        }
+      }
+      cur = nxt;
+    }
+  }
+  uint32_t a1w[NS], bprev[NS], w2[NS], w3[NS], far0[NS], far1[NS], out2[NS], out3[NS];
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    a1w[s] = (a1[s] ^ ((a[s] ^ (a[s] >> 30)) * 1664525u)) + key[s];
+    a[s] = BG_GENRAND.blk[0].v[0];
+    a[s] = (BG_GENRAND.blk[0].v[1] ^ ((a[s] ^ (a[s] >> 30)) * 1664525u)) + key[s];
+    bprev[s] = a1w[s]; w2[s] = w3[s] = far0[s] = far1[s] = out2[s] = out3[s] = 0;
+  }
+  {
+    BgG16 cur = BG_GENRAND.blk[0];
+#pragma unroll 1
+    for (int b = 0; b < NB; b++) {
+      const BgG16 nxt = BG_GENRAND.blk[b + 1 < NB ? b + 1 : NB - 1];
+      uint32_t v[NS][16];
+#pragma unroll
+      for (int c = 0; c < 16; c++) {
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+          v[s][c] = 0;
+          if (b > 0 || c >= 2) {
+            a[s] = (cur.v[c] ^ ((a[s] ^ (a[s] >> 30)) * 1664525u)) + key[s];
+            bprev[s] = (a[s] ^ ((bprev[s] ^ (bprev[s] >> 30)) * 1566083941u)) - (uint32_t)(16 * b + c);
+            v[s][c] = bprev[s];
+          }
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < NS; s++) {
+        uint4* p4 = (uint4*)p[s];
+        if (b == 0) { w2[s] = v[s][2]; w3[s] = v[s][3]; }
+        if (b < 4) {
+#pragma unroll
+          for (int k = 0; k < 4; k++) if (4 * b + k > 0) p4[4 * b + k] = make_uint4(v[s][4 * k], v[s][4 * k + 1], v[s][4 * k + 2], v[s][4 * k + 3]);
+        } else if (b >= 24 && b <= 28) {
+          const int kb = 16 * b - BG_MT_M;
+          if (b == 24) { far0[s] = v[s][13]; far1[s] = v[s][14]; out2[s] = bg_temper(bg_twist(w2[s], w3[s], v[s][15])); }
+          else {
+            const int g0 = kb >> 2;
+            uint32_t nr[20];
+#pragma unroll
+            for (int g = 0; g < 5; g++) {
+              uint4 t = make_uint4(0u, 0u, 0u, 0u);
+              if (g0 + g > 0 && g0 + g < BG_SLOT_WORDS / 4) t = p4[g0 + g];
+              nr[4 * g] = t.x; nr[4 * g + 1] = t.y; nr[4 * g + 2] = t.z; nr[4 * g + 3] = t.w;
+            }
+            if (b == 25) nr[3] = w3[s];
+#pragma unroll
+            for (int c = 0; c < 16; c++) {
+              const int k = kb + c;
+              if (k < BG_SW_T) {
+                const uint32_t o = bg_temper(bg_twist(nr[3 + c], nr[4 + c], v[s][c]));
+                if (k == 3) out3[s] = o; else p[s][k] = o;
+              }
+            }
+          }
+        }
+      }
+      cur = nxt;
+    }
+  }
+#pragma unroll
+  for (int s = 0; s < NS; s++) {
+    const uint32_t w1 = (a1w[s] ^ ((bprev[s] ^ (bprev[s] >> 30)) * 1566083941u)) - 1u;
+    ((uint4*)p[s])[0] = make_uint4(bg_temper(bg_twist(0x80000000u, w1, far0[s])), bg_temper(bg_twist(w1, w2[s], far1[s])), out2[s], out3[s]);
+    p[s][BG_SW_SEED] = key[s];
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // Lazy MT19937 for the streams only the refill kernels read (deck shuffles, shop seeds).  genrand_uint32() regenerates
 // all 624 words when the block is exhausted; computing word k of the next block just before it is read gives the same
@@ -539,6 +634,22 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop_kernel(BgDev d) {
     bg_mt_seed_slot(bg_sblock(d, (int)(es & 0xffffffu), (int)(es >> 24)), seed);
   }
 }
+// the same with TWO streams per lane, interleaved (BG_SHOP_ILP=2: a measurement, see bg_mt_seed_slot_n); an odd last item is seeded alone
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop2_kernel(BgDev d) {
+  const uint32_t count = d.wl_count[3], pairs = count >> 1;
+  for (uint32_t q = blockIdx.x * BG_BLOCK + threadIdx.x; q < pairs; q += gridDim.x * BG_BLOCK) {
+    const uint32_t e0 = d.wl_shop[4 * (size_t)q], s0 = d.wl_shop[4 * (size_t)q + 1], e1 = d.wl_shop[4 * (size_t)q + 2], s1 = d.wl_shop[4 * (size_t)q + 3];
+    uint32_t* const p[2] = {bg_sblock(d, (int)(e0 & 0xffffffu), (int)(e0 >> 24)), bg_sblock(d, (int)(e1 & 0xffffffu), (int)(e1 >> 24))};
+    const uint32_t key[2] = {s0, s1};
+    bg_mt_seed_slot_n<2>(p, key);
+  }
+  if ((count & 1u) && blockIdx.x == 0 && threadIdx.x == 0) {
+    const uint32_t es = d.wl_shop[2 * (size_t)(count - 1)], seed = d.wl_shop[2 * (size_t)(count - 1) + 1];
+    uint32_t* const p1[1] = {bg_sblock(d, (int)(es & 0xffffffu), (int)(es >> 24))};
+    const uint32_t key1[1] = {seed};
+    bg_mt_seed_slot_n<1>(p1, key1);   // (not bg_mt_seed_slot: a second call site would stop its inlining into bg_refill_shop_kernel -- 56 -> 70 VGPRs there)
+  }
+}
 
 // Next 624-word block(s) of the per-env global stream, ONE WAVE PER ENV: lane l holds words l, l + 64, ... of the block (ten
 // registers), so the block is read and written as ten 256-byte rows (a lane per env read 16 bytes of 64 different blocks per
@@ -670,6 +781,7 @@ struct bg_handle {
   // refill pipeline: double-buffered producer counters, a side stream and per-parity completion events
   uint32_t* d_prod[2];
   long refill_seq;       // refills launched so far; refill #i writes d_prod[i & 1]
+  long refill_done;      // highest refill index KNOWN to have completed (hipEventQuery): launches that read its view need no stream wait any more
   long view_min;         // index of the last SYNCHRONOUS refill: no launch may read producer counters older than its
   bool async_refill;     // BG_ASYNC_REFILL (default on): bg_rollout overlaps refill #i with rollout chunk i+1
   hipStream_t side, side2, side3; // side: overlapped refills; side2/3: the deck and block kernels of one refill run beside the shop kernel
@@ -679,12 +791,12 @@ struct bg_handle {
   std::vector<hipEvent_t> ev_rollout_t, ev_refill_t, ev_step_t; // start/stop pairs
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
   // tunables read ONCE per handle in bg_create (environment variables)
-  int refill_blocks, refill_blocks_shop, dev_skip_refill, refill_order, refill_min;
+  int refill_blocks, refill_blocks_shop, dev_skip_refill, refill_order, refill_min, shop_ilp;
   uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_smask; int eng_waves, eng_copiers; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
   int engine;            // BG_ENGINE: 3 = bg_engine3.h (owner + service waves in one workgroup) for packed-record rollouts (default), 1 = bg_engine.h everywhere
   // bg_engine3.h: workgroup shape (BG_E3_CFG = 100 * owner waves + 10 * slices + service waves; 0 = by env count) and the service waves' batch
   // thresholds (BG_E3_TH requests, or after BG_E3_WAIT ticks of 10 ns)
-  int e3_cfg; uint32_t e3_th, e3_wait;
+  int e3_cfg, e3_epw; uint32_t e3_th, e3_wait;
 };
 
 static std::string g_create_err;
@@ -841,6 +953,7 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->refill_blocks = geti("BG_REFILL_BLOCKS", 4096); h->refill_blocks_shop = geti("BG_REFILL_BLOCKS_SHOP", 0);
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0);
     h->refill_order = geti("BG_REFILL_ORDER", 2);
+    h->shop_ilp = geti("BG_SHOP_ILP", 1);   // 2: the shop-seeding kernel with two streams per lane (a measurement; profiles/r05/shop_seeding_ilp.txt)
     // BG_REFILL_MIN = m > 0: a rollout launch of >= m steps (since the last refill) takes a refill beside it.  Default 0 = only when the rings demand one:
     // 20 steps' worth of refill is ~320 us of five small latency-bound kernels against 129 us per 20 steps in bulk (profiles/r05/refill_policy_ab.txt:
     // a refill beside every 20-step launch costs 21 % of the sustained rate)
@@ -853,8 +966,10 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->e3_cfg = geti("BG_E3_CFG", 0);
     if (h->e3_cfg != 0 && h->e3_cfg != 113 && h->e3_cfg != 213 && h->e3_cfg != 413 && h->e3_cfg != 414) { delete h; g_create_err = "bg_create: BG_E3_CFG must be 113, 213, 413 or 414 (100 x owner waves + 10 x slices + service waves)"; return BG_E_ARG; }
     h->e3_th = (uint32_t)geti("BG_E3_TH", 0x7fffffff); h->e3_wait = (uint32_t)geti("BG_E3_WAIT", 0);
+    h->e3_epw = geti("BG_E3_EPW", 0);   // live envs per 64-env workgroup (0 = by env count)
+    if (h->e3_epw != 0 && (h->e3_epw < 1 || h->e3_epw > 64)) { delete h; g_create_err = "bg_create: BG_E3_EPW must be in [1, 64]"; return BG_E_ARG; }
   }
-  h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->view_min = 0; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
+  h->d_prod[0] = h->d_prod[1] = nullptr; h->refill_seq = 0; h->view_min = 0; h->refill_done = -1; h->side = h->side2 = h->side3 = nullptr; h->ev_scan = h->ev_deck = h->ev_gblk = nullptr;
   h->ev_refill[0] = h->ev_refill[1] = nullptr; h->ev_rollout = nullptr;
   h->d_seeds = nullptr; h->d_mask = nullptr; h->d_jtab = nullptr; h->steps_since_refill = 0;
   memset(&h->dev, 0, sizeof(h->dev));
@@ -1043,7 +1158,7 @@ static int bg_refill_on(bg_handle* h, hipStream_t s, int steps_hint = -1) {
   // one after the other on `s` (a kernel's duration is then its own work, not its wait for a neighbour's registers)
   const bool shop_last = h->refill_order >= 1, serial = h->refill_order == 2;
   hipStream_t s_deck = serial ? s : h->side2, s_blk = serial ? s : h->side3;
-  if (!shop_last && !(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); // lowest-priority stream
+  if (!shop_last && !(skip & 1)) { if (h->shop_ilp == 2) hipLaunchKernelGGL(bg_refill_shop2_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); else hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); } // lowest-priority stream
   if (!(skip & 2)) hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_deck, d);
   if (!(skip & 4)) hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_blk, d);
   if (!(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_blk, d);
@@ -1053,7 +1168,7 @@ static int bg_refill_on(bg_handle* h, hipStream_t s, int steps_hint = -1) {
     BG_HIP(hipStreamWaitEvent(s, h->ev_deck, 0));
     BG_HIP(hipStreamWaitEvent(s, h->ev_gblk, 0));
   }
-  if (shop_last && !(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d);
+  if (shop_last && !(skip & 1)) { if (h->shop_ilp == 2) hipLaunchKernelGGL(bg_refill_shop2_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); else hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); }
   bg_ev_end(h, h->ev_refill_t, s);
   BG_HIP(hipGetLastError());
   BG_HIP(hipEventRecord(h->ev_refill[h->refill_seq & 1], s));
@@ -1187,7 +1302,16 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
     // workgroup up to 16 384 envs (256 workgroups = one per CU: 2.89 G env-steps/s against 2.59 G at 128 per workgroup), 128 up to 32 768
     // (profiles/r04_engine3/small_jobs.txt).  Unknown shapes are refused by bg_create_ex.
     const int cfg = h->e3_cfg ? h->e3_cfg : (h->dev.N <= 16384 ? 113 : (h->dev.N <= 32768 ? 213 : 413));
-#define BG_E3K(HV, CV, NOWV, KSV, NSVV) hipLaunchKernelGGL((bg_engine3_kernel<HV, CV, NOWV, KSV, NSVV>), dim3((h->dev.N + NOWV * KSV * 64 - 1) / (NOWV * KSV * 64)), dim3((NOWV + NSVV) * BG_BLOCK), 0, st, dv, a)
+    // 64-env shape: live envs per workgroup (BG_E3_EPW, or by env count)
+    int epw = 64;
+    if (cfg == 113) {
+      epw = h->e3_epw ? h->e3_epw : 64;
+      // by itself: at least 256 workgroups (one per CU) of at least 16 live envs -- measured at 372 steps (profiles/r05/small_jobs.txt): 4 096 envs
+      // 0.72 G env-steps/s at 64 per workgroup, 0.80 at 32, 0.87 at 16, 0.79 at 8; 8 192 envs 1.47 / 1.55 / 1.42 / 0.89; 16 384 envs 2.87 / 2.55 / 1.55
+      if (!h->e3_epw) { while (epw > 16 && (h->dev.N + epw - 1) / epw < 256) epw >>= 1; }
+      a.epw = (uint32_t)epw;
+    }
+#define BG_E3K(HV, CV, NOWV, KSV, NSVV) hipLaunchKernelGGL((bg_engine3_kernel<HV, CV, NOWV, KSV, NSVV>), dim3((NOWV * KSV == 1) ? (h->dev.N + epw - 1) / epw : (h->dev.N + NOWV * KSV * 64 - 1) / (NOWV * KSV * 64)), dim3((NOWV + NSVV) * BG_BLOCK), 0, st, dv, a)
 #define BG_E3(NOWV, KSV, NSVV) do { \
       if (hash && cards) BG_E3K(true, true, NOWV, KSV, NSVV); else if (hash) BG_E3K(true, false, NOWV, KSV, NSVV); \
       else if (cards) BG_E3K(false, true, NOWV, KSV, NSVV); else BG_E3K(false, false, NOWV, KSV, NSVV); } while (0)
@@ -1379,7 +1503,13 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
     long vi = h->refill_seq - 1;
     if (refill_after) vi = s0 - 1;   // (R, queued below, will be refill s0: the one before it)
     else if (async && vi - 1 >= h->view_min) vi--;
-    if (vi >= 0) BG_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_refill[vi & 1], 0));
+    // (a refill is long complete for all but the first launch or two that read its view: once hipEventQuery has said so, no wait is queued -- a
+    //  cross-stream wait is a barrier packet in front of every launch, a few microseconds of a 230 us one.  vi >= refill_seq - 2, so the event of
+    //  this parity still belongs to refill vi.)
+    if (vi >= 0 && vi > h->refill_done) {
+      if (hipEventQuery(h->ev_refill[vi & 1]) == hipSuccess) h->refill_done = vi;
+      else BG_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_refill[vi & 1], 0));
+    }
     const uint32_t* view = vi >= 0 ? h->d_prod[vi & 1] : bg_prod_latest(h);
     bg_ev_begin(h, h->ev_rollout_t, (hipStream_t)stream); // after the waits: the events bracket the kernel, not the stream's wait for the refill
     BgDev dv = bg_dev_view(h, view);

@@ -528,16 +528,18 @@ __device__ __forceinline__ void bg_chain_main(const BgDev& d, int env, Env& e, R
   // The nj draws are `_randbelow(24)`: 5-bit words, rejected when >= 24.  Instead of a rejection loop per joker (a wave
   // iterates until its unluckiest lane is done), look at the next 12 words at once: the j-th ACCEPTED word is joker
   // j's draw.  Only Misprint uses the value.
+  // (Round 5: everything below is written as masks and selects on purpose.  As nested `?:` under `if (j < nj)` / `if (ok)` the compiler turned the five
+  //  joker slots into 24 branches and 35 exec-mask saves -- 255 instructions on one source line, ~7 k cycles per play for what is ~150 arithmetic
+  //  instructions; a slot beyond njokers holds id 0, whose descriptor's condition (31) is never set, so no slot needs a guard.)
   uint32_t mis_of[5] = {0, 0, 0, 0, 0};
   {
     bg_gnorm(d, e);
-    uint32_t acc = 0;
-    uint64_t r5lo = 0, r5hi = 0; // the twelve 5-bit candidates, one per byte
+    uint32_t acc = 0, r5a = 0, r5b = 0; // the twelve 5-bit candidates: six per word
 #pragma unroll
     for (int i = 0; i < 12; i++) {
       const uint32_t r5 = mw[i] >> 27;
       acc |= (r5 < 24u ? 1u : 0u) << i;
-      if (i < 8) r5lo |= (uint64_t)r5 << (8 * i); else r5hi |= (uint64_t)r5 << (8 * (i - 8));
+      if (i < 6) r5a |= r5 << (5 * i); else r5b |= r5 << (5 * (i - 6));
     }
     // usable only up to the last word the ring holds, and only if the nj-th accepted word lies inside
     uint32_t usable = acc & avail;
@@ -551,12 +553,14 @@ __device__ __forceinline__ void bg_chain_main(const BgDev& d, int env, Env& e, R
       uint32_t m = usable;
       int last = 0;
 #pragma unroll
-      for (int j = 0; j < 5; j++)
-        if (j < nj) {
-          last = __ffs((int)m) - 1;
-          m &= m - 1;
-          if (((dms[j] >> 5) & 7u) == 3u) mis_of[j] = (uint32_t)(((last < 8 ? r5lo : r5hi) >> (8 * (last & 7))) & 0x1fu);
-        }
+      for (int j = 0; j < 5; j++) {
+        const bool on = j < nj;
+        const int pos = __ffs((int)m) - 1;            // (m != 0 while j < nj: popc(usable) >= nj)
+        last = on ? pos : last;
+        m = on ? (m & (m - 1u)) : m;
+        const uint32_t word = pos < 6 ? r5a : r5b;
+        mis_of[j] = (word >> (5u * (uint32_t)(pos < 6 ? pos : pos - 6) & 31u)) & 0x1fu;   // (only looked at by a Misprint in slot j)
+      }
       e.g_idx += last + 1;
     } else {
 #pragma unroll 1
@@ -567,20 +571,24 @@ __device__ __forceinline__ void bg_chain_main(const BgDev& d, int env, Env& e, R
       }
     }
   }
+  const uint32_t k4 = 3u * (uint32_t)nj, k5 = 30u * (uint32_t)e.discards_left, k7 = 13u * (uint32_t)queens;
+  uint32_t blue = 104u;   // Blue Joker: 2 * len(deck) = 104 until Immolate / Cryptid change the deck
+  if constexpr (GENERAL) blue = 2u * (uint32_t)in.deck_len;
+  else if constexpr (DK::kCards) blue = 2u * (uint32_t)(52 - e.ndrop + e.nfo);
 #pragma unroll
   for (int j = 0; j < 5; j++) {
-    if (j < nj) {
-      uint32_t dm = dms[j];
-      bool ok = (cond >> (dm & 31u)) & 1u;
-      uint32_t vk = (dm >> 5) & 7u;
-      int c = (int)(dm >> 8);
-      int madd = vk == 0 ? c : (vk == 3 ? (int)mis_of[j] : (vk == 4 ? 3 * nj : (vk == 7 ? 13 * queens : 0)));
-      int cadd = vk == 1 ? c : (vk == 5 ? 30 * e.discards_left : 0);
-      if constexpr (GENERAL) { if (vk == 1u && c == 104) cadd = 2 * in.deck_len; } // Blue Joker: 2 * len(deck)
-      else if constexpr (DK::kCards) if (vk == 1u && c == 104) cadd = 2 * (52 - e.ndrop + e.nfo); // ... once Immolate / Cryptid changed it
-      double xf = vk == 2 ? (double)c : (vk == 6 ? baron : 1.0);
-      if (ok) { chips += cadd; mult += madd; x_mult *= xf; }
-    }
+    const uint32_t dm = dms[j];
+    const uint32_t okm = 0u - ((cond >> (dm & 31u)) & 1u);          // all ones when the joker's condition holds
+    const uint32_t vk = (dm >> 5) & 7u, c = dm >> 8;
+    const uint32_t is0 = 0u - (uint32_t)(vk == 0u), is1 = 0u - (uint32_t)(vk == 1u), is3 = 0u - (uint32_t)(vk == 3u), is4 = 0u - (uint32_t)(vk == 4u),
+                   is5 = 0u - (uint32_t)(vk == 5u), is7 = 0u - (uint32_t)(vk == 7u);
+    const uint32_t madd = (c & is0) | (mis_of[j] & is3) | (k4 & is4) | (k7 & is7);
+    const uint32_t c1 = (c == 104u) ? blue : c;                       // (+chips 104 is the Blue Joker's descriptor)
+    const uint32_t cadd = (c1 & is1) | (k5 & is5);
+    chips += (int64_t)(cadd & okm); mult += (int64_t)(madd & okm);
+    double xf = vk == 2u ? (double)c : (vk == 6u ? baron : 1.0);
+    xf = okm ? xf : 1.0;                                              // (a factor of exactly 1.0 leaves x_mult's bits alone)
+    x_mult *= xf;
   }
   BG_PROBE(14);
 }

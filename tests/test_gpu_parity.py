@@ -455,7 +455,7 @@ def test_packed_record_rollout_vs_oracle(policy, scorer, n):
     env.close()
 
 
-@pytest.mark.parametrize("engine,cfg", [(1, None), (3, "413"), (3, "113"), (3, "213"), (3, "414")])
+@pytest.mark.parametrize("engine,cfg", [(1, None), (3, "413"), (3, "113"), (3, "113/64"), (3, "113/24"), (3, "213"), (3, "414")])
 @pytest.mark.parametrize("stride", [352, 384])
 def test_packed_record_rollout_every_engine(engine, cfg, stride, monkeypatch):
     """The step engines behind bg_rollout_rows -- bg_engine.h (workers + copiers) and bg_engine3.h (owner waves + service waves in one
@@ -465,8 +465,10 @@ def test_packed_record_rollout_every_engine(engine, cfg, stride, monkeypatch):
     from balatro_gym_amd.vec_env import RowBuffers
     from oracle.gen_golden import IMPLEMENTED
     monkeypatch.setenv("BG_ENGINE", str(engine))
-    if cfg:
-        monkeypatch.setenv("BG_E3_CFG", cfg)
+    if cfg:   # "113/k": k live envs per 64-env workgroup (BG_E3_EPW; by itself the library picks 8 for a job this small)
+        monkeypatch.setenv("BG_E3_CFG", cfg.split("/")[0])
+        if "/" in cfg:
+            monkeypatch.setenv("BG_E3_EPW", cfg.split("/")[1])
     n, T, chunks = 333, 64, 3
     seeds = [88_000 + SEED_OFFSET + 3 * i for i in range(n)]
     jokers = [random.Random(2600 + i).sample(IMPLEMENTED, 5) for i in range(n)]
