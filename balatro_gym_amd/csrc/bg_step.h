@@ -87,6 +87,9 @@ typedef uint32_t bg_pv_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const bg_pv_u32x4 lds_cu4;
 template <class DK>
 __device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, DK& dk, const uint4* pre = nullptr, lds_cu4* pv = nullptr, int pv_stride = 0) {
+  // the reset template (applied at the end) is requested FIRST: its HBM round trip then runs beside the cold stores and the deck copy instead of
+  // behind them (the compiler cannot move a load above stores through other pointers)
+  const uint4 t0 = d.tmpl[env], t1 = d.tmpl[(size_t)d.N + env];
   e.ante = 1; e.round = 1; e.phase = 2; e.chips_needed = 300; e.chips_scored = 0; e.round_chips = 0; e.money = 4;
   e.hand = 0; e.nhand = 0; e.sel = 0; e.nsel = 0; e.hands_left = 4; e.discards_left = 3; e.hand_size = 8;
   e.njokers = 0; e.jokers = 0; e.ncons = 0; e.cons0 = 0; e.cons1 = 0; e.n_magic = 0; e.n_minim = 0;
@@ -115,7 +118,6 @@ __device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, DK
     e.d_ready--; e.d_cons = (e.d_cons + 1) & 0xff;
   }
   // reset template (harness injection, applied after every reset)
-  uint4 t0 = d.tmpl[env], t1 = d.tmpl[(size_t)d.N + env];
   int tnj = (int)bg_b(t0.y, 1);
   if (t0.y & 0x80000000u) { e.njokers = tnj; e.jokers = (uint64_t)t0.x | ((uint64_t)(t0.y & 0xffu) << 32); }
   if (t0.y & 0x40000000u) e.money = (int32_t)t0.z;
@@ -165,10 +167,28 @@ __device__ __forceinline__ int bg_candidate(uint64_t sorted, int j) {
   return id;
 }
 
+// byte i (0..23) of six packed words, i per lane (registers cannot be indexed by a lane's value: a select chain; six scalars, not an array --
+// an array handed around by reference ended up in scratch memory)
+struct BgPk6 { uint32_t a, b, c, d, e, f; };
+__device__ __forceinline__ uint32_t bg_pk_byte(const BgPk6 pk, int i) {
+  const int g = i >> 2;
+  uint32_t wv = pk.a;
+  wv = g == 1 ? pk.b : wv; wv = g == 2 ? pk.c : wv; wv = g == 3 ? pk.d : wv; wv = g == 4 ? pk.e : wv; wv = g == 5 ? pk.f : wv;
+  return (wv >> (8 * (i & 3))) & 0xffu;
+}
+// bit 7 of every byte of f -> bits 0..3 (byte k -> bit k): (f >> 7) has its bits at 0, 8, 16, 24, and the four shifted copies a multiply by
+// 2^24 + 2^17 + 2^10 + 2^3 adds land on 16 different positions (no carries); bits 24..27 collect byte 0..3
+__device__ __forceinline__ uint32_t bg_movemask4(uint32_t f) { return (((f >> 7) & 0x01010101u) * 0x01020408u) >> 24; }
+
 __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr) {
   BG_PROBE_BEGIN();
-  bg_sprefetch(d, env, e, w, 24); // shop.py:111-139
-  BG_PROBE(18);
+  // the 24 words of a fresh stream are REQUESTED first (six independent 16-byte loads) and looked at behind the cost factor and the sorted joker
+  // list: ~200 instructions that do not need them
+  bool full_state;
+  const uint32_t* S = bg_sbase(d, env, e, full_state);
+  const bool fresh = e.s_idx == 0 && !full_state;
+  uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;
+  if (fresh) { const uint4* S4 = (const uint4*)S; q0 = S4[0]; q1 = S4[1]; q2 = S4[2]; q3 = S4[3]; q4 = S4[4]; q5 = S4[5]; }
   double mult = bg_shop_cost_mult(e, w.jt);
   const uint64_t sj = bg_sorted_jokers(e);
   int owned145 = 0;
@@ -178,43 +198,55 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
   // The seven draws -- choice of the third pack (_randbelow(3)), random.sample(candid, 3) by the selection-set method
   // (Lib/random.py sample(), n > 21: _randbelow(nc) until new), the voucher (_randbelow(2)), two randint(0, 51) -- are
   // rejection loops over consecutive words.  A loop per draw makes the wave iterate until its unluckiest lane accepts;
-  // instead classify all 24 window words at once (one acceptance mask per kind of draw) and walk the masks with ffs.
+  // instead classify the next 24 words at once (one acceptance mask per kind of draw) and walk the masks with ffs.
   int third_r = 0, p0 = 0, p1 = 0, p2 = 0, v = 0, ca = 0, cb = 0;
-  bool fast = w.s_len >= 24 && w.s_start == e.s_idx;
-  if (fast) {
+  bool fast = false;
+  // Round 5, a FRESH stream (every generate_shop): every draw looks at the TOP BYTE of its word only -- getrandbits(2) = byte >> 6, getrandbits(8) = byte,
+  // getrandbits(6) = byte >> 2 -- so the 24 words (six 16-byte loads of finished, tempered words) are packed into six registers of top bytes as they
+  // arrive and classified four bytes at a time (SWAR): no LDS window, no 24 dependent LDS reads, a quarter of the instructions.  (It was ~1 000
+  // instructions and three memory phases -- ~15 k cycles in nearly every play batch, since a batch of 20-30 plays nearly always holds a won blind.)
+  if (fresh) {
+    auto top = [](const uint4 q) { return (q.x >> 24) | ((q.y >> 24) << 8) | ((q.z >> 24) << 16) | (q.w & 0xff000000u); };
+    const BgPk6 pk{top(q0), top(q1), top(q2), top(q3), top(q4), top(q5)};
+    BG_PROBE(18);
+    const uint32_t H = 0x80808080u;
+    const uint32_t addnc = (0x80u - (nc & 0x7fu)) * 0x01010101u;   // nc = 140..145 has bit 7 set: byte >= nc <=> bit 7 and low seven bits >= nc & 127
     uint32_t m3 = 0, m2 = 0, m8 = 0, m52 = 0;
-    uint32_t r8[6] = {0, 0, 0, 0, 0, 0}; // the 8-bit candidates, packed (kept for the "until new" tests)
-#pragma unroll
-    for (int i = 0; i < 24; i++) {
-      const uint32_t y = w.lds[i * BG_BLOCK];   // (the shop window holds finished, tempered words)
-      m3 |= ((y >> 30) < 3u ? 1u : 0u) << i; m2 |= ((y >> 30) < 2u ? 1u : 0u) << i;
-      m8 |= ((y >> 24) < nc ? 1u : 0u) << i; m52 |= ((y >> 26) < 52u ? 1u : 0u) << i;
-      r8[i >> 2] |= (y >> 24) << (8 * (i & 3));
-      if ((i & 3) == 3) __builtin_amdgcn_sched_barrier(0); // four words in flight are enough; 24 would cost ~30 registers
-    }
-    // word of accepted position i (dynamic): re-read from the window
-#define BG_SW(i) (w.lds[(i) * BG_BLOCK])
+#define BG_INV_CLASS(x, g) do { \
+      const uint32_t ge192 = (x) & ((x) << 1);                                   /* bit 7: byte >= 192 (top two bits == 3) */ \
+      const uint32_t ge208 = ge192 & (((x) << 2) | ((x) << 3));                  /* byte >= 208 = 0xD0 <=> byte >> 2 >= 52 */ \
+      const uint32_t genc = (x) & (((x) & 0x7f7f7f7fu) + addnc);                 /* byte >= nc (no carry between bytes: 0x7f + 0x74 < 0x100) */ \
+      m3 |= bg_movemask4(~ge192 & H) << (4 * (g)); \
+      m2 |= bg_movemask4(~(x) & H) << (4 * (g));                                 /* byte < 128 (top two bits < 2) */ \
+      m52 |= bg_movemask4(~ge208 & H) << (4 * (g)); \
+      m8 |= bg_movemask4(~genc & H) << (4 * (g)); } while (0)
+    BG_INV_CLASS(pk.a, 0); BG_INV_CLASS(pk.b, 1); BG_INV_CLASS(pk.c, 2); BG_INV_CLASS(pk.d, 3); BG_INV_CLASS(pk.e, 4); BG_INV_CLASS(pk.f, 5);
+#undef BG_INV_CLASS
+    auto nz = [H](uint32_t x) { return bg_movemask4((((x & 0x7f7f7f7fu) + 0x7f7f7f7fu) | x) & H); };   // bit k: byte k of x is not zero
+    auto ne_mask = [&](uint32_t pv) {   // bit i: byte i != pv
+      const uint32_t rep = pv * 0x01010101u;
+      return nz(pk.a ^ rep) | (nz(pk.b ^ rep) << 4) | (nz(pk.c ^ rep) << 8) | (nz(pk.d ^ rep) << 12) | (nz(pk.e ^ rep) << 16) | (nz(pk.f ^ rep) << 20);
+    };
+    fast = true;
     uint32_t rem = 0xffffffu; // words not consumed yet
     int i0 = __ffs((int)(m3 & rem)) - 1; fast = fast && i0 >= 0; rem &= ~((2u << (i0 & 31)) - 1u);
     int i1 = __ffs((int)(m8 & rem)) - 1; fast = fast && i1 >= 0; rem &= ~((2u << (i1 & 31)) - 1u);
-    p0 = (int)(BG_SW(i1 & 31) >> 24);
-    uint32_t ne = 0;
-#pragma unroll
-    for (int i = 0; i < 24; i++) ne |= (((r8[i >> 2] >> (8 * (i & 3))) & 0xffu) != (uint32_t)p0 ? 1u : 0u) << i;
+    p0 = (int)bg_pk_byte(pk, i1 & 31);
+    uint32_t ne = ne_mask((uint32_t)p0);
     int i2 = __ffs((int)(m8 & ne & rem)) - 1; fast = fast && i2 >= 0; rem &= ~((2u << (i2 & 31)) - 1u);
-    p1 = (int)(BG_SW(i2 & 31) >> 24);
-#pragma unroll
-    for (int i = 0; i < 24; i++) ne &= ~((((r8[i >> 2] >> (8 * (i & 3))) & 0xffu) == (uint32_t)p1 ? 1u : 0u) << i);
+    p1 = (int)bg_pk_byte(pk, i2 & 31);
+    ne &= ne_mask((uint32_t)p1);
     int i3 = __ffs((int)(m8 & ne & rem)) - 1; fast = fast && i3 >= 0; rem &= ~((2u << (i3 & 31)) - 1u);
-    p2 = (int)(BG_SW(i3 & 31) >> 24);
+    p2 = (int)bg_pk_byte(pk, i3 & 31);
     int i4 = __ffs((int)(m2 & rem)) - 1; fast = fast && i4 >= 0; rem &= ~((2u << (i4 & 31)) - 1u);
     int i5 = __ffs((int)(m52 & rem)) - 1; fast = fast && i5 >= 0; rem &= ~((2u << (i5 & 31)) - 1u);
     int i6 = __ffs((int)(m52 & rem)) - 1; fast = fast && i6 >= 0;
-    third_r = (int)(BG_SW(i0 & 31) >> 30); v = (int)(BG_SW(i4 & 31) >> 30);
-    ca = (int)(BG_SW(i5 & 31) >> 26); cb = (int)(BG_SW(i6 & 31) >> 26);
-#undef BG_SW
+    third_r = (int)(bg_pk_byte(pk, i0 & 31) >> 6); v = (int)(bg_pk_byte(pk, i4 & 31) >> 6);
+    ca = (int)(bg_pk_byte(pk, i5 & 31) >> 2); cb = (int)(bg_pk_byte(pk, i6 & 31) >> 2);
     if (fast) e.s_idx += i6 + 1;
+    w.s_start = e.s_idx; w.s_len = 0; w.g_len = 0; w.g_blk = -1;   // (as bg_sprefetch leaves the window: nothing of either stream is in it)
   }
+  if (!fast) bg_sprefetch(d, env, e, w, 24); // shop.py:111-139: a rerolled stream (or the overflow block), or the one visit in thousands whose rejections outrun 24 words
   if (!fast) { // window too short for this lane's rejections (or no window): the plain loops
     third_r = (int)bg_randbelow<true>(d, env, e, w, 3u); // rng.choice([...]) is evaluated before the loop
     int guard = 0;
@@ -665,6 +697,9 @@ __device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, 
     uint32_t ra[8];
     uint32_t vm = 0;
     bool bad = false;
+    // (requesting these eight words EARLY -- right behind the gather, so that their round trip runs beside the classification -- was measured in round 5:
+    //  -2 % at 20 steps, -1 % at 372, profiles/r05/play_path_ab.txt; like round 3's line touches, loads that only owners issue still cost every
+    //  other load of the batch more than they save)
 #pragma unroll
     for (int c = 0; c < 8; c++) {
       const bool v = boff[c] >= 0;

@@ -25,7 +25,8 @@ torch.cuda.synchronize()
 p = env.get_profile()
 L.bg_debug_counters(env._h, out)
 o = [float(v) for v in out]
-wgs = (n + 255) // 256
+epw = int(os.environ.get("BG_E3_EPW", "0")) or 256
+wgs = (n + epw - 1) // epw
 it = max(o[4], 1)
 print(f"launch {p['rollout_ms'] * 1e3:.0f} us, T {T}, {n * T / (p['rollout_ms'] * 1e-3) / 1e9:.2f} G env-steps/s")
 print(f"OWNER (4 waves per workgroup): {it / (4 * wgs):.0f} iterations per wave; per iteration: step phase {o[0] / it:.0f} cycles, copy-out {o[1] / it:.0f}, idle {o[2] / it:.0f}; records per iteration {o[5] / it:.1f}")
