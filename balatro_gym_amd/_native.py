@@ -174,6 +174,7 @@ def load(build_if_missing: bool = True):
     L.bg_step_many.argtypes = [vp, i32, vp, C.POINTER(ObsPtrs), i32, vp, vp, vp, C.POINTER(InfoPtrs), vp]
     L.bg_rollout.argtypes = [vp, i32, i32, u64, u64, u64, C.POINTER(ObsPtrs), i32, vp, vp, vp, vp, vp]
     L.bg_rollout_rows.argtypes = [vp, i32, i32, u64, u64, u64, vp, u64, i32, vp, vp]
+    L.bg_set_gather_peers.argtypes = [vp, vp, i32, i32]
     L.bg_inject.argtypes = [vp, vp, vp, vp, vp, vp, vp, i32, vp]
     L.bg_inject_cards.argtypes = [vp, vp, vp, vp, vp, i32, vp]
     L.bg_inject_consumables.argtypes = [vp, vp, vp, vp, i32, vp]

@@ -74,6 +74,10 @@ struct EngineArgs {
   uint32_t autoreset;          // SAME_STEP auto-reset of terminated envs
   uint32_t copier;             // packed records: wave `n_waves` is the COPIER (it writes the records and hands the envs back), the workers never copy
   uint32_t epw;                // bg_engine3.h, the 64-env workgroup shape only: envs per workgroup that are LIVE (8 .. 64; 0 = all 64) -- a small job spreads over more CUs
+  // bg_engine3.h, sharded jobs (bg_set_gather_peers): the record of the launch's LAST step is also written into every rank's gather buffer
+  // ([world][N][352] bytes, rank `grank`'s shard), by the owner waves' copy-out, while the launch runs.  gworld = 0: no gather.
+  uint8_t* gpeer[8];
+  uint32_t gworld, grank;
 };
 
 __device__ __forceinline__ uint32_t bg_lds_ld(uint32_t* p) {

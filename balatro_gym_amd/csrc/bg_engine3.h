@@ -182,6 +182,7 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
       if (__ballot(busy) == 0ull) break;
       E3T_CNT(4, 1);
       uint32_t nb = 0;   // records finished in this iteration (all slices): the copy-out list
+      bool glast = false; // ... one of them is a last-step record of a launch whose current records are gathered (a.gworld)
 #pragma unroll
       for (int s = 0; s < KS; s++) {
         const int l = (wave * KS + s) * BG_BLOCK + lane, env = env0 + l;
@@ -273,8 +274,11 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
           t[s]++;
         }
         const unsigned long long fms = __ballot(fin);
-        if (fin) s_list[wave][nb + __builtin_amdgcn_mbcnt_hi((uint32_t)(fms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fms, 0u))] = make_uint2((uint32_t)row, (uint32_t)l);
+        // (.y bit 8: the record of the launch's last step -- the one a sharded job gathers; the copy-out reads the lane out of the low byte)
+        const bool lastrec = fin && a.gworld != 0u && t[s] == T;
+        if (fin) s_list[wave][nb + __builtin_amdgcn_mbcnt_hi((uint32_t)(fms >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fms, 0u))] = make_uint2((uint32_t)row, (uint32_t)l | (lastrec ? 0x100u : 0u));
         nb += (uint32_t)__popcll(fms);
+        glast = glast || lastrec;
       }
       E3T(0);
       // ---- copy-out: lane <-> 16-byte piece, non-temporal (32 records per round of loads: the LDS round trips overlap)
@@ -331,6 +335,24 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
             for (int k = 0; k < 4; k++)
               if (q0 + (uint32_t)k * BG_BLOCK < total)
                 __builtin_nontemporal_store(v[k], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + (size_t)ce[k].x * (size_t)a.obs.row_stride + 16u * cpc[k]));
+          }
+        }
+        // ---- sharded jobs: the CURRENT record of every env (the launch's last step) also goes into every rank's gather buffer, from here -- peer-mapped
+        // stores over xGMI (own buffer: local HBM), 22 pieces per record and rank -- so that the gather is part of the launch instead of a collective
+        // that can only start when the launch has retired (RCCL's multi-wave workgroups do not fit beside a resident engine workgroup).  Only iterations
+        // that finished such a record come here (once per env and launch).
+        if (a.gworld != 0u && __ballot(glast) != 0ull) {
+          const uint32_t total = 22u * nb;
+          for (uint32_t q = (uint32_t)lane; q < total; q += BG_BLOCK) {
+            const uint32_t r = (q * 2979u) >> 16, pc = q - 22u * r;   // q / 22 (exact below 8 000)
+            const bg_u32x2 ce = *(__attribute__((address_space(3))) const bg_u32x2*)(lsb + (r << 3));
+            if (ce.y & 0x100u) {
+              const uint32_t gl = ce.y & 0xffu;
+              const bg_u32x4 v = s_img[gl][pc];
+              const size_t off = ((size_t)a.grank * N + (size_t)(env0 + (int)gl)) * 352u + 16u * pc;
+#pragma unroll   // (constant indexes: a rank count known at run time only must not turn the kernel's arguments into a scratch array)
+              for (int g = 0; g < 8; g++) if ((uint32_t)g < a.gworld) __builtin_nontemporal_store(v, (__attribute__((address_space(1))) bg_u32x4*)(a.gpeer[g] + off));
+            }
           }
         }
         BG_WAVE_SYNC();   // the images have been read (a wave's LDS operations complete in order): the next iteration may patch them

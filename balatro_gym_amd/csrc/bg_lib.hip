@@ -797,6 +797,8 @@ struct bg_handle {
   // bg_engine3.h: workgroup shape (BG_E3_CFG = 100 * owner waves + 10 * slices + service waves; 0 = by env count) and the service waves' batch
   // thresholds (BG_E3_TH requests, or after BG_E3_WAIT ticks of 10 ns)
   int e3_cfg, e3_epw; uint32_t e3_th, e3_wait;
+  // sharded jobs (bg_set_gather_peers): every rank's gather buffer as mapped into THIS process, the size of the job and this handle's rank
+  uint8_t* gpeer[8]; int gworld, grank;
 };
 
 static std::string g_create_err;
@@ -966,6 +968,8 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->e3_cfg = geti("BG_E3_CFG", 0);
     if (h->e3_cfg != 0 && h->e3_cfg != 113 && h->e3_cfg != 213 && h->e3_cfg != 413 && h->e3_cfg != 414) { delete h; g_create_err = "bg_create: BG_E3_CFG must be 113, 213, 413 or 414 (100 x owner waves + 10 x slices + service waves)"; return BG_E_ARG; }
     h->e3_th = (uint32_t)geti("BG_E3_TH", 0x7fffffff); h->e3_wait = (uint32_t)geti("BG_E3_WAIT", 0);
+    for (int g = 0; g < 8; g++) h->gpeer[g] = nullptr;
+    h->gworld = 0; h->grank = 0;
     h->e3_epw = geti("BG_E3_EPW", 0);   // live envs per 64-env workgroup (0 = by env count)
     if (h->e3_epw != 0 && (h->e3_epw < 1 || h->e3_epw > 64)) { delete h; g_create_err = "bg_create: BG_E3_EPW must be in [1, 64]"; return BG_E_ARG; }
   }
@@ -1526,6 +1530,10 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       ea.T = chunk; ea.policy = pol; ea.policy_seed = policy_seed; ea.env_index0 = env_index0; ea.t0 = tt;
       ea.obs = o; ea.obs_stride_steps = obs_stride_steps; ea.reward = rw; ea.term = tm; ea.actions_out = ac; ea.stats = stats_dev;
       ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.serve_mask = h->eng_smask; ea.autoreset = 1;
+      if (h->gworld > 0 && rows_dev && h->engine == 3 && done + chunk == T) { // the call's LAST launch: its last step is every env's current record
+        for (int g = 0; g < h->gworld; g++) ea.gpeer[g] = h->gpeer[g];
+        ea.gworld = (uint32_t)h->gworld; ea.grank = (uint32_t)h->grank;
+      }
       bg_engine_launch(h, dv, ea, hash, false, st);
     }
     bg_ev_end(h, h->ev_rollout_t, (hipStream_t)stream);
@@ -1540,6 +1548,19 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
     h->steps_since_refill += chunk;
     done += chunk;
   }
+  return 0;
+}
+
+int bg_set_gather_peers(bg_handle* h, void* const* bufs, int world, int rank) {
+  if (!h) return BG_E_ARG;
+  if (world == 0) { h->gworld = 0; return 0; }
+  if (!bufs || world < 1 || world > 8 || rank < 0 || rank >= world) { h->err = "bg_set_gather_peers: world must be 1..8, rank inside it, bufs the world gather buffers"; return BG_E_ARG; }
+  if (h->engine != 3) { h->err = "bg_set_gather_peers: only bg_engine3.h's packed-record rollouts write gather buffers (BG_ENGINE=3)"; return BG_E_ARG; }
+  for (int g = 0; g < world; g++) {
+    if (!bufs[g] || ((uintptr_t)bufs[g] & 15)) { h->err = "bg_set_gather_peers: every gather buffer must be a 16-byte aligned device pointer"; return BG_E_ARG; }
+    h->gpeer[g] = (uint8_t*)bufs[g];
+  }
+  h->gworld = world; h->grank = rank;
   return 0;
 }
 

@@ -39,6 +39,40 @@ def all_gather_bytes(out: torch.Tensor, inp: torch.Tensor, group=None) -> None:
     dist.all_gather_into_tensor(out, inp, group=group)
 
 
+def setup_peer_gather(env, rank: int, world: int, group=None) -> Optional[torch.Tensor]:
+    """The gather WITHOUT a collective: every rank allocates uint8 [world, n, 352], hands its CUDA IPC handle to the others (all_gather_object: a few
+    hundred bytes, once), opens theirs, and tells its engine (BalatroVecEnv.set_gather_peers): from then on the last launch of every packed-record rollout
+    writes every env's current record into slot [rank] of ALL buffers from its copy-out -- peer-mapped stores over xGMI while the launch runs.  After
+    the rollout and a barrier between the ranks, the returned tensor holds the current record of every env of the job.  Returns None (on every rank)
+    when the mapping is not available on some rank: the caller then uses the RCCL all_gather (`gather_records`)."""
+    from torch.multiprocessing.reductions import reduce_tensor
+    n = env.num_envs
+    ok, mine, peers, err = True, None, [None] * world, ""
+    try:
+        mine = torch.zeros((world, n, 352), dtype=torch.uint8, device=env.device)
+        fn, args = reduce_tensor(mine)
+    except Exception as ex:  # noqa: BLE001
+        ok, fn, args, err = False, None, None, repr(ex)
+    handles = [None] * world
+    dist.all_gather_object(handles, (ok, fn, args, n), group=group)
+    if ok and all(h[0] and h[3] == n for h in handles):
+        try:
+            for r in range(world):
+                peers[r] = mine if r == rank else handles[r][1](*handles[r][2])
+                if tuple(peers[r].shape) != (world, n, 352):
+                    raise RuntimeError("peer gather buffer has another shape")
+        except Exception as ex:  # noqa: BLE001
+            ok, err = False, repr(ex)
+    else:
+        ok = False
+    flags = [None] * world
+    dist.all_gather_object(flags, (ok, err), group=group)
+    if not all(f[0] for f in flags):
+        return None
+    env.set_gather_peers(peers, rank)
+    return mine
+
+
 class ShardedBalatroVecEnv:
     """total_envs games split over the process group; every rank drives its own shard on its own GPU."""
 
@@ -57,6 +91,7 @@ class ShardedBalatroVecEnv:
         self.local = local_env_factory(self.hi - self.lo, list(seeds[self.lo:self.hi]), **env_kwargs)
         self._gathered = None
         self._pad_bytes = None
+        self.peer_records = None
 
     @property
     def env_index0(self) -> int:
@@ -96,6 +131,14 @@ class ShardedBalatroVecEnv:
             self._gathered = torch.empty(self.world * n, dtype=torch.uint8, device=flat.device)
         all_gather_bytes(self._gathered, flat.contiguous(), group=self.group)
         return self._gathered.view(self.world, n)
+
+    def enable_peer_gather(self) -> bool:
+        """Switch the record gather to peer-mapped writes from the engine (setup_peer_gather).  True: after every packed-record `rollout` and a
+        barrier between the ranks, `peer_records` holds [world, n, 352]; False: not available here, `gather_records` (RCCL) is the way."""
+        if self.total_envs % self.world:
+            return False
+        self.peer_records = setup_peer_gather(self.local, self.rank, self.world, self.group)
+        return self.peer_records is not None
 
     def gather_records(self, rows: torch.Tensor) -> torch.Tensor:
         """all_gather of one packed-record row of this shard (uint8 [n, 352], e.g. `RowBuffers.rows[T - 1]`) ->

@@ -168,6 +168,22 @@ class BalatroVecEnv:
     def obs_flat(self) -> torch.Tensor:
         return self._rowbuf.rows[0].reshape(-1) if self._rowbuf is not None else self._obs.flat
 
+    def set_gather_peers(self, buffers: Sequence[Optional[torch.Tensor]], rank: int) -> None:
+        """Sharded jobs: `buffers[r]` = rank r's gather buffer (uint8 [world, N, 352]) as a tensor in THIS process -- the own one allocated here, the
+        peers' opened from their CUDA IPC handles.  From now on the last launch of every packed-record `rollout` also writes every env's current
+        record into slot [rank] of all of them (bg_set_gather_peers).  An empty list switches it off."""
+        world = len(buffers)
+        if world == 0:
+            self._check(self._L.bg_set_gather_peers(self._h, None, 0, 0), "bg_set_gather_peers")
+            self._gather_keep = None
+            return
+        for b in buffers:
+            if b.dtype != torch.uint8 or tuple(b.shape) != (world, self.num_envs, nat.ROW_BYTES) or not b.is_contiguous():
+                raise ValueError(f"every gather buffer must be a contiguous uint8 [{world}, {self.num_envs}, {nat.ROW_BYTES}] tensor")
+        arr = (C.c_void_p * world)(*[b.data_ptr() for b in buffers])
+        self._check(self._L.bg_set_gather_peers(self._h, C.cast(arr, C.c_void_p), world, int(rank)), "bg_set_gather_peers")
+        self._gather_keep = list(buffers)   # the mappings must outlive the handle's use of them
+
     def obs_flat_bytes(self, n: int) -> int:
         """Bytes `obs_flat` takes for `n` envs in THIS env's layout: n records of `row_stride` bytes with obs_layout "rows", else the per-key
         arrays as `ObsBuffers` lays them out (what a sharded gather pads every rank's buffer to)."""

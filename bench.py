@@ -188,7 +188,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-small-n", action="store_true", help="skip the 4 096-env sub-record")
     ap.add_argument("--no-step-path", action="store_true", help="skip the bg_step / bg_step_many sample")
-    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the RCCL all_gather of the current observation out")
+    ap.add_argument("--no-gather", action="store_true", help="N > 1: leave the gather of the current observation out")
+    ap.add_argument("--gather", choices=["peer", "rccl"], default="peer",
+                    help="N > 1: peer = the engine's copy-out writes every env's current record straight into every rank's gather buffer (CUDA IPC mappings over xGMI: "
+                         "inside the launch); rccl = an all_gather on a side stream behind the launch.  peer falls back to rccl where the mapping is not available")
     ap.add_argument("--force-gather", action="store_true", help="N = 1: run the gather path anyway (a one-rank RCCL group; exercises the N > 1 code on a one-GPU box)")
     args = ap.parse_args()
     if args.internal_warmup_s is not None:
@@ -238,6 +241,14 @@ def main():
     # the design's one collective: all_gather of the CURRENT observation record of every env, once per launch, on a side
     # stream so that it runs beside the next launch (what a central evaluator / logger sees; learners train on their own shard)
     do_gather = use_dist and not args.no_gather and isinstance(ob, RowBuffers)
+    # the gather WITHOUT a collective (round 5): every rank's engine writes the current record of its envs into every rank's buffer from its copy-out --
+    # peer-mapped stores while the launch runs; the barrier that ends the timed region is all the synchronisation it needs
+    peer_buf = None
+    if do_gather and args.gather == "peer":
+        from balatro_gym_amd.sharded import setup_peer_gather
+        peer_buf = setup_peer_gather(env, rank, world)
+    gather_method = "none" if not do_gather else ("peer" if peer_buf is not None else "rccl")
+    do_gather = do_gather and peer_buf is None   # (from here on: the RCCL path)
     gather_stream = torch.cuda.Stream(device=dev) if do_gather else None
     # N > 1: the launch's last record row of every shard is gathered (RCCL all_gather) on a side stream beside the NEXT launch.  Two
     # record buffers alternate, so the next launch never writes what the gather is still reading; a buffer is reused only after the
@@ -444,8 +455,11 @@ def main():
         out["roofline"]["refill_launches_in_timed_region"] = prof["refill_launches"]
         out["roofline"]["refill_kernel_us_in_timed_region"] = prof["refill_ms"] * 1e3
         if use_dist:
-            out["gather"] = {"in_timed_region": bool(do_gather), "what": "all_gather_into_tensor of the current 352-byte record of every env, once per launch, side stream",
-                             "bytes_per_gpu_per_launch": (gather_bytes_timed // max(1, launches)) if do_gather else 0}
+            out["gather"] = {"in_timed_region": gather_method != "none", "method": gather_method,
+                             "what": ("the engine's copy-out writes the current 352-byte record of every env into every rank's gather buffer (peer-mapped stores over xGMI, inside the launch); "
+                                      "the region's closing barrier is its synchronisation") if gather_method == "peer" else
+                                     "all_gather_into_tensor of the current 352-byte record of every env, once per launch, side stream",
+                             "bytes_per_gpu_per_launch": n * 352 if gather_method == "peer" else ((gather_bytes_timed // max(1, launches)) if do_gather else 0)}
     env.close()
     del ob, bufs
 

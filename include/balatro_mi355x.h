@@ -255,7 +255,16 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
 #define BG_ROW_PHASE 339
 #define BG_ROW_BOSS_BLIND_ACTIVE 340
 #define BG_ROW_BOSS_BLIND_TYPE 341
-#define BG_ROW_TERMINATED 342         /* uint8: the step ended the episode (SAME_STEP auto-reset: the record already shows the new episode) */
+#define BG_ROW_TERMINATED 342         /* Sharded jobs (one process per GPU): the exchange of the design -- every rank sees the CURRENT record of every env -- without a collective
+ * behind the launch.  bufs[r] is rank r's gather buffer, uint8 [world][N][BG_ROW_BYTES], as mapped into THIS process (own buffer: an ordinary device
+ * pointer; peers': hipIpcOpenMemHandle / torch's CUDA IPC over xGMI); N = this handle's env count, the same on every rank.  From then on the LAST launch
+ * of every bg_rollout_rows call also writes the record of its last step into slot [rank] of all `world` buffers, from the engine's copy-out, while the
+ * launch runs: when every rank's call has completed (a barrier between the ranks), every buffer holds all world x N current records.  world = 0 switches
+ * it off.  Replaces: SubprocVecEnv's pipe traffic of observations to the learner process (hpc_train.py:60-65); the RCCL all_gather of
+ * balatro_gym_amd/sharded.py stays as the fallback where peer mapping is not available. */
+int bg_set_gather_peers(bg_handle* h, void* const* bufs, int world, int rank);
+
+/* uint8: the step ended the episode (SAME_STEP auto-reset: the record already shows the new episode) */
 int bg_rollout_rows(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t env_index0, uint64_t t0,
                     uint8_t* rows_dev, uint64_t row_stride_bytes, int rows_stride_steps, bg_rollout_stats* stats_dev,
                     void* stream);

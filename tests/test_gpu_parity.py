@@ -476,8 +476,14 @@ def test_packed_record_rollout_every_engine(engine, cfg, stride, monkeypatch):
     env.inject(jokers=jokers, apply_now=True)
     rb = RowBuffers(n, env.device, steps=T * chunks, row_stride=stride)
     rbc = [RowBuffers(n, env.device, steps=T, row_stride=stride) for _ in range(chunks)]
+    import torch
+    gbuf = torch.zeros((1, n, 352), dtype=torch.uint8, device=env.device)
+    if engine == 3:   # a one-rank "sharded job": the copy-out also writes every env's current record (each call's last step) into the gather buffer
+        env.set_gather_peers([gbuf], 0)
     for c in range(chunks):   # several launches: hand-overs, images and queue positions carry over from one to the next
         env.rollout(T, policy=0, policy_seed=5, env_index0=1, t0=c * T, obs_buffers=rbc[c], zero_stats=(c == 0))
+        if engine == 3:
+            assert torch.equal(gbuf[0], rbc[c].rows[T - 1][:, :352]), f"launch {c}: gathered current records differ from the launch's last row"
     env.check()
     got_stats = env.stats()
     wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, T * chunks, 0, 5, True, 4, jokers, env_index0=1, t0=0)

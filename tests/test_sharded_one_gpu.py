@@ -29,13 +29,30 @@ def _worker(rank, world, port, total, T, kind, q):
     wl = sharded_workload(kind, total)
     env = ShardedBalatroVecEnv(total, wl["seeds"], device=0, **wl["env_kwargs"])
     apply_sharded_workload(env.local, wl, env.lo, env.hi)
+    # the gather WITHOUT a collective: every rank's engine writes its current records into every rank's buffer (CUDA IPC handles work between two
+    # processes on one device as they do between two GPUs); compared below, byte for byte, with the all_gather of the same rows
+    peer_ok = env.enable_peer_gather()
     rb = RowBuffers(env.hi - env.lo, env.local.device, steps=T)
     env.rollout(T, policy=2, policy_seed=5, obs_buffers=rb)
     rec = env.gather_records(rb.rows[T - 1])
+    torch.cuda.synchronize()
+    dist.barrier()   # every rank's launch has completed: every buffer is whole
+    if peer_ok:
+        assert torch.equal(env.peer_records, rec), "peer-written records differ from the all_gather of the same rows"
     env.local.observe()
     flat = env.gather_obs()
     st = env.local.stats()
-    q.put((rank, rec.cpu().numpy(), flat.cpu().numpy(), st))
+    q.put((rank, rec.cpu().numpy(), flat.cpu().numpy(), st, peer_ok))
+    dist.barrier()
+    # a second, shorter call: the buffers follow the LAST launch of every call
+    rb2 = RowBuffers(env.hi - env.lo, env.local.device, steps=7)
+    env.rollout(7, policy=2, policy_seed=5, t0=T, obs_buffers=rb2)
+    rec2 = env.gather_records(rb2.rows[6])
+    torch.cuda.synchronize()
+    dist.barrier()
+    if peer_ok:
+        assert torch.equal(env.peer_records, rec2)
+        assert not torch.equal(rec, rec2)
     dist.barrier()
     env.close()
     dist.destroy_process_group()
@@ -72,7 +89,8 @@ def test_two_ranks_one_gpu_match_one_process(kind):
     env.check()
     env.close()
     half = total // world
-    for rank, rec, flat, st in results:
+    assert all(r[4] for r in results), "peer-mapped gather buffers could not be set up on this box (CUDA IPC between two processes on one device)"
+    for rank, rec, flat, st, _ in results:
         assert rec.shape == (world, half, 352)
         assert np.array_equal(rec.reshape(total, 352), want), rank   # every rank holds every env's current record
         assert flat.shape[0] == world
