@@ -1319,7 +1319,7 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
 #define BG_E3(NOWV, KSV, NSVV) do { \
       if (hash && cards) BG_E3K(true, true, NOWV, KSV, NSVV); else if (hash) BG_E3K(true, false, NOWV, KSV, NSVV); \
       else if (cards) BG_E3K(false, true, NOWV, KSV, NSVV); else BG_E3K(false, false, NOWV, KSV, NSVV); } while (0)
-    switch (cfg) {   // (other shapes were measured and dropped: profiles/r04_engine3/wave_split_ab.txt, small_jobs.txt)
+    switch (cfg) {   // (other shapes were measured and dropped: profiles/r04_engine3/wave_split_ab.txt, small_jobs.txt, profiles/r05/scheduling_ab.txt)
       case 113: BG_E3(1, 1, 3); break;
       case 213: BG_E3(2, 1, 3); break;
       case 414: BG_E3(4, 1, 4); break;   // eight waves: no room for the refill beside the launch (it then runs when the workgroups retire)
