@@ -69,6 +69,9 @@ struct E3Lds {
 #define BG_E3_VGPR_ATTR
 #endif
 template <bool HASH, bool CARDS, int NOW, int KS, int NSV>
+// (Round 5 measured reading the arguments THROUGH the kernarg segment pointer instead of as by-value parameters -- whose 16-register blocks the compiler
+//  spills to VGPR lanes and reloads whole, 12 % of the kernel's instructions being v_readlane / v_writelane / s_nop: SGPR spills 237 -> 61, 14 454 -> 13 114
+//  instructions, and 3.4 % SLOWER at both launch lengths: a scalar load per use waits longer than sixteen lane reads.  profiles/r05/play_path_ab.txt.)
 __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_engine3_kernel(BgDev d, EngineArgs a) {
   constexpr int NE = NOW * KS * BG_BLOCK, LNE = NE == 256 ? 8 : (NE == 128 ? 7 : 6);
   static_assert(NE == 64 || NE == 128 || NE == 256, "envs per workgroup (a request carries the env's lane in 8 bits)");

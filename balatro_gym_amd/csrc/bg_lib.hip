@@ -1556,10 +1556,23 @@ int bg_set_gather_peers(bg_handle* h, void* const* bufs, int world, int rank) {
   if (world == 0) { h->gworld = 0; return 0; }
   if (!bufs || world < 1 || world > 8 || rank < 0 || rank >= world) { h->err = "bg_set_gather_peers: world must be 1..8, rank inside it, bufs the world gather buffers"; return BG_E_ARG; }
   if (h->engine != 3) { h->err = "bg_set_gather_peers: only bg_engine3.h's packed-record rollouts write gather buffers (BG_ENGINE=3)"; return BG_E_ARG; }
+  BG_GUARD(h);
   for (int g = 0; g < world; g++) {
     if (!bufs[g] || ((uintptr_t)bufs[g] & 15)) { h->err = "bg_set_gather_peers: every gather buffer must be a 16-byte aligned device pointer"; return BG_E_ARG; }
-    h->gpeer[g] = (uint8_t*)bufs[g];
+    // A buffer that lives on ANOTHER device (a peer's, opened from its IPC handle) is written by this device's kernels: that needs peer access, and a
+    // store without it is a GPU memory fault, not an error code -- so it is established here, or the call fails and the caller keeps its collective
+    hipPointerAttribute_t at;
+    memset(&at, 0, sizeof(at));
+    if (hipPointerGetAttributes(&at, bufs[g]) != hipSuccess) { (void)hipGetLastError(); h->err = "bg_set_gather_peers: a gather buffer is not a device allocation this process knows"; return BG_E_ARG; }
+    if (at.device != h->device_id) {
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, h->device_id, at.device) != hipSuccess || !can) { (void)hipGetLastError(); h->err = "bg_set_gather_peers: this device cannot access a peer's gather buffer (no peer access between the two devices)"; return BG_E_ARG; }
+      const hipError_t pe = hipDeviceEnablePeerAccess(at.device, 0);
+      if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); h->err = std::string("bg_set_gather_peers: hipDeviceEnablePeerAccess: ") + hipGetErrorString(pe); return BG_E_HIP; }
+      (void)hipGetLastError();
+    }
   }
+  for (int g = 0; g < world; g++) h->gpeer[g] = (uint8_t*)bufs[g];
   h->gworld = world; h->grank = rank;
   return 0;
 }

@@ -65,11 +65,19 @@ def setup_peer_gather(env, rank: int, world: int, group=None) -> Optional[torch.
             ok, err = False, repr(ex)
     else:
         ok = False
+    if ok:
+        try:   # (the library checks that this device may write every buffer -- peer access to the device it lives on -- and refuses otherwise)
+            env.set_gather_peers(peers, rank)
+        except Exception as ex:  # noqa: BLE001
+            ok, err = False, repr(ex)
     flags = [None] * world
     dist.all_gather_object(flags, (ok, err), group=group)
-    if not all(f[0] for f in flags):
+    if not all(f[0] for f in flags):   # one rank could not: NO rank writes peers (a rank that kept writing would write into buffers nobody reads)
+        try:
+            env.set_gather_peers([], rank)
+        except Exception:  # noqa: BLE001
+            pass
         return None
-    env.set_gather_peers(peers, rank)
     return mine
 
 
