@@ -315,10 +315,27 @@ def main():
         torch.cuda.synchronize(dev)
         t_off += k * chunk
         left -= k
-    # (round 4 ran four untimed launches of the timed shape here "so that the lazy refill falls outside" the timed one.  The refill -- the MT19937
-    #  seeding and the deck shuffles: row a1/a2 work -- is part of the job: since round 5 every launch of >= 16 steps carries its own share of it
-    #  beside it (bg_lib.hip, BG_REFILL_MIN), so there is nothing to steer around and the W warm-up steps of the contract are the only launches of
-    #  the timed shape in front of the timed region.)
+    # (round 4 ran four untimed launches of the timed shape here "so that the lazy refill falls outside" the timed one.  They are gone: the W warm-up
+    #  steps of the contract are the only launches in front of the timed region.  The refill -- the MT19937 seeding and the deck shuffles, row a1/a2 work --
+    #  is queued beside a launch whenever the rings ask for one (every 18th launch at 20 steps; a refill beside EVERY short launch was measured: -21 %,
+    #  profiles/r05/refill_policy_ab.txt); `sustained` below carries all of it, and since the engine is issued before the refill's kernels it equals `value`.)
+    if peer_buf is not None and launch_no > 0:
+        # the peer-written gather buffers after the warm-up's launches, checked before anything is timed: this rank's slot must be the last row of its last
+        # launch, every other slot must have been written by its rank.  If not (a mapping that does not carry stores on this box), every rank falls back to RCCL.
+        barrier()
+        last = bufs[(launch_no - 1) % len(bufs)].rows[chunk - 1][:, :352]
+        good = bool(torch.equal(peer_buf[rank], last)) and all(bool(peer_buf[r].any()) for r in range(world))
+        flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            print("bench.py: peer-written gather buffers failed their check after the warm-up; falling back to the RCCL all_gather", file=sys.stderr)
+            env.set_gather_peers([], rank)
+            peer_buf, gather_method, do_gather = None, "rccl (peer writes failed their check)", True
+            gather_stream = torch.cuda.Stream(device=dev)
+            gathered = torch.empty((world, n, 352), dtype=torch.uint8, device=dev)
+            bufs = [ob, RowBuffers(n, dev, steps=chunk, row_stride=args.row_stride)]
+            gather_done = [None] * len(bufs)
     # (the error check and the zeroing of the statistics come BEFORE the W warm-up steps: nothing but the barrier may stand between the
     #  warm-up and the timed region, or the timed launch starts on a GPU that has idled through a host round trip)
     env.check()
