@@ -655,32 +655,41 @@ __device__ __forceinline__ int bg_classify(uint64_t cards, int n) {
       suits |= 1u << (c & 3);
     }
   }
-  uint32_t present = 0;
-  int c0 = 0, c1 = 0;
-#pragma unroll
-  for (int r = 0; r < 13; r++) {
-    int c = (int)((hist >> (4 * r)) & 0xf);
-    present |= (c ? 1u : 0u) << r;
-    if (c > c0) { c1 = c0; c0 = c; } else if (c > c1) c1 = c;
-  }
+  // counts, sorted: counts[0] == 4 / counts[0] == 3 and counts[1] == 2 / ... (:77-91) from "how many ranks hold >= k cards", all 13 nibbles at once
+  // (round 5: it was a 13-step compare-select chain tracking the two largest counts).  A nibble holds 0..8 (eight cards of one rank at most).
+  const uint64_t M = 0x1111111111111ull;
+  const uint64_t b0 = hist & M, b1 = (hist >> 1) & M, b2 = (hist >> 2) & M, b3 = (hist >> 3) & M;
+  const uint64_t ge1 = b0 | b1 | b2 | b3, ge2 = b1 | b2 | b3, ge3 = b3 | b2 | (b1 & b0), ge4 = b3 | b2, ge5 = b3 | (b2 & (b1 | b0));
+  const int n2 = __popcll(ge2), n3 = __popcll(ge3), n4 = __popcll(ge4), n5 = __popcll(ge5);
   bool flush = (__popc(suits) == 1) && n >= 5;                                    // :60
-  uint32_t run = present & (present >> 1) & (present >> 2) & (present >> 3) & (present >> 4); // 5 consecutive ranks
-  bool straight = run != 0 || ((present & 0x100fu) == 0x100fu);                   // :66-73 (A,2,3,4,5)
+  // five consecutive ranks present, on the nibble-spaced presence bits themselves; A,2,3,4,5 = ranks 12, 0, 1, 2, 3 (:66-73)
+  const uint64_t run = ge1 & (ge1 >> 4) & (ge1 >> 8) & (ge1 >> 12) & (ge1 >> 16);
+  const uint64_t wheel = 0x1000000001111ull;
+  bool straight = run != 0ull || (ge1 & wheel) == wheel;
   // (>= 5 distinct ranks is implied by either pattern)
   if (straight && flush) return 8;
-  if (c0 == 4) return 7;
-  if (c0 == 3 && c1 == 2) return 6;
+  if (n4 >= 1 && n5 == 0) return 7;              // counts[0] == 4
+  if (n3 == 1 && n4 == 0 && n2 >= 2) return 6;   // counts[0] == 3 and counts[1] == 2
   if (flush) return 5;
   if (straight && n >= 5) return 4;
-  if (c0 == 3) return 3;
-  if (c0 == 2 && c1 == 2) return 2;
-  if (c0 == 2) return 1;
+  if (n3 >= 1 && n4 == 0) return 3;              // counts[0] == 3
+  if (n2 >= 2 && n3 == 0) return 2;              // counts[0] == 2 and counts[1] == 2
+  if (n2 >= 1 && n3 == 0) return 1;              // counts[0] == 2
   return 0;
 }
 
 // balatro_game.py:95-109 _draw_cards: append the lowest deck indexes not in hand until len == hand_size
 __device__ __forceinline__ void bg_draw_cards(Env& e) {
   if (e.nhand >= e.hand_size || e.nhand >= 8) return; // nothing to draw (the usual case at the end of a shop: played cards never left the hand)
+  if (e.nhand == 0) { // an EMPTY hand (every blind select, every reset: most "other" service steps): the lowest free indexes are 0, 1, 2, ... -- no loop
+    int k = e.hand_size < 8 ? e.hand_size : 8;
+    const int have = 52 - e.ndrop;
+    k = k < have ? k : have;
+    const uint64_t km = k >= 8 ? ~0ull : ((1ull << (8 * k)) - 1ull);
+    e.hand = (e.hand & ~km) | (0x0706050403020100ull & km);   // (bytes beyond the hand keep what they held, as the loop below leaves them)
+    e.nhand = k;
+    return;
+  }
   uint64_t inhand = 0;
 #pragma unroll 1
   for (int i = 0; i < e.nhand; i++) inhand |= 1ull << bg_get8(e.hand, i);

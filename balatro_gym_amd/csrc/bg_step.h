@@ -1473,13 +1473,27 @@ struct RowExtra { double reward; int32_t action; uint32_t terminated; bool cache
 // them and the env lane carry them): the hand as card codes (8 LDS byte reads) and progress_ratio (a float64 division).
 template <class DK>
 __device__ __forceinline__ uint64_t bg_obs_handb(const BgDev& d, int env, const Env& e, const DK& dk) {
-  uint64_t handb = 0;
+  // (round 5: eight selects and ONE branch for the rare deck index beyond the 16 cards held in registers -- it was a branch per hand position, in
+  //  every image build of every service step)
   const DeckHead dh = bg_deck_head(d, env, dk);
+  uint32_t lo = 0, hi = 0;
+  bool far = false;
 #pragma unroll
   for (int i = 0; i < 8; i++) {
-    int v = 0xff;
-    if (i < e.nhand) v = bg_card_h(d, env, dk, dh, bg_get8(e.hand, i));
-    handb |= (uint64_t)(v & 0xff) << (8 * i);
+    const uint32_t idx = (uint32_t)bg_get8(e.hand, i);
+    const bool on = i < e.nhand;
+    far = far || (on && idx >= 16u);
+    const uint32_t c = (uint32_t)(((idx & 8u) ? dh.hi : dh.lo) >> (8u * (idx & 7u))) & 0xffu;
+    const uint32_t v = on ? c : 0xffu;
+    if (i < 4) lo |= v << (8 * i); else hi |= v << (8 * (i - 4));
+  }
+  uint64_t handb = ((uint64_t)hi << 32) | lo;
+  if (far) { // Immolate / Cryptid workloads only
+#pragma unroll 1
+    for (int i = 0; i < e.nhand && i < 8; i++) {
+      const int idx = bg_get8(e.hand, i);
+      if (idx >= 16) handb = bg_set8(handb, i, bg_card(d, env, dk, idx));
+    }
   }
   return handb;
 }
