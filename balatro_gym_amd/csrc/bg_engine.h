@@ -78,7 +78,6 @@ struct EngineArgs {
   // ([world][N][352] bytes, rank `grank`'s shard), by the owner waves' copy-out, while the launch runs.  gworld = 0: no gather.
   uint8_t* gpeer[8];
   uint32_t gworld, grank;
-  uint8_t* dump;               // 1 KB nobody reads: where the lanes of a copy-out store that hold no record may write (-DBG_E3_DUMP: no branch per store)
 };
 
 __device__ __forceinline__ uint32_t bg_lds_ld(uint32_t* p) {

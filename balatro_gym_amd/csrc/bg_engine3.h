@@ -311,20 +311,13 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
             for (int u = 0; u < 4; u++)
 #pragma unroll
               for (int j = 0; j < 3; j++)
-#ifdef BG_E3_DUMP   // development: unconditional stores, lanes without a record aim at the dump line (no exec-mask save / branch per store)
-              {
-                const bool okl = g0 + 8u * (uint32_t)u + rsel[j] < nb;
-                uint8_t* const pd = okl ? a.obs.rows + ((size_t)ce[u][j].x * 384u + cgl[j]) : a.dump + 16u * (uint32_t)lane;
-                BG_E3_REC_STORE(v[u][j], (__attribute__((address_space(1))) bg_u32x4*)pd);
-              }
-#elif !defined(BG_E3_NOSTORE)   // development (sensitivity only)
+#ifndef BG_E3_NOSTORE   // development (sensitivity only).  (Round 5: unconditional stores with the empty lanes aimed at a dump line -- no exec-mask save and
+                        // branch per store -- cost 7-8 % at both launch lengths: profiles/r05/play_path_ab.txt)
                 if (g0 + 8u * (uint32_t)u + rsel[j] < nb)
 #else
                 if (g0 + 8u * (uint32_t)u + rsel[j] < nb && a.T == 0x7fffffff)
 #endif
-#ifdef BG_E3_DUMP
-                  ;
-#elif defined(BG_E3_STORE_L2)   // development (sensitivity only): every record into the first 64 rows -- the same instructions, no HBM write stream
+#ifdef BG_E3_STORE_L2   // development (sensitivity only): every record into the first 64 rows -- the same instructions, no HBM write stream
                   BG_E3_REC_STORE(v[u][j], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)(ce[u][j].x & 63u) * 384u + cgl[j])));
 #else
                   BG_E3_REC_STORE(v[u][j], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)ce[u][j].x * 384u + cgl[j])));
