@@ -552,6 +552,35 @@ def test_card_states_every_workgroup_shape_vs_oracle(cfg, n, monkeypatch):
     env.close()
 
 
+def test_configs1_all_4096_envs_vs_oracle():
+    """BASELINE configs[1] at its full size and EVERY env against the oracle: 4 096 envs, vanilla deck, no jokers, Ante-1 three blinds (the blind by env
+    index), two launches (48 + 20 steps) of packed 384-byte records -- the shape the library picks for a job this small (256 workgroups of 16 live envs)."""
+    from balatro_gym_amd.vec_env import RowBuffers
+    n, chunks = 4096, (48, 20)
+    seeds = [1000 + SEED_OFFSET + i for i in range(n)]
+    env = _vec(n, seeds, autoreset=True)
+    rbc = [RowBuffers(n, env.device, steps=T, row_stride=384) for T in chunks]
+    t0 = 0
+    for T, rb in zip(chunks, rbc):
+        env.rollout(T, policy=2, policy_seed=17, env_index0=0, t0=t0, obs_buffers=rb, zero_stats=(t0 == 0))
+        t0 += T
+    env.check()
+    got_stats = env.stats()
+    wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, sum(chunks), 2, 17, False, 0, None)
+    t0 = 0
+    for T, rb in zip(chunks, rbc):
+        sl = slice(t0, t0 + T)
+        assert np.array_equal(rb.action.cpu().numpy(), wa[sl])
+        assert np.array_equal(rb.terminated.cpu().numpy(), wt[sl])
+        assert np.array_equal(rb.reward.contiguous().cpu().numpy().view(np.uint64), wr[sl].view(np.uint64))
+        for k in OBS_KEYS:
+            assert np.array_equal(rb.tensors[k].contiguous().cpu().numpy(), wobs[k][sl]), f"steps {t0}..{t0 + T}: record key {k} differs"
+        t0 += T
+    for k in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
+        assert got_stats[k] == wstats[k], (k, got_stats[k], wstats[k])
+    env.close()
+
+
 @pytest.mark.parametrize("config", ["configs2_jokers_antes_1_4", "configs3_share_consumables_all_jokers_antes_1_8"])
 def test_full_size_slice_vs_oracle(config):
     """BASELINE.json's full size, compared with the ORACLE (not with itself): 65 536 envs on the benchmark's path -- 256 envs per workgroup,

@@ -7,6 +7,8 @@ tag="$1"; out="gpurun_out/$tag"; mkdir -p "$out"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
 (timeout 1500 python -m pytest tests -m gpu -q > "$out/gpu_tests.txt" 2>&1; echo rc=$? >> "$out/gpu_tests.txt"); tail -2 "$out/gpu_tests.txt"
+# longer randomised parity runs than the suite holds (every record byte against the oracle; tools/stress_parity.py)
+(for mode in "" "wide 5 6" "wide 11 6" long consumables; do echo "== mode [$mode] STRIDE=384"; STRIDE=384 timeout 900 python tools/stress_parity.py $mode 2>&1 | grep -v amdgpu.ids; done) > "$out/stress_parity.txt" 2>&1; grep -c "^ok" "$out/stress_parity.txt"; grep "STRESS OK" "$out/stress_parity.txt" | tr '\n' ' '; echo
 python bench.py > "$out/bench_default.json" 2> "$out/bench_default.err"
 python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver_shape.json" 2> "$out/bench_driver_shape.err"
 rocprofv3 --kernel-trace --stats -d "$out/prof_driver" -o runc -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver_prof.json" 2> "$out/bench_driver_prof.err"
