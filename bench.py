@@ -15,12 +15,15 @@ Workload = BASELINE.json configs[2] (the config the metric is quoted on, fits on
 jokers per env out of the 51 that complete_joker_effects implements (scorer-level joker chain live), Antes 1-4 cap,
 policy: blind 45/46/47 by env index, shop -> 31, otherwise uniform over valid actions.  Envs are independent, so
 multi-GPU is pure sharding with no data-path collective ("weak" scaling: 65 536 envs per GPU); the one exchange of the
-design -- an RCCL all_gather of the CURRENT observation record of every env ([N, 352] bytes per GPU, once per launch) --
-runs on a side stream beside the next launch and is inside the timed region when N > 1 (`gather` in the JSON line).
+design -- every rank sees the CURRENT observation record of every env ([N, 352] bytes per GPU, once per launch) -- is inside the
+timed region when N > 1 (`gather` in the JSON line): written by the engine's copy-out straight into every rank's buffer (peer-mapped
+stores over xGMI, `--gather peer`, the default), or an RCCL all_gather on a side stream (`--gather rccl`, and the fallback).
 
-`value` is the contract's K-step region.  `samples` repeats that same region (default 30 times, each its own launch sequence
-between two synchronisations, so the every-so-often lazy RNG refill falls inside some of them): median / p10 / p90; `sustained` times
-enough back-to-back repeats of the K-step region WITHOUT a synchronisation in between to span at least one refill period.
+`value` is the contract's K-step region; `roofline.frac` its algorithmic bytes over its WALL time (the kernel's own HIP-event figure beside it as
+`kernel_frac`).  `samples` repeats that same region (default 30 times, each its own launch sequence between two synchronisations of the launch
+stream): median / p10 / p90; `sustained` times enough back-to-back repeats of the K-step region WITHOUT a synchronisation in between to span at least
+one period of the RNG look-ahead refill -- the refill is queued beside a launch whenever the rings ask for one (every 18th launch at 20 steps), so a
+single 20-step region right behind the warm-up holds none of it and `sustained` holds all of it: the two agree within a few per cent.
 
 `python bench.py --gpus N` without torchrun (WORLD_SIZE unset) starts N child ranks itself -- before this process touches a GPU -- and
 exits non-zero with a message if fewer than N devices are visible.
