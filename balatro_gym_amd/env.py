@@ -116,11 +116,12 @@ class BalatroEnv(_EnvBase):
                                   autoreset=False, max_ante=max_ante, card_states=card_states,
                                   fused_steps=16)  # one step per call: shallow look-ahead rings (42 KB instead of 0.66 MB)
         self._action = torch.zeros(1, dtype=torch.int32, device=self._vec.device)
+        self._cached_obs: Optional[Dict[str, Any]] = None   # the observation of the last reset() / step(), as numpy (what `state` reads)
 
     # -- helpers
     def _np_obs(self) -> Dict[str, Any]:
         out = {}
-        flat = self._vec.obs_flat.cpu().numpy()
+        flat = self._vec.obs_flat.cpu().numpy()   # (one device-to-host copy of the 330 bytes; it synchronises the stream)
         for k in nat.OBS_KEYS:
             dt, shape = nat.OBS_SPEC[k]
             off, nb = self._vec._obs.layout[k]
@@ -131,7 +132,9 @@ class BalatroEnv(_EnvBase):
     @property
     def state(self):
         """Read-only view of the scalars wrappers poke at (`env.state.ante` etc., train_balatro_agent.py:150)."""
-        o = self._np_obs()
+        # (served from the observation the last reset() / step() / load_state() already brought to the host: the wrappers that poke at `env.state` do
+        #  so between steps, and every access used to cost a device copy and a synchronisation of its own)
+        o = self._cached_obs if self._cached_obs is not None else self._np_obs()
         return SimpleNamespace(ante=int(o["ante"]), round=int(o["round"]), money=int(o["money"]), phase=int(o["phase"]),
                                chips_needed=int(o["chips_needed"]), chips_scored=int(o["chips_scored"]),
                                round_chips_scored=int(o["round_chips_scored"]), hands_left=int(o["hands_left"]),
@@ -145,7 +148,8 @@ class BalatroEnv(_EnvBase):
             self._vec.reset(seed=[seed])
         else:
             self._vec.reset()
-        return self._np_obs(), {}
+        self._cached_obs = self._np_obs()
+        return self._cached_obs, {}
 
     def step(self, action: int):
         self._action[0] = int(action)
@@ -197,13 +201,15 @@ class BalatroEnv(_EnvBase):
             out["curriculum_limit_reached"] = True
         if int(inf["aux"]) and not (flags & (8 | 32 | 64 | 128)) and not err and ht < 0:
             out["boss_blind"] = BOSS_BLIND_NAMES[int(inf["aux"])]
-        return self._np_obs(), r, terminated, False, out
+        self._cached_obs = self._np_obs()
+        return self._cached_obs, r, terminated, False, out
 
     def save_state(self):
         return {"blob": self._vec.get_state(0)}
 
     def load_state(self, saved):
         self._vec.set_state(0, saved["blob"])
+        self._cached_obs = None
 
     def render(self):
         if self.render_mode != "human":
@@ -219,14 +225,17 @@ class BalatroEnv(_EnvBase):
     # harness helper used by the parity tests
     def inject(self, **kw):
         self._vec.inject(**kw)
+        self._cached_obs = None
 
     def inject_consumables(self, ids, apply_now: bool = True):
         """env.state.consumables = [names of ids] (ids as in balatro_env_2.py:1545-1567)."""
         self._vec.inject_consumables([list(ids)], apply_now=apply_now)
+        self._cached_obs = None
 
     def inject_cards(self, cards, apply_now: bool = True):
         """cards = iterable of (deck_index, enhancement, edition, seal): env.card_states[idx] = CardState(...) (card_states=True)."""
         self._vec.inject_cards([list(cards)], apply_now=apply_now)
+        self._cached_obs = None
 
 
 def make_balatro_env(**kwargs):
