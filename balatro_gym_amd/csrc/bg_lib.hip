@@ -317,6 +317,7 @@ __device__ __forceinline__ uint32_t bg_q156(uint32_t q) { return q >= 156u ? q -
 #ifndef BG_LAZY_U_SEEDRING
 #define BG_LAZY_U_SEEDRING 2 // the seed ring draws ~34 words per env and refill: shorter iterations, 70 registers -> three waves beside the engine
 #endif
+#define BG_WL_COUNTERS 32 // refill work-list counters: [0..3] list lengths, [4] the deck kernel's cursor, [8 + p] the cursor of its part p (p < 16)
 #ifndef BG_REFILL_WAVE_PRIO
 #define BG_REFILL_WAVE_PRIO 0 // s_setprio of the deck / seed-ring / block waves (the shop seeding stays at 0, the step engine runs at 3)
 #endif
@@ -468,7 +469,12 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_seed_kernel(BgDev d, const int64_
 //   * shops : `shop_seed = rng.get_int('shop_generation', 0, 2**31 - 1)` (:1389), `random.Random(shop_seed)` (shop.py:96)
 //   * gblk  : next 624-word block(s) of the per-env global stream
 // ---------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(BG_BLOCK) void bg_refill_zero_kernel(BgDev d) { if (threadIdx.x < 8) d.wl_count[threadIdx.x] = 0; } // [4]: the deck kernel's list cursor
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_zero_kernel(BgDev d) { if (threadIdx.x < BG_WL_COUNTERS) d.wl_count[threadIdx.x] = 0; } // [4]: the deck kernel's list cursor, [8 + p]: the cursor of its part p
+
+// A refill in PIECES (short launches, bg_refill_pieces): a dense kernel is launched once per part and works on part p of q equal parts of its work list
+struct BgPart { uint32_t p, q; };
+__device__ __forceinline__ uint32_t bg_part_lo(uint32_t count, BgPart pt) { return (uint32_t)(((uint64_t)count * pt.p) / pt.q); }
+__device__ __forceinline__ uint32_t bg_part_hi(uint32_t count, BgPart pt) { return (uint32_t)(((uint64_t)count * (pt.p + 1u)) / pt.q); }
 
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
   int env = blockIdx.x * BG_BLOCK + threadIdx.x;
@@ -521,12 +527,14 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_scan_kernel(BgDev d) {
 // draws x ~45 instructions).  The deck under construction is the kernel's only LDS (52 bytes per lane: random.shuffle indexes
 // it with a per-lane j): 3.3 KB per wave, 128 registers: two waves fit beside a step-engine workgroup (it leaves 256 registers of one SIMD
 // and 10 KB of LDS per CU).
-__global__ __launch_bounds__(BG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void bg_refill_deck_kernel(BgDev d) {
+__global__ __launch_bounds__(BG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))) void bg_refill_deck_kernel(BgDev d, BgPart pt, uint32_t cursor_idx, uint32_t max_made) {
   __builtin_amdgcn_s_setprio(BG_REFILL_WAVE_PRIO);
   __shared__ uint8_t sdeck[52][BG_BLOCK];
   const size_t N = d.N;
   const int tid = threadIdx.x;
-  const uint32_t count = d.wl_count[0];
+  const uint32_t count0 = d.wl_count[0], lo = bg_part_lo(count0, pt), count = bg_part_hi(count0, pt);   // this launch's part of the list: [lo, count)
+  uint32_t* const cursor = &d.wl_count[cursor_idx];   // [4], or [8 + k] for piece k of a refill in pieces
+  const int cap = max_made ? (int)max_made : 1 << 30;   // decks per env and launch (a piece: an env's shuffles are serial -- ~17 per 372 steps -- so a piece is cut in DEPTH too)
   int env = 0, d_head = 0, d_ready = 0, made = 0;
   uint32_t prod = 0, cur = 0;
   uint32_t* mt = bg_deckmt(d, 0);
@@ -538,8 +546,8 @@ __global__ __launch_bounds__(BG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
       if (freem != 0ull) {
         const int leader = __ffsll(freem) - 1, nfree = __popcll(freem);
         uint32_t base = 0;
-        if (tid == leader) base = atomicAdd(&d.wl_count[4], (uint32_t)nfree);
-        base = (uint32_t)__shfl((int)base, leader);
+        if (tid == leader) base = atomicAdd(cursor, (uint32_t)nfree);
+        base = lo + (uint32_t)__shfl((int)base, leader);
         dry = base + (uint32_t)nfree >= count;
         const uint32_t my = base + (uint32_t)__popcll(freem & ((1ull << tid) - 1ull));
         if (!have && my < count) {
@@ -579,8 +587,8 @@ __global__ __launch_bounds__(BG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
         d.ndeck[((size_t)slot * BG_NDECK + k) * N + env] = make_uint4(wv[0], wv[1], wv[2], wv[3]);
       }
       d_ready++; made++;
-      need = d_ready < d.KD;
-      if (!need) { // this env's ring is full: cursor and producer byte back, the lane is free for the next env
+      need = d_ready < d.KD && made < cap;
+      if (!need) { // this env's ring is full (or has its share of this piece): cursor and producer byte back, the lane is free for the next env
         mt[BG_MT_N] = cur | BG_LAZY_SEEDED;
         ((uint8_t*)&d.prod_out[env])[0] = (uint8_t)((prod + (uint32_t)made) & 0xffu); // byte store: the block kernel may run concurrently
         have = false;
@@ -591,11 +599,11 @@ __global__ __launch_bounds__(BG_BLOCK) __attribute__((amdgpu_waves_per_eu(4, 4))
 
 // top up the per-env ring of pre-drawn shop seeds: `rng.get_int('shop_generation', 0, 2**31 - 1)` (:1389) in stream order
 // (_randbelow(2**31): k = 32 bits, accept r < 2**31)
-__global__ __launch_bounds__(BG_BLOCK) void bg_refill_seedring_kernel(BgDev d) {
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_seedring_kernel(BgDev d, BgPart pt) {
   __builtin_amdgcn_s_setprio(BG_REFILL_WAVE_PRIO);
   size_t N = d.N;
-  const uint32_t count = d.wl_count[1];
-  for (uint32_t base = blockIdx.x * BG_BLOCK; base < count; base += gridDim.x * BG_BLOCK) {
+  const uint32_t count0 = d.wl_count[1], lo = bg_part_lo(count0, pt), count = bg_part_hi(count0, pt);
+  for (uint32_t base = lo + blockIdx.x * BG_BLOCK; base < count; base += gridDim.x * BG_BLOCK) {
     const bool valid = base + threadIdx.x < count;
     const int env = valid ? (int)d.wl[N + base + threadIdx.x] : 0;
     uint32_t* mt = bg_shopgenmt(d, env);
@@ -621,15 +629,15 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_seedring_kernel(BgDev d) {
 
 // `random.Random(shop_seed)` (shop.py:96): one stream per lane, pure ALU + 156 stores.  The slot holds the SEEDED state;
 // the consumer regenerates the few words a shop visit reads (bg_sprefetch), so no block twist is ever run for a shop.
-__global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop_kernel(BgDev d) {
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop_kernel(BgDev d, BgPart pt) {
 #ifdef BG_SHOP_VGPR128
   asm volatile("v_mov_b32 v127, 0" ::: "v127"); // development: at most 2 of these waves on the SIMD the step engine leaves free
 #endif
 #ifdef BG_SHOP_VGPR200
   asm volatile("v_mov_b32 v199, 0" ::: "v199");
 #endif
-  uint32_t count = d.wl_count[3];
-  for (uint32_t item = blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
+  const uint32_t count0 = d.wl_count[3], lo = bg_part_lo(count0, pt), count = bg_part_hi(count0, pt);
+  for (uint32_t item = lo + blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
     uint32_t es = d.wl_shop[2 * (size_t)item], seed = d.wl_shop[2 * (size_t)item + 1];
     bg_mt_seed_slot(bg_sblock(d, (int)(es & 0xffffffu), (int)(es >> 24)), seed);
   }
@@ -655,13 +663,13 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop2_kernel(BgDev d) {
 // registers), so the block is read and written as ten 256-byte rows (a lane per env read 16 bytes of 64 different blocks per
 // instruction), word k+1 and word k+397 / k-227 come from other lanes (`__shfl`), and a block that is twisted again stays in
 // registers.  Row r only needs NEW rows r-4 / r-3, so the rows go in order; word 623 pairs with the new word 0.
-__global__ __launch_bounds__(BG_BLOCK) void bg_refill_gblk_kernel(BgDev d) {
+__global__ __launch_bounds__(BG_BLOCK) void bg_refill_gblk_kernel(BgDev d, BgPart pt) {
   __builtin_amdgcn_s_setprio(BG_REFILL_WAVE_PRIO);
   const size_t N = d.N;
-  const uint32_t count = d.wl_count[2];
+  const uint32_t count0 = d.wl_count[2], lo = bg_part_lo(count0, pt), count = bg_part_hi(count0, pt);
   const int l = threadIdx.x;
   constexpr int NR = (BG_MT_N + 63) / 64; // 10 rows, the last one 48 words
-  for (uint32_t item = blockIdx.x; item < count; item += gridDim.x) {
+  for (uint32_t item = lo + blockIdx.x; item < count; item += gridDim.x) {
     const int env = (int)d.wl[2 * N + item];
     const uint32_t w6 = ((const uint32_t*)&d.hot[(size_t)6 * N + env])[3];
     const uint32_t prod = d.prod_out[env];
@@ -792,6 +800,15 @@ struct bg_handle {
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
   // tunables read ONCE per handle in bg_create (environment variables)
   int refill_blocks, refill_blocks_shop, dev_skip_refill, refill_order, refill_min, shop_ilp;
+  // a refill in PIECES (bg_refill_pieces): the kernels of refill #(refill_seq - 1) that are still to be issued, one (or a few) beside every short launch
+  struct RefillPiece { int kind; uint32_t part, nparts; int grid; uint32_t cursor, max_made; };   // kind: 0 deck, 1 seed ring, 2 global blocks, 3 shop streams
+  std::vector<RefillPiece> pieces;
+  size_t piece_next;
+  double piece_credit;
+  BgDev piece_dev;
+  int refill_sliced, piece_parts[4], piece_grid[4];
+  double refill_spread;
+  int deck_passes, deck_rounds, refill_interleave;
   uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_smask; int eng_waves, eng_copiers; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
   int engine;            // BG_ENGINE: 3 = bg_engine3.h (owner + service waves in one workgroup) for packed-record rollouts (default), 1 = bg_engine.h everywhere
   // bg_engine3.h: workgroup shape (BG_E3_CFG = 100 * owner waves + 10 * slices + service waves; 0 = by env count) and the service waves' batch
@@ -960,6 +977,21 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     // 20 steps' worth of refill is ~320 us of five small latency-bound kernels against 129 us per 20 steps in bulk (profiles/r05/refill_policy_ab.txt:
     // a refill beside every 20-step launch costs 21 % of the sustained rate)
     h->refill_min = geti("BG_REFILL_MIN", 0);
+    // BG_REFILL_SLICED = 1: the refill a run of SHORT launches demands (every 18th launch at 20 steps) is issued in pieces -- its scan beside the launch that
+    // demanded it, then one dense kernel over a PART of a work list beside each of the next launches (BG_REFILL_PARTS = deck,seedring,blocks,shop parts;
+    // BG_REFILL_GRIDS = their grids: no more one-wave workgroups than fit beside a resident engine, so that none is left to be placed in the gap between
+    // two launches, where it would take the registers the next engine workgroup needs)
+    h->refill_sliced = geti("BG_REFILL_SLICED", 1);
+    { const int dp[4] = {2, 1, 2, 8}, dg[4] = {512, 768, 1024, 1024};
+      for (int k = 0; k < 4; k++) { h->piece_parts[k] = dp[k]; h->piece_grid[k] = dg[k]; }
+      auto get4 = [](const char* k, int* out, int lo, int hi) { const char* v = getenv(k); if (!v) return; int a[4]; if (sscanf(v, "%d,%d,%d,%d", &a[0], &a[1], &a[2], &a[3]) == 4) for (int i = 0; i < 4; i++) out[i] = a[i] < lo ? lo : a[i] > hi ? hi : a[i]; };
+      get4("BG_REFILL_PARTS", h->piece_parts, 1, 16); get4("BG_REFILL_GRIDS", h->piece_grid, 64, 65536); }
+    h->piece_next = 0; h->piece_credit = 0.0;
+    h->refill_interleave = geti("BG_REFILL_INTERLEAVE", 1);
+    h->deck_passes = geti("BG_REFILL_DECK_PASSES", 3); h->deck_rounds = geti("BG_REFILL_DECK_ROUNDS", 6);
+    if (h->deck_passes < 1) h->deck_passes = 1; if (h->deck_rounds < 1) h->deck_rounds = 1;
+    while (h->deck_passes * h->piece_parts[0] > BG_WL_COUNTERS - 8) { if (h->deck_passes > 1) h->deck_passes--; else h->piece_parts[0]--; }
+    { const char* v = getenv("BG_REFILL_SPREAD"); h->refill_spread = v ? atof(v) : 0.95; if (!(h->refill_spread >= 0.05 && h->refill_spread <= 1.0)) h->refill_spread = 0.95; }
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
     h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0); h->eng_copiers = geti("BG_ENG_COPIERS", 0); if (h->eng_copiers < 0 || h->eng_copiers > 3) h->eng_copiers = 0;   // 0 = by launch length (bg_engine_launch)
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
@@ -1019,7 +1051,7 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
   }
   if (e == hipSuccess) e = bg_alloc(h, &d.deckmt, (size_t)BG_MTS * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.shopgenmt, (size_t)BG_MTS * N);
-  if (e == hipSuccess) e = bg_alloc(h, &d.wl_count, 8);
+  if (e == hipSuccess) e = bg_alloc(h, &d.wl_count, BG_WL_COUNTERS);
   if (e == hipSuccess) e = bg_alloc(h, &d.wl, 3 * N);
   if (e == hipSuccess) e = bg_alloc(h, &d.wl_shop, 2 * N * (size_t)(d.KS - 1));
   if (e == hipSuccess) e = bg_alloc(h, &d.sseed, (size_t)BG_SSEED * N);
@@ -1125,15 +1157,39 @@ static BgDev bg_dev_view(bg_handle* h, const uint32_t* view) {
 }
 
 // make `s` wait until refill #(seq-1-back) is complete (events are recorded per parity)
+static int bg_refill_pieces(bg_handle* h, int n);
 static int bg_wait_refill(bg_handle* h, hipStream_t s, int back) {
   long i = h->refill_seq - 1 - back;
   if (i < 0) return 0;
+  if (back == 0 && h->piece_next < h->pieces.size()) { int rc = bg_refill_pieces(h, 1 << 30); if (rc) return rc; }   // the latest refill is not even issued in full yet
   BG_HIP(hipStreamWaitEvent(s, h->ev_refill[i & 1], 0));
   return 0;
 }
 
+// Issue up to n of the pending pieces of the latest refill on the side stream (each bracketed by its own profiling events); behind the last one the
+// refill's completion event.  The pieces only depend on the scan in front of them on that stream and on consumer counters, which may be newer than the
+// scan's (more free slots, never fewer); the engine launches of the meantime read the view of the refill BEFORE this one.
+static int bg_refill_pieces(bg_handle* h, int n) {
+  const BgDev& d = h->piece_dev;
+  hipStream_t s = h->side;
+  while (n-- > 0 && h->piece_next < h->pieces.size()) {
+    const bg_handle::RefillPiece& pc = h->pieces[h->piece_next++];
+    const BgPart pt{pc.part, pc.nparts};
+    bg_ev_begin(h, h->ev_refill_t, s);
+    if (pc.kind == 0) hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(pc.grid), dim3(BG_BLOCK), 0, s, d, pt, pc.cursor, pc.max_made);
+    else if (pc.kind == 1) hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(pc.grid), dim3(BG_BLOCK), 0, s, d, pt);
+    else if (pc.kind == 2) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(pc.grid), dim3(BG_BLOCK), 0, s, d, pt);
+    else hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(pc.grid), dim3(BG_BLOCK), 0, s, d, pt);
+    bg_ev_end(h, h->ev_refill_t, s);
+    BG_HIP(hipGetLastError());
+    if (h->piece_next == h->pieces.size()) BG_HIP(hipEventRecord(h->ev_refill[(h->refill_seq - 1) & 1], s));   // refill #(refill_seq - 1) is complete behind this
+  }
+  return 0;
+}
+
 // steps_hint: env steps launched since the previous refill plus those of the chunk this one runs beside (< 0: unknown, size the grids for a full-depth refill)
-static int bg_refill_on(bg_handle* h, hipStream_t s, int steps_hint = -1) {
+// sliced: only zero + scan now, the dense kernels as pieces beside the next launches (bg_refill_pieces; anything that waits for this refill issues the rest)
+static int bg_refill_on(bg_handle* h, hipStream_t s, int steps_hint = -1, bool sliced = false) {
   BgDev d = h->dev;
   d.prod_in = bg_prod_latest(h);
   d.prod_out = h->d_prod[h->refill_seq & 1];
@@ -1143,6 +1199,41 @@ static int bg_refill_on(bg_handle* h, hipStream_t s, int steps_hint = -1) {
   // beside a resident step-engine workgroup (only one SIMD per CU has free registers) -- the whole refill would wait for the engine
   hipLaunchKernelGGL(bg_refill_zero_kernel, dim3(1), dim3(BG_BLOCK), 0, s, d);
   hipLaunchKernelGGL(bg_refill_scan_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, d);
+  if (sliced && s == h->side && h->shop_ilp != 2 && h->dev_skip_refill == 0) {
+    bg_ev_end(h, h->ev_refill_t, s);
+    BG_HIP(hipGetLastError());
+    h->pieces.clear(); h->piece_next = 0; h->piece_credit = 0.5; h->piece_dev = d;
+    // the order of the serial refill: decks, seed rings, blocks, shop streams (the shop items of THIS refill were listed by the scan from seeds drawn earlier)
+    // decks: an env's shuffles are one serial chain (~17 per 372 steps, up to the ring), so the deck work is cut in DEPTH as well -- `deck_passes` passes
+    // over the list, all but the last one giving every env at most `deck_rounds` decks
+    std::vector<bg_handle::RefillPiece> q[4];
+    for (int pass = 0; pass < h->deck_passes; pass++)
+      for (int p = 0; p < h->piece_parts[0]; p++)
+        q[0].push_back({0, (uint32_t)p, (uint32_t)h->piece_parts[0], h->piece_grid[0], (uint32_t)(8 + pass * h->piece_parts[0] + p), pass + 1 < h->deck_passes ? (uint32_t)h->deck_rounds : 0u});
+    for (int kind = 1; kind < 4; kind++)
+      for (int p = 0; p < h->piece_parts[kind]; p++) q[kind].push_back({kind, (uint32_t)p, (uint32_t)h->piece_parts[kind], h->piece_grid[kind], 0u, 0u});
+    // The four kinds are independent once the lists exist (the shop items were listed from seeds drawn by EARLIER refills): they are interleaved -- always
+    // the kind with the largest share of its pieces still to go, the shop streams first -- so that the memory-bound pieces (an env's MT state is 2.5 KB
+    // of its own: the deck and seed-ring kernels read 64 different lines per instruction, and a launch beside one takes ~40 us longer) do not sit beside
+    // consecutive launches, with the ALU-bound shop pieces (~7 us) between them.  BG_REFILL_INTERLEAVE=0: kind after kind, decks first.
+    static const int order[4] = {3, 0, 2, 1};
+    size_t taken[4] = {0, 0, 0, 0};
+    for (;;) {
+      int best = -1; double share = 0.0;
+      for (int o = 0; o < 4; o++) {
+        const int k = h->refill_interleave ? order[o] : o;
+        if (taken[k] >= q[k].size()) continue;
+        const double sh = h->refill_interleave ? (double)(q[k].size() - taken[k]) / (double)q[k].size() : 1.0;
+        if (best < 0 || sh > share + 1e-9) { best = k; share = sh; }
+      }
+      if (best < 0) break;
+      h->pieces.push_back(q[best][taken[best]++]);
+    }
+    h->refill_seq++;
+    h->steps_since_refill = 0;
+    return 0;
+  }
+  const BgPart whole{0u, 1u};
   // Grids of ONE-WAVE workgroups, grid-stride over the compacted work lists: they are placed beside the resident step-engine
   // workgroups (bg_engine.h: one SIMD per CU and ~5 KB of LDS are left to them) or, with nothing else running, several per SIMD.
   // (a refill behind a short launch finds short work lists: a grid sized for 372 steps' worth would be thousands of one-wave workgroups that are
@@ -1162,17 +1253,17 @@ static int bg_refill_on(bg_handle* h, hipStream_t s, int steps_hint = -1) {
   // one after the other on `s` (a kernel's duration is then its own work, not its wait for a neighbour's registers)
   const bool shop_last = h->refill_order >= 1, serial = h->refill_order == 2;
   hipStream_t s_deck = serial ? s : h->side2, s_blk = serial ? s : h->side3;
-  if (!shop_last && !(skip & 1)) { if (h->shop_ilp == 2) hipLaunchKernelGGL(bg_refill_shop2_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); else hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); } // lowest-priority stream
-  if (!(skip & 2)) hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_deck, d);
-  if (!(skip & 4)) hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_blk, d);
-  if (!(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_blk, d);
+  if (!shop_last && !(skip & 1)) { if (h->shop_ilp == 2) hipLaunchKernelGGL(bg_refill_shop2_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); else hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d, whole); } // lowest-priority stream
+  if (!(skip & 2)) hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_deck, d, whole, 4u, 0u);
+  if (!(skip & 4)) hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_blk, d, whole);
+  if (!(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_blk, d, whole);
   if (!serial) {
     BG_HIP(hipEventRecord(h->ev_deck, h->side2));
     BG_HIP(hipEventRecord(h->ev_gblk, h->side3));
     BG_HIP(hipStreamWaitEvent(s, h->ev_deck, 0));
     BG_HIP(hipStreamWaitEvent(s, h->ev_gblk, 0));
   }
-  if (shop_last && !(skip & 1)) { if (h->shop_ilp == 2) hipLaunchKernelGGL(bg_refill_shop2_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); else hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); }
+  if (shop_last && !(skip & 1)) { if (h->shop_ilp == 2) hipLaunchKernelGGL(bg_refill_shop2_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); else hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d, whole); }
   bg_ev_end(h, h->ev_refill_t, s);
   BG_HIP(hipGetLastError());
   BG_HIP(hipEventRecord(h->ev_refill[h->refill_seq & 1], s));
@@ -1487,6 +1578,10 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
     // Overlapped and the chunk reads the view of the refill BEFORE this one (the usual case): the engine is launched FIRST, the refill's six small
     // kernels are queued on the side stream behind it -- their host-side issue time (~30 us) is then not in front of a 220 us launch.
     const bool refill_after = need && async && s0 >= 1 && s0 - 1 >= h->view_min;
+    // Pieces of an earlier refill still to be issued (BG_REFILL_SLICED): this launch takes its share beside it, queued BEHIND the launch and ordered after
+    // the launches before it -- a piece then starts while this launch's workgroups are resident and fills what they leave free
+    const bool pieces_after = !need && async && h->piece_next < h->pieces.size();
+    if (pieces_after) BG_HIP(hipEventRecord(h->ev_rollout, (hipStream_t)stream));
     if (need && async) {
       BG_HIP(hipEventRecord(h->ev_rollout, (hipStream_t)stream));   // everything the stream has done so far (the previous launches)
       if (!refill_after) { // R beside this chunk, queued before it (the chunk reads R's own view: right behind a synchronous refill)
@@ -1542,8 +1637,21 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));
       rc = bg_wait_refill(h, h->side, 0);
       if (rc) return rc;
-      rc = bg_refill_on(h, h->side, h->steps_since_refill + chunk); // (sets steps_since_refill = 0: the chunk beside it counts below)
+      // a SHORT launch (the refill's ~1.1 ms of kernels would run beside the next three to five launches, and whatever of them is still to be placed when a
+      // launch ends takes the whole machine in the gap before the next one): only the scan now, the dense kernels in pieces beside the launches to come
+      const bool sliced = h->refill_sliced != 0 && 4 * chunk <= max_chunk;
+      rc = bg_refill_on(h, h->side, h->steps_since_refill + chunk, sliced); // (sets steps_since_refill = 0: the chunk beside it counts below)
       if (rc) return rc;
+    } else if (pieces_after) {
+      // all pieces within `refill_spread` (0.95) of the steps that remain until the next refill is due: at 20 steps per launch one piece per launch
+      h->piece_credit += (double)h->pieces.size() * (double)chunk / (h->refill_spread * (double)max_chunk);
+      const int np = (int)h->piece_credit;
+      h->piece_credit -= (double)np;
+      if (np > 0) {
+        BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));
+        rc = bg_refill_pieces(h, np);
+        if (rc) return rc;
+      }
     }
     h->steps_since_refill += chunk;
     done += chunk;

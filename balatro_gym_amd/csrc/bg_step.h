@@ -1313,18 +1313,32 @@ __device__ __forceinline__ void bg_use_consumable(const BgDev& d, int env, Env& 
       case 58: // Ectoplasm :511-517
         if (e.njokers > 0) { hs = -1; success = true; }
         break;
-      case 59: { // Immolate :519-531: random.sample(deck, 5) by index (selection set: n > 21), then deck.remove(card) for
-                 // each: every later deck index -- hand indexes, card_states keys -- now names another card
+      case 59: { // Immolate :519-531: random.sample(deck, 5) by index (Lib/random.py sample(): a selection set for n > 21, a pool of the n indexes
+                 // below), then deck.remove(card) for each: every later deck index -- hand indexes, card_states keys -- now names another card
         const int nn = 52 - e.ndrop, n = nn + e.nfo;
-        if (nn < 24) { unsupported = true; break; } // the hand's indexes (always 0..7) must stay valid
+        if (nn < 13) { unsupported = true; break; } // the hand's indexes (always 0..7) must stay valid: at least 8 real cards behind this use
         uint64_t gone = 0; int nfgone = 0;
-        uint32_t p0 = 0xffu, p1 = 0xffu, p2 = 0xffu, p3 = 0xffu;
+        if (n > 21) {
+          uint32_t p0 = 0xffu, p1 = 0xffu, p2 = 0xffu, p3 = 0xffu;
 #pragma unroll 1
-        for (int i = 0; i < 5; i++) {
-          uint32_t j; int guard = 0;
-          do { j = bg_randbelow<false>(d, env, e, w, (uint32_t)n); } while ((j == p0 || j == p1 || j == p2 || j == p3) && ++guard < 4096);
-          p3 = p2; p2 = p1; p1 = p0; p0 = j;
-          if ((int)j < nn) gone |= 1ull << j; else nfgone++;
+          for (int i = 0; i < 5; i++) {
+            uint32_t j; int guard = 0;
+            do { j = bg_randbelow<false>(d, env, e, w, (uint32_t)n); } while ((j == p0 || j == p1 || j == p2 || j == p3) && ++guard < 4096);
+            p3 = p2; p2 = p1; p1 = p0; p0 = j;
+            if ((int)j < nn) gone |= 1ull << j; else nfgone++;
+          }
+        } else { // pool = list(range(n)); result[i] = pool[j]; pool[j] = pool[n - i - 1] -- up to 21 five-bit entries in two registers (the RNG window may hold drawn words)
+          uint64_t plo = 0, phi = 0;
+#pragma unroll 1
+          for (int i = 0; i < n; i++) { if (i < 12) plo |= (uint64_t)i << (5 * i); else phi |= (uint64_t)i << (5 * (i - 12)); }
+#pragma unroll 1
+          for (int i = 0; i < 5; i++) {
+            const int j = (int)bg_randbelow<false>(d, env, e, w, (uint32_t)(n - i)), last = n - i - 1;
+            const uint32_t pick = (uint32_t)((j < 12 ? plo >> (5 * j) : phi >> (5 * (j - 12))) & 31ull);
+            const uint64_t lv = (last < 12 ? plo >> (5 * last) : phi >> (5 * (last - 12))) & 31ull;
+            if (j < 12) plo = (plo & ~(31ull << (5 * j))) | (lv << (5 * j)); else phi = (phi & ~(31ull << (5 * (j - 12)))) | (lv << (5 * (j - 12)));
+            if ((int)pick < nn) gone |= 1ull << pick; else nfgone++;
+          }
         }
         // compact the deck through this lane's RNG window (nothing is cached in it here), then HBM copy + kernel-local copy
         DK& mdk = const_cast<DK&>(dk);
@@ -1361,7 +1375,7 @@ __device__ __forceinline__ void bg_use_consumable(const BgDev& d, int env, Env& 
         if (e.njokers > 0) { (void)bg_randbelow<false>(d, env, e, w, (uint32_t)e.njokers); success = true; }
         break;
       case 65: // Cryptid :581-591: two consumables.Card copies appended to the live deck (counted, never drawn)
-        if (nt >= 1) { if (e.nfo > 60) { unsupported = true; break; } e.nfo += 2; ncreated = 2; success = true; }
+        if (nt >= 1) { if (52 - e.ndrop + e.nfo + 2 > 127) { unsupported = true; break; } e.nfo += 2; ncreated = 2; success = true; } // deck_size = np.int8(len(deck)) (:1491) stops at 127
         break;
       case 66: // The Soul :593-601
         if (e.njokers < 5) { jc = 146 + (int)bg_randbelow<false>(d, env, e, w, 5u); njc = 1; success = true; }

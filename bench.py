@@ -22,8 +22,10 @@ stores over xGMI, `--gather peer`, the default), or an RCCL all_gather on a side
 `value` is the contract's K-step region; `roofline.frac` its algorithmic bytes over its WALL time (the kernel's own HIP-event figure beside it as
 `kernel_frac`).  `samples` repeats that same region (default 30 times, each its own launch sequence between two synchronisations of the launch
 stream): median / p10 / p90; `sustained` times enough back-to-back repeats of the K-step region WITHOUT a synchronisation in between to span at least
-one period of the RNG look-ahead refill -- the refill is queued beside a launch whenever the rings ask for one (every 18th launch at 20 steps), so a
-single 20-step region right behind the warm-up holds none of it and `sustained` holds all of it: the two agree within a few per cent.
+one period of the RNG look-ahead refill.  The rings ask for a refill every 18th launch at 20 steps; beside short launches it is issued IN PIECES (its
+scan beside the launch that asked, then one dense kernel over a part of a work list beside each of the next ~17 launches: bg_lib.hip, bg_refill_pieces),
+so the single 20-step region of the contract carries its piece like every other launch, `sustained` carries a whole period, and `samples` shows the
+spread between the launches beside a cheap piece (shop-stream seeding: ALU) and a dear one (deck shuffles: every lane in its own 2.5 KB MT state).
 
 `python bench.py --gpus N` without torchrun (WORLD_SIZE unset) starts N child ranks itself -- before this process touches a GPU -- and
 exits non-zero with a message if fewer than N devices are visible.
@@ -320,8 +322,8 @@ def main():
         left -= k
     # (round 4 ran four untimed launches of the timed shape here "so that the lazy refill falls outside" the timed one.  They are gone: the W warm-up
     #  steps of the contract are the only launches in front of the timed region.  The refill -- the MT19937 seeding and the deck shuffles, row a1/a2 work --
-    #  is queued beside a launch whenever the rings ask for one (every 18th launch at 20 steps; a refill beside EVERY short launch was measured: -21 %,
-    #  profiles/r05/refill_policy_ab.txt); `sustained` below carries all of it, and since the engine is issued before the refill's kernels it equals `value`.)
+    #  is due every 18th launch at 20 steps and issued in PIECES beside the launches that follow (profiles/r05/refill_pieces.txt; a full-depth-sliced
+    #  refill beside every short launch was measured too: -21 %, profiles/r05/refill_policy_ab.txt): the timed launch carries a piece, `sustained` a period.)
     if peer_buf is not None and launch_no > 0:
         # the peer-written gather buffers after the warm-up's launches, checked before anything is timed: this rank's slot must be the last row of its last
         # launch, every other slot must have been written by its rank.  If not (a mapping that does not carry stores on this box), every rank falls back to RCCL.
@@ -452,7 +454,8 @@ def main():
                          "kernel": kernel, "algorithmic_bytes_per_env_step": a_step,
                          "mean_launch_us": mean_launch_s * 1e6, "launches": launches,
                          "refill_mean_launch_us": prof["refill_ms"] / max(1, prof["refill_launches"]) * 1e3,
-                         "refill": "the RNG look-ahead refill (deck shuffles, shop-stream seeding, global-stream blocks: 2.4 ms of kernels per 372 env steps) is queued on a side stream BESIDE a launch whenever the steps launched since the last one would exhaust half a ring -- every launch at 372 fused steps, every 18th at 20 -- and runs beside the following launches (one SIMD per CU is left to it); a 20-step timed region right behind the warm-up holds none of it, `sustained` holds all of it: compare the two"},
+                         "refill_launches_are": "kernel groups of the look-ahead refill issued inside the region: a whole refill beside a 372-step launch, ONE PIECE (the scan, or a dense kernel over a part of a work list) beside a short one",
+                         "refill": "the RNG look-ahead refill (deck shuffles, shop-stream seeding, global-stream blocks: 2.4 ms of kernels per 372 env steps) is due whenever the steps launched since the last one would exhaust half a ring -- every launch at 372 fused steps, every 18th at 20 -- and runs on a side stream BESIDE the launches (one SIMD per CU is left to it).  Beside short launches it is issued in pieces, one per launch (BG_REFILL_SLICED), each small enough to be resident beside the engine at once: none is left to be placed in the gap before the next launch, where it would take the registers that launch's workgroups need (that made one launch in 18 2.5x slower)"},
             "episodes": int(agg[1].item()), "accepted_plays": int(agg[2].item()), "episode_counts_cover": "warm-up steps + timed steps",
             "state_bytes_per_gpu": env.state_bytes(),
         }
@@ -460,7 +463,7 @@ def main():
             vs = sorted(total * args.steps / t for t in sample_s)
             pick = lambda q: vs[min(len(vs) - 1, max(0, int(round(q * (len(vs) - 1)))))]
             nl = max(1, prof_samples["rollout_launches"])
-            out["samples"] = {"n": len(vs), "what": f"the same {args.steps}-step region again, each between two synchronisations of the LAUNCH stream (the records are complete; a look-ahead refill queued beside a launch keeps running beside the next ones)",
+            out["samples"] = {"n": len(vs), "what": f"the same {args.steps}-step region again, each between two synchronisations of the LAUNCH stream (the records are complete; the piece of the look-ahead refill beside a launch may end a few microseconds behind it)",
                               "min_over_median": vs[0] / pick(0.5),
                               "median": pick(0.5), "p10": pick(0.1), "p90": pick(0.9), "min": vs[0], "max": vs[-1],
                               "value_inside_p10_p90": bool(pick(0.1) <= value <= pick(0.9)),

@@ -1150,8 +1150,8 @@ static void use_consumable(bo_env* e, int ci, double* reward, bo_info* info) {
     case 59: { /* Immolate :519-531: random.sample(deck, 5) by index (Lib/random.py sample(): selection set for n > 21, pool
                 * below), then deck.remove(card) for each: every later index shifts down, card_states keep their keys */
       int n = e->ndeck + e->nforeign, k = n < 5 ? n : 5, picked[5];
-      if (e->ndeck < 24) { unsupported = 1; break; } /* restated while the hand's indexes (always 0..7) stay valid; below that the
-                                                      * reference's unguarded deck[i] reads (:577,670,937) would raise */
+      if (e->ndeck < 13) { unsupported = 1; break; } /* restated while the hand's indexes (always 0..7) stay valid (8 real cards or more behind
+                                                      * this use); below that the reference's unguarded deck[i] reads (:577,670,937) would raise */
       if (n <= 21) {
         int pool[21];
         for (int i = 0; i < n; i++) pool[i] = i;
@@ -1183,7 +1183,10 @@ static void use_consumable(bo_env* e, int ci, double* reward, bo_info* info) {
       if (e->njokers > 0) { bo_mt_randbelow(g, (uint32_t)e->njokers); success = 1; }
       break;
     case 65: /* Cryptid :581-591: two consumables.Card copies appended to the live deck */
-      if (nt >= 1) { if (e->nforeign > 60) { unsupported = 1; break; } e->nforeign += 2; ncreated = 2; success = 1; } /* deck_size is an int8 */
+      if (nt >= 1) { /* deck_size = np.int8(len(deck)) (balatro_env_2.py:1491): 128 cards raise OverflowError under numpy >= 2 and wrap under numpy 1 */
+        if (e->ndeck + e->nforeign + 2 > 127) { unsupported = 1; break; }
+        e->nforeign += 2; ncreated = 2; success = 1;
+      }
       break;
     case 66: /* The Soul :593-601 */
       if (e->njokers < e->joker_slots) { jcreated[njc++] = SOUL_JOKER[bo_mt_randbelow(g, 5)]; success = 1; }

@@ -400,6 +400,46 @@ def test_many_short_launches_vs_oracle(monkeypatch, rings, async_refill):
     env.close()
 
 
+@pytest.mark.parametrize("sliced,parts", [("1", None), ("1", "16,16,16,16"), ("1", "1,1,1,1"), ("0", None)])
+def test_sliced_refill_vs_oracle(monkeypatch, sliced, parts):
+    """A LONG run of short launches with the default rings: 1 400 steps as 20 / 13 / 30 / 7-step bg_rollout_rows calls cross the point where the rings
+    demand a refill several times.  Each of those refills is issued in PIECES (BG_REFILL_SLICED, the default): its scan beside the launch that demanded it,
+    then one dense kernel over a part of a work list beside each of the next launches -- with the default parts, with 16 parts per list (a piece beside
+    nearly every launch), with one part per list, and with the pieces switched off.  Every record byte and the statistics against the oracle; a step
+    (bg_step: a synchronous refill has to issue what is left of the pieces first) and a state blob in the middle."""
+    from balatro_gym_amd.vec_env import RowBuffers
+    from oracle.gen_golden import IMPLEMENTED
+    monkeypatch.setenv("BG_REFILL_SLICED", sliced)
+    if parts:
+        monkeypatch.setenv("BG_REFILL_PARTS", parts)
+    n, T = 192, 1400
+    seeds = [77_000 + SEED_OFFSET + 5 * i for i in range(n)]
+    jokers = [random.Random(4100 + i).sample(IMPLEMENTED, 5) for i in range(n)]
+    env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4)
+    env.inject(jokers=jokers, apply_now=True)
+    rb = RowBuffers(n, env.device, steps=T)
+    sizes, done, k = [20, 13, 30, 7, 20, 20], 0, 0
+    while done < T:
+        c = min(sizes[k % len(sizes)], T - done)
+        part = RowBuffers.__new__(RowBuffers)
+        part.n, part.steps, part.rows = n, c, rb.rows[done:done + c]
+        env.rollout(c, policy=2, policy_seed=57, env_index0=3, t0=done, obs_buffers=part, zero_stats=(done == 0))
+        done += c; k += 1
+        if k == 37:   # in the middle of a refill period: a state blob read (synchronises) -- the run must not notice
+            env.get_state(5)
+    env.check()
+    got_stats = env.stats()
+    wobs, wr, wt, wa, wstats = _oracle_rollout(n, seeds, T, 2, 57, True, 4, jokers, env_index0=3, t0=0)
+    assert np.array_equal(rb.action.cpu().numpy(), wa)
+    assert np.array_equal(rb.terminated.cpu().numpy(), wt)
+    assert np.array_equal(rb.reward.contiguous().cpu().numpy().view(np.uint64), wr.view(np.uint64))
+    for key in OBS_KEYS:
+        assert np.array_equal(rb.tensors[key].contiguous().cpu().numpy(), wobs[key]), f"record key {key} differs"
+    for key in ("steps", "episodes", "plays", "score_sum", "reward_bits"):
+        assert got_stats[key] == wstats[key], (key, got_stats[key], wstats[key])
+    env.close()
+
+
 def test_packed_records_padded_stride():
     """bg_rollout_rows with padded records: the same 352 bytes per record as the dense layout.  Stride 384 is the FAST layout (every
     record written as three whole 128-byte lines): its bytes 352..383 are zeros; with any other stride (416 here) the bytes behind a
@@ -761,6 +801,48 @@ def test_immolate_cryptid_rollout_vs_oracle():
     wobs = _run_consumables_rollout(n, T, seeds, True, jokers, cons, cards, 53, 300)
     sizes = wobs["deck_size"]
     assert sizes.min() <= 42 and sizes.max() >= 54, (sizes.min(), sizes.max())  # decks really shrank and grew
+
+
+def test_deck_length_fences_vs_oracle():
+    """Where the deck-length consumables stop being followed (BG_ERR_CONSUMABLE_DECK), through bg_step in lockstep with the oracle: Immolate down to 12
+    real cards (eight uses of a full deck; the ninth is refused with the state untouched), with Cryptid's copies in the deck before (random.sample's pool
+    method then draws over real cards AND copies), alternating the two, and Cryptid alone up to 126 cards (the 38th use would make np.int8(128)).  One
+    consumable is injected per use; observation, reward and error code of every step are compared."""
+    import torch
+    programs = [[59] * 10, [65, 65] + [59] * 10, [59, 65] * 8 + [59] * 4, [65] * 39, [65, 59, 59] * 5 + [59] * 3, [59] * 4 + [65] * 6 + [59] * 6]
+    n = 2 * len(programs)
+    seeds = [97_000 + SEED_OFFSET + 11 * i for i in range(n)]
+    env = _vec(n, seeds, scorer_jokers=False, autoreset=False, max_ante=20, card_states=True)
+    orc = _oracle_envs(n, seeds, False, 20)
+    jokers = [[53] if i % 2 else [] for i in range(n)]   # Blue Joker counts the deck (copies included)
+    env.inject(jokers=jokers, apply_now=True)
+    for o, js in zip(orc, jokers):
+        o.set_jokers(js)
+
+    def step_all(acts, ctx):
+        res = [o.step(int(a)) for o, a in zip(orc, acts)]
+        _, reward, term, _, info = env.step(torch.from_numpy(np.asarray(acts, np.int32)).to(env.device))
+        assert np.array_equal(reward.cpu().numpy().view(np.uint64), np.array([r[1] for r in res]).view(np.uint64)), ctx
+        assert np.array_equal(info["error"].cpu().numpy(), np.array([r[4].error for r in res], dtype=np.int32)), ctx
+        assert not term.cpu().numpy().any() and not any(r[2] for r in res), ctx
+        _assert_obs(_obs_np(env), {k: np.stack([r[0][k] for r in res]) for k in OBS_KEYS}, ctx)
+        return res
+
+    step_all([45] * n, "blind select")
+    refused, sizes = 0, set()
+    for it in range(max(len(p) for p in programs)):
+        cons = [[programs[i // 2][it]] if it < len(programs[i // 2]) else [] for i in range(n)]
+        env.inject_consumables(cons, apply_now=True)
+        for o, c in zip(orc, cons):
+            o.set_consumables(c)
+        for act in (2, 3):
+            step_all([act] * n, f"use {it} select {act}")
+        res = step_all([10 if c else 59 for c in cons], f"use {it}")
+        refused += sum(r[4].error == 12 for r in res)
+        sizes.update(int(r[0]["deck_size"]) for r in res)
+    assert refused >= 6 and min(sizes) <= 12 and max(sizes) == 126, (refused, min(sizes), max(sizes))
+    env.check()
+    env.close()
 
 
 def test_inject_consumables_needs_card_states():

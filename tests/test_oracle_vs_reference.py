@@ -195,19 +195,19 @@ def test_reseed_reproduces_first_shuffle():
 
 
 def test_consumable_deck_fence_placement():
-    """WHERE the `BG_ERR_CONSUMABLE_DECK` fence stands relative to the reference (two corners are fenced, not followed).
-    Immolate (consumables.py:519-531) removes five sampled cards from the live deck list.  The restatement follows it while 24 or more real
-    cards are left -- six uses in one episode, 52 -> 22 cards, in lockstep with the reference -- and REFUSES the seventh (reward -1.0, error 12,
-    state untouched).  The reference itself accepts it and every later one (reward 7.0: $20 / 10 + 5 destroyed cards), plays on with a deck
-    of 17, 12, 7, 2 cards, and raises IndexError on the first step after the deck is empty (eleven uses).  So the fence is a documented
-    deviation that starts at the seventh Immolate of ONE episode (an episode is injected two consumables; The Fool can copy one more), not
-    the point where the reference breaks.  Cryptid (:581-591): the fence stands at 60 foreign copies (deck_size is an int8 observation)."""
+    """WHERE the `BG_ERR_CONSUMABLE_DECK` fence stands relative to the reference.
+    Immolate (consumables.py:519-531) removes five sampled cards from the live deck list.  The restatement follows it while the hand's deck indexes
+    (always 0..7) stay valid behind the use, i.e. while 13 or more real cards are left -- EIGHT uses in one episode, 52 -> 12 cards, in lockstep with the
+    reference, the last two sampled from a pool (random.sample's method for n <= 21) -- and REFUSES the ninth (reward -1.0, error 12, state untouched).
+    The reference accepts it (reward 7.0) and plays on with a deck of 7, 2, 0 cards while its hand still holds indexes up to 7: from there on its
+    unguarded deck[i] reads (balatro_env_2.py:577,670,937) raise IndexError as soon as a play or a boss blind touches one -- the first step after the
+    deck is empty at the latest.  So the fence now stands where the reference's own state stops being one it can step from."""
     r = rh.RefEnv(4242, scorer_jokers=False, max_ante=20)
     o = po.OracleEnv(4242, scorer_jokers=False, max_ante=20)
     for e in (r, o):
         e.step(45)
     uses_followed = 0
-    for it in range(7):
+    for it in range(9):
         for e in (r, o):
             e.set_consumables([59])   # Immolate
         for act in (2, 3, 10):
@@ -216,16 +216,16 @@ def test_consumable_deck_fence_placement():
             if act != 10:
                 assert_obs_equal(obs_o, obs_r, f"use {it} action {act}")
                 continue
-            if it < 6:
+            if it < 8:
                 assert_obs_equal(obs_o, obs_r, f"Immolate {it}")
                 assert ro == rr == 7.0 and int(obs_r["deck_size"]) == 47 - 5 * it
                 uses_followed += 1
             else:   # the fence: the reference goes on, the restatement refuses
-                assert rr == 7.0 and len(r.env.state.deck) == 17
-                assert ro == -1.0 and io.error == 12 and int(obs_o["deck_size"]) == 22
-    assert uses_followed == 6
+                assert rr == 7.0 and len(r.env.state.deck) == 7
+                assert ro == -1.0 and io.error == 12 and int(obs_o["deck_size"]) == 12
+    assert uses_followed == 8
     # ... and the reference alone: down to an empty deck, then IndexError on the next play
-    for it in range(4):
+    for it in range(2):
         r.set_consumables([59])
         for act in (2, 3, 10):
             r.step(act)
@@ -233,6 +233,63 @@ def test_consumable_deck_fence_placement():
     with pytest.raises(IndexError):
         for act in (2, 3, 0):
             r.step(act)
+
+
+def test_immolate_pool_with_cryptid_copies_vs_reference():
+    """random.sample's POOL method (n <= 21) over a deck that ends in Cryptid's copies (consumables.Card objects behind the real cards): two Cryptids,
+    then Immolates down to 12 real cards -- the last ones draw from a pool whose tail are copies (a picked copy leaves through deck.remove of an equal
+    copy, a picked real card shifts every later index) -- in lockstep with the reference, observation by observation."""
+    r = rh.RefEnv(5151, scorer_jokers=False, max_ante=20)
+    o = po.OracleEnv(5151, scorer_jokers=False, max_ante=20)
+    for e in (r, o):
+        e.step(45)
+    def counts():
+        real = sum(1 for c in r.env.state.deck if type(c).__module__.endswith("cards"))
+        return real, len(r.env.state.deck)
+    pool_with_copies, uses = 0, 0
+    for it, cid in enumerate([65, 65] + [59] * 10):
+        real, total = counts()
+        if cid == 59 and real < 13:
+            break
+        pool_with_copies += cid == 59 and total <= 21 and total > real
+        for e in (r, o):
+            e.set_consumables([cid])
+        for act in (2, 3, 10):
+            obs_r, rr, tr, _, ir = r.step(act)
+            obs_o, ro, to, _, io = o.step(act)
+            assert_obs_equal(obs_o, obs_r, f"use {it} (id {cid}) action {act}")
+            assert ro == rr, (it, act, ro, rr)
+        uses += 1
+    assert pool_with_copies >= 1 and uses >= 10, (pool_with_copies, uses)   # the pool method really ran with copies in the pool
+
+
+def test_cryptid_int8_fence_placement():
+    """Cryptid (consumables.py:581-591) appends two copies per use; `deck_size` is np.int8(len(deck)) (balatro_env_2.py:1491).  The restatement follows the
+    reference up to 126 cards (37 uses on a full deck) and refuses the use that would make 128 -- where the reference's OWN observation stops being
+    defined: np.int8(128) raises OverflowError under numpy >= 2 and wraps to -128 under numpy 1 (it was fenced at 60 copies before)."""
+    r = rh.RefEnv(6262, scorer_jokers=False, max_ante=20)
+    o = po.OracleEnv(6262, scorer_jokers=False, max_ante=20)
+    for e in (r, o):
+        e.step(45)
+    for it in range(37):
+        for e in (r, o):
+            e.set_consumables([65])
+        for act in (2, 3, 10):
+            obs_r, rr, tr, _, ir = r.step(act)
+            obs_o, ro, to, _, io = o.step(act)
+            assert_obs_equal(obs_o, obs_r, f"Cryptid {it} action {act}")
+            assert ro == rr, (it, act)
+    assert int(obs_o["deck_size"]) == 126 and len(r.env.state.deck) == 126
+    o.set_consumables([65]); r.set_consumables([65])
+    for act in (2, 3):
+        o.step(act); r.step(act)
+    obs_o, ro, to, _, io = o.step(10)
+    assert ro == -1.0 and io.error == 12 and int(obs_o["deck_size"]) == 126
+    try:
+        obs_r, rr, *_ = r.step(10)
+        assert int(obs_r["deck_size"]) == -128 and len(r.env.state.deck) == 128      # numpy 1: wrapped
+    except OverflowError:
+        assert len(r.env.state.deck) == 128                                            # numpy >= 2: the reference's step raises out of _get_observation
 
 
 def test_reference_wrapper_over_the_drop_in_space():
