@@ -50,9 +50,11 @@ extern "C" {
 #define BG_ERR_MAX_SCORE 10     /* balatro_env_2.py:623 terminated 'max_score_reached' */
 #define BG_ERR_CONSUMABLE_RAISES 11 /* the reference RAISES here (consumables.py:246,381,418,444 list.remove of a target class;
                                      * :496,506 assignment to a frozen dataclass): reward -1.0, state as the exception leaves it */
-#define BG_ERR_CONSUMABLE_DECK 12   /* Immolate on a deck of fewer than 24 real cards / Cryptid beyond 60 copies (consumables.py:519-531,
-                                     * 581-591): outside the accelerated domain (the reference's unguarded deck[i] reads would raise
-                                     * soon after); reward -1.0, state untouched */
+#define BG_ERR_CONSUMABLE_DECK 12   /* Immolate on a deck of fewer than 13 real cards (consumables.py:519-531: fewer than 8 would be left, and the
+                                     * hand's deck indexes 0..7 go stale -- the reference's unguarded deck[i] reads, balatro_env_2.py:577,670,937,
+                                     * raise from there on) / a Cryptid that would make the deck 128 cards (:581-591: deck_size is
+                                     * np.int8(len(deck)), :1491 -- OverflowError under numpy >= 2, a wrapped value under numpy 1);
+                                     * reward -1.0, state untouched */
 
 /* info.flags bits */
 #define BG_INFO_BEAT_BLIND 1     /* info['beat_blind'] */

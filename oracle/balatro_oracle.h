@@ -50,7 +50,7 @@ enum {
   BO_ERR_MAX_ANTE = 9,           /* balatro_env_2.py:620 (terminated, reward 0) */
   BO_ERR_MAX_SCORE = 10,         /* balatro_env_2.py:623 */
   BO_ERR_CONSUMABLE_RAISES = 11, /* the reference raises here (consumables.py:246,381,496,506): reward -1.0 by harness convention */
-  BO_ERR_CONSUMABLE_DECK = 12    /* Immolate on a deck of fewer than 24 cards / Cryptid beyond 60 copies: outside the restated domain, state untouched */
+  BO_ERR_CONSUMABLE_DECK = 12    /* Immolate on fewer than 13 real cards (fewer than 8 would be left: the hand's indexes go stale) / a Cryptid that would make 128 cards (deck_size is an int8): state untouched */
 };
 
 /* info.flags */

@@ -29,6 +29,13 @@ for d in pmc_FETCH_SIZE pmc_WRITE_SIZE pmc20_FETCH_SIZE pmc20_WRITE_SIZE; do
   (head -1 "$out/$d/runc_counter_collection.csv"; grep "bg_engine" "$out/$d/runc_counter_collection.csv" | head -400) > "$out/$d.csv" 2>/dev/null
   rm -rf "$out/$d"
 done
+# the refill in pieces (the default) against the whole refill beside the next launches (BG_REFILL_SLICED=0), interleaved, at the driver's shape
+for rep in 1 2 3; do for sl in 1 0; do
+  BG_REFILL_SLICED=$sl python bench.py --no-cpu-baseline --no-step-path --no-small-n --steps 20 --warmup 5 --samples 60 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']; s=d['samples']
+print('BG_REFILL_SLICED=$sl rep $rep: value %.3f G  wall frac %.4f  kernel frac %.4f  sustained %.3f G  samples median %.3f  p10 %.3f  min %.3f  min/median %.3f' % (d['value']/1e9, r['frac'], r['kernel_frac'], d['sustained']['value']/1e9, s['median']/1e9, s['p10']/1e9, s['min']/1e9, s['min_over_median']))"
+done; done > "$out/refill_pieces_ab.txt" 2>&1
+[ -n "${SKIP_SHOP_ILP:-}" ] && exit 0
 # shop seeding: one stream per lane against two interleaved (BG_SHOP_ILP), the kernel's SQ counters with nothing beside it (synchronous refill)
 export BG_ASYNC_REFILL=0
 for ilp in 1 2; do
