@@ -804,11 +804,9 @@ struct bg_handle {
   struct RefillPiece { int kind; uint32_t part, nparts; int grid; uint32_t cursor, max_made; };   // kind: 0 deck, 1 seed ring, 2 global blocks, 3 shop streams
   std::vector<RefillPiece> pieces;
   size_t piece_next;
-  double piece_credit;
   BgDev piece_dev;
   int refill_sliced, piece_parts[4], piece_grid[4];
-  double refill_spread;
-  int deck_passes, deck_rounds, refill_interleave;
+  int deck_passes, deck_rounds, refill_interleave, refill_sliced_div;
   uint32_t eng_run, eng_play, eng_other, eng_part, eng_more, eng_smask; int eng_waves, eng_copiers; // queue thresholds of the step engine (BG_ENG_RUN / _PLAY / _OTHER)
   int engine;            // BG_ENGINE: 3 = bg_engine3.h (owner + service waves in one workgroup) for packed-record rollouts (default), 1 = bg_engine.h everywhere
   // bg_engine3.h: workgroup shape (BG_E3_CFG = 100 * owner waves + 10 * slices + service waves; 0 = by env count) and the service waves' batch
@@ -986,12 +984,12 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
       for (int k = 0; k < 4; k++) { h->piece_parts[k] = dp[k]; h->piece_grid[k] = dg[k]; }
       auto get4 = [](const char* k, int* out, int lo, int hi) { const char* v = getenv(k); if (!v) return; int a[4]; if (sscanf(v, "%d,%d,%d,%d", &a[0], &a[1], &a[2], &a[3]) == 4) for (int i = 0; i < 4; i++) out[i] = a[i] < lo ? lo : a[i] > hi ? hi : a[i]; };
       get4("BG_REFILL_PARTS", h->piece_parts, 1, 16); get4("BG_REFILL_GRIDS", h->piece_grid, 64, 65536); }
-    h->piece_next = 0; h->piece_credit = 0.0;
+    h->piece_next = 0;
     h->refill_interleave = geti("BG_REFILL_INTERLEAVE", 1);
+    h->refill_sliced_div = geti("BG_REFILL_SLICED_DIV", 2); if (h->refill_sliced_div < 1) h->refill_sliced_div = 1;   // launches of at most max_chunk / div steps get the refill in pieces
     h->deck_passes = geti("BG_REFILL_DECK_PASSES", 3); h->deck_rounds = geti("BG_REFILL_DECK_ROUNDS", 6);
     if (h->deck_passes < 1) h->deck_passes = 1; if (h->deck_rounds < 1) h->deck_rounds = 1;
     while (h->deck_passes * h->piece_parts[0] > BG_WL_COUNTERS - 8) { if (h->deck_passes > 1) h->deck_passes--; else h->piece_parts[0]--; }
-    { const char* v = getenv("BG_REFILL_SPREAD"); h->refill_spread = v ? atof(v) : 0.95; if (!(h->refill_spread >= 0.05 && h->refill_spread <= 1.0)) h->refill_spread = 0.95; }
     h->eng_run = (uint32_t)geti("BG_ENG_RUN", 64); h->eng_play = (uint32_t)geti("BG_ENG_PLAY", 64); h->eng_other = (uint32_t)geti("BG_ENG_OTHER", 64);
     h->eng_part = (uint32_t)geti("BG_ENG_PART", 1); h->eng_more = (uint32_t)geti("BG_ENG_MORE", 0); h->eng_smask = (uint32_t)geti("BG_ENG_SMASK", BG_ENG_SMASK_DEFAULT); h->eng_waves = geti("BG_ENG_WAVES", 0); h->eng_copiers = geti("BG_ENG_COPIERS", 0); if (h->eng_copiers < 0 || h->eng_copiers > 3) h->eng_copiers = 0;   // 0 = by launch length (bg_engine_launch)
     if (h->eng_smask == 0 || h->eng_smask >= (1u << BG_ENG_NW) || __builtin_popcount(h->eng_smask) > BG_ENG_NSV) h->eng_smask = BG_ENG_SMASK_DEFAULT;
@@ -1202,7 +1200,7 @@ static int bg_refill_on(bg_handle* h, hipStream_t s, int steps_hint = -1, bool s
   if (sliced && s == h->side && h->shop_ilp != 2 && h->dev_skip_refill == 0) {
     bg_ev_end(h, h->ev_refill_t, s);
     BG_HIP(hipGetLastError());
-    h->pieces.clear(); h->piece_next = 0; h->piece_credit = 0.5; h->piece_dev = d;
+    h->pieces.clear(); h->piece_next = 0; h->piece_dev = d;
     // the order of the serial refill: decks, seed rings, blocks, shop streams (the shop items of THIS refill were listed by the scan from seeds drawn earlier)
     // decks: an env's shuffles are one serial chain (~17 per 372 steps, up to the ring), so the deck work is cut in DEPTH as well -- `deck_passes` passes
     // over the list, all but the last one giving every env at most `deck_rounds` decks
@@ -1584,6 +1582,14 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
     if (pieces_after) BG_HIP(hipEventRecord(h->ev_rollout, (hipStream_t)stream));
     if (need && async) {
       BG_HIP(hipEventRecord(h->ev_rollout, (hipStream_t)stream));   // everything the stream has done so far (the previous launches)
+      // Pieces of the latest refill still to be issued (launch lengths that changed inside a period): this launch reads THAT refill's view, so they go now,
+      // in front of it -- the completion event behind the last piece is what the launch waits for below (a view whose pieces were still to come would
+      // be read beside its writers, and its event would still be the one of two refills ago)
+      if (h->piece_next < h->pieces.size()) {
+        BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));
+        rc = bg_refill_pieces(h, 1 << 30);
+        if (rc) return rc;
+      }
       if (!refill_after) { // R beside this chunk, queued before it (the chunk reads R's own view: right behind a synchronous refill)
         BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));
         rc = bg_wait_refill(h, h->side, 0);
@@ -1637,18 +1643,25 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));
       rc = bg_wait_refill(h, h->side, 0);
       if (rc) return rc;
-      // a SHORT launch (the refill's ~1.1 ms of kernels would run beside the next three to five launches, and whatever of them is still to be placed when a
-      // launch ends takes the whole machine in the gap before the next one): only the scan now, the dense kernels in pieces beside the launches to come
-      const bool sliced = h->refill_sliced != 0 && 4 * chunk <= max_chunk;
+      // A launch of at most HALF a refill period (the refill's kernels would run beside the next launches too, and whatever of them is still to be placed
+      // when a launch ends takes the whole machine in the gap before the next one): the scan now, the dense kernels in pieces beside this launch and the ones
+      // to come.  A launch that is a period of its own keeps the whole refill beside it (in pieces the refill -- held to what is resident beside the engine --
+      // takes longer than the launch, and the next launch needs it: 372 steps 8.1 -> 7.4 G, profiles/r05/refill_pieces.txt).
+      const bool sliced = h->refill_sliced != 0 && h->refill_sliced_div * chunk <= max_chunk;
       rc = bg_refill_on(h, h->side, h->steps_since_refill + chunk, sliced); // (sets steps_since_refill = 0: the chunk beside it counts below)
       if (rc) return rc;
-    } else if (pieces_after) {
-      // all pieces within `refill_spread` (0.95) of the steps that remain until the next refill is due: at 20 steps per launch one piece per launch
-      h->piece_credit += (double)h->pieces.size() * (double)chunk / (h->refill_spread * (double)max_chunk);
-      const int np = (int)h->piece_credit;
-      h->piece_credit -= (double)np;
+    }
+    if ((refill_after || pieces_after) && h->piece_next < h->pieces.size()) {
+      // This launch's share: the pieces still to go over the launches still to come before the next refill is due (this one included, launches of this
+      // length assumed), the scan counted as a piece of the launch it runs beside -- one piece per launch at 20 steps, eight or nine at 180, and none
+      // left for the launch that asks for the next refill (which waits for this one)
+      const int u = h->steps_since_refill;   // (0 behind a refill that was just queued)
+      int m = 1 + (max_chunk - (u + chunk)) / (chunk > 0 ? chunk : 1);
+      if (m < 1) m = 1;
+      const int pending = (int)(h->pieces.size() - h->piece_next), extra = refill_after ? 1 : 0;
+      const int np = (pending + extra + m - 1) / m - extra;
       if (np > 0) {
-        BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));
+        if (!refill_after) BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));   // (the scan in front of the pieces already waits for it)
         rc = bg_refill_pieces(h, np);
         if (rc) return rc;
       }

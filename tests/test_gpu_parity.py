@@ -400,12 +400,14 @@ def test_many_short_launches_vs_oracle(monkeypatch, rings, async_refill):
     env.close()
 
 
-@pytest.mark.parametrize("sliced,parts", [("1", None), ("1", "16,16,16,16"), ("1", "1,1,1,1"), ("0", None)])
-def test_sliced_refill_vs_oracle(monkeypatch, sliced, parts):
+@pytest.mark.parametrize("sliced,parts,sizes", [("1", None, (20, 13, 30, 7, 20, 20)), ("1", "16,16,16,16", (20, 13, 30, 7, 20, 20)), ("1", "1,1,1,1", (20, 13, 30, 7, 20, 20)),
+                                                ("0", None, (20, 13, 30, 7, 20, 20)), ("1", None, (100, 180, 60, 20, 186, 150)), ("1", None, (180,))])
+def test_sliced_refill_vs_oracle(monkeypatch, sliced, parts, sizes):
     """A LONG run of short launches with the default rings: 1 400 steps as 20 / 13 / 30 / 7-step bg_rollout_rows calls cross the point where the rings
     demand a refill several times.  Each of those refills is issued in PIECES (BG_REFILL_SLICED, the default): its scan beside the launch that demanded it,
     then one dense kernel over a part of a work list beside each of the next launches -- with the default parts, with 16 parts per list (a piece beside
-    nearly every launch), with one part per list, and with the pieces switched off.  Every record byte and the statistics against the oracle; a step
+    nearly every launch), with one part per list, with the pieces switched off, and with launches of up to half a refill period (100 / 180 / 186 steps:
+    several pieces beside one launch, the first ones beside the launch that asked).  Every record byte and the statistics against the oracle; a step
     (bg_step: a synchronous refill has to issue what is left of the pieces first) and a state blob in the middle."""
     from balatro_gym_amd.vec_env import RowBuffers
     from oracle.gen_golden import IMPLEMENTED
@@ -418,14 +420,14 @@ def test_sliced_refill_vs_oracle(monkeypatch, sliced, parts):
     env = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4)
     env.inject(jokers=jokers, apply_now=True)
     rb = RowBuffers(n, env.device, steps=T)
-    sizes, done, k = [20, 13, 30, 7, 20, 20], 0, 0
+    done, k = 0, 0
     while done < T:
         c = min(sizes[k % len(sizes)], T - done)
         part = RowBuffers.__new__(RowBuffers)
         part.n, part.steps, part.rows = n, c, rb.rows[done:done + c]
         env.rollout(c, policy=2, policy_seed=57, env_index0=3, t0=done, obs_buffers=part, zero_stats=(done == 0))
         done += c; k += 1
-        if k == 37:   # in the middle of a refill period: a state blob read (synchronises) -- the run must not notice
+        if k == 37 or (k == 5 and len(sizes) < 6):   # in the middle of a refill period: a state blob read (synchronises) -- the run must not notice
             env.get_state(5)
     env.check()
     got_stats = env.stats()

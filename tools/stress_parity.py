@@ -33,7 +33,19 @@ def run(n, T, policy, scorer, cards_on, seed0, max_ante, cons_on=False):
         env.inject_consumables(cons, apply_now=True)
     rb = RowBuffers(n, env.device, steps=T, row_stride=int(os.environ.get("STRIDE", "0")))   # STRIDE=384: the whole-line record layout
     t = time.time()
-    env.rollout(T, policy=policy, policy_seed=seed0, obs_buffers=rb)
+    chunks = [int(c) for c in os.environ.get("CHUNKS", "").split(",") if c]   # CHUNKS=20,13,30: the T steps as that cycle of SHORT launches (the refill then goes in pieces)
+    if chunks:
+        done, k = 0, 0
+        while done < T:
+            c = min(chunks[k % len(chunks)], T - done)
+            part = RowBuffers.__new__(RowBuffers)
+            part.n, part.steps, part.rows = n, c, rb.rows[done:done + c]
+            if hasattr(rb, "row_stride"):
+                part.row_stride = rb.row_stride
+            env.rollout(c, policy=policy, policy_seed=seed0, t0=done, obs_buffers=part, zero_stats=(done == 0))
+            done += c; k += 1
+    else:
+        env.rollout(T, policy=policy, policy_seed=seed0, obs_buffers=rb)
     env.check()
     st = env.stats()
     wobs, wr, wt, wa, wst = _oracle_rollout(n, seeds, T, policy, seed0, scorer, max_ante, jokers, cards=cards, consumables=cons)
@@ -57,6 +69,14 @@ if __name__ == "__main__":
         run(2048, 1500, 2, True, False, 987005, 4)
         run(1024, 1200, 0, True, True, 987006, 8)
         print("LONG STRESS OK")
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "short":  # the same games as MANY short launches: three refill periods in pieces, rings wrap
+        os.environ["CHUNKS"] = "20,13,30,7,20,20"
+        run(4096, 1300, 2, True, False, 987007, 4)
+        run(2048, 1100, 0, True, True, 987008, 8, cons_on=True)
+        os.environ["CHUNKS"] = "20"
+        run(8192, 800, 2, True, False, 987009, 4)
+        print("SHORT STRESS OK")
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wide":  # configurations drawn from a seed (argv[2]): flags, policy, caps, sizes
         rr = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
