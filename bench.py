@@ -515,7 +515,7 @@ def main():
     if rank == 0 and world == 1 and not args.no_step_path:
         # ---- the Gymnasium-surface path: bg_step with actions from a device tensor (recorded from a fused rollout of a twin
         # handle, so every action is the valid policy action of that state), then the same steps through bg_step_many
-        ks = 200
+        ks = 800   # more than two refill periods (372 steps): the look-ahead refill runs beside these launches too (in pieces), and is inside the figure
         twin = make_env()
         acts = torch.zeros((ks, n), dtype=torch.int32, device=dev)
         twin.rollout(ks, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, env_index0=lo, actions=acts)

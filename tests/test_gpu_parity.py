@@ -158,6 +158,69 @@ def test_step_vs_oracle_fresh_seeds(policy, scorer):
     env.close()
 
 
+@pytest.mark.parametrize("many", [0, 40])
+def test_step_path_across_refill_periods_vs_oracle(many):
+    """900 steps through bg_step (one launch per step) and through bg_step_many (40 steps per call): more than two refill periods, so the look-ahead refill
+    runs BESIDE the step launches -- its scan behind the launch that asks for it, its dense kernels in pieces behind the following ones (round 5; a
+    synchronous refill on the stream before) -- with a masked reset and a state blob in between.  Observation, reward, termination and info of every
+    step against the oracle."""
+    import torch
+    from oracle.gen_golden import IMPLEMENTED
+    n, T = 160, 900
+    seeds = [915_000 + SEED_OFFSET + 3 * i for i in range(n)]
+    jokers = [random.Random(8000 + i).sample(IMPLEMENTED, i % 6) for i in range(n)]
+    env = _vec(n, seeds, scorer_jokers=True, autoreset=False, max_ante=4)
+    env.inject(jokers=jokers, apply_now=True)
+    env.observe()
+    orc = _oracle_envs(n, seeds, True, 4, jokers)
+    if many:
+        from balatro_gym_amd.vec_env import ObsBuffers
+        ob_k = ObsBuffers(n, env.device, steps=many)
+        reward_k = torch.zeros((many, n), dtype=torch.float64, device=env.device)
+        term_k = torch.zeros((many, n), dtype=torch.uint8, device=env.device)
+    t = 0
+    while t < T:
+        k = min(many, T - t) if many else 1
+        acts = np.zeros((k, n), np.int32)
+        res_k = []
+        for j in range(k):
+            acts[j] = [o.policy_action(2, 77, i, t + j) for i, o in enumerate(orc)]
+            res = [o.step(int(a)) for o, a in zip(orc, acts[j])]
+            res_k.append(res)
+            for i, r in enumerate(res):   # autoreset off: the oracle side resets what terminated (the device side below, by mask, when stepping one by one)
+                if r[2]:
+                    orc[i].reset(); orc[i].set_jokers(jokers[i])
+            if many and any(r[2] for r in res):   # step_many stops nowhere: end the block at a termination so that both sides reset here
+                acts = acts[:j + 1]; k = j + 1
+                break
+        if many:
+            env.step_many(torch.from_numpy(acts).to(env.device), obs_buffers=ob_k, reward=reward_k, terminated=term_k)
+            wr = np.array([[r[1] for r in res] for res in res_k])
+            assert np.array_equal(reward_k[:k].cpu().numpy().view(np.uint64), wr.view(np.uint64)), f"t {t}"
+            wt = np.array([[r[2] for r in res] for res in res_k], dtype=np.uint8)
+            assert np.array_equal(term_k[:k].cpu().numpy(), wt), f"t {t}"
+            for j in (0, k - 1):
+                _assert_obs({key: ob_k.tensors[key][j].cpu().numpy() for key in OBS_KEYS}, {key: np.stack([r[0][key] for r in res_k[j]]) for key in OBS_KEYS}, f"t {t} + {j}")
+            tm = wt[-1]
+        else:
+            _, reward, term, _, info = env.step(torch.from_numpy(acts[0]).to(env.device))
+            last = res_k[0]
+            assert np.array_equal(reward.cpu().numpy().view(np.uint64), np.array([r[1] for r in last]).view(np.uint64)), f"t {t}"
+            tm = np.array([r[2] for r in last], dtype=np.uint8)
+            assert np.array_equal(term.cpu().numpy(), tm), f"t {t}"
+            assert np.array_equal(info["error"].cpu().numpy(), np.array([r[4].error for r in last], dtype=np.int32)), f"t {t}"
+            _assert_obs(_obs_np(env), {key: np.stack([r[0][key] for r in last]) for key in OBS_KEYS}, f"t {t}")
+        if tm.any():
+            env.reset(mask=torch.from_numpy(tm).to(env.device))
+        t += k
+        if t in (401, 440):
+            env.get_state(3)
+    env.observe()
+    _assert_obs(_obs_np(env), {key: np.stack([o.obs()[key] for o in orc]) for key in OBS_KEYS}, "final")
+    env.check()
+    env.close()
+
+
 def test_shop_stream_beyond_slot_vs_oracle():
     """A shop visit with dozens of rerolls reads far more of `random.Random(shop_seed)` than a ring slot keeps (words
     0..131 and 396..527 of the seeded state): the stream is re-seeded in full into the overflow block and the visit carries
