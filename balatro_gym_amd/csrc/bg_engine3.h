@@ -38,6 +38,15 @@
 #else
 #define BG_E3_REC_STORE(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory")
 #endif
+#ifndef BG_E3_SPARSE
+#define BG_E3_SPARSE 8u   // records finished in an owner iteration up to which the copy-out takes its one-group path (0: never)
+#endif
+#ifndef BG_E3_SPARSE2
+#define BG_E3_SPARSE2 16u // ... its two-group path
+#endif
+#ifndef BG_E3_SPARSE3
+#define BG_E3_SPARSE3 0u  // ... and a three-group path (0: none; profiles/r05/sparse_copy_out.txt)
+#endif
 template <int NOW, int KS, int NSV>
 struct E3Lds {
   static constexpr int NE = NOW * KS * BG_BLOCK;
@@ -293,36 +302,45 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
         BG_WAVE_SYNC();
         typedef uint32_t bg_u32x2 __attribute__((ext_vector_type(2)));
         lds_cc* const lsb = (lds_cc*)&s_list[wave][0];
-        if (whole) {
-          for (uint32_t g0 = 0; g0 < nb; g0 += 32u) {
-            bg_u32x2 ce[4][3];
-            bg_u32x4 v[4][3];
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-#pragma unroll
-              for (int j = 0; j < 3; j++)
-                ce[u][j] = *(__attribute__((address_space(3))) const bg_u32x2*)(lsb + (((g0 + 8u * (uint32_t)u + rsel[j]) & (KS * BG_BLOCK - 1u)) << 3));
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-#pragma unroll
-              for (int j = 0; j < 3; j++)
-                v[u][j] = *(__attribute__((address_space(3))) const bg_u32x4*)(imgb + __umul24(ce[u][j].y & 0xffu, cmul[j]) + cib[j]);
-#pragma unroll
-            for (int u = 0; u < 4; u++)
-#pragma unroll
-              for (int j = 0; j < 3; j++)
-#ifndef BG_E3_NOSTORE   // development (sensitivity only).  (Round 5: unconditional stores with the empty lanes aimed at a dump line -- no exec-mask save and
-                        // branch per store -- cost 7-8 % at both launch lengths: profiles/r05/play_path_ab.txt)
-                if (g0 + 8u * (uint32_t)u + rsel[j] < nb)
+        // NU groups of eight records from list position G0: 3 NU list reads, 3 NU image reads (the LDS round trips of a group overlap), 3 NU stores.
+        // (BG_E3_NOSTORE / BG_E3_STORE_L2: development, sensitivity only.  Round 5: unconditional stores with the empty lanes aimed at a dump line -- no
+        //  exec-mask save and branch per store -- cost 7-8 % at both launch lengths: profiles/r05/play_path_ab.txt)
+#ifndef BG_E3_NOSTORE
+#define BG_E3_LIVE(idx) ((idx) < nb)
 #else
-                if (g0 + 8u * (uint32_t)u + rsel[j] < nb && a.T == 0x7fffffff)
+#define BG_E3_LIVE(idx) ((idx) < nb && a.T == 0x7fffffff)
 #endif
-#ifdef BG_E3_STORE_L2   // development (sensitivity only): every record into the first 64 rows -- the same instructions, no HBM write stream
-                  BG_E3_REC_STORE(v[u][j], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)(ce[u][j].x & 63u) * 384u + cgl[j])));
+#ifdef BG_E3_STORE_L2   // every record into the first 64 rows -- the same instructions, no HBM write stream
+#define BG_E3_ROW(x) ((x) & 63u)
 #else
-                  BG_E3_REC_STORE(v[u][j], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)ce[u][j].x * 384u + cgl[j])));
+#define BG_E3_ROW(x) (x)
 #endif
-          }
+#define BG_E3_COPY_GROUPS(NU, G0) do { \
+          bg_u32x2 ce[NU][3]; \
+          bg_u32x4 v[NU][3]; \
+          _Pragma("unroll") for (int u = 0; u < NU; u++) _Pragma("unroll") for (int j = 0; j < 3; j++) \
+            ce[u][j] = *(__attribute__((address_space(3))) const bg_u32x2*)(lsb + ((((G0) + 8u * (uint32_t)u + rsel[j]) & (KS * BG_BLOCK - 1u)) << 3)); \
+          _Pragma("unroll") for (int u = 0; u < NU; u++) _Pragma("unroll") for (int j = 0; j < 3; j++) \
+            v[u][j] = *(__attribute__((address_space(3))) const bg_u32x4*)(imgb + __umul24(ce[u][j].y & 0xffu, cmul[j]) + cib[j]); \
+          _Pragma("unroll") for (int u = 0; u < NU; u++) _Pragma("unroll") for (int j = 0; j < 3; j++) \
+            if (BG_E3_LIVE((G0) + 8u * (uint32_t)u + rsel[j])) \
+              BG_E3_REC_STORE(v[u][j], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)BG_E3_ROW(ce[u][j].x) * 384u + cgl[j]))); \
+        } while (0)
+        const uint32_t nbs = (uint32_t)__builtin_amdgcn_readfirstlane((int)nb);   // (wave-uniform: counted from ballots)
+        if (whole && nbs <= BG_E3_SPARSE) {
+          // A SPARSE iteration (a small job's 16 live envs per workgroup; the first and last iterations of a short launch): at most eight records = ONE
+          // group -- three list reads, three image reads, three stores instead of twelve of each (nine of which had no lane to serve)
+          BG_E3_COPY_GROUPS(1, 0u);
+#if BG_E3_SPARSE2
+        } else if (whole && nbs <= BG_E3_SPARSE2) {
+          BG_E3_COPY_GROUPS(2, 0u);
+#endif
+#if BG_E3_SPARSE3
+        } else if (whole && nbs <= BG_E3_SPARSE3) {
+          BG_E3_COPY_GROUPS(3, 0u);
+#endif
+        } else if (whole) {
+          for (uint32_t g0 = 0; g0 < nb; g0 += 32u) BG_E3_COPY_GROUPS(4, g0);
         } else {
           const uint32_t total = 22u * nb;
           for (uint32_t q0 = (uint32_t)lane; q0 < total; q0 += 4u * BG_BLOCK) {
