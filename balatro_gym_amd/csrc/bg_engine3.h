@@ -170,10 +170,23 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
     // no LDS read: the step phase of an iteration was five dependent LDS round trips); they go to LDS with a request and come back with its answer
     uint4 rc3[KS], rc4[KS];
     uint64_t rmask[KS];
+    // the policy's counter-hash input x0 = seed_env + PSI * (t0 + t + 1) and the record's row env + t * N advance by an ADD per finished step (they
+    // were two 64-bit multiplies and a 32 x 32 one in every owner iteration: ~10 quarter-rate multiplies of a ~600-instruction step phase); the blind a
+    // scripted policy picks is a constant of the env
+    uint64_t px[KS];
+    size_t prow[KS];
+    int pblind[KS];
 #pragma unroll
     for (int s = 0; s < KS; s++) {
       t[s] = 0; nreq[s] = 0; waiting[s] = false;
       const int l = (wave * KS + s) * BG_BLOCK + lane;
+      {
+        const int env = env0 + l;
+        const uint64_t gi0 = a.env_index0 + (uint64_t)env;
+        px[s] = a.policy_seed + 0x9E3779B97F4A7C15ull * (gi0 + 1) + BG_POLICY_PSI * (a.t0 + 1);
+        prow[s] = (size_t)env;
+        pblind[s] = a.policy == 2 ? 45 + (int)((bmod3 + (uint32_t)env % 3u) % 3u) : 45;
+      }
       rc3[s] = s_c34[0][l]; rc4[s] = s_c34[1][l]; rmask[s] = s_mask[l];
       const lds_u32* im = (const lds_u32*)&s_img[l][0];
       terminal[s] = bg_b(rc3[s].x, 0) > 100u || (int64_t)(((uint64_t)im[33] << 32) | im[32]) > 1000000000ll;   // :619-623
@@ -201,7 +214,7 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
         const bool live = l < n_live;
         lds_u32* const img32 = (lds_u32*)&s_img[l][0];
         lds_u8* const img8 = (lds_u8*)&s_img[l][0];
-        const size_t row = (size_t)env + (a.obs_stride_steps ? (size_t)t[s] * N : 0);
+        const size_t row = prow[s];   // env + t * N (a.obs_stride_steps), or env
         // ---- answers: the service wave has left the finished image, chunks 3 / 4 and the mask in LDS
         bool fin = false;
         if (waiting[s] && bg_lds_ld(&s_ans[l]) == nreq[s]) {
@@ -223,11 +236,9 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
           const uint32_t phase = bg_b(c3.x, 2), discards_left = bg_b(c3.y, 0), nsel0 = bg_b(c3.y, 3);
           int action;
           {
-            const uint64_t gi0 = a.env_index0 + (uint64_t)env;
             Env pe; pe.phase = (int)phase; // the policy only looks at the phase and the mask
-            PolicyLane pl; pl.seed_env = a.policy_seed + 0x9E3779B97F4A7C15ull * (gi0 + 1);
-            pl.blind = a.policy == 2 ? 45 + (int)((bmod3 + (uint32_t)env % 3u) % 3u) : 45;
-            action = bg_policy_action_fast(pe, mask, a.policy, pl, pl.seed_env + BG_POLICY_PSI * (a.t0 + (uint64_t)t[s] + 1), (lds_JTables*)&jt);
+            PolicyLane pl; pl.seed_env = 0; pl.blind = pblind[s];   // (bg_policy_action_fast reads the blind and x0 only)
+            action = bg_policy_action_fast(pe, mask, a.policy, pl, px[s], (lds_JTables*)&jt);
           }
           double reward = 0.0;
           const bool valid = action >= 0 && action < 60 && ((mask >> (action & 63)) & 1ull);
@@ -284,6 +295,8 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
           n_steps++;
           rbits ^= rb * (2 * (uint64_t)(a.t0 + t[s]) + 1);
           t[s]++;
+          px[s] += BG_POLICY_PSI;
+          if (a.obs_stride_steps) prow[s] += N;
         }
         const unsigned long long fms = __ballot(fin);
         // (.y bit 8: the record of the launch's last step -- the one a sharded job gathers; the copy-out reads the lane out of the low byte)
