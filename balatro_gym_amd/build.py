@@ -58,7 +58,18 @@ def sources_part(signature: str) -> str:
 
 
 def needs_build() -> bool:
-    return not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS)
+    """No library, or sources newer than it -- unless the library SAYS it was built from exactly these sources: a snapshot that does not keep
+    modification times (a copy, a fresh checkout beside a travelled .so) must not set off a three-minute rebuild of unchanged code, and must not
+    replace the library the committed measurements belong to."""
+    if not os.path.exists(LIB):
+        return True
+    if not any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS):
+        return False
+    try:
+        with open(LIB, "rb") as f:
+            return sources_part(source_signature()).encode() not in f.read()   # (the signature is a string literal of the library: bg_build_signature)
+    except OSError:
+        return True
 
 
 def build(force: bool = False, verbose: bool = False, out: str | None = None) -> str:
