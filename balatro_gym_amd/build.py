@@ -28,13 +28,8 @@ def hipcc_path() -> str:
 FLAGS = ["-O3", f"--offload-arch={ARCH}", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-Wno-unused-value"]
 
 
-def source_signature() -> str:
-    """What identifies the DEVICE CODE of a build, reproducibly: 16 hex digits = sha256 prefix (12) over every source the library is
-    compiled from and the compiler flags, then sha256 prefix (4) of the compiler's version line.  Two builds of unchanged sources with the
-    same hipcc carry the same signature (the bytes of the code object do not: rebuilding unchanged sources gave three different .hip_fatbin
-    hashes), so a committed PMC traffic measurement (profiles/*_hbm_traffic.json) stays attached to the code it was taken on across
-    rebuilds.  The first 12 digits do not depend on the box (`sources_part`): a library that travelled to a box with another ROCm still
-    says which sources it was built from."""
+def _sources_digest() -> str:
+    """12 hex digits over every source the library is compiled from and the compiler flags: the box-independent part of the signature."""
     import hashlib
     h = hashlib.sha256()
     for d in DEPS:
@@ -43,13 +38,34 @@ def source_signature() -> str:
             h.update(f.read())
         h.update(b"\0")
     h.update(" ".join(FLAGS).encode())
-    c = hashlib.sha256()
-    try:
-        ver = subprocess.run([hipcc_path(), "--version"], capture_output=True, text=True, timeout=60).stdout
-        c.update("\n".join(l for l in ver.splitlines() if "version" in l.lower()).encode())
-    except Exception:
-        c.update(b"hipcc-unknown")
-    return h.hexdigest()[:12] + c.hexdigest()[:4]
+    return h.hexdigest()[:12]
+
+
+_compiler_digest_cache: list = []
+
+
+def _compiler_digest() -> str:
+    """4 hex digits over hipcc's version lines (one `hipcc --version` per process)."""
+    import hashlib
+    if not _compiler_digest_cache:
+        c = hashlib.sha256()
+        try:
+            ver = subprocess.run([hipcc_path(), "--version"], capture_output=True, text=True, timeout=60).stdout
+            c.update("\n".join(l for l in ver.splitlines() if "version" in l.lower()).encode())
+        except Exception:
+            c.update(b"hipcc-unknown")
+        _compiler_digest_cache.append(c.hexdigest()[:4])
+    return _compiler_digest_cache[0]
+
+
+def source_signature() -> str:
+    """What identifies the DEVICE CODE of a build, reproducibly: 16 hex digits = sha256 prefix (12) over every source the library is
+    compiled from and the compiler flags, then sha256 prefix (4) of the compiler's version line.  Two builds of unchanged sources with the
+    same hipcc carry the same signature (the bytes of the code object do not: rebuilding unchanged sources gave three different .hip_fatbin
+    hashes), so a committed PMC traffic measurement (profiles/*_hbm_traffic.json) stays attached to the code it was taken on across
+    rebuilds.  The first 12 digits do not depend on the box (`sources_part`): a library that travelled to a box with another ROCm still
+    says which sources it was built from."""
+    return _sources_digest() + _compiler_digest()
 
 
 def sources_part(signature: str) -> str:
@@ -57,19 +73,37 @@ def sources_part(signature: str) -> str:
     return signature[:12]
 
 
+def library_signature(path: str = LIB) -> str | None:
+    """The signature a built library carries (the string bg_build_signature() returns), read from the file: the 16 hex digits behind the marker
+    the library stores in front of it.  None for a library without one (an ad-hoc build says "unsigned")."""
+    import re
+    try:
+        with open(path, "rb") as f:
+            m = re.search(rb"bgsig:([0-9a-f]{16})\0", f.read())
+    except OSError:
+        return None
+    return m.group(1).decode() if m else None
+
+
 def needs_build() -> bool:
     """No library, or sources newer than it -- unless the library SAYS it was built from exactly these sources: a snapshot that does not keep
     modification times (a copy, a fresh checkout beside a travelled .so) must not set off a three-minute rebuild of unchanged code, and must not
-    replace the library the committed measurements belong to."""
+    replace the library the committed measurements belong to.  The library's own signature string is compared (not "these 12 digits occur
+    somewhere in the file"); a library of the same sources built by ANOTHER compiler is kept -- it travelled from the build container -- and said so on stderr."""
     if not os.path.exists(LIB):
         return True
     if not any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in DEPS):
         return False
-    try:
-        with open(LIB, "rb") as f:
-            return sources_part(source_signature()).encode() not in f.read()   # (the signature is a string literal of the library: bg_build_signature)
-    except OSError:
+    have = library_signature()
+    if have is None or sources_part(have) != _sources_digest():
         return True
+    try:
+        if have != source_signature():
+            print(f"balatro_gym_amd.build: {LIB} was built from the current sources by another compiler (signature {have}, here {source_signature()}): kept",
+                  file=sys.stderr)
+    except Exception:
+        pass
+    return False
 
 
 def build(force: bool = False, verbose: bool = False, out: str | None = None) -> str:

@@ -217,16 +217,19 @@ __device__ __forceinline__ int bg_level(const Env& e, int ht) { return (int)((e.
 __device__ __forceinline__ uint32_t* bg_gblock(const BgDev& d, int env, int slot) { return d.gblk + ((size_t)env * d.KG + slot) * BG_MTS; }
 // A shop-stream ring slot holds the first BG_SW_T OUTPUT words of random.Random(shop_seed) -- regenerated and tempered by the refill
 // kernel that seeds the stream (word k of the first output block is S[k+397] ^ twist(S[k], S[k+1]) for k < 227: the seeding pass has all
-// three in hand) -- plus the seed: 256 bytes = two lines.  An inventory reads ~11 words (a 24-word window covers the rejection loops of all
-// but one visit in thousands), so 62 words are a visit with three or four rerolls; a visit that reads further re-seeds the FULL state into
-// the env's overflow block once (bg_shop_overflow) and carries on there.  Rounds 1-2 kept the seeded state itself (two 68-word windows,
-// 576 bytes) and the consumer regenerated what it read: 14 scattered 16-byte loads, 24 twists and 31 temperings on the winning play's
-// critical path (~13 k cycles of a play batch); now it is six loads of finished words.
-#define BG_SW_T 62                 // output words per slot
-#define BG_SW_SEED BG_SW_T         // slot word holding the seed
-#define BG_SLOT_WORDS 64           // 62 words + the seed + one of padding = 256 bytes
+// three in hand) --, the TOP BYTES of output words 0..23 packed into six words, and the seed: 256 bytes = two lines.  A FRESH inventory (every
+// generate_shop) looks at nothing but those top bytes (getrandbits(2 / 6 / 8) of consecutive words: bg_shop_inventory), so it reads the slot's
+// last two 16-byte pieces -- ONE line, and small enough to be fetched ahead into the wave's LDS window without a register (bg_prefetch_shop; round 6: it
+// was six pieces of the first 24 words, two lines) --; a rerolled inventory reads ~11 full words from where the last one stopped, so 56 words are a
+// visit with three rerolls; a visit that reads further re-seeds the FULL state into the env's overflow block once (bg_shop_overflow) and
+// carries on there.  Rounds 1-2 kept the seeded state itself (two 68-word windows, 576 bytes) and the consumer regenerated what it read: 14
+// scattered 16-byte loads, 24 twists and 31 temperings on the winning play's critical path (~13 k cycles of a play batch).
+#define BG_SW_T 56                 // output words per slot
+#define BG_SW_PK 56                // slot words 56..61: top byte of output word k in byte k & 3 of word 56 + (k >> 2), k < 24
+#define BG_SW_SEED 62              // slot word holding the seed
+#define BG_SLOT_WORDS 64           // 56 words + 6 packed + the seed + one of padding = 256 bytes
 #define BG_S_FASTMAX (BG_SW_T - 1) // largest k the slot holds
-static_assert(BG_SW_T >= 28 && BG_SW_T + 1 <= BG_SLOT_WORDS && BG_SLOT_WORDS % 4 == 0, "shop slot");
+static_assert(BG_SW_T >= 28 && BG_SW_PK == BG_SW_T && BG_SW_PK % 4 == 0 && BG_SW_PK + 6 == BG_SW_SEED && BG_SW_SEED + 2 == BG_SLOT_WORDS, "shop slot");
 #define BG_BF_SHOP_OVF 4           // bflags: the current shop stream lives in the overflow block (full state)
 __device__ __forceinline__ uint32_t* bg_sblock(const BgDev& d, int env, int slot) { return d.sblk + ((size_t)env * d.KS + slot) * BG_SLOT_WORDS; }
 __device__ __forceinline__ uint32_t* bg_sovf(const BgDev& d, int env) { return d.sovf + (size_t)env * BG_MTS; }
@@ -391,16 +394,54 @@ struct JTables {
 // LDS pointers keep their address space in the type: a generic pointer stored in a struct compiles to FLAT loads (the
 // vector-memory path, ~1-2k cycles when nothing hides it) instead of ds_read (~100 cycles).
 typedef __attribute__((address_space(3))) const JTables lds_JTables;
+// Round 6: the window is also where a service step's LATE global reads are fetched AHEAD without a register (LDS-DMA, `global_load_lds_dword[x4]`:
+// every active lane's 4 / 16 bytes land at wave base + 4 / 16 x lane).  A play's Bloodstone words, the fresh shop slot of a winning play and the reset
+// template of an episode that ends were three DEPENDENT global-memory round trips of ~2 us each under load in the middle of a service batch
+// (profiles/r05/play_probes_at_load.txt); requested early into registers they lost every time (rounds 3 and 5: the registers they hold).  Layout of the
+// 24 words x 64 lanes of a wave (bytes from the wave's base):
+//   [0, 2048)     word slots 0..7 in the window's own [word][lane] layout: the first Bloodstone's candidate word of played card c (bg_prefetch_blood)
+//   [2048, 4096)  two 16-byte pieces per lane, [piece][lane]: the packed top bytes + seed of the NEXT shop slot (bg_prefetch_shop)
+//   [4096, 6144)  two 16-byte pieces per lane: the env's reset template (bg_prefetch_tmpl)
+// The ordinary window users (The Wheel's 16 words, a rerolled shop's 24, Immolate's deck compaction) come later in a step and overwrite them: they
+// call bg_win_quiesce first (a DMA still in flight must not land on top of their words) and the flags below say what is still valid.
+#define BG_WIN_SHOP_W 512    // u32 index of shop piece 0, lane 0
+#define BG_WIN_TMPL_W 1024   // u32 index of template piece 0, lane 0
 struct RngWin {
   lds_JTables* jt;
-  lds_u32* lds;   // &win[0][lane]
+  lds_u32* lds;   // &win[0][lane]; nullptr in kernels without a window (they prefetch nothing)
   int g_blk, g_start, g_len; // window over the global stream: block, first index, words
   int s_start, s_len;        // window over the current shop stream
   bool defer_adv;            // a winning play leaves _advance_round (and the shop it generates) to a second work item
   bool need_inv;             // a shop inventory is due: generated ONCE at the end of the dispatch, whichever action asked for it
+  // What LDS-DMA has put (or is putting) into this lane's part of the window, in ONE word (every live word of a service step is a register the play
+  // path does not have): bits 0..7 ring slot + 1 whose tail pieces are there (0 = none) | 8..10 joker slot + 1 of the Bloodstone whose candidate words
+  // are (0 = none) | 11..18 which of the eight cards' words the ring held | 19 the reset template
+  uint32_t pre;
 };
+#define BG_PRE_SHOP(w) ((int)((w).pre & 0xffu))
+#define BG_PRE_BLOOD(w) ((int)(((w).pre >> 8) & 7u))
+#define BG_PRE_BLOOD_OK(w) (((w).pre >> 11) & 0xffu)
+#define BG_PRE_TMPL 0x80000u
+typedef __attribute__((address_space(3))) void bg_lds_void;
+typedef __attribute__((address_space(1))) const void bg_g_cvoid;
+typedef uint32_t bg_win_u32x4 __attribute__((ext_vector_type(4)));
+// &win[0][0] of this wave (wave-uniform: the LDS-DMA destination); every window is [BG_WIN][BG_BLOCK] of one wave, lane = threadIdx.x mod 64
+__device__ __forceinline__ lds_u32* bg_win_base(const RngWin& w) { return w.lds - (threadIdx.x & (BG_BLOCK - 1)); }
+__device__ __forceinline__ void bg_dma16(const void* src, lds_u32* wave_base) { __builtin_amdgcn_global_load_lds((bg_g_cvoid*)src, (bg_lds_void*)wave_base, 16, 0, 0); }
+__device__ __forceinline__ void bg_dma4(const void* src, lds_u32* wave_base) { __builtin_amdgcn_global_load_lds((bg_g_cvoid*)src, (bg_lds_void*)wave_base, 4, 0, 0); }
+// every LDS-DMA this wave has issued has landed (vmcnt counts them with the other vector-memory loads, in order); the "memory" clobber keeps the LDS reads behind it
+__device__ __forceinline__ void bg_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ bg_win_u32x4 bg_win_piece(const lds_u32* lds_lane, int word0, int p) {   // 16-byte piece p of this lane (behind bg_dma_wait)
+  return *(const __attribute__((address_space(3))) bg_win_u32x4*)(lds_lane + word0 + p * (4 * BG_BLOCK) + 3 * (int)(threadIdx.x & (BG_BLOCK - 1)));   // base + word0 + 256 p + 4 lane
+}
+__device__ __forceinline__ void bg_win_quiesce(RngWin& w) {   // before the window's own users write it
+  if (w.pre) bg_dma_wait();
+  w.pre &= BG_PRE_TMPL;
+}
 __device__ __forceinline__ void bg_win_init(RngWin& w, uint32_t* lds_lane, const JTables* jt = nullptr) {
-  w.jt = (lds_JTables*)jt; w.lds = (lds_u32*)lds_lane; w.g_blk = -1; w.g_start = 0; w.g_len = 0; w.s_start = 0; w.s_len = 0; w.defer_adv = false; w.need_inv = false;
+  w.jt = (lds_JTables*)jt; w.lds = (lds_u32*)lds_lane;
+  w.g_blk = -1; w.g_start = 0; w.g_len = 0; w.s_start = 0; w.s_len = 0; w.defer_adv = false; w.need_inv = false;
+  w.pre = 0;
 }
 __device__ __noinline__ void bg_win_fill(lds_u32* lds, const uint32_t* src, int len) {
 #pragma unroll 1
@@ -498,6 +539,8 @@ __device__ __forceinline__ void bg_gpeek12_raw(const BgDev& d, int env, const En
 __device__ __forceinline__ void bg_gprefetch(const BgDev& d, int env, Env& e, RngWin& w, int count) {
   bg_gnorm(d, e);
   if (e.g_valid <= 0) return;
+  bg_win_quiesce(w);
+  if (count > 16) w.pre &= ~BG_PRE_TMPL;
   int len = BG_MT_N - e.g_idx;
   if (len > count) len = count;
   if (len > BG_WIN) len = BG_WIN;
@@ -589,6 +632,8 @@ __device__ __forceinline__ void bg_sprefetch(const BgDev& d, int env, Env& e, Rn
   if (len > 24) len = 24;
   if (len > BG_WIN) len = BG_WIN;
   if (len < 0) len = 0;
+  bg_win_quiesce(w);
+  if (len > 16) w.pre &= ~BG_PRE_TMPL;
   if (e.s_idx == 0 && len == 24 && !full) bg_swin_fill0(w.lds, S);
   else if (len > 0) bg_swin_fill(w.lds, S, full, e.s_idx, len);
   w.s_start = e.s_idx; w.s_len = len;

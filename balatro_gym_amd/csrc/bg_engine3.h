@@ -57,7 +57,7 @@ struct E3Lds {
   uint32_t s_ans[NE];              // service steps completed for this env in this launch (the owner counts its requests)
   uint32_t s_q[2][NE];             // request rings: env lane | generation of the ring position << 8 | action << 16 | VALID
   __attribute__((aligned(16))) uint32_t s_ctl[8];   // [0..1] requests ever queued per class, [4..5] ever claimed
-  uint32_t s_win[NSV][BG_WIN][BG_BLOCK];
+  __attribute__((aligned(16))) uint32_t s_win[NSV][BG_WIN][BG_BLOCK];   // RNG windows of the service waves + their LDS-DMA prefetch areas (bg_device.h RngWin)
   uint2 s_list[NOW][KS * BG_BLOCK]; // copy-out list of an owner wave: .x = record row, .y = env lane
   // The NEXT pre-shuffled deck of every env (the ring slot a reset will consume) and its state: 0 = not here (the reset reads the ring itself), 1 = here,
   // 2 | slot << 8 = consumed, the owner is to fetch ring slot `slot`.  A reset's copy ring -> deck is a dependent HBM round trip in the middle of a
@@ -496,13 +496,16 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
           for (int k = 0; k < BG_NHOT; k++) if (k != 3 && k != 4) c[k] = d.hot[(size_t)k * N + env];
           c[3] = s_c34[0][l]; c[4] = s_c34[1][l];
           DeckT dk; static_cast<Deck0&>(dk) = bg_load_deck0(d, env);
+          RngWin w;
+          bg_win_init(w, &s_win[sidx][0][lane], &jt);
+          // the env's reset template on its way into the window (LDS-DMA, behind the state loads): an episode that ends in this step -- a batch nearly
+          // always holds one -- finds it there instead of waiting for two loads in the middle of its reset
+          if (a.autoreset) bg_prefetch_tmpl(d, env, w);
           Env e;
           bg_unpack(c, e);
           BG_PROBE(23);
           bg_derive_ready(e, s_prod[l]);
           ShopRegs sr; sr.valid = false;
-          RngWin w;
-          bg_win_init(w, &s_win[sidx][0][lane], &jt);
           StepOut o;
           bg_step_init(o);
           o.bd_dst = nullptr;
@@ -512,7 +515,8 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
           if (o.terminated) n_eps++;
           if (o.terminated && a.autoreset) {
             const bool have = bg_lds_ld(&s_ndst[l]) == 1u;
-            bg_env_reset(d, env, e, dk, nullptr, have ? (lds_cu4*)&s_nd[0][l] : (lds_cu4*)nullptr, NE);
+            // (the template is in the window unless a rerolled shop's 24 words or The Wheel's have taken its place: then the reset loads it)
+            bg_env_reset(d, env, e, dk, nullptr, have ? (lds_cu4*)&s_nd[0][l] : (lds_cu4*)nullptr, NE, TmplWin{w.lds, (w.pre & BG_PRE_TMPL) != 0u});
             // the slot after it, if the ring (as this launch may see it) holds one: the env's owner fetches it
             bg_lds_st(&s_ndst[l], e.d_ready > 0 ? (2u | ((uint32_t)e.d_head << 8)) : 0u);
           }

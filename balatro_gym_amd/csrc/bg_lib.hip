@@ -105,7 +105,8 @@ static_assert(BG_MT_N % 16 == 0, "624 = 39 blocks of 16");
 static constexpr BgGenrandTab BG_GENRAND{};
 
 // SLOT = false: the whole seeded state (156 16-byte stores).  SLOT = true: a shop-stream ring slot -- the first BG_SW_T OUTPUT words of
-// the stream, tempered, plus the seed (bg_device.h): output word k = temper(S[k+397] ^ twist(S[k], S[k+1])).  The pass produces S in index
+// the stream, tempered, then the TOP BYTES of output words 0..23 packed into six words (BG_SW_PK: all a fresh inventory looks at, bg_shop_inventory --
+// two 16-byte pieces of ONE line instead of six of two), then the seed (bg_device.h): output word k = temper(S[k+397] ^ twist(S[k], S[k+1])).  The pass produces S in index
 // order, so the near words S[2..63] are parked RAW in the slot as they appear (blocks 0..3) and, when S[k+397] appears (blocks 24..28),
 // read back (they are this lane's own stores of ~20 000 cycles ago), combined, tempered and written over S[k] -- which nothing needs any
 // more.  S[1] is the last word the seeding produces, so outputs 0 and 1 (and the group they share with 2 and 3) are written at the end.
@@ -136,6 +137,7 @@ __device__ __forceinline__ void bg_mt_seed_impl(uint32_t* p, uint32_t key) {
   a = (BG_GENRAND.blk[0].v[1] ^ ((a ^ (a >> 30)) * 1664525u)) + key; // pass-1 mt[1] (before the wrap)
   uint32_t bprev = a1w, w2 = 0, w3 = 0;
   uint32_t far0 = 0, far1 = 0, out2 = 0, out3 = 0;   // SLOT: S[397], S[398]; output words 2 and 3 (group 0 is written last)
+  uint32_t pk[6] = {0u, 0u, 0u, 0u, 0u, 0u};         // SLOT: top byte of output word k -> byte k & 3 of pk[k >> 2], k < 24
   {
     BgG16 cur = BG_GENRAND.blk[0];
 #pragma unroll 1
@@ -184,6 +186,7 @@ __device__ __forceinline__ void bg_mt_seed_impl(uint32_t* p, uint32_t key) {
               if (k < BG_SW_T) {
                 const uint32_t o = bg_temper(bg_twist(nr[3 + c], nr[4 + c], v[c]));
                 if (k == 3) out3 = o; else p[k] = o;       // S[k] is dead: its place takes the output word
+                if (k < 24) pk[k >> 2] |= (o >> 24) << (8 * (k & 3));
               }
             }
           }
@@ -195,107 +198,17 @@ __device__ __forceinline__ void bg_mt_seed_impl(uint32_t* p, uint32_t key) {
   const uint32_t w1 = (a1w ^ ((bprev ^ (bprev >> 30)) * 1566083941u)) - 1u; // mt[0] = mt[623], wrapped step at i = 1
   if constexpr (!SLOT) p4[0] = make_uint4(0x80000000u, w1, w2, w3);
   else {
-    p4[0] = make_uint4(bg_temper(bg_twist(0x80000000u, w1, far0)), bg_temper(bg_twist(w1, w2, far1)), out2, out3);
-    p[BG_SW_SEED] = key;
+    const uint32_t out0 = bg_temper(bg_twist(0x80000000u, w1, far0)), out1 = bg_temper(bg_twist(w1, w2, far1));
+    p4[0] = make_uint4(out0, out1, out2, out3);
+    pk[0] |= (out0 >> 24) | ((out1 >> 24) << 8) | ((out2 >> 24) << 16) | (out3 & 0xff000000u);
+    // the slot's last two 16-byte groups (the raw S[56..63] parked there have been read back by block 28): packed top bytes, seed, padding
+    static_assert(BG_SW_PK == 56 && BG_SW_SEED == 62 && BG_SLOT_WORDS == 64, "slot tail layout");
+    p4[BG_SW_PK / 4] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+    p4[BG_SW_PK / 4 + 1] = make_uint4(pk[4], pk[5], key, 0u);
   }
 }
 __device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) { bg_mt_seed_impl<false>(p, key); }
 __device__ void bg_mt_seed_slot(uint32_t* __restrict__ p, uint32_t key) { bg_mt_seed_impl<true>(p, key); }
-
-// The slot seeding for NS streams per lane, interleaved step by step (the measurement VERDICT r4 #9 asked for: does instruction-level parallelism
-// across streams shorten the quarter-rate multiply chains?  BG_SHOP_ILP=2 selects it; profiles/r05/shop_seeding_ilp.txt).  Same arithmetic as
-// bg_mt_seed_impl<true>, every per-stream scalar an array of NS.
-template <int NS>
-__device__ __forceinline__ void bg_mt_seed_slot_n(uint32_t* const (&p)[NS], const uint32_t (&key)[NS]) {
-  constexpr int NB = BG_MT_N / 16;
-  uint32_t a[NS], a1[NS];
-#pragma unroll
-  for (int s = 0; s < NS; s++) { a[s] = BG_GENRAND.blk[0].v[0]; a1[s] = 0; }
-  {
-    BgG16 cur = BG_GENRAND.blk[0];
-#pragma unroll 1
-    for (int b = 0; b < NB; b++) {
-      const BgG16 nxt = BG_GENRAND.blk[b + 1 < NB ? b + 1 : NB - 1];
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-        if (b > 0 || c >= 1) {
-#pragma unroll
-          for (int s = 0; s < NS; s++) {
-            a[s] = (cur.v[c] ^ ((a[s] ^ (a[s] >> 30)) * 1664525u)) + key[s];
-            if (b == 0 && c == 1) a1[s] = a[s];
-          }
-        }
-      }
-      cur = nxt;
-    }
-  }
-  uint32_t a1w[NS], bprev[NS], w2[NS], w3[NS], far0[NS], far1[NS], out2[NS], out3[NS];
-#pragma unroll
-  for (int s = 0; s < NS; s++) {
-    a1w[s] = (a1[s] ^ ((a[s] ^ (a[s] >> 30)) * 1664525u)) + key[s];
-    a[s] = BG_GENRAND.blk[0].v[0];
-    a[s] = (BG_GENRAND.blk[0].v[1] ^ ((a[s] ^ (a[s] >> 30)) * 1664525u)) + key[s];
-    bprev[s] = a1w[s]; w2[s] = w3[s] = far0[s] = far1[s] = out2[s] = out3[s] = 0;
-  }
-  {
-    BgG16 cur = BG_GENRAND.blk[0];
-#pragma unroll 1
-    for (int b = 0; b < NB; b++) {
-      const BgG16 nxt = BG_GENRAND.blk[b + 1 < NB ? b + 1 : NB - 1];
-      uint32_t v[NS][16];
-#pragma unroll
-      for (int c = 0; c < 16; c++) {
-#pragma unroll
-        for (int s = 0; s < NS; s++) {
-          v[s][c] = 0;
-          if (b > 0 || c >= 2) {
-            a[s] = (cur.v[c] ^ ((a[s] ^ (a[s] >> 30)) * 1664525u)) + key[s];
-            bprev[s] = (a[s] ^ ((bprev[s] ^ (bprev[s] >> 30)) * 1566083941u)) - (uint32_t)(16 * b + c);
-            v[s][c] = bprev[s];
-          }
-        }
-      }
-#pragma unroll
-      for (int s = 0; s < NS; s++) {
-        uint4* p4 = (uint4*)p[s];
-        if (b == 0) { w2[s] = v[s][2]; w3[s] = v[s][3]; }
-        if (b < 4) {
-#pragma unroll
-          for (int k = 0; k < 4; k++) if (4 * b + k > 0) p4[4 * b + k] = make_uint4(v[s][4 * k], v[s][4 * k + 1], v[s][4 * k + 2], v[s][4 * k + 3]);
-        } else if (b >= 24 && b <= 28) {
-          const int kb = 16 * b - BG_MT_M;
-          if (b == 24) { far0[s] = v[s][13]; far1[s] = v[s][14]; out2[s] = bg_temper(bg_twist(w2[s], w3[s], v[s][15])); }
-          else {
-            const int g0 = kb >> 2;
-            uint32_t nr[20];
-#pragma unroll
-            for (int g = 0; g < 5; g++) {
-              uint4 t = make_uint4(0u, 0u, 0u, 0u);
-              if (g0 + g > 0 && g0 + g < BG_SLOT_WORDS / 4) t = p4[g0 + g];
-              nr[4 * g] = t.x; nr[4 * g + 1] = t.y; nr[4 * g + 2] = t.z; nr[4 * g + 3] = t.w;
-            }
-            if (b == 25) nr[3] = w3[s];
-#pragma unroll
-            for (int c = 0; c < 16; c++) {
-              const int k = kb + c;
-              if (k < BG_SW_T) {
-                const uint32_t o = bg_temper(bg_twist(nr[3 + c], nr[4 + c], v[s][c]));
-                if (k == 3) out3[s] = o; else p[s][k] = o;
-              }
-            }
-          }
-        }
-      }
-      cur = nxt;
-    }
-  }
-#pragma unroll
-  for (int s = 0; s < NS; s++) {
-    const uint32_t w1 = (a1w[s] ^ ((bprev[s] ^ (bprev[s] >> 30)) * 1566083941u)) - 1u;
-    ((uint4*)p[s])[0] = make_uint4(bg_temper(bg_twist(0x80000000u, w1, far0[s])), bg_temper(bg_twist(w1, w2[s], far1[s])), out2[s], out3[s]);
-    p[s][BG_SW_SEED] = key[s];
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------------
 // Lazy MT19937 for the streams only the refill kernels read (deck shuffles, shop seeds).  genrand_uint32() regenerates
@@ -630,35 +543,12 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_seedring_kernel(BgDev d, B
 // `random.Random(shop_seed)` (shop.py:96): one stream per lane, pure ALU + 156 stores.  The slot holds the SEEDED state;
 // the consumer regenerates the few words a shop visit reads (bg_sprefetch), so no block twist is ever run for a shop.
 __global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop_kernel(BgDev d, BgPart pt) {
-#ifdef BG_SHOP_VGPR128
-  asm volatile("v_mov_b32 v127, 0" ::: "v127"); // development: at most 2 of these waves on the SIMD the step engine leaves free
-#endif
-#ifdef BG_SHOP_VGPR200
-  asm volatile("v_mov_b32 v199, 0" ::: "v199");
-#endif
   const uint32_t count0 = d.wl_count[3], lo = bg_part_lo(count0, pt), count = bg_part_hi(count0, pt);
   for (uint32_t item = lo + blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
     uint32_t es = d.wl_shop[2 * (size_t)item], seed = d.wl_shop[2 * (size_t)item + 1];
     bg_mt_seed_slot(bg_sblock(d, (int)(es & 0xffffffu), (int)(es >> 24)), seed);
   }
 }
-// the same with TWO streams per lane, interleaved (BG_SHOP_ILP=2: a measurement, see bg_mt_seed_slot_n); an odd last item is seeded alone
-__global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop2_kernel(BgDev d) {
-  const uint32_t count = d.wl_count[3], pairs = count >> 1;
-  for (uint32_t q = blockIdx.x * BG_BLOCK + threadIdx.x; q < pairs; q += gridDim.x * BG_BLOCK) {
-    const uint32_t e0 = d.wl_shop[4 * (size_t)q], s0 = d.wl_shop[4 * (size_t)q + 1], e1 = d.wl_shop[4 * (size_t)q + 2], s1 = d.wl_shop[4 * (size_t)q + 3];
-    uint32_t* const p[2] = {bg_sblock(d, (int)(e0 & 0xffffffu), (int)(e0 >> 24)), bg_sblock(d, (int)(e1 & 0xffffffu), (int)(e1 >> 24))};
-    const uint32_t key[2] = {s0, s1};
-    bg_mt_seed_slot_n<2>(p, key);
-  }
-  if ((count & 1u) && blockIdx.x == 0 && threadIdx.x == 0) {
-    const uint32_t es = d.wl_shop[2 * (size_t)(count - 1)], seed = d.wl_shop[2 * (size_t)(count - 1) + 1];
-    uint32_t* const p1[1] = {bg_sblock(d, (int)(es & 0xffffffu), (int)(es >> 24))};
-    const uint32_t key1[1] = {seed};
-    bg_mt_seed_slot_n<1>(p1, key1);   // (not bg_mt_seed_slot: a second call site would stop its inlining into bg_refill_shop_kernel -- 56 -> 70 VGPRs there)
-  }
-}
-
 // Next 624-word block(s) of the per-env global stream, ONE WAVE PER ENV: lane l holds words l, l + 64, ... of the block (ten
 // registers), so the block is read and written as ten 256-byte rows (a lane per env read 16 bytes of 64 different blocks per
 // instruction), word k+1 and word k+397 / k-227 come from other lanes (`__shfl`), and a block that is twisted again stays in
@@ -799,7 +689,7 @@ struct bg_handle {
   std::vector<hipEvent_t> ev_rollout_t, ev_refill_t, ev_step_t; // start/stop pairs
   std::vector<int> rollout_steps;                         // fused steps of each timed rollout launch
   // tunables read ONCE per handle in bg_create (environment variables)
-  int refill_blocks, refill_blocks_shop, dev_skip_refill, refill_order, refill_min, shop_ilp;
+  int refill_blocks, refill_blocks_shop, dev_skip_refill, refill_order, refill_min;
   // a refill in PIECES (bg_refill_pieces): the kernels of refill #(refill_seq - 1) that are still to be issued, one (or a few) beside every short launch
   struct RefillPiece { int kind; uint32_t part, nparts; int grid; uint32_t cursor, max_made; };   // kind: 0 deck, 1 seed ring, 2 global blocks, 3 shop streams
   std::vector<RefillPiece> pieces;
@@ -886,7 +776,9 @@ static double bg_ev_sum(bg_handle* h, std::vector<hipEvent_t>& v) {
 extern "C" {
 
 // sha256 prefix of the sources + flags + compiler this library was built from (balatro_gym_amd/build.py source_signature()); "unsigned" for ad-hoc builds
-const char* bg_build_signature(void) { return BG_BUILD_SIGNATURE; }
+// (stored behind a marker so that build.py can read the signature OF THE LIBRARY out of the file without loading it: build.library_signature)
+static const char bg_sig_marker[] = "bgsig:" BG_BUILD_SIGNATURE;
+const char* bg_build_signature(void) { return bg_sig_marker + 6; }
 
 // development hook: copy (and clear) the 16 phase counters written by -DBG_TIMING builds
 int bg_debug_counters(bg_handle* h, unsigned long long* out16) {
@@ -970,7 +862,6 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     h->refill_blocks = geti("BG_REFILL_BLOCKS", 4096); h->refill_blocks_shop = geti("BG_REFILL_BLOCKS_SHOP", 0);
     h->dev_skip_refill = geti("BG_DEV_SKIP_REFILL", 0);
     h->refill_order = geti("BG_REFILL_ORDER", 2);
-    h->shop_ilp = geti("BG_SHOP_ILP", 1);   // 2: the shop-seeding kernel with two streams per lane (a measurement; profiles/r05/shop_seeding_ilp.txt)
     // BG_REFILL_MIN = m > 0: a rollout launch of >= m steps (since the last refill) takes a refill beside it.  Default 0 = only when the rings demand one:
     // 20 steps' worth of refill is ~320 us of five small latency-bound kernels against 129 us per 20 steps in bulk (profiles/r05/refill_policy_ab.txt:
     // a refill beside every 20-step launch costs 21 % of the sustained rate)
@@ -1197,7 +1088,7 @@ static int bg_refill_on(bg_handle* h, hipStream_t s, int steps_hint = -1, bool s
   // beside a resident step-engine workgroup (only one SIMD per CU has free registers) -- the whole refill would wait for the engine
   hipLaunchKernelGGL(bg_refill_zero_kernel, dim3(1), dim3(BG_BLOCK), 0, s, d);
   hipLaunchKernelGGL(bg_refill_scan_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, d);
-  if (sliced && s == h->side && h->shop_ilp != 2 && h->dev_skip_refill == 0) {
+  if (sliced && s == h->side && h->dev_skip_refill == 0) {
     bg_ev_end(h, h->ev_refill_t, s);
     BG_HIP(hipGetLastError());
     h->pieces.clear(); h->piece_next = 0; h->piece_dev = d;
@@ -1251,7 +1142,7 @@ static int bg_refill_on(bg_handle* h, hipStream_t s, int steps_hint = -1, bool s
   // one after the other on `s` (a kernel's duration is then its own work, not its wait for a neighbour's registers)
   const bool shop_last = h->refill_order >= 1, serial = h->refill_order == 2;
   hipStream_t s_deck = serial ? s : h->side2, s_blk = serial ? s : h->side3;
-  if (!shop_last && !(skip & 1)) { if (h->shop_ilp == 2) hipLaunchKernelGGL(bg_refill_shop2_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); else hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d, whole); } // lowest-priority stream
+  if (!shop_last && !(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d, whole); // lowest-priority stream
   if (!(skip & 2)) hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_deck, d, whole, 4u, 0u);
   if (!(skip & 4)) hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_blk, d, whole);
   if (!(skip & 8)) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(dense), dim3(BG_BLOCK), 0, s_blk, d, whole);
@@ -1261,7 +1152,7 @@ static int bg_refill_on(bg_handle* h, hipStream_t s, int steps_hint = -1, bool s
     BG_HIP(hipStreamWaitEvent(s, h->ev_deck, 0));
     BG_HIP(hipStreamWaitEvent(s, h->ev_gblk, 0));
   }
-  if (shop_last && !(skip & 1)) { if (h->shop_ilp == 2) hipLaunchKernelGGL(bg_refill_shop2_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d); else hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d, whole); }
+  if (shop_last && !(skip & 1)) hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(dense_shop), dim3(BG_BLOCK), 0, s, d, whole);
   bg_ev_end(h, h->ev_refill_t, s);
   BG_HIP(hipGetLastError());
   BG_HIP(hipEventRecord(h->ev_refill[h->refill_seq & 1], s));
@@ -1528,6 +1419,7 @@ int bg_observe_rows(bg_handle* h, uint8_t* rows_dev, uint64_t row_stride_bytes, 
   BG_GUARD(h);
   ObsPtrs o = bg_obs(nullptr);
   o.rows = rows_dev; o.row_stride = (uint32_t)row_stride_bytes;
+  { const int rcw = bg_wait_refill(h, (hipStream_t)stream, 0); if (rcw) return rcw; }   // the view read below is the latest refill's: all of it must have run
   hipLaunchKernelGGL(bg_observe_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), o);
   BG_HIP(hipGetLastError());
   return 0;
@@ -1536,6 +1428,7 @@ int bg_observe_rows(bg_handle* h, uint8_t* rows_dev, uint64_t row_stride_bytes, 
 int bg_observe(bg_handle* h, const bg_obs_ptrs* obs, void* stream) {
   if (!h) return BG_E_ARG;
   BG_GUARD(h);
+  { const int rcw = bg_wait_refill(h, (hipStream_t)stream, 0); if (rcw) return rcw; }
   hipLaunchKernelGGL(bg_observe_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, (hipStream_t)stream, bg_dev_view(h, bg_prod_latest(h)), bg_obs(obs));
   BG_HIP(hipGetLastError());
   return 0;
@@ -1797,6 +1690,7 @@ int bg_inject(bg_handle* h, const int32_t* jokers_host, const int32_t* njokers_h
   BG_HIP(hipMemcpyAsync(h->dev.tmpl, h->h_tmpl.data(), BG_NTMPL * N * sizeof(uint4), hipMemcpyHostToDevice, s));
   if (apply_now) {
     if (mask_host) BG_HIP(hipMemcpyAsync(h->d_mask, mask_host, N, hipMemcpyHostToDevice, s));
+    { const int rcw = bg_wait_refill(h, s, 0); if (rcw) return rcw; }
     hipLaunchKernelGGL(bg_inject_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, bg_dev_view(h, bg_prod_latest(h)),
                        mask_host ? (const uint8_t*)h->d_mask : (const uint8_t*)nullptr);
     BG_HIP(hipGetLastError());
@@ -1829,6 +1723,7 @@ int bg_inject_consumables(bg_handle* h, const int32_t* ids_host, const int32_t* 
   BG_HIP(hipMemcpyAsync(h->dev.tmpl, h->h_tmpl.data(), BG_NTMPL * N * sizeof(uint4), hipMemcpyHostToDevice, s));
   if (apply_now) {
     if (mask_host) BG_HIP(hipMemcpyAsync(h->d_mask, mask_host, N, hipMemcpyHostToDevice, s));
+    { const int rcw = bg_wait_refill(h, s, 0); if (rcw) return rcw; }
     hipLaunchKernelGGL(bg_inject_kernel, dim3(bg_grid(h)), dim3(BG_BLOCK), 0, s, bg_dev_view(h, bg_prod_latest(h)),
                        mask_host ? (const uint8_t*)h->d_mask : (const uint8_t*)nullptr);
     BG_HIP(hipGetLastError());
@@ -1859,7 +1754,7 @@ uint64_t bg_state_blob_bytes(const bg_handle* h) {
   return b;
 }
 #define BG_BLOB_MAGIC 0x42474d58u
-#define BG_BLOB_VERSION 6u // 6: shop-stream slots hold finished output words (256 bytes); 5: 576-byte shop-stream slots; 4: the curriculum cap in the hot state, card-state flag in the header; 3: compact shop-stream slots + overflow block; 2: stream 13 ('seal_applications') joins the card-state slices, consumables in the reset template
+#define BG_BLOB_VERSION 7u // 7: a shop-stream slot = 56 output words + the packed top bytes of the first 24 + the seed; 6: shop-stream slots hold finished output words (256 bytes); 5: 576-byte shop-stream slots; 4: the curriculum cap in the hot state, card-state flag in the header; 3: compact shop-stream slots + overflow block; 2: stream 13 ('seal_applications') joins the card-state slices, consumables in the reset template
 // what is wrong with a blob handed to bg_set_state (or with the buffer handed to bg_get_state), as text
 static int bg_blob_args(bg_handle* h, const char* fn, int env_index, const void* blob, uint64_t blob_bytes) {
   if (!h) return BG_E_ARG;
@@ -1878,6 +1773,10 @@ int bg_get_state(bg_handle* h, int env_index, void* blob_host, uint64_t blob_byt
   int rc = bg_blob_args(h, "bg_get_state", env_index, blob_host, blob_bytes);
   if (rc) return rc;
   BG_GUARD(h);
+  // a refill issued in pieces (bg_refill_pieces) has already advanced the producer counters the blob copies (the scan did): the dense kernels that fill
+  // those ring slots must have RUN before the state is read -- issue what is pending, then wait for the device
+  rc = bg_refill_pieces(h, 1 << 30);
+  if (rc) return rc;
   BG_HIP(hipDeviceSynchronize());
   uint8_t* out = (uint8_t*)blob_host;
   uint32_t hdr[4] = {BG_BLOB_MAGIC, BG_BLOB_VERSION, (uint32_t)h->dev.KG | (h->dev.cstate ? 0x10000u : 0u), (uint32_t)h->dev.KS | ((uint32_t)h->dev.KD << 16)};
@@ -1906,6 +1805,10 @@ int bg_set_state(bg_handle* h, int env_index, const void* blob_host, uint64_t bl
              (hdr[2] & 0x10000u) ? " + card states" : "", h->dev.KG, h->dev.KS, h->dev.KD, h->dev.cstate ? " + card states" : "");
     h->err = buf; return BG_E_ARG;
   }
+  // pending refill pieces hold work items of the state that is about to be replaced (shop seeds listed by the scan): they must write their ring slots
+  // BEFORE the blob lands, not on top of it
+  rc = bg_refill_pieces(h, 1 << 30);
+  if (rc) return rc;
   BG_HIP(hipDeviceSynchronize());
   std::vector<BgSlice> v;
   bg_slices(h, v);

@@ -85,11 +85,20 @@ __device__ __forceinline__ uint64_t bg_action_mask(const BgDev& d, int env, cons
 // `pv`: the same in LDS (bg_engine3.h keeps the next deck of every env there), chunk k at pv[k * pv_stride]
 typedef uint32_t bg_pv_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const bg_pv_u32x4 lds_cu4;
+// `tw`: the window of a service wave that fetched the env's reset template ahead by LDS-DMA (bg_prefetch_tmpl); not fetched (or no window): loaded here.
+// (By value: a pointer to the caller's RngWin put the whole struct into scratch memory.)
+struct TmplWin { lds_u32* lds; bool have; };
 template <class DK>
-__device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, DK& dk, const uint4* pre = nullptr, lds_cu4* pv = nullptr, int pv_stride = 0) {
+__device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, DK& dk, const uint4* pre = nullptr, lds_cu4* pv = nullptr, int pv_stride = 0,
+                                             const TmplWin tw = TmplWin{nullptr, false}) {
   // the reset template (applied at the end) is requested FIRST: its HBM round trip then runs beside the cold stores and the deck copy instead of
   // behind them (the compiler cannot move a load above stores through other pointers)
-  const uint4 t0 = d.tmpl[env], t1 = d.tmpl[(size_t)d.N + env];
+  uint4 t0, t1;
+  if (tw.have) {
+    bg_dma_wait();
+    const bg_win_u32x4 a = bg_win_piece(tw.lds, BG_WIN_TMPL_W, 0), b = bg_win_piece(tw.lds, BG_WIN_TMPL_W, 1);
+    t0 = make_uint4(a.x, a.y, a.z, a.w); t1 = make_uint4(b.x, b.y, b.z, b.w);
+  } else { t0 = d.tmpl[env]; t1 = d.tmpl[(size_t)d.N + env]; }
   e.ante = 1; e.round = 1; e.phase = 2; e.chips_needed = 300; e.chips_scored = 0; e.round_chips = 0; e.money = 4;
   e.hand = 0; e.nhand = 0; e.sel = 0; e.nsel = 0; e.hands_left = 4; e.discards_left = 3; e.hand_size = 8;
   e.njokers = 0; e.jokers = 0; e.ncons = 0; e.cons0 = 0; e.cons1 = 0; e.n_magic = 0; e.n_minim = 0;
@@ -182,13 +191,16 @@ __device__ __forceinline__ uint32_t bg_movemask4(uint32_t f) { return (((f >> 7)
 
 __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& e, RngWin& w, ShopRegs& sr) {
   BG_PROBE_BEGIN();
-  // the 24 words of a fresh stream are REQUESTED first (six independent 16-byte loads) and looked at behind the cost factor and the sorted joker
-  // list: ~200 instructions that do not need them
   bool full_state;
   const uint32_t* S = bg_sbase(d, env, e, full_state);
   const bool fresh = e.s_idx == 0 && !full_state;
-  uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0, q2 = q0, q3 = q0, q4 = q0, q5 = q0;
-  if (fresh) { const uint4* S4 = (const uint4*)S; q0 = S4[0]; q1 = S4[1]; q2 = S4[2]; q3 = S4[3]; q4 = S4[4]; q5 = S4[5]; }
+  // A FRESH stream (every generate_shop): every draw looks at the TOP BYTE of its word only -- getrandbits(2) = byte >> 6, getrandbits(8) = byte,
+  // getrandbits(6) = byte >> 2 -- and the slot's tail holds exactly those, packed by the seeding kernel (BG_SW_PK: six words): two 16-byte pieces of one
+  // line.  A play that wins had them fetched into the wave's window at its start (bg_prefetch_shop, no register held them); any other way here (a
+  // skipped blind) REQUESTS them first and looks at them behind the cost factor and the sorted joker list: ~200 instructions that do not need them.
+  const bool prefetched = fresh && BG_PRE_SHOP(w) == e.s_cur + 1;
+  uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
+  if (fresh && !prefetched) { const uint4* S4 = (const uint4*)(S + BG_SW_PK); q0 = S4[0]; q1 = S4[1]; }
   double mult = bg_shop_cost_mult(e, w.jt);
   const uint64_t sj = bg_sorted_jokers(e);
   int owned145 = 0;
@@ -201,13 +213,15 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
   // instead classify the next 24 words at once (one acceptance mask per kind of draw) and walk the masks with ffs.
   int third_r = 0, p0 = 0, p1 = 0, p2 = 0, v = 0, ca = 0, cb = 0;
   bool fast = false;
-  // Round 5, a FRESH stream (every generate_shop): every draw looks at the TOP BYTE of its word only -- getrandbits(2) = byte >> 6, getrandbits(8) = byte,
-  // getrandbits(6) = byte >> 2 -- so the 24 words (six 16-byte loads of finished, tempered words) are packed into six registers of top bytes as they
-  // arrive and classified four bytes at a time (SWAR): no LDS window, no 24 dependent LDS reads, a quarter of the instructions.  (It was ~1 000
-  // instructions and three memory phases -- ~15 k cycles in nearly every play batch, since a batch of 20-30 plays nearly always holds a won blind.)
+  // The 24 top bytes are classified four at a time (SWAR): no LDS window of words, no 24 dependent LDS reads.  (Round 4: ~1 000 instructions and three
+  // memory phases -- ~15 k cycles in nearly every play batch, since a batch of 20-30 plays nearly always holds a won blind.)
   if (fresh) {
-    auto top = [](const uint4 q) { return (q.x >> 24) | ((q.y >> 24) << 8) | ((q.z >> 24) << 16) | (q.w & 0xff000000u); };
-    const BgPk6 pk{top(q0), top(q1), top(q2), top(q3), top(q4), top(q5)};
+    if (prefetched) {
+      bg_dma_wait();
+      const bg_win_u32x4 a = bg_win_piece(w.lds, BG_WIN_SHOP_W, 0), b = bg_win_piece(w.lds, BG_WIN_SHOP_W, 1);
+      q0 = make_uint4(a.x, a.y, a.z, a.w); q1 = make_uint4(b.x, b.y, b.z, b.w);
+    }
+    const BgPk6 pk{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
     BG_PROBE(18);
     const uint32_t H = 0x80808080u;
     const uint32_t addnc = (0x80u - (nc & 0x7fu)) * 0x01010101u;   // nc = 140..145 has bit 7 set: byte >= nc <=> bit 7 and low seven bits >= nc & 127
@@ -245,6 +259,7 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
     ca = (int)(bg_pk_byte(pk, i5 & 31) >> 2); cb = (int)(bg_pk_byte(pk, i6 & 31) >> 2);
     if (fast) e.s_idx += i6 + 1;
     w.s_start = e.s_idx; w.s_len = 0; w.g_len = 0; w.g_blk = -1;   // (as bg_sprefetch leaves the window: nothing of either stream is in it)
+    w.pre &= ~0xffu;
   }
   if (!fast) bg_sprefetch(d, env, e, w, 24); // shop.py:111-139: a rerolled stream (or the overflow block), or the one visit in thousands whose rejections outrun 24 words
   if (!fast) { // window too short for this lane's rejections (or no window): the plain loops
@@ -476,6 +491,43 @@ __device__ __forceinline__ void bg_boss_on_hand_drawn(const BgDev& d, int env, E
   }
 }
 
+// ---- LDS-DMA prefetches of a step's late global reads (bg_device.h RngWin; round 6) --------------------------------------------------------------
+// the NEXT shop slot's tail (packed top bytes of its first 24 words + seed): what a play that beats the blind will read ~30 k cycles from now
+__device__ __forceinline__ void bg_prefetch_shop(const BgDev& d, int env, const Env& e, RngWin& w) {
+  if (e.s_ready > 0) {
+    const int nxt = (e.s_cur + 1 == d.KS) ? 0 : e.s_cur + 1;
+    const uint32_t* p = bg_sblock(d, env, nxt) + BG_SW_PK;
+    lds_u32* const base = bg_win_base(w);
+    bg_dma16(p, base + BG_WIN_SHOP_W);
+    bg_dma16(p + 4, base + BG_WIN_SHOP_W + 4 * BG_BLOCK);
+    w.pre = (w.pre & ~0xffu) | (uint32_t)(nxt + 1);
+  }
+}
+// The FIRST Bloodstone's candidate words: pair (card c, joker slot jb) draws its random() 2 * (c * nj + jb) words ahead of the cursor (no 8 Ball owned:
+// nothing shifts them), and x2 is decided by the top bit of that ONE word (bg_joker_chain) -- one dword per played card, whether it turns out to be a
+// Heart or not (that is known behind the gather; the words share one or two lines), into word slot c of the window.
+__device__ __forceinline__ void bg_prefetch_blood(const BgDev& d, int env, const Env& e, RngWin& w, int ncards, int jb) {
+  const int nj = e.njokers;
+  uint32_t okm = 0;
+  lds_u32* const base = bg_win_base(w);
+#pragma unroll
+  for (int c = 0; c < 8; c++) {
+    if (c < ncards) {
+      bool ok;
+      const uint32_t* p = bg_gpeek_addr(d, env, e, 2 * (c * nj + jb), ok);
+      if (ok) { bg_dma4(p, base + c * BG_BLOCK); okm |= 1u << c; }
+    }
+  }
+  w.pre = (w.pre & ~0x7ff00u) | ((uint32_t)(jb + 1) << 8) | (okm << 11);
+}
+__device__ __forceinline__ void bg_prefetch_tmpl(const BgDev& d, int env, RngWin& w) {
+  lds_u32* const base = bg_win_base(w);
+  bg_dma16(&d.tmpl[env], base + BG_WIN_TMPL_W);
+  bg_dma16(&d.tmpl[(size_t)d.N + env], base + BG_WIN_TMPL_W + 4 * BG_BLOCK);
+  w.pre |= BG_PRE_TMPL;
+}
+
+
 // unified_scoring.py:174-244: the joker chain of one scored hand -- individual phase (card-major, joker-minor), then the
 // main phase in joker order -- with the eager RNG draws of complete_joker_effects.py:42,161.  What it needs of
 // the hand is a few small histograms (ChainIn).  GENERAL = false is the step path (bg_step_play_hand: scoring cards == cards,
@@ -495,16 +547,7 @@ struct ChainIn {
 // The main phase's 12 candidate words, requested EARLY (bg_step_play_hand issues the loads before it gathers and classifies the
 // cards, so their HBM round trip runs beside ~5k cycles of LDS work instead of after it): valid when `skip` equals the number
 // of words the individual phase turns out to consume.
-// tl: LINE TOUCHES for the owners of an 8 Ball (the main phase's words then sit 2 words further per 8 played and per 8 Ball: known only after
-// the gather, but inside a span of <= 52 words) and of a Bloodstone (one word per Heart played, somewhere in the individual phase's words):
-// one dword per 128-byte line of the span, requested with the early words, so that the exact loads -- issued once the cards are known --
-// come from the L2 (~400 cycles beside the record stream) instead of HBM (~3 000: tools/micro/readlat.hip).  Only owners issue them: the
-// chip's random-line read rate is nearly spent, a touch of a line that is only probably needed costs every other load more than it saves.
-struct ChainPeek { uint32_t mw[12]; uint32_t avail; int skip; bool ok;
-#ifdef BG_CHAIN_TOUCH
-  uint32_t tl[5];
-#endif
-};
+struct ChainPeek { uint32_t mw[12]; uint32_t avail; int skip; bool ok; };
 // One joker's share of the individual phase: matching cards = sum of the histogram nibbles selected by the rank mask, or the
 // suit's count; (chips, mult) = count x the descriptor's constants; x2 per matching card for Triboulet.  sp = the descriptor's
 // "special" field (1 = 8 Ball, 2 = Bloodstone: settled card by card from the RNG words).
@@ -675,9 +718,6 @@ __device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, 
     for (int i = 0; i < 12; i++) mw[i] = pre->mw[i];
     avail = pre->avail;
   } else bg_gpeek12_raw(d, env, e, consumed, mw, avail);
-#ifdef BG_CHAIN_TOUCH
-  if (pre) asm volatile("" ::"v"(pre->tl[0]), "v"(pre->tl[1]), "v"(pre->tl[2]), "v"(pre->tl[3]), "v"(pre->tl[4])); // the touched words are dead: the touches have landed
-#endif
 #pragma unroll 1
   while (mm) {
     const int jb = __ffs((int)mm) - 1;
@@ -692,22 +732,32 @@ __device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, 
       boff[c] = bg_chain_blood_off(c, code, st, n, nj, jb, m8, nb8, true, eights);
       if (c < n && nb8 && !st && rk == 8) eights++;
     }
-    // eight loads side by side (unconditional, from a harmless address where there is no word), looked at together: as eight `if (...) bg_gpeek()`
-    // every Heart was a branch region with its own wait -- up to five HBM round trips in a row inside a play batch
     uint32_t ra[8];
     uint32_t vm = 0;
     bool bad = false;
-    // (requesting these eight words EARLY -- right behind the gather, so that their round trip runs beside the classification -- was measured in round 5:
-    //  -2 % at 20 steps, -1 % at 372, profiles/r05/play_path_ab.txt; like round 3's line touches, loads that only owners issue still cost every
-    //  other load of the batch more than they save)
+    uint32_t need = 0;
 #pragma unroll
-    for (int c = 0; c < 8; c++) {
-      const bool v = boff[c] >= 0;
-      bool okc;
-      const uint32_t* p = bg_gpeek_addr(d, env, e, v ? boff[c] : 0, okc);
-      ra[c] = *p;
-      bad = bad || (v && !okc);
-      vm |= (v && okc ? 1u : 0u) << c;
+    for (int c = 0; c < 8; c++) need |= (boff[c] >= 0 ? 1u : 0u) << c;
+    // Round 6: the words of the first Bloodstone were fetched into the window when the play began (bg_prefetch_blood: one dword per played card, by
+    // LDS-DMA) -- word slot c holds the word of pair (c, jb) whenever no 8 Ball shifts the pairs (the prefetch is only issued then) and the ring held it
+    if (BG_PRE_BLOOD(w) == jb + 1 && nb8 == 0 && (need & ~BG_PRE_BLOOD_OK(w)) == 0u) {
+      bg_dma_wait();
+#pragma unroll
+      for (int c = 0; c < 8; c++) ra[c] = w.lds[c * BG_BLOCK];
+      vm = need;
+      w.pre &= ~0x7ff00u;
+    } else {
+      // eight loads side by side (unconditional, from a harmless address where there is no word), looked at together: as eight `if (...) bg_gpeek()`
+      // every Heart was a branch region with its own wait -- up to five HBM round trips in a row inside a play batch
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        const bool v = boff[c] >= 0;
+        bool okc;
+        const uint32_t* p = bg_gpeek_addr(d, env, e, v ? boff[c] : 0, okc);
+        ra[c] = *p;
+        bad = bad || (v && !okc);
+        vm |= (v && okc ? 1u : 0u) << c;
+      }
     }
     if (bad) atomicOr(d.err, BG_DEVERR_GSTREAM);
 #pragma unroll
@@ -743,41 +793,23 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
 #pragma unroll
     for (int i = 0; i < 8; i++) npre += (i < e.nsel && bg_get8(e.sel, i) < e.nhand) ? 1 : 0;
     bool ball = false;
+    int blood = -1;   // the first slot holding a Bloodstone
 #pragma unroll
-    for (int j = 0; j < 5; j++) ball = ball || (j < e.njokers && bg_get8(e.jokers, j) == 26);
+    for (int j = 4; j >= 0; j--) { const int id = j < e.njokers ? bg_get8(e.jokers, j) : 0; ball = ball || id == 26; blood = id == 117 ? j : blood; }
     if (!ball) {
       bg_gnorm(d, e);
       pre.skip = 2 * npre * e.njokers;
       bg_gpeek12_raw(d, env, e, pre.skip, pre.mw, pre.avail);
       pre.ok = true;
+      // a Bloodstone's words, one per played card, on their way into the window beside the main phase's (they were a dependent ~2 us round trip of
+      // their own in the middle of the chain, for the whole batch: nearly every batch of 20-30 plays holds an owner with a Heart played)
+      if (blood >= 0 && w.lds) bg_prefetch_blood(d, env, e, w, npre, blood);
     }
-#ifdef BG_CHAIN_TOUCH
-    {
-      int nb8 = 0; bool blood = false;
-#pragma unroll
-      for (int j = 0; j < 5; j++) { const int id = j < e.njokers ? (int)bg_get8(e.jokers, j) : 0; nb8 += id == 26 ? 1 : 0; blood = blood || id == 117; }
-#pragma unroll
-      for (int m = 0; m < 5; m++) pre.tl[m] = 0u;
-      if (ball || blood) {
-        bg_gnorm(d, e);
-        const int cons_min = 2 * npre * e.njokers, cons_max = cons_min + 2 * (npre < 4 ? npre : 4) * nb8;
-        const int lo = blood ? 0 : cons_min, hi = ball ? cons_max + 11 : cons_min - 1; // (without an 8 Ball the main phase's words are `pre`)
-#pragma unroll
-        for (int m = 0; m < 4; m++) if (lo + 32 * m < hi) pre.tl[m] = bg_gtouch(d, env, e, lo + 32 * m);
-        if (hi >= lo) pre.tl[4] = bg_gtouch(d, env, e, hi);
-      }
-    }
-#endif
   }
-  // A play that beats the blind generates a shop, whose inventory reads two lines of the next pre-seeded shop stream: touch
-  // them now (two dword loads nobody waits for) so that they come from L2, not from HBM, if the play wins
-  uint32_t touch0 = 0, touch1 = 0;
-#ifndef BG_NO_SHOP_TOUCH
-  if (e.s_ready > 0) {
-    const uint32_t* nxt = bg_sblock(d, env, (e.s_cur + 1 == d.KS) ? 0 : e.s_cur + 1);
-    touch0 = nxt[0]; touch1 = nxt[32];   // (a slot is two lines)
-  }
-#endif
+  // A play that beats the blind generates a shop, whose fresh inventory reads the tail of the next pre-seeded shop slot (32 bytes of one line): fetched
+  // into the window NOW, by LDS-DMA -- nobody waits for it unless the play wins, and then it has long landed (it was six 16-byte loads of two lines behind
+  // _advance_round, ~6 k cycles of every play batch; rounds 3-5 could only TOUCH the lines from here: loads into registers cost more than they saved)
+  if (w.lds) bg_prefetch_shop(d, env, e, w);
   // card states (CardAdapter.to_scoring_format :287-325): BONUS +30, STONE +50 and no rank / suit, FOIL +50; the seals
   // and the GLASS / LUCKY rolls are settled after the scorer (:703-734)
   uint32_t stone = 0;                      // bit per play index
@@ -1013,7 +1045,6 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   }
   BG_PROBE(12);
   o.reward = r;
-  asm volatile("" ::"v"(touch0), "v"(touch1)); // the touched words are dead: this only keeps the two loads alive
 }
 
 // DISCARD  balatro_env_2.py:962-1050
@@ -1341,6 +1372,7 @@ __device__ __forceinline__ void bg_use_consumable(const BgDev& d, int env, Env& 
           }
         }
         // compact the deck through this lane's RNG window (nothing is cached in it here), then HBM copy + kernel-local copy
+        bg_win_quiesce(w);   // (words 0..15: no prefetch may still be landing there)
         DK& mdk = const_cast<DK&>(dk);
         uint32_t cur = 0; int wpos = 0; uint64_t played = 0;
 #pragma unroll 1

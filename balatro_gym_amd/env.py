@@ -116,7 +116,9 @@ class BalatroEnv(_EnvBase):
                                   autoreset=False, max_ante=max_ante, card_states=card_states,
                                   fused_steps=16)  # one step per call: shallow look-ahead rings (42 KB instead of 0.66 MB)
         self._action = torch.zeros(1, dtype=torch.int32, device=self._vec.device)
-        self._cached_obs: Optional[Dict[str, Any]] = None   # the observation of the last reset() / step(), as numpy (what `state` reads)
+        # the scalars `state` reports, taken from the observation of the last reset() / step() -- a PRIVATE copy: the dict handed to the caller is the
+        # caller's (a wrapper may edit it in place, train_balatro_fixed.py:125-207 does), `state` must keep saying what the env holds
+        self._cached_obs: Optional[Dict[str, int]] = None
 
     # -- helpers
     def _np_obs(self) -> Dict[str, Any]:
@@ -134,12 +136,14 @@ class BalatroEnv(_EnvBase):
         """Read-only view of the scalars wrappers poke at (`env.state.ante` etc., train_balatro_agent.py:150)."""
         # (served from the observation the last reset() / step() / load_state() already brought to the host: the wrappers that poke at `env.state` do
         #  so between steps, and every access used to cost a device copy and a synchronisation of its own)
-        o = self._cached_obs if self._cached_obs is not None else self._np_obs()
-        return SimpleNamespace(ante=int(o["ante"]), round=int(o["round"]), money=int(o["money"]), phase=int(o["phase"]),
-                               chips_needed=int(o["chips_needed"]), chips_scored=int(o["chips_scored"]),
-                               round_chips_scored=int(o["round_chips_scored"]), hands_left=int(o["hands_left"]),
-                               discards_left=int(o["discards_left"]), joker_slots=int(o["joker_slots"]),
-                               hand_size=int(o["hand_size"]))
+        o = self._cached_obs if self._cached_obs is not None else self._state_scalars(self._np_obs())
+        return SimpleNamespace(**o)
+
+    _STATE_KEYS = ("ante", "round", "money", "phase", "chips_needed", "chips_scored", "round_chips_scored", "hands_left", "discards_left",
+                   "joker_slots", "hand_size")
+
+    def _state_scalars(self, obs: Dict[str, Any]) -> Dict[str, int]:
+        return {k: int(obs[k]) for k in self._STATE_KEYS}
 
     # -- gymnasium surface
     def reset(self, *, seed: int | None = None, options: dict | None = None):
@@ -148,8 +152,9 @@ class BalatroEnv(_EnvBase):
             self._vec.reset(seed=[seed])
         else:
             self._vec.reset()
-        self._cached_obs = self._np_obs()
-        return self._cached_obs, {}
+        obs = self._np_obs()
+        self._cached_obs = self._state_scalars(obs)
+        return obs, {}
 
     def step(self, action: int):
         self._action[0] = int(action)
@@ -201,8 +206,9 @@ class BalatroEnv(_EnvBase):
             out["curriculum_limit_reached"] = True
         if int(inf["aux"]) and not (flags & (8 | 32 | 64 | 128)) and not err and ht < 0:
             out["boss_blind"] = BOSS_BLIND_NAMES[int(inf["aux"])]
-        self._cached_obs = self._np_obs()
-        return self._cached_obs, r, terminated, False, out
+        obs = self._np_obs()
+        self._cached_obs = self._state_scalars(obs)
+        return obs, r, terminated, False, out
 
     def save_state(self):
         return {"blob": self._vec.get_state(0)}

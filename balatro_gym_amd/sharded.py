@@ -77,8 +77,22 @@ def setup_peer_gather(env, rank: int, world: int, group=None) -> Optional[torch.
             env.set_gather_peers([], rank)
         except Exception:  # noqa: BLE001
             pass
+        # every rank comes through here together (the flags were all-gathered): no engine writes peers any more once all have passed the barrier --
+        # only then may `mine` (which the others hold IPC mappings of) and the mappings of theirs go out of scope
+        dist.barrier(group=group)
         return None
     return mine
+
+
+def teardown_peer_gather(env, rank: int, group=None) -> None:
+    """Switch the peer-written gather off on EVERY rank (collective): the engines stop writing, a barrier, and only then does a rank let go of the
+    buffer its peers have mapped (`BalatroVecEnv.set_gather_peers([])` drops the handle's references; the caller drops the tensor
+    `setup_peer_gather` returned AFTER this call)."""
+    keep = getattr(env, "_gather_keep", None)   # our buffer and the peers' mappings: alive until every rank has stopped writing
+    env.set_gather_peers([], rank)
+    torch.cuda.synchronize(env.device)
+    dist.barrier(group=group)
+    del keep
 
 
 class ShardedBalatroVecEnv:
@@ -158,5 +172,12 @@ class ShardedBalatroVecEnv:
         all_gather_bytes(out.view(-1), rows.view(-1), group=self.group)
         return out
 
+    def disable_peer_gather(self) -> None:
+        """Back to `gather_records` (collective: every rank calls it)."""
+        if self.peer_records is not None:
+            teardown_peer_gather(self.local, self.rank, self.group)
+            self.peer_records = None
+
     def close(self):
+        self.disable_peer_gather()
         self.local.close()

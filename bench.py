@@ -324,18 +324,28 @@ def main():
     #  steps of the contract are the only launches in front of the timed region.  The refill -- the MT19937 seeding and the deck shuffles, row a1/a2 work --
     #  is due every 18th launch at 20 steps and issued in PIECES beside the launches that follow (profiles/r05/refill_pieces.txt; a full-depth-sliced
     #  refill beside every short launch was measured too: -21 %, profiles/r05/refill_policy_ab.txt): the timed launch carries a piece, `sustained` a period.)
+    gather_verified = None
     if peer_buf is not None and launch_no > 0:
-        # the peer-written gather buffers after the warm-up's launches, checked before anything is timed: this rank's slot must be the last row of its last
-        # launch, every other slot must have been written by its rank.  If not (a mapping that does not carry stores on this box), every rank falls back to RCCL.
+        # The peer-written gather buffers after the warm-up's launches, checked before anything is timed -- BYTE FOR BYTE against one untimed all_gather
+        # (RCCL over xGMI; host-staged under gloo) of the same rows: every slot of this rank's buffer, i.e. what every OTHER rank's engine wrote into
+        # it through its peer mapping, must be exactly the last record row of that rank's last launch (a slot that was only partly written, or
+        # written through a mapping that does not carry non-temporal stores on this box, fails here and not in a learner).  On a mismatch on ANY
+        # rank every rank falls back to the RCCL all_gather.
         barrier()
-        last = bufs[(launch_no - 1) % len(bufs)].rows[chunk - 1][:, :352]
-        good = bool(torch.equal(peer_buf[rank], last)) and all(bool(peer_buf[r].any()) for r in range(world))
+        last = bufs[(launch_no - 1) % len(bufs)].rows[chunk - 1][:, :352].contiguous()
+        chk = torch.empty((world, n, 352), dtype=torch.uint8, device=dev)
+        all_gather_bytes(chk.view(-1), last.view(-1))
+        torch.cuda.synchronize(dev)
+        good = bool(torch.equal(peer_buf, chk))
         flag = torch.tensor([1 if good else 0], dtype=torch.int32, device=dev)
         if world > 1:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
-            print("bench.py: peer-written gather buffers failed their check after the warm-up; falling back to the RCCL all_gather", file=sys.stderr)
-            env.set_gather_peers([], rank)
+        gather_verified = int(flag.item()) == 1
+        del chk
+        if not gather_verified:
+            print("bench.py: peer-written gather buffers differ from the all_gather of the same rows after the warm-up; falling back to the RCCL all_gather", file=sys.stderr)
+            from balatro_gym_amd.sharded import teardown_peer_gather
+            teardown_peer_gather(env, rank)   # every engine stops writing peers, a barrier, then the buffers the others have mapped may go
             peer_buf, gather_method, do_gather = None, "rccl (peer writes failed their check)", True
             gather_stream = torch.cuda.Stream(device=dev)
             gathered = torch.empty((world, n, 352), dtype=torch.uint8, device=dev)
@@ -482,7 +492,9 @@ def main():
                              "what": ("the engine's copy-out writes the current 352-byte record of every env into every rank's gather buffer (peer-mapped stores over xGMI, inside the launch); "
                                       "the region's closing barrier is its synchronisation") if gather_method == "peer" else
                                      "all_gather_into_tensor of the current 352-byte record of every env, once per launch, side stream",
-                             "bytes_per_gpu_per_launch": n * 352 if gather_method == "peer" else ((gather_bytes_timed // max(1, launches)) if do_gather else 0)}
+                             "bytes_per_gpu_per_launch": n * 352 if gather_method == "peer" else ((gather_bytes_timed // max(1, launches)) if do_gather else 0),
+                             # peer writes: every slot of this rank's buffer == an untimed all_gather of the same rows, byte for byte, on every rank (checked after the warm-up)
+                             "verified": gather_verified}
     env.close()
     del ob, bufs
 

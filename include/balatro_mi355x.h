@@ -141,7 +141,7 @@ typedef struct bg_rollout_stats {
 
 /* Identity of the device code: sha256 prefix over the sources, compiler flags and compiler version the library was built from
  * ("unsigned" for ad-hoc builds).  Reproducible across rebuilds of unchanged sources -- the bytes of the code object are not --, so
- * profiles/*_hbm_traffic.json measurements are keyed on it (bench.py roofline.traffic).  No reference counterpart. */
+ * profiles/rNN_hbm_traffic.json measurements are keyed on it (bench.py roofline.traffic).  No reference counterpart. */
 const char* bg_build_signature(void);
 
 /* Replaces: constructing n_envs `BalatroEnv` objects (balatro_env_2.py:359-384) + SB3 SubprocVecEnv (hpc_train.py:60-65).
@@ -257,7 +257,12 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
 #define BG_ROW_PHASE 339
 #define BG_ROW_BOSS_BLIND_ACTIVE 340
 #define BG_ROW_BOSS_BLIND_TYPE 341
-#define BG_ROW_TERMINATED 342         /* Sharded jobs (one process per GPU): the exchange of the design -- every rank sees the CURRENT record of every env -- without a collective
+#define BG_ROW_TERMINATED 342         /* uint8: the step ended the episode (SAME_STEP auto-reset: the record already shows the new episode) */
+int bg_rollout_rows(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t env_index0, uint64_t t0,
+                    uint8_t* rows_dev, uint64_t row_stride_bytes, int rows_stride_steps, bg_rollout_stats* stats_dev,
+                    void* stream);
+
+/* Sharded jobs (one process per GPU): the exchange of the design -- every rank sees the CURRENT record of every env -- without a collective
  * behind the launch.  bufs[r] is rank r's gather buffer, uint8 [world][N][BG_ROW_BYTES], as mapped into THIS process (own buffer: an ordinary device
  * pointer; peers': hipIpcOpenMemHandle / torch's CUDA IPC over xGMI); N = this handle's env count, the same on every rank.  From then on the LAST launch
  * of every bg_rollout_rows call also writes the record of its last step into slot [rank] of all `world` buffers, from the engine's copy-out, while the
@@ -265,11 +270,6 @@ int bg_rollout(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t e
  * it off.  Replaces: SubprocVecEnv's pipe traffic of observations to the learner process (hpc_train.py:60-65); the RCCL all_gather of
  * balatro_gym_amd/sharded.py stays as the fallback where peer mapping is not available. */
 int bg_set_gather_peers(bg_handle* h, void* const* bufs, int world, int rank);
-
-/* uint8: the step ended the episode (SAME_STEP auto-reset: the record already shows the new episode) */
-int bg_rollout_rows(bg_handle* h, int T, int policy, uint64_t policy_seed, uint64_t env_index0, uint64_t t0,
-                    uint8_t* rows_dev, uint64_t row_stride_bytes, int rows_stride_steps, bg_rollout_stats* stats_dev,
-                    void* stream);
 
 /* Harness injection (configs 3-4): per-env "reset template" applied by every reset of that env -- owned jokers (ids
  * from jokers.py), money, ante and hand levels; -1 / NULL leaves a field at its reset default.  apply_now != 0 also

@@ -231,7 +231,7 @@ def test_blob_geometry_constants_match_the_device_header():
     assert int(define("BG_NHOT")) == nat.BLOB_NHOT and int(define("BG_NDECK")) == nat.BLOB_NDECK
     assert int(define("BG_NCOLD")) == nat.BLOB_NCOLD and int(define("BG_NTMPL")) == nat.BLOB_NTMPL
     assert int(define("BG_MTS")) == nat.BLOB_MTS and int(define("BG_NCST")) == nat.BLOB_NCST
-    assert nat.SHOP_SLOT_SEED_WORD == int(define("BG_SW_T")) and nat.SHOP_SLOT_WORDS == int(define("BG_SLOT_WORDS"))
+    assert nat.SHOP_SLOT_SEED_WORD == int(define("BG_SW_SEED")) and nat.SHOP_SLOT_WORDS == int(define("BG_SLOT_WORDS"))
     m = re.search(r"^#define BG_SSEED (\d+)", open(os.path.join(ROOT, "balatro_gym_amd", "csrc", "bg_device.h")).read() +
                   open(os.path.join(ROOT, "balatro_gym_amd", "csrc", "bg_lib.hip")).read(), flags=re.M)
     assert m and int(m.group(1)) == nat.BLOB_SSEED
@@ -269,3 +269,5 @@ def test_build_signature_is_reproducible(tmp_path):
     L.bg_build_signature.restype = C.c_char_p
     assert L.bg_build_signature().decode() == want
     assert nat.device_code_signature(other) == want
+    assert build.library_signature(other) == want          # read out of the file, without loading it (what needs_build compares)
+    assert build.library_signature(__file__) is None

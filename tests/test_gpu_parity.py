@@ -1249,6 +1249,47 @@ def test_state_blob_into_another_handle_vs_oracle(monkeypatch):
     E_.close()
 
 
+def test_state_blob_mid_sliced_refill_vs_oracle(monkeypatch):
+    """A state blob taken while a refill is still being issued IN PIECES (bg_refill_pieces: the scan has advanced the producer counters, the dense
+    kernels that fill those ring slots are handed out over the next launches).  bg_get_state / bg_set_state must issue what is pending first: the blob
+    would otherwise claim shop-stream slots that hold the streams of 12 shops ago, and pieces issued after a bg_set_state would overwrite the restored
+    env's slots with the replaced env's seeds.  Shallow rings (a refill every third 5-step launch, every slot reached within ~150 steps); env j's blob is
+    taken behind launch j + 1 -- every phase of the period -- restored into ANOTHER handle and continued for 200 steps (~14 shops) against the oracle."""
+    from balatro_gym_amd.vec_env import RowBuffers
+    from oracle.gen_golden import IMPLEMENTED
+    monkeypatch.setenv("BG_KG", "8"); monkeypatch.setenv("BG_KS", "13"); monkeypatch.setenv("BG_KD", "12")
+    monkeypatch.setenv("BG_REFILL_SLICED", "1")
+    n, L, K, M = 64, 5, 24, 200
+    seeds = [83_000 + SEED_OFFSET + 11 * i for i in range(n)]
+    jokers = [random.Random(5200 + i).sample(IMPLEMENTED, 5) for i in range(n)]
+    A = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4)
+    assert L <= A.max_fused_steps // 2, A.max_fused_steps   # short enough for the refill to be issued in pieces
+    A.inject(jokers=jokers, apply_now=True)
+    rbA = RowBuffers(n, A.device, steps=L)
+    blobs = []
+    for j in range(K):
+        A.rollout(L, policy=2, policy_seed=57, env_index0=0, t0=L * j, obs_buffers=rbA, zero_stats=(j == 0))
+        blobs.append(A.get_state(j))
+    A.check()
+    A.close()
+    wobs, wr, wt, wa, _ = _oracle_rollout(K, seeds[:K], L * K + M, 2, 57, True, 4, jokers[:K])
+    B = _vec(n, [5 + i for i in range(n)], scorer_jokers=True, autoreset=True, max_ante=4)
+    rbB = RowBuffers(n, B.device, steps=M)
+    for j in range(K):
+        t0 = L * (j + 1)
+        B.set_state(j, blobs[j])
+        B.rollout(M, policy=2, policy_seed=57, env_index0=0, t0=t0, obs_buffers=rbB, zero_stats=True)
+        B.check()
+        ctx = f"blob of env {j} taken behind launch {j + 1}"
+        assert np.array_equal(rbB.action[:, j].cpu().numpy(), wa[t0:t0 + M, j]), ctx
+        assert np.array_equal(rbB.terminated[:, j].cpu().numpy(), wt[t0:t0 + M, j]), ctx
+        assert np.array_equal(rbB.reward[:, j].contiguous().cpu().numpy().view(np.uint64), wr[t0:t0 + M, j].view(np.uint64)), ctx
+        for key in OBS_KEYS:
+            g, w = rbB.tensors[key][:, j].contiguous().cpu().numpy(), wobs[key][t0:t0 + M, j]
+            assert np.array_equal(g, w), f"{ctx}: record key {key} differs at step {t0 + int(np.argwhere(g.reshape(M, -1) != w.reshape(M, -1))[0][0])}"
+    B.close()
+
+
 def test_invalid_actions_and_no_raise():
     """Invalid actions never raise: reward -1.0, state unchanged (balatro_env_2.py:626-627)."""
     import torch

@@ -26,13 +26,27 @@ def _worker(rank, world, port, total, T, kind, q):
     wl = sharded_workload(kind, total)
     env = ShardedBalatroVecEnv(total, wl["seeds"], device=rank, **wl["env_kwargs"])
     apply_sharded_workload(env.local, wl, env.lo, env.hi)
+    # the gather WITHOUT a collective, ACROSS devices: every rank's engine writes its current records into the OTHER GPU's buffer through a CUDA IPC
+    # mapping (non-temporal stores over xGMI into the peer's HBM, which the peer then reads through its own L2) -- compared byte for byte with the
+    # RCCL all_gather of the same rows, for two calls, exactly as tests/test_sharded_one_gpu.py does with two processes on one device
+    peer_ok = env.enable_peer_gather()
     rb = RowBuffers(env.hi - env.lo, env.local.device, steps=T)
     env.rollout(T, policy=2, policy_seed=5, obs_buffers=rb)
     rec = env.gather_records(rb.rows[T - 1])
+    torch.cuda.synchronize()
+    dist.barrier()   # every rank's launch has completed: every buffer is whole
+    peer_equal = bool(torch.equal(env.peer_records, rec)) if peer_ok else None
     env.local.observe()
     flat = env.gather_obs()
     st = env.local.stats()
-    q.put((rank, rec.cpu().numpy(), flat.cpu().numpy(), st))
+    dist.barrier()
+    rb2 = RowBuffers(env.hi - env.lo, env.local.device, steps=7)   # a second, shorter call: the buffers follow the LAST launch of every call
+    env.rollout(7, policy=2, policy_seed=5, t0=T, obs_buffers=rb2)
+    rec2 = env.gather_records(rb2.rows[6])
+    torch.cuda.synchronize()
+    dist.barrier()
+    peer_equal2 = bool(torch.equal(env.peer_records, rec2)) and not bool(torch.equal(rec, rec2)) if peer_ok else None
+    q.put((rank, rec.cpu().numpy(), flat.cpu().numpy(), st, peer_ok, peer_equal, peer_equal2))
     dist.barrier()
     env.close()
     dist.destroy_process_group()
@@ -70,7 +84,9 @@ def test_two_gpu_sharding_matches_one_gpu(kind):
     st1 = env.stats()
     env.close()
     half = total // world
-    for rank, rec, flat, st in results:
+    assert all(r[4] for r in results), "peer-mapped gather buffers could not be set up between the two GPUs (CUDA IPC / peer access)"
+    assert all(r[5] and r[6] for r in results), "peer-written records (xGMI stores into the other GPU's buffer) differ from the RCCL all_gather of the same rows"
+    for rank, rec, flat, st, *_ in results:
         assert rec.shape == (world, half, 352)
         assert np.array_equal(rec.reshape(total, 352), want), rank   # every rank holds every env's current record
     for k in ("steps", "episodes", "plays", "score_sum"):

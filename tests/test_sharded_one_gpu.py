@@ -121,6 +121,8 @@ def test_bench_two_ranks_one_gpu():
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["total_envs"] == 4096 and j["steps"] == 20
     assert j["gather"]["in_timed_region"] and j["gather"]["bytes_per_gpu_per_launch"] == 2048 * 352
+    # the peer-written buffers were compared with an all_gather of the same rows, byte for byte, on both ranks, before anything was timed
+    assert j["gather"]["method"] == "peer" and j["gather"]["verified"] is True, j["gather"]
     assert j["samples"]["n"] == 3 and j["sustained"]["regions"] >= 2
     assert j["value"] > 0
 
