@@ -271,7 +271,11 @@ __shared__ unsigned long long bg_probe_lds[32];
 #define BG_PROBE_FLUSH(d) do { __syncthreads(); if (threadIdx.x < 32 && (d).dbg && bg_probe_lds[threadIdx.x]) atomicAdd(&(d).dbg[threadIdx.x], bg_probe_lds[threadIdx.x]); } while (0)
 #else
 #define BG_PROBE_BEGIN() do {} while (0)
+#ifdef BG_PHASE_FENCES   // experiment: the phase boundaries as compiler scheduling barriers (no instruction is emitted)
+#define BG_PROBE(k) __builtin_amdgcn_sched_barrier(0)
+#else
 #define BG_PROBE(k) do {} while (0)
+#endif
 #define BG_PROBE_INIT() do {} while (0)
 #define BG_PROBE_FLUSH(d) do {} while (0)
 #endif
@@ -376,7 +380,8 @@ __device__ __forceinline__ double bg_lazy_random(uint32_t* S) {
 // (card, joker) pair) or of a shop generation are consecutive words of ONE block, so they are fetched with
 // independent loads up front and then consumed from LDS: the serial chain of dependent HBM round trips (one per
 // draw, ~1 us each at one wave per SIMD) becomes one batch.  Layout [word][lane] (bank = lane: conflict-free).
-#define BG_WIN 24 // the longest batch is the 24-word window of a shop inventory (bg_sprefetch); The Hook needs 16
+#define BG_WIN 16 // words per lane of the window proper: The Wheel's 16 words, Immolate's 16-word deck; a rerolled shop reads its words 16 at a time
+#define BG_WIN_PIECES 16 // bg_engine3.h only: 16 more words per lane behind them = four 16-byte pieces per lane, written by LDS-DMA alone (RngWin below)
 // Per-workgroup lookup tables in LDS (filled once per launch by bg_tables_init): per-lane-different joker ids make
 // `switch` statements fully divergent (a wave walks every case some lane takes) and constant-memory tables cost an HBM
 // round trip per lookup at one wave per SIMD; an LDS read is ~100 cycles and never diverges.
@@ -397,15 +402,18 @@ typedef __attribute__((address_space(3))) const JTables lds_JTables;
 // Round 6: the window is also where a service step's LATE global reads are fetched AHEAD without a register (LDS-DMA, `global_load_lds_dword[x4]`:
 // every active lane's 4 / 16 bytes land at wave base + 4 / 16 x lane).  A play's Bloodstone words, the fresh shop slot of a winning play and the reset
 // template of an episode that ends were three DEPENDENT global-memory round trips of ~2 us each under load in the middle of a service batch
-// (profiles/r05/play_probes_at_load.txt); requested early into registers they lost every time (rounds 3 and 5: the registers they hold).  Layout of the
-// 24 words x 64 lanes of a wave (bytes from the wave's base):
-//   [0, 2048)     word slots 0..7 in the window's own [word][lane] layout: the first Bloodstone's candidate word of played card c (bg_prefetch_blood)
-//   [2048, 4096)  two 16-byte pieces per lane, [piece][lane]: the packed top bytes + seed of the NEXT shop slot (bg_prefetch_shop)
-//   [4096, 6144)  two 16-byte pieces per lane: the env's reset template (bg_prefetch_tmpl)
-// The ordinary window users (The Wheel's 16 words, a rerolled shop's 24, Immolate's deck compaction) come later in a step and overwrite them: they
-// call bg_win_quiesce first (a DMA still in flight must not land on top of their words) and the flags below say what is still valid.
-#define BG_WIN_SHOP_W 512    // u32 index of shop piece 0, lane 0
-#define BG_WIN_TMPL_W 1024   // u32 index of template piece 0, lane 0
+// (profiles/r05/play_probes_at_load.txt); requested early into registers they lost every time (rounds 3 and 5: the registers they hold).  Layout of a
+// wave's window (bytes from the wave's base):
+//   [0, 4096)     the window proper, [word 0..15][lane]: a lane only ever touches ITS column.  Word slots 0..7 double as the destination of the first
+//                 Bloodstone's candidate word of played card c (bg_prefetch_blood, 4-byte DMA: the same column)
+//   [4096, 6144)  bg_engine3.h only (BG_WIN_PIECES): two 16-byte pieces per lane, [piece][lane]: the packed top bytes + seed of the NEXT shop slot (bg_prefetch_shop)
+//   [6144, 8192)  two 16-byte pieces per lane: the env's reset template (bg_prefetch_tmpl)
+// A lane's 16-byte piece covers word positions of FOUR lanes' columns in the [word][lane] layout, so the pieces live behind the window proper, where no
+// lane's ordinary use (The Wheel's 16 words, a rerolled shop's, Immolate's deck compaction: later in a step, other lanes of the same batch) can land on
+// them.  (First version of this round: pieces inside a 24-word window -- another lane's Wheel words overwrote a neighbour's prefetched shop tail.)
+// The same-column users call bg_win_quiesce first: a Bloodstone DMA still in flight must not land on top of their words.
+#define BG_WIN_SHOP_W (BG_WIN * BG_BLOCK)                   // u32 index of shop piece 0, lane 0
+#define BG_WIN_TMPL_W (BG_WIN * BG_BLOCK + 8 * BG_BLOCK)    // u32 index of template piece 0, lane 0
 struct RngWin {
   lds_JTables* jt;
   lds_u32* lds;   // &win[0][lane]; nullptr in kernels without a window (they prefetch nothing)
@@ -415,9 +423,13 @@ struct RngWin {
   bool need_inv;             // a shop inventory is due: generated ONCE at the end of the dispatch, whichever action asked for it
   // What LDS-DMA has put (or is putting) into this lane's part of the window, in ONE word (every live word of a service step is a register the play
   // path does not have): bits 0..7 ring slot + 1 whose tail pieces are there (0 = none) | 8..10 joker slot + 1 of the Bloodstone whose candidate words
-  // are (0 = none) | 11..18 which of the eight cards' words the ring held | 19 the reset template
+  // are (0 = none) | 11..18 which of the eight cards' words the ring held | 19 the reset template | 31 the window has the piece area (BG_WIN_PIECES)
   uint32_t pre;
+  // LDS byte address of &win[0][0] of this wave, made a SCALAR once (v_readfirstlane): it is the M0 of every LDS-DMA.  (As `lds - lane` it was a vector
+  // value per destination; those were spilled to scratch memory, and every reload was an `s_waitcnt vmcnt(0)` -- each DMA waited for the one before it.)
+  uint32_t base_s;
 };
+#define BG_PRE_HAS_PIECES 0x80000000u
 #define BG_PRE_SHOP(w) ((int)((w).pre & 0xffu))
 #define BG_PRE_BLOOD(w) ((int)(((w).pre >> 8) & 7u))
 #define BG_PRE_BLOOD_OK(w) (((w).pre >> 11) & 0xffu)
@@ -425,32 +437,33 @@ struct RngWin {
 typedef __attribute__((address_space(3))) void bg_lds_void;
 typedef __attribute__((address_space(1))) const void bg_g_cvoid;
 typedef uint32_t bg_win_u32x4 __attribute__((ext_vector_type(4)));
-// &win[0][0] of this wave (wave-uniform: the LDS-DMA destination); every window is [BG_WIN][BG_BLOCK] of one wave, lane = threadIdx.x mod 64
-__device__ __forceinline__ lds_u32* bg_win_base(const RngWin& w) { return w.lds - (threadIdx.x & (BG_BLOCK - 1)); }
-__device__ __forceinline__ void bg_dma16(const void* src, lds_u32* wave_base) { __builtin_amdgcn_global_load_lds((bg_g_cvoid*)src, (bg_lds_void*)wave_base, 16, 0, 0); }
-__device__ __forceinline__ void bg_dma4(const void* src, lds_u32* wave_base) { __builtin_amdgcn_global_load_lds((bg_g_cvoid*)src, (bg_lds_void*)wave_base, 4, 0, 0); }
+// every window is [BG_WIN (+ BG_WIN_PIECES)][BG_BLOCK] of one wave, lane = threadIdx.x mod 64; `lds_byte` = wave-uniform LDS byte address (w.base_s + offset)
+__device__ __forceinline__ void bg_dma16(const void* src, uint32_t lds_byte) { __builtin_amdgcn_global_load_lds((bg_g_cvoid*)src, (bg_lds_void*)(uintptr_t)lds_byte, 16, 0, 0); }
+__device__ __forceinline__ void bg_dma4(const void* src, uint32_t lds_byte) { __builtin_amdgcn_global_load_lds((bg_g_cvoid*)src, (bg_lds_void*)(uintptr_t)lds_byte, 4, 0, 0); }
 // every LDS-DMA this wave has issued has landed (vmcnt counts them with the other vector-memory loads, in order); the "memory" clobber keeps the LDS reads behind it
 __device__ __forceinline__ void bg_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 __device__ __forceinline__ bg_win_u32x4 bg_win_piece(const lds_u32* lds_lane, int word0, int p) {   // 16-byte piece p of this lane (behind bg_dma_wait)
   return *(const __attribute__((address_space(3))) bg_win_u32x4*)(lds_lane + word0 + p * (4 * BG_BLOCK) + 3 * (int)(threadIdx.x & (BG_BLOCK - 1)));   // base + word0 + 256 p + 4 lane
 }
-__device__ __forceinline__ void bg_win_quiesce(RngWin& w) {   // before the window's own users write it
-  if (w.pre) bg_dma_wait();
-  w.pre &= BG_PRE_TMPL;
+__device__ __forceinline__ void bg_win_quiesce(RngWin& w) {   // before the window's own users write this lane's column: no Bloodstone word may still be landing there
+  if (w.pre & 0x7ff00u) bg_dma_wait();
+  w.pre &= ~0x7ff00u;
 }
-__device__ __forceinline__ void bg_win_init(RngWin& w, uint32_t* lds_lane, const JTables* jt = nullptr) {
+// pieces: the window is [BG_WIN + BG_WIN_PIECES][BG_BLOCK] (bg_engine3.h); otherwise [BG_WIN][BG_BLOCK]
+__device__ __forceinline__ void bg_win_init(RngWin& w, uint32_t* lds_lane, const JTables* jt = nullptr, bool pieces = false) {
   w.jt = (lds_JTables*)jt; w.lds = (lds_u32*)lds_lane;
   w.g_blk = -1; w.g_start = 0; w.g_len = 0; w.s_start = 0; w.s_len = 0; w.defer_adv = false; w.need_inv = false;
-  w.pre = 0;
+  w.pre = pieces ? BG_PRE_HAS_PIECES : 0u;
+  w.base_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)((lds_u32*)lds_lane - (threadIdx.x & (BG_BLOCK - 1))));
 }
 __device__ __noinline__ void bg_win_fill(lds_u32* lds, const uint32_t* src, int len) {
 #pragma unroll 1
-  for (int base = 0; base < len; base += 24) { // 24 independent loads in flight, then one wait
-    uint32_t v[24];
+  for (int base = 0; base < len; base += BG_WIN) { // BG_WIN independent loads in flight, then one wait
+    uint32_t v[BG_WIN];
 #pragma unroll
-    for (int j = 0; j < 24; j++) v[j] = (base + j < len) ? src[base + j] : 0u;
+    for (int j = 0; j < BG_WIN; j++) v[j] = (base + j < len) ? src[base + j] : 0u;
 #pragma unroll
-    for (int j = 0; j < 24; j++) if (base + j < len) lds[(base + j) * BG_BLOCK] = v[j];
+    for (int j = 0; j < BG_WIN; j++) if (base + j < len) lds[(base + j) * BG_BLOCK] = v[j];
   }
 }
 
@@ -540,7 +553,6 @@ __device__ __forceinline__ void bg_gprefetch(const BgDev& d, int env, Env& e, Rn
   bg_gnorm(d, e);
   if (e.g_valid <= 0) return;
   bg_win_quiesce(w);
-  if (count > 16) w.pre &= ~BG_PRE_TMPL;
   int len = BG_MT_N - e.g_idx;
   if (len > count) len = count;
   if (len > BG_WIN) len = BG_WIN;
@@ -595,33 +607,25 @@ __device__ __forceinline__ uint32_t bg_sdraw(const BgDev& d, int env, Env& e, Rn
   e.s_idx++;
   return y;
 }
-// the next `count` (<= 24) words of the shop stream into the window: six 16-byte loads of finished words for a fresh stream (s_idx == 0,
-// every generate_shop); the overflow block (full seeded state) regenerates and tempers them
-__device__ __forceinline__ void bg_swin_fill0(lds_u32* lds, const uint32_t* S) { // the slot of a fresh stream
-  const uint4* S4 = (const uint4*)S;
-  uint4 v[6];
-#pragma unroll
-  for (int g = 0; g < 6; g++) v[g] = S4[g];
-#pragma unroll
-  for (int g = 0; g < 6; g++) { lds[(4 * g) * BG_BLOCK] = v[g].x; lds[(4 * g + 1) * BG_BLOCK] = v[g].y; lds[(4 * g + 2) * BG_BLOCK] = v[g].z; lds[(4 * g + 3) * BG_BLOCK] = v[g].w; }
-}
+// the next `len` (<= BG_WIN) words of the shop stream into the window: finished words out of the slot; the overflow block (full seeded state)
+// regenerates and tempers them
 __device__ __forceinline__ void bg_swin_fill(lds_u32* lds, const uint32_t* S, bool full, int k0, int len) {
   if (!full) { // finished words
-    uint32_t A[24];
+    uint32_t A[BG_WIN];
 #pragma unroll
-    for (int j = 0; j < 24; j++) A[j] = (j < len) ? S[k0 + j] : 0u;
+    for (int j = 0; j < BG_WIN; j++) A[j] = (j < len) ? S[k0 + j] : 0u;
 #pragma unroll
-    for (int j = 0; j < 24; j++) if (j < len) lds[j * BG_BLOCK] = A[j];
+    for (int j = 0; j < BG_WIN; j++) if (j < len) lds[j * BG_BLOCK] = A[j];
     return;
   }
-  uint32_t A[25], F[24];
+  uint32_t A[BG_WIN + 1], F[BG_WIN];
   const uint32_t* SF = S + k0 + BG_MT_M; // &S[k0 + 397]
 #pragma unroll
-  for (int j = 0; j < 25; j++) A[j] = (j <= len) ? S[k0 + j] : 0u;
+  for (int j = 0; j < BG_WIN + 1; j++) A[j] = (j <= len) ? S[k0 + j] : 0u;
 #pragma unroll
-  for (int j = 0; j < 24; j++) F[j] = (j < len) ? SF[j] : 0u;
+  for (int j = 0; j < BG_WIN; j++) F[j] = (j < len) ? SF[j] : 0u;
 #pragma unroll
-  for (int j = 0; j < 24; j++) if (j < len) lds[j * BG_BLOCK] = bg_temper(bg_twist(A[j], A[j + 1], F[j]));
+  for (int j = 0; j < BG_WIN; j++) if (j < len) lds[j * BG_BLOCK] = bg_temper(bg_twist(A[j], A[j + 1], F[j]));
 }
 __device__ __forceinline__ void bg_sprefetch(const BgDev& d, int env, Env& e, RngWin& w, int count) {
   bool full;
@@ -629,13 +633,10 @@ __device__ __forceinline__ void bg_sprefetch(const BgDev& d, int env, Env& e, Rn
   // stay where the words are at hand: k <= BG_S_FASTMAX in the slot, k < 227 (every operand a seeded word) in the full state
   int len = (full ? (BG_MT_N - BG_MT_M) : (BG_S_FASTMAX + 1)) - e.s_idx;
   if (len > count) len = count;
-  if (len > 24) len = 24;
   if (len > BG_WIN) len = BG_WIN;
   if (len < 0) len = 0;
   bg_win_quiesce(w);
-  if (len > 16) w.pre &= ~BG_PRE_TMPL;
-  if (e.s_idx == 0 && len == 24 && !full) bg_swin_fill0(w.lds, S);
-  else if (len > 0) bg_swin_fill(w.lds, S, full, e.s_idx, len);
+  if (len > 0) bg_swin_fill(w.lds, S, full, e.s_idx, len);
   w.s_start = e.s_idx; w.s_len = len;
   w.g_len = 0; w.g_blk = -1;
 }

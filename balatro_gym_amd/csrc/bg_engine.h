@@ -89,6 +89,15 @@ __device__ __forceinline__ void bg_lds_st(uint32_t* p, uint32_t v) {
   asm volatile("" ::: "memory");
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
+__device__ __forceinline__ uint32_t bg_lds_ld(uint16_t* p) {
+  uint16_t v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  asm volatile("" ::: "memory");
+  return (uint32_t)v;
+}
+__device__ __forceinline__ void bg_lds_st(uint16_t* p, uint32_t v) {
+  asm volatile("" ::: "memory");
+  __hip_atomic_store(p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
 __device__ __forceinline__ void bg_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 

@@ -137,7 +137,7 @@ __device__ __forceinline__ void bg_mt_seed_impl(uint32_t* p, uint32_t key) {
   a = (BG_GENRAND.blk[0].v[1] ^ ((a ^ (a >> 30)) * 1664525u)) + key; // pass-1 mt[1] (before the wrap)
   uint32_t bprev = a1w, w2 = 0, w3 = 0;
   uint32_t far0 = 0, far1 = 0, out2 = 0, out3 = 0;   // SLOT: S[397], S[398]; output words 2 and 3 (group 0 is written last)
-  uint32_t pk[6] = {0u, 0u, 0u, 0u, 0u, 0u};         // SLOT: top byte of output word k -> byte k & 3 of pk[k >> 2], k < 24
+  uint32_t acc = 0;   // SLOT: the packed word under construction -- top byte of output word k -> byte k & 3 of slot word BG_SW_PK + (k >> 2), k < 24
   {
     BgG16 cur = BG_GENRAND.blk[0];
 #pragma unroll 1
@@ -180,15 +180,30 @@ __device__ __forceinline__ void bg_mt_seed_impl(uint32_t* p, uint32_t key) {
               nr[4 * g] = t.x; nr[4 * g + 1] = t.y; nr[4 * g + 2] = t.z; nr[4 * g + 3] = t.w;
             }
             if (b == 25) nr[3] = w3;                       // (group 0 is not in memory: S[3])
+            // output words kb .. kb + 15 (its near words are nr[3 + c], nr[4 + c]); S[k] is dead: its place takes the output word.  Blocks 25 and 26 also
+            // collect the top bytes of words 4..23 into the packed words 1..5, each stored as soon as it is whole (slot words 57..61: the raw S[57..61]
+            // parked there are needed by nobody -- block 28 only looks at S[56] of that group); word 0 waits for outputs 0..2 at the end.  b is uniform, so
+            // each block is its own copy of the loop with COMPILE-TIME k.  (Six packed words kept to the end cost the kernel its fourth wave beside the
+            // step engine -- 69 registers --, and indexed by a run-time k they went to scratch memory: the kernel ran 40 % longer.)
+            auto outputs = [&](auto kbc) {
+              constexpr int KB = decltype(kbc)::value;
 #pragma unroll
-            for (int c = 0; c < 16; c++) {
-              const int k = kb + c;                        // output word index; its near words are nr[3 + c], nr[4 + c]
-              if (k < BG_SW_T) {
-                const uint32_t o = bg_temper(bg_twist(nr[3 + c], nr[4 + c], v[c]));
-                if (k == 3) out3 = o; else p[k] = o;       // S[k] is dead: its place takes the output word
-                if (k < 24) pk[k >> 2] |= (o >> 24) << (8 * (k & 3));
+              for (int c = 0; c < 16; c++) {
+                const int k = KB + c;
+                if (k < BG_SW_T) {
+                  const uint32_t o = bg_temper(bg_twist(nr[3 + c], nr[4 + c], v[c]));
+                  if (k == 3) out3 = o; else p[k] = o;
+                  if (k >= 4 && k < 24) {
+                    acc |= (o >> 24) << (8 * (k & 3));
+                    if ((k & 3) == 3) { p[BG_SW_PK + (k >> 2)] = acc; acc = 0u; }
+                  }
+                }
               }
-            }
+            };
+            if (b == 25) outputs(std::integral_constant<int, 16 * 25 - BG_MT_M>{});
+            else if (b == 26) outputs(std::integral_constant<int, 16 * 26 - BG_MT_M>{});
+            else if (b == 27) outputs(std::integral_constant<int, 16 * 27 - BG_MT_M>{});
+            else outputs(std::integral_constant<int, 16 * 28 - BG_MT_M>{});
           }
         }
       }
@@ -200,11 +215,10 @@ __device__ __forceinline__ void bg_mt_seed_impl(uint32_t* p, uint32_t key) {
   else {
     const uint32_t out0 = bg_temper(bg_twist(0x80000000u, w1, far0)), out1 = bg_temper(bg_twist(w1, w2, far1));
     p4[0] = make_uint4(out0, out1, out2, out3);
-    pk[0] |= (out0 >> 24) | ((out1 >> 24) << 8) | ((out2 >> 24) << 16) | (out3 & 0xff000000u);
-    // the slot's last two 16-byte groups (the raw S[56..63] parked there have been read back by block 28): packed top bytes, seed, padding
+    // the slot's tail: packed word 0 (the raw S[56] parked in its place has been read back by block 28), seed, padding
     static_assert(BG_SW_PK == 56 && BG_SW_SEED == 62 && BG_SLOT_WORDS == 64, "slot tail layout");
-    p4[BG_SW_PK / 4] = make_uint4(pk[0], pk[1], pk[2], pk[3]);
-    p4[BG_SW_PK / 4 + 1] = make_uint4(pk[4], pk[5], key, 0u);
+    p[BG_SW_PK] = (out0 >> 24) | ((out1 >> 24) << 8) | ((out2 >> 24) << 16) | (out3 & 0xff000000u);
+    *(uint2*)(p + BG_SW_SEED) = make_uint2(key, 0u);
   }
 }
 __device__ void bg_mt_seed(uint32_t* __restrict__ p, uint32_t key) { bg_mt_seed_impl<false>(p, key); }
@@ -542,7 +556,8 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_refill_seedring_kernel(BgDev d, B
 
 // `random.Random(shop_seed)` (shop.py:96): one stream per lane, pure ALU + 156 stores.  The slot holds the SEEDED state;
 // the consumer regenerates the few words a shop visit reads (bg_sprefetch), so no block twist is ever run for a shop.
-__global__ __launch_bounds__(BG_BLOCK) void bg_refill_shop_kernel(BgDev d, BgPart pt) {
+// (eight waves per SIMD = at most 64 registers: FOUR of these waves then fit on the SIMD the step engine leaves free -- with 66 it was three)
+__global__ __launch_bounds__(BG_BLOCK, 8) void bg_refill_shop_kernel(BgDev d, BgPart pt) {
   const uint32_t count0 = d.wl_count[3], lo = bg_part_lo(count0, pt), count = bg_part_hi(count0, pt);
   for (uint32_t item = lo + blockIdx.x * BG_BLOCK + threadIdx.x; item < count; item += gridDim.x * BG_BLOCK) {
     uint32_t es = d.wl_shop[2 * (size_t)item], seed = d.wl_shop[2 * (size_t)item + 1];

@@ -261,7 +261,7 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
     w.s_start = e.s_idx; w.s_len = 0; w.g_len = 0; w.g_blk = -1;   // (as bg_sprefetch leaves the window: nothing of either stream is in it)
     w.pre &= ~0xffu;
   }
-  if (!fast) bg_sprefetch(d, env, e, w, 24); // shop.py:111-139: a rerolled stream (or the overflow block), or the one visit in thousands whose rejections outrun 24 words
+  if (!fast) bg_sprefetch(d, env, e, w, BG_WIN); // shop.py:111-139: a rerolled stream (or the overflow block), or the one visit in thousands whose rejections outrun 24 words
   if (!fast) { // window too short for this lane's rejections (or no window): the plain loops
     third_r = (int)bg_randbelow<true>(d, env, e, w, 3u); // rng.choice([...]) is evaluated before the loop
     int guard = 0;
@@ -497,36 +497,31 @@ __device__ __forceinline__ void bg_prefetch_shop(const BgDev& d, int env, const 
   if (e.s_ready > 0) {
     const int nxt = (e.s_cur + 1 == d.KS) ? 0 : e.s_cur + 1;
     const uint32_t* p = bg_sblock(d, env, nxt) + BG_SW_PK;
-    lds_u32* const base = bg_win_base(w);
-    bg_dma16(p, base + BG_WIN_SHOP_W);
-    bg_dma16(p + 4, base + BG_WIN_SHOP_W + 4 * BG_BLOCK);
+    bg_dma16(p, w.base_s + 4u * BG_WIN_SHOP_W);
+    bg_dma16(p + 4, w.base_s + 4u * (BG_WIN_SHOP_W + 4 * BG_BLOCK));
     w.pre = (w.pre & ~0xffu) | (uint32_t)(nxt + 1);
   }
 }
 // The FIRST Bloodstone's candidate words: pair (card c, joker slot jb) draws its random() 2 * (c * nj + jb) words ahead of the cursor (no 8 Ball owned:
 // nothing shifts them), and x2 is decided by the top bit of that ONE word (bg_joker_chain) -- one dword per played card, whether it turns out to be a
-// Heart or not (that is known behind the gather; the words share one or two lines), into word slot c of the window.
+// Heart or not (that is known behind the gather; the words share one or two lines), into word slot c of the lane's own window column.  Only when the
+// whole span lies inside the current block (one base address, a multiply-add per card: 7 plays in 8; the others read their words in the chain as before).
+// The caller has normalised the cursor (bg_gnorm).
 __device__ __forceinline__ void bg_prefetch_blood(const BgDev& d, int env, const Env& e, RngWin& w, int ncards, int jb) {
   const int nj = e.njokers;
-  uint32_t okm = 0;
-  lds_u32* const base = bg_win_base(w);
+  if (e.g_valid >= 1 && ncards >= 1 && e.g_idx + 2 * ((ncards - 1) * nj + jb) < BG_MT_N) {
+    const uint32_t* p0 = bg_gblock(d, env, e.g_cur) + e.g_idx + 2 * jb;
 #pragma unroll
-  for (int c = 0; c < 8; c++) {
-    if (c < ncards) {
-      bool ok;
-      const uint32_t* p = bg_gpeek_addr(d, env, e, 2 * (c * nj + jb), ok);
-      if (ok) { bg_dma4(p, base + c * BG_BLOCK); okm |= 1u << c; }
-    }
+    for (int c = 0; c < 8; c++)
+      if (c < ncards) bg_dma4(p0 + 2 * c * nj, w.base_s + 4u * (uint32_t)(c * BG_BLOCK));
+    w.pre = (w.pre & ~0x7ff00u) | ((uint32_t)(jb + 1) << 8) | (((1u << ncards) - 1u) << 11);
   }
-  w.pre = (w.pre & ~0x7ff00u) | ((uint32_t)(jb + 1) << 8) | (okm << 11);
 }
 __device__ __forceinline__ void bg_prefetch_tmpl(const BgDev& d, int env, RngWin& w) {
-  lds_u32* const base = bg_win_base(w);
-  bg_dma16(&d.tmpl[env], base + BG_WIN_TMPL_W);
-  bg_dma16(&d.tmpl[(size_t)d.N + env], base + BG_WIN_TMPL_W + 4 * BG_BLOCK);
+  bg_dma16(&d.tmpl[env], w.base_s + 4u * BG_WIN_TMPL_W);
+  bg_dma16(&d.tmpl[(size_t)d.N + env], w.base_s + 4u * (BG_WIN_TMPL_W + 4 * BG_BLOCK));
   w.pre |= BG_PRE_TMPL;
 }
-
 
 // unified_scoring.py:174-244: the joker chain of one scored hand -- individual phase (card-major, joker-minor), then the
 // main phase in joker order -- with the eager RNG draws of complete_joker_effects.py:42,161.  What it needs of
@@ -809,7 +804,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   // A play that beats the blind generates a shop, whose fresh inventory reads the tail of the next pre-seeded shop slot (32 bytes of one line): fetched
   // into the window NOW, by LDS-DMA -- nobody waits for it unless the play wins, and then it has long landed (it was six 16-byte loads of two lines behind
   // _advance_round, ~6 k cycles of every play batch; rounds 3-5 could only TOUCH the lines from here: loads into registers cost more than they saved)
-  if (w.lds) bg_prefetch_shop(d, env, e, w);
+  if (w.pre & BG_PRE_HAS_PIECES) bg_prefetch_shop(d, env, e, w);
   // card states (CardAdapter.to_scoring_format :287-325): BONUS +30, STONE +50 and no rank / suit, FOIL +50; the seals
   // and the GLASS / LUCKY rolls are settled after the scorer (:703-734)
   uint32_t stone = 0;                      // bit per play index

@@ -59,7 +59,7 @@ for step in "$@"; do
       brief "$out"/T20_${var}_*.json "$out"/default_${var}_*.json | tee "$out/abenv_${var}_summary.txt" ;;
     timing:*)
       p=$(libpath "${step#timing:}")
-      (BALATRO_MI355X_LIB=$p timeout 600 python tools/e3_timing.py) > "$out/e3_timing_$(basename "$p" .so).txt" 2>&1; cat "$out/e3_timing_$(basename "$p" .so).txt" ;;
+      (for T in 372 20; do echo "== T $T"; BALATRO_MI355X_LIB=$p T=$T timeout 600 python tools/e3_timing.py 2>&1 | grep -v amdgpu.ids; done) > "$out/e3_timing_$(basename "$p" .so).txt" 2>&1; cat "$out/e3_timing_$(basename "$p" .so).txt" ;;
     probes:*)
       p=$(libpath "${step#probes:}")
       (BALATRO_MI355X_LIB=$p timeout 600 python tools/probes4.py) > "$out/probes_$(basename "$p" .so).txt" 2>&1; tail -70 "$out/probes_$(basename "$p" .so).txt" ;;

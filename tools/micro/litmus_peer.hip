@@ -27,14 +27,14 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 #define PIECES 22   // 16-byte pieces of a 352-byte record, as the engine writes them
 
 struct Shared {
-  std::atomic<int> arrive[2];
+  std::atomic<int> arrive;
   hipIpcMemHandle_t handle[2];
   int ndev;
 };
-static void barrier(Shared* s, int gen_index, int& gen) {
+static void barrier(Shared* s, int& gen) {   // both ranks arrive gen times each
   gen++;
-  s->arrive[gen_index].fetch_add(1);
-  while (s->arrive[gen_index].load() < 2 * gen) usleep(50);
+  s->arrive.fetch_add(1);
+  while (s->arrive.load() < 2 * gen) usleep(50);
 }
 
 __device__ __forceinline__ u32x4 pattern(unsigned round, unsigned rank, unsigned rec, unsigned pc) {
@@ -73,7 +73,7 @@ static int run_rank(int rank, Shared* sh, int rounds, unsigned n_rec) {
   CK(hipMalloc(&bad, 8)); CK(hipMemset(bad, 0, 8));
   CK(hipIpcGetMemHandle(&sh->handle[rank], mine));
   int gen = 0;
-  barrier(sh, 0, gen);
+  barrier(sh, gen);
   u32x4* peer = nullptr;
   CK(hipIpcOpenMemHandle((void**)&peer, sh->handle[1 - rank], hipIpcMemLazyEnablePeerAccess));
   unsigned long long stale = 0, words = 0;
@@ -82,10 +82,10 @@ static int run_rank(int rank, Shared* sh, int rounds, unsigned n_rec) {
     hipLaunchKernelGGL(reader, dim3(512), dim3(256), 0, 0, mine, n_rec, (unsigned)(r - 1), (unsigned)(1 - rank), bad);
     CK(hipDeviceSynchronize());
     if (r == 1) CK(hipMemset(bad, 0, 8));   // (round 0 is the zero fill)
-    barrier(sh, 1, gen);                    // nobody still reads round r-1 when round r is written
+    barrier(sh, gen);                    // nobody still reads round r-1 when round r is written
     hipLaunchKernelGGL(writer, dim3(512), dim3(256), 0, 0, peer, n_rec, (unsigned)r, (unsigned)rank);
     CK(hipDeviceSynchronize());             // (1) the writer's end of kernel
-    barrier(sh, 0, gen);                    // (2) the ranks meet
+    barrier(sh, gen);                    // (2) the ranks meet
     hipLaunchKernelGGL(reader, dim3(512), dim3(256), 0, 0, mine, n_rec, (unsigned)r, (unsigned)(1 - rank), bad);   // (3) the reader's next kernel
     CK(hipDeviceSynchronize());
     unsigned long long b = 0;
@@ -93,12 +93,13 @@ static int run_rank(int rank, Shared* sh, int rounds, unsigned n_rec) {
     CK(hipMemset(bad, 0, 8));
     stale += b; words += (unsigned long long)n_rec * PIECES * 4;
   }
-  barrier(sh, 1, gen);
+  barrier(sh, gen);
   CK(hipIpcCloseMemHandle(peer));
-  barrier(sh, 0, gen);   // both mappings are closed before either buffer is freed
+  barrier(sh, gen);   // both mappings are closed before either buffer is freed
   CK(hipFree(mine)); CK(hipFree(bad));
   printf("rank %d (device %d of %d%s): stale %llu of %llu words over %d rounds of %u records\n", rank, rank % ndev, ndev,
          ndev < 2 ? ", both ranks on ONE device: same-device IPC mapping, not xGMI" : ": peer mapping", stale, words, rounds, n_rec);
+  fflush(stdout);   // (the child leaves through _exit)
   return stale ? 1 : 0;
 }
 
