@@ -219,8 +219,7 @@ __device__ __forceinline__ uint32_t* bg_gblock(const BgDev& d, int env, int slot
 // kernel that seeds the stream (word k of the first output block is S[k+397] ^ twist(S[k], S[k+1]) for k < 227: the seeding pass has all
 // three in hand) --, the TOP BYTES of output words 0..23 packed into six words, and the seed: 256 bytes = two lines.  A FRESH inventory (every
 // generate_shop) looks at nothing but those top bytes (getrandbits(2 / 6 / 8) of consecutive words: bg_shop_inventory), so it reads the slot's
-// last two 16-byte pieces -- ONE line, and small enough to be fetched ahead into the wave's LDS window without a register (bg_prefetch_shop; round 6: it
-// was six pieces of the first 24 words, two lines) --; a rerolled inventory reads ~11 full words from where the last one stopped, so 56 words are a
+// last two 16-byte pieces -- ONE line (round 6: it was six pieces of the first 24 words, two lines) --; a rerolled inventory reads ~11 full words from where the last one stopped, so 56 words are a
 // visit with three rerolls; a visit that reads further re-seeds the FULL state into the env's overflow block once (bg_shop_overflow) and
 // carries on there.  Rounds 1-2 kept the seeded state itself (two 68-word windows, 576 bytes) and the consumer regenerated what it read: 14
 // scattered 16-byte loads, 24 twists and 31 temperings on the winning play's critical path (~13 k cycles of a play batch).
@@ -271,11 +270,7 @@ __shared__ unsigned long long bg_probe_lds[32];
 #define BG_PROBE_FLUSH(d) do { __syncthreads(); if (threadIdx.x < 32 && (d).dbg && bg_probe_lds[threadIdx.x]) atomicAdd(&(d).dbg[threadIdx.x], bg_probe_lds[threadIdx.x]); } while (0)
 #else
 #define BG_PROBE_BEGIN() do {} while (0)
-#ifdef BG_PHASE_FENCES   // experiment: the phase boundaries as compiler scheduling barriers (no instruction is emitted)
-#define BG_PROBE(k) __builtin_amdgcn_sched_barrier(0)
-#else
 #define BG_PROBE(k) do {} while (0)
-#endif
 #define BG_PROBE_INIT() do {} while (0)
 #define BG_PROBE_FLUSH(d) do {} while (0)
 #endif
@@ -380,8 +375,7 @@ __device__ __forceinline__ double bg_lazy_random(uint32_t* S) {
 // (card, joker) pair) or of a shop generation are consecutive words of ONE block, so they are fetched with
 // independent loads up front and then consumed from LDS: the serial chain of dependent HBM round trips (one per
 // draw, ~1 us each at one wave per SIMD) becomes one batch.  Layout [word][lane] (bank = lane: conflict-free).
-#define BG_WIN 16 // words per lane of the window proper: The Wheel's 16 words, Immolate's 16-word deck; a rerolled shop reads its words 16 at a time
-#define BG_WIN_PIECES 16 // bg_engine3.h only: 16 more words per lane behind them = four 16-byte pieces per lane, written by LDS-DMA alone (RngWin below)
+#define BG_WIN 16 // words per lane: The Wheel's 16 words, Immolate's 16-word deck; a rerolled shop reads its words 16 at a time (a FRESH one reads the slot's packed tail, no window)
 // Per-workgroup lookup tables in LDS (filled once per launch by bg_tables_init): per-lane-different joker ids make
 // `switch` statements fully divergent (a wave walks every case some lane takes) and constant-memory tables cost an HBM
 // round trip per lookup at one wave per SIMD; an LDS read is ~100 cycles and never diverges.
@@ -399,62 +393,19 @@ struct JTables {
 // LDS pointers keep their address space in the type: a generic pointer stored in a struct compiles to FLAT loads (the
 // vector-memory path, ~1-2k cycles when nothing hides it) instead of ds_read (~100 cycles).
 typedef __attribute__((address_space(3))) const JTables lds_JTables;
-// Round 6: the window is also where a service step's LATE global reads are fetched AHEAD without a register (LDS-DMA, `global_load_lds_dword[x4]`:
-// every active lane's 4 / 16 bytes land at wave base + 4 / 16 x lane).  A play's Bloodstone words, the fresh shop slot of a winning play and the reset
-// template of an episode that ends were three DEPENDENT global-memory round trips of ~2 us each under load in the middle of a service batch
-// (profiles/r05/play_probes_at_load.txt); requested early into registers they lost every time (rounds 3 and 5: the registers they hold).  Layout of a
-// wave's window (bytes from the wave's base):
-//   [0, 4096)     the window proper, [word 0..15][lane]: a lane only ever touches ITS column.  Word slots 0..7 double as the destination of the first
-//                 Bloodstone's candidate word of played card c (bg_prefetch_blood, 4-byte DMA: the same column)
-//   [4096, 6144)  bg_engine3.h only (BG_WIN_PIECES): two 16-byte pieces per lane, [piece][lane]: the packed top bytes + seed of the NEXT shop slot (bg_prefetch_shop)
-//   [6144, 8192)  two 16-byte pieces per lane: the env's reset template (bg_prefetch_tmpl)
-// A lane's 16-byte piece covers word positions of FOUR lanes' columns in the [word][lane] layout, so the pieces live behind the window proper, where no
-// lane's ordinary use (The Wheel's 16 words, a rerolled shop's, Immolate's deck compaction: later in a step, other lanes of the same batch) can land on
-// them.  (First version of this round: pieces inside a 24-word window -- another lane's Wheel words overwrote a neighbour's prefetched shop tail.)
-// The same-column users call bg_win_quiesce first: a Bloodstone DMA still in flight must not land on top of their words.
-#define BG_WIN_SHOP_W (BG_WIN * BG_BLOCK)                   // u32 index of shop piece 0, lane 0
-#define BG_WIN_TMPL_W (BG_WIN * BG_BLOCK + 8 * BG_BLOCK)    // u32 index of template piece 0, lane 0
 struct RngWin {
   lds_JTables* jt;
-  lds_u32* lds;   // &win[0][lane]; nullptr in kernels without a window (they prefetch nothing)
+  lds_u32* lds;   // &win[0][lane]
   int g_blk, g_start, g_len; // window over the global stream: block, first index, words
   int s_start, s_len;        // window over the current shop stream
   bool defer_adv;            // a winning play leaves _advance_round (and the shop it generates) to a second work item
   bool need_inv;             // a shop inventory is due: generated ONCE at the end of the dispatch, whichever action asked for it
-  // What LDS-DMA has put (or is putting) into this lane's part of the window, in ONE word (every live word of a service step is a register the play
-  // path does not have): bits 0..7 ring slot + 1 whose tail pieces are there (0 = none) | 8..10 joker slot + 1 of the Bloodstone whose candidate words
-  // are (0 = none) | 11..18 which of the eight cards' words the ring held | 19 the reset template | 31 the window has the piece area (BG_WIN_PIECES)
-  uint32_t pre;
-  // LDS byte address of &win[0][0] of this wave, made a SCALAR once (v_readfirstlane): it is the M0 of every LDS-DMA.  (As `lds - lane` it was a vector
-  // value per destination; those were spilled to scratch memory, and every reload was an `s_waitcnt vmcnt(0)` -- each DMA waited for the one before it.)
-  uint32_t base_s;
 };
-#define BG_PRE_HAS_PIECES 0x80000000u
-#define BG_PRE_SHOP(w) ((int)((w).pre & 0xffu))
-#define BG_PRE_BLOOD(w) ((int)(((w).pre >> 8) & 7u))
-#define BG_PRE_BLOOD_OK(w) (((w).pre >> 11) & 0xffu)
-#define BG_PRE_TMPL 0x80000u
-typedef __attribute__((address_space(3))) void bg_lds_void;
-typedef __attribute__((address_space(1))) const void bg_g_cvoid;
-typedef uint32_t bg_win_u32x4 __attribute__((ext_vector_type(4)));
-// every window is [BG_WIN (+ BG_WIN_PIECES)][BG_BLOCK] of one wave, lane = threadIdx.x mod 64; `lds_byte` = wave-uniform LDS byte address (w.base_s + offset)
-__device__ __forceinline__ void bg_dma16(const void* src, uint32_t lds_byte) { __builtin_amdgcn_global_load_lds((bg_g_cvoid*)src, (bg_lds_void*)(uintptr_t)lds_byte, 16, 0, 0); }
-__device__ __forceinline__ void bg_dma4(const void* src, uint32_t lds_byte) { __builtin_amdgcn_global_load_lds((bg_g_cvoid*)src, (bg_lds_void*)(uintptr_t)lds_byte, 4, 0, 0); }
-// every LDS-DMA this wave has issued has landed (vmcnt counts them with the other vector-memory loads, in order); the "memory" clobber keeps the LDS reads behind it
-__device__ __forceinline__ void bg_dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-__device__ __forceinline__ bg_win_u32x4 bg_win_piece(const lds_u32* lds_lane, int word0, int p) {   // 16-byte piece p of this lane (behind bg_dma_wait)
-  return *(const __attribute__((address_space(3))) bg_win_u32x4*)(lds_lane + word0 + p * (4 * BG_BLOCK) + 3 * (int)(threadIdx.x & (BG_BLOCK - 1)));   // base + word0 + 256 p + 4 lane
-}
-__device__ __forceinline__ void bg_win_quiesce(RngWin& w) {   // before the window's own users write this lane's column: no Bloodstone word may still be landing there
-  if (w.pre & 0x7ff00u) bg_dma_wait();
-  w.pre &= ~0x7ff00u;
-}
-// pieces: the window is [BG_WIN + BG_WIN_PIECES][BG_BLOCK] (bg_engine3.h); otherwise [BG_WIN][BG_BLOCK]
-__device__ __forceinline__ void bg_win_init(RngWin& w, uint32_t* lds_lane, const JTables* jt = nullptr, bool pieces = false) {
-  w.jt = (lds_JTables*)jt; w.lds = (lds_u32*)lds_lane;
-  w.g_blk = -1; w.g_start = 0; w.g_len = 0; w.s_start = 0; w.s_len = 0; w.defer_adv = false; w.need_inv = false;
-  w.pre = pieces ? BG_PRE_HAS_PIECES : 0u;
-  w.base_s = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)((lds_u32*)lds_lane - (threadIdx.x & (BG_BLOCK - 1))));
+// (Round 6 fetched a step's late global reads -- the next shop slot's tail, the Bloodstone words, the reset template -- into this window ahead of time by
+//  LDS-DMA, `global_load_lds_dword[x4]`, so that no register held them: parity-green, and inside +-1.5 % of the code without it at both launch shapes --
+//  the product build already overlaps those waits; profiles/r06/lds_dma_prefetch.txt, tools/micro/ldsdma.hip.  Not kept.)
+__device__ __forceinline__ void bg_win_init(RngWin& w, uint32_t* lds_lane, const JTables* jt = nullptr) {
+  w.jt = (lds_JTables*)jt; w.lds = (lds_u32*)lds_lane; w.g_blk = -1; w.g_start = 0; w.g_len = 0; w.s_start = 0; w.s_len = 0; w.defer_adv = false; w.need_inv = false;
 }
 __device__ __noinline__ void bg_win_fill(lds_u32* lds, const uint32_t* src, int len) {
 #pragma unroll 1
@@ -552,7 +503,6 @@ __device__ __forceinline__ void bg_gpeek12_raw(const BgDev& d, int env, const En
 __device__ __forceinline__ void bg_gprefetch(const BgDev& d, int env, Env& e, RngWin& w, int count) {
   bg_gnorm(d, e);
   if (e.g_valid <= 0) return;
-  bg_win_quiesce(w);
   int len = BG_MT_N - e.g_idx;
   if (len > count) len = count;
   if (len > BG_WIN) len = BG_WIN;
@@ -635,7 +585,6 @@ __device__ __forceinline__ void bg_sprefetch(const BgDev& d, int env, Env& e, Rn
   if (len > count) len = count;
   if (len > BG_WIN) len = BG_WIN;
   if (len < 0) len = 0;
-  bg_win_quiesce(w);
   if (len > 0) bg_swin_fill(w.lds, S, full, e.s_idx, len);
   w.s_start = e.s_idx; w.s_len = len;
   w.g_len = 0; w.g_blk = -1;

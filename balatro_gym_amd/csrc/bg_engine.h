@@ -126,7 +126,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   uint32_t* const s_head = &s_ctl[4];
 #define s_done s_ctl[3]
 #define s_busy s_ctl[7]
-  __shared__ __attribute__((aligned(16))) uint32_t s_win[NSV][BG_WIN][BG_BLOCK]; // RNG windows of the service-capable waves (+ LDS-DMA prefetch areas: 16-byte pieces)
+  __shared__ uint32_t s_win[NSV][BG_WIN][BG_BLOCK]; // RNG windows of the service-capable waves
   // copy queue (packed records): one entry per finished step -- .x = record row of this launch, .y = env lane | done << 8 | generation of the
   // ring position << 16 | VALID -- written by the workers, read by the copier wave alone (its head is a register)
   __shared__ uint2 s_cq[NE];

@@ -57,7 +57,7 @@ struct E3Lds {
   uint16_t s_ans[NE];              // service steps completed for this env in this launch, mod 2**16 (the owner counts its requests; a launch fuses < 2**16 steps)
   uint32_t s_q[2][NE];             // request rings: env lane | generation of the ring position << 8 | action << 16 | VALID
   __attribute__((aligned(16))) uint32_t s_ctl[8];   // [0..1] requests ever queued per class, [4..5] ever claimed
-  __attribute__((aligned(16))) uint32_t s_win[NSV][BG_WIN + BG_WIN_PIECES][BG_BLOCK];   // RNG windows of the service waves + their LDS-DMA piece areas (bg_device.h RngWin)
+  uint32_t s_win[NSV][BG_WIN][BG_BLOCK];
   uint2 s_list[NOW][KS * BG_BLOCK]; // copy-out list of an owner wave: .x = record row, .y = env lane
   // The NEXT pre-shuffled deck of every env (the ring slot a reset will consume) and its state: 0 = not here (the reset reads the ring itself), 1 = here,
   // 2 | slot << 8 = consumed, the owner is to fetch ring slot `slot`.  A reset's copy ring -> deck is a dependent HBM round trip in the middle of a
@@ -497,17 +497,9 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
           c[3] = s_c34[0][l]; c[4] = s_c34[1][l];
           DeckT dk; static_cast<Deck0&>(dk) = bg_load_deck0(d, env);
           RngWin w;
-          bg_win_init(w, &s_win[sidx][0][lane], &jt, true);
-          // the env's reset template on its way into the window (LDS-DMA, behind the state loads): an episode that ends in this step -- a batch nearly
-          // always holds one -- finds it there instead of waiting for two loads in the middle of its reset
-#if !defined(BG_NO_TMPL_PREFETCH) && !defined(BG_TMPL_AFTER_STATE)
-          if (a.autoreset) bg_prefetch_tmpl(d, env, w);
-#endif
+          bg_win_init(w, &s_win[sidx][0][lane], &jt);
           Env e;
           bg_unpack(c, e);
-#ifdef BG_TMPL_AFTER_STATE   // experiment: the DMA behind the state loads' arrival (its address is made to depend on the last chunk)
-          { uint32_t z = c[7].w; asm volatile("v_and_b32 %0, 0, %0" : "+v"(z)); if (a.autoreset) bg_prefetch_tmpl(d, env + (int)z, w); }
-#endif
           BG_PROBE(23);
           bg_derive_ready(e, s_prod[l]);
           ShopRegs sr; sr.valid = false;
@@ -520,7 +512,7 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
           if (o.terminated) n_eps++;
           if (o.terminated && a.autoreset) {
             const bool have = bg_lds_ld(&s_ndst[l]) == 1u;
-            bg_env_reset(d, env, e, dk, nullptr, have ? (lds_cu4*)&s_nd[0][l] : (lds_cu4*)nullptr, NE, TmplWin{w.lds, (w.pre & BG_PRE_TMPL) != 0u});
+            bg_env_reset(d, env, e, dk, nullptr, have ? (lds_cu4*)&s_nd[0][l] : (lds_cu4*)nullptr, NE);
             // the slot after it, if the ring (as this launch may see it) holds one: the env's owner fetches it
             bg_lds_st(&s_ndst[l], e.d_ready > 0 ? (2u | ((uint32_t)e.d_head << 8)) : 0u);
           }

@@ -10,6 +10,7 @@
 // There is no CPU path: every entry point needs the HIP device bg_create() opened.
 #include "../../include/balatro_mi355x.h"
 #include "bg_step.h"
+#include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: a launch whose own dispatch packet carries the start / stop timestamps of the profile
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -769,6 +770,14 @@ static void bg_ev_begin(bg_handle* h, std::vector<hipEvent_t>& v, hipStream_t s)
   v.push_back(a); v.push_back(b);
   (void)hipEventRecord(a, s);
 }
+// a start / stop pair for a launch that records them itself (hipExtLaunchKernelGGL); both null when profiling is off
+static void bg_ev_pair(bg_handle* h, std::vector<hipEvent_t>& v, hipEvent_t& a, hipEvent_t& b) {
+  a = b = nullptr;
+  if (!h->profiling) return;
+  a = bg_ev_take(h); b = bg_ev_take(h);
+  if (!a || !b) { if (a) h->ev_pool.push_back(a); if (b) h->ev_pool.push_back(b); a = b = nullptr; return; }
+  v.push_back(a); v.push_back(b);
+}
 static void bg_ev_end(bg_handle* h, std::vector<hipEvent_t>& v, hipStream_t s) {
   if (!h->profiling || v.empty()) return;
   (void)hipEventRecord(v.back(), s);
@@ -1079,12 +1088,20 @@ static int bg_refill_pieces(bg_handle* h, int n) {
   while (n-- > 0 && h->piece_next < h->pieces.size()) {
     const bg_handle::RefillPiece& pc = h->pieces[h->piece_next++];
     const BgPart pt{pc.part, pc.nparts};
-    bg_ev_begin(h, h->ev_refill_t, s);
-    if (pc.kind == 0) hipLaunchKernelGGL(bg_refill_deck_kernel, dim3(pc.grid), dim3(BG_BLOCK), 0, s, d, pt, pc.cursor, pc.max_made);
-    else if (pc.kind == 1) hipLaunchKernelGGL(bg_refill_seedring_kernel, dim3(pc.grid), dim3(BG_BLOCK), 0, s, d, pt);
-    else if (pc.kind == 2) hipLaunchKernelGGL(bg_refill_gblk_kernel, dim3(pc.grid), dim3(BG_BLOCK), 0, s, d, pt);
-    else hipLaunchKernelGGL(bg_refill_shop_kernel, dim3(pc.grid), dim3(BG_BLOCK), 0, s, d, pt);
-    bg_ev_end(h, h->ev_refill_t, s);
+    hipEvent_t ea = nullptr, eb = nullptr;   // (profiling: the piece's own dispatch packet carries its timestamps -- no event packets around it)
+    bg_ev_pair(h, h->ev_refill_t, ea, eb);
+    const dim3 g(pc.grid), b(BG_BLOCK);
+    if (ea) {
+      if (pc.kind == 0) hipExtLaunchKernelGGL(bg_refill_deck_kernel, g, b, 0, s, ea, eb, 0, d, pt, pc.cursor, pc.max_made);
+      else if (pc.kind == 1) hipExtLaunchKernelGGL(bg_refill_seedring_kernel, g, b, 0, s, ea, eb, 0, d, pt);
+      else if (pc.kind == 2) hipExtLaunchKernelGGL(bg_refill_gblk_kernel, g, b, 0, s, ea, eb, 0, d, pt);
+      else hipExtLaunchKernelGGL(bg_refill_shop_kernel, g, b, 0, s, ea, eb, 0, d, pt);
+    } else {
+      if (pc.kind == 0) hipLaunchKernelGGL(bg_refill_deck_kernel, g, b, 0, s, d, pt, pc.cursor, pc.max_made);
+      else if (pc.kind == 1) hipLaunchKernelGGL(bg_refill_seedring_kernel, g, b, 0, s, d, pt);
+      else if (pc.kind == 2) hipLaunchKernelGGL(bg_refill_gblk_kernel, g, b, 0, s, d, pt);
+      else hipLaunchKernelGGL(bg_refill_shop_kernel, g, b, 0, s, d, pt);
+    }
     BG_HIP(hipGetLastError());
     if (h->piece_next == h->pieces.size()) BG_HIP(hipEventRecord(h->ev_refill[(h->refill_seq - 1) & 1], s));   // refill #(refill_seq - 1) is complete behind this
   }
@@ -1287,7 +1304,9 @@ static int bg_engine_waves(const bg_handle* h, int T) {
   if (T <= 192) return BG_ENG_NW - 1;
   return BG_ENG_NW;
 }
-static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0, bool hash, bool info, hipStream_t st) {
+// ev_a / ev_b (both or neither): the launch's own start / stop events (hipExtLaunchKernelGGL: the timestamps ride on the kernel's dispatch packet; two
+// hipEventRecord calls around the launch are two more barrier packets on the stream, ~2-3 us each in front of and behind a 220 us launch)
+static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0, bool hash, bool info, hipStream_t st, hipEvent_t ev_a = nullptr, hipEvent_t ev_b = nullptr) {
   const bool cards = h->dev.cstate != nullptr;
   EngineArgs a = a0;
   if (h->engine == 3 && a.obs.rows && !info && !a.actions_in && !a.reward && !a.term && !a.actions_out) { // packed-record rollouts: owner waves + service waves (bg_engine3.h)
@@ -1310,7 +1329,10 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
       if (!h->e3_epw) { while (epw > 16 && (h->dev.N + epw - 1) / epw < 256) epw >>= 1; }
       a.epw = (uint32_t)epw;
     }
-#define BG_E3K(HV, CV, NOWV, KSV, NSVV) hipLaunchKernelGGL((bg_engine3_kernel<HV, CV, NOWV, KSV, NSVV>), dim3((NOWV * KSV == 1) ? (h->dev.N + epw - 1) / epw : (h->dev.N + NOWV * KSV * 64 - 1) / (NOWV * KSV * 64)), dim3((NOWV + NSVV) * BG_BLOCK), 0, st, dv, a)
+#define BG_E3K(HV, CV, NOWV, KSV, NSVV) do { \
+      const dim3 g_((NOWV * KSV == 1) ? (h->dev.N + epw - 1) / epw : (h->dev.N + NOWV * KSV * 64 - 1) / (NOWV * KSV * 64)), b_((NOWV + NSVV) * BG_BLOCK); \
+      if (ev_a) hipExtLaunchKernelGGL((bg_engine3_kernel<HV, CV, NOWV, KSV, NSVV>), g_, b_, 0, st, ev_a, ev_b, 0, dv, a); \
+      else hipLaunchKernelGGL((bg_engine3_kernel<HV, CV, NOWV, KSV, NSVV>), g_, b_, 0, st, dv, a); } while (0)
 #define BG_E3(NOWV, KSV, NSVV) do { \
       if (hash && cards) BG_E3K(true, true, NOWV, KSV, NSVV); else if (hash) BG_E3K(true, false, NOWV, KSV, NSVV); \
       else if (cards) BG_E3K(false, true, NOWV, KSV, NSVV); else BG_E3K(false, false, NOWV, KSV, NSVV); } while (0)
@@ -1342,7 +1364,9 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
   if ((a.serve_mask & ((1u << a.n_waves) - 1u)) == 0u)
     a.serve_mask = a.n_waves <= BG_ENG_NSV ? (1u << a.n_waves) - 1u : ((1u << BG_ENG_NSV) - 1u) << (a.n_waves - BG_ENG_NSV);
   const dim3 g((h->dev.N + BG_ENG_NE - 1) / BG_ENG_NE), b(BG_ENG_NW * BG_BLOCK);
-#define BG_ENG(HASHV, CARDSV, INFOV) hipLaunchKernelGGL((bg_engine_kernel<HASHV, CARDSV, INFOV>), g, b, 0, st, dv, a)
+#define BG_ENG(HASHV, CARDSV, INFOV) do { \
+    if (ev_a) hipExtLaunchKernelGGL((bg_engine_kernel<HASHV, CARDSV, INFOV>), g, b, 0, st, ev_a, ev_b, 0, dv, a); \
+    else hipLaunchKernelGGL((bg_engine_kernel<HASHV, CARDSV, INFOV>), g, b, 0, st, dv, a); } while (0)
   if (info) { if (cards) BG_ENG(false, true, true); else BG_ENG(false, false, true); }
   else if (hash && cards) BG_ENG(true, true, false);
   else if (hash) BG_ENG(true, false, false);
@@ -1380,7 +1404,8 @@ static int bg_step_impl(bg_handle* h, int K, const int32_t* actions_dev, const b
     rc = bg_wait_refill(h, st, 0);
     if (rc) return rc;
     const BgDev dv = bg_dev_view(h, bg_prod_latest(h));
-    bg_ev_begin(h, h->ev_step_t, st);
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;
+    bg_ev_pair(h, h->ev_step_t, ev_a, ev_b);
     {
       EngineArgs ea;
       memset(&ea, 0, sizeof(ea));
@@ -1395,9 +1420,8 @@ static int bg_step_impl(bg_handle* h, int K, const int32_t* actions_dev, const b
       if (off) bg_info_advance(ea.info, off);
       ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.serve_mask = h->eng_smask;
       ea.autoreset = (h->dev.flags & BG_FLAG_AUTORESET) ? 1u : 0u;
-      bg_engine_launch(h, dv, ea, false, true, st);
+      bg_engine_launch(h, dv, ea, false, true, st, ev_a, ev_b);
     }
-    bg_ev_end(h, h->ev_step_t, st);
     BG_HIP(hipGetLastError());
     h->steps_since_refill += chunk;
     done += chunk;
@@ -1524,7 +1548,8 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       else BG_HIP(hipStreamWaitEvent((hipStream_t)stream, h->ev_refill[vi & 1], 0));
     }
     const uint32_t* view = vi >= 0 ? h->d_prod[vi & 1] : bg_prod_latest(h);
-    bg_ev_begin(h, h->ev_rollout_t, (hipStream_t)stream); // after the waits: the events bracket the kernel, not the stream's wait for the refill
+    hipEvent_t ev_a = nullptr, ev_b = nullptr;   // the events bracket the kernel, not the stream's wait for the refill
+    bg_ev_pair(h, h->ev_rollout_t, ev_a, ev_b);
     BgDev dv = bg_dev_view(h, view);
     {
       const bool hash = (policy & BG_POLICY_HASH_OBS) != 0;
@@ -1543,9 +1568,8 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
         for (int g = 0; g < h->gworld; g++) ea.gpeer[g] = h->gpeer[g];
         ea.gworld = (uint32_t)h->gworld; ea.grank = (uint32_t)h->grank;
       }
-      bg_engine_launch(h, dv, ea, hash, false, st);
+      bg_engine_launch(h, dv, ea, hash, false, st, ev_a, ev_b);
     }
-    bg_ev_end(h, h->ev_rollout_t, (hipStream_t)stream);
     BG_HIP(hipGetLastError());
     if (refill_after) { // R beside this chunk: after everything the stream had done BEFORE the chunk (ev_rollout) and after the latest refill
       BG_HIP(hipStreamWaitEvent(h->side, h->ev_rollout, 0));

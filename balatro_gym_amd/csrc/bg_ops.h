@@ -121,7 +121,7 @@ __device__ __forceinline__ void bg_score_store(const BgDev& d, int i, Env& e, in
 
 // lane = case
 __global__ __launch_bounds__(BG_BLOCK) void bg_score_hand_batch_kernel(BgDev d, const int32_t* __restrict__ cases, int64_t* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) uint32_t win[BG_WIN][BG_BLOCK];
+  __shared__ uint32_t win[BG_WIN][BG_BLOCK];
   __shared__ JTables jt;
   bg_tables_init(&jt);
   const int i = blockIdx.x * BG_BLOCK + threadIdx.x;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_score_hand_batch_kernel(BgDev d, 
 // lane = card again for Bloodstone's RNG words; the main phase (joker ORDER matters: x factors) runs redundantly on all eight
 // lanes through the same bg_chain_main as the step path.  Lane 0 stores.
 __global__ __launch_bounds__(BG_BLOCK) void bg_score_hand_batch_l8_kernel(BgDev d, const int32_t* __restrict__ cases, int64_t* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) uint32_t win[BG_WIN][BG_BLOCK];
+  __shared__ uint32_t win[BG_WIN][BG_BLOCK];
   __shared__ JTables jt;
   bg_tables_init(&jt);
   const int i = blockIdx.x * (BG_BLOCK / 8) + (threadIdx.x >> 3), g = threadIdx.x & 7;

@@ -150,7 +150,7 @@ __global__ __launch_bounds__(BG_BLOCK) void bg_sim_evaluate_batch_kernel(const i
 
 // calculate_score :402-548 after random.seed(seed)
 __global__ __launch_bounds__(BG_BLOCK) void bg_sim_score_batch_kernel(BgDev d, const int32_t* __restrict__ cases, int64_t* __restrict__ out) {
-  __shared__ __attribute__((aligned(16))) uint32_t win[BG_WIN][BG_BLOCK];
+  __shared__ uint32_t win[BG_WIN][BG_BLOCK];
   __shared__ JTables jt;
   bg_tables_init(&jt);
   const int i = blockIdx.x * BG_BLOCK + threadIdx.x;

@@ -85,20 +85,11 @@ __device__ __forceinline__ uint64_t bg_action_mask(const BgDev& d, int env, cons
 // `pv`: the same in LDS (bg_engine3.h keeps the next deck of every env there), chunk k at pv[k * pv_stride]
 typedef uint32_t bg_pv_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) const bg_pv_u32x4 lds_cu4;
-// `tw`: the window of a service wave that fetched the env's reset template ahead by LDS-DMA (bg_prefetch_tmpl); not fetched (or no window): loaded here.
-// (By value: a pointer to the caller's RngWin put the whole struct into scratch memory.)
-struct TmplWin { lds_u32* lds; bool have; };
 template <class DK>
-__device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, DK& dk, const uint4* pre = nullptr, lds_cu4* pv = nullptr, int pv_stride = 0,
-                                             const TmplWin tw = TmplWin{nullptr, false}) {
+__device__ __forceinline__ void bg_env_reset(const BgDev& d, int env, Env& e, DK& dk, const uint4* pre = nullptr, lds_cu4* pv = nullptr, int pv_stride = 0) {
   // the reset template (applied at the end) is requested FIRST: its HBM round trip then runs beside the cold stores and the deck copy instead of
   // behind them (the compiler cannot move a load above stores through other pointers)
-  uint4 t0, t1;
-  if (tw.have) {
-    bg_dma_wait();
-    const bg_win_u32x4 a = bg_win_piece(tw.lds, BG_WIN_TMPL_W, 0), b = bg_win_piece(tw.lds, BG_WIN_TMPL_W, 1);
-    t0 = make_uint4(a.x, a.y, a.z, a.w); t1 = make_uint4(b.x, b.y, b.z, b.w);
-  } else { t0 = d.tmpl[env]; t1 = d.tmpl[(size_t)d.N + env]; }
+  const uint4 t0 = d.tmpl[env], t1 = d.tmpl[(size_t)d.N + env];
   e.ante = 1; e.round = 1; e.phase = 2; e.chips_needed = 300; e.chips_scored = 0; e.round_chips = 0; e.money = 4;
   e.hand = 0; e.nhand = 0; e.sel = 0; e.nsel = 0; e.hands_left = 4; e.discards_left = 3; e.hand_size = 8;
   e.njokers = 0; e.jokers = 0; e.ncons = 0; e.cons0 = 0; e.cons1 = 0; e.n_magic = 0; e.n_minim = 0;
@@ -196,11 +187,10 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
   const bool fresh = e.s_idx == 0 && !full_state;
   // A FRESH stream (every generate_shop): every draw looks at the TOP BYTE of its word only -- getrandbits(2) = byte >> 6, getrandbits(8) = byte,
   // getrandbits(6) = byte >> 2 -- and the slot's tail holds exactly those, packed by the seeding kernel (BG_SW_PK: six words): two 16-byte pieces of one
-  // line.  A play that wins had them fetched into the wave's window at its start (bg_prefetch_shop, no register held them); any other way here (a
-  // skipped blind) REQUESTS them first and looks at them behind the cost factor and the sorted joker list: ~200 instructions that do not need them.
-  const bool prefetched = fresh && BG_PRE_SHOP(w) == e.s_cur + 1;
+  // line (a winning play touched that line when it began), REQUESTED first and looked at behind the cost factor and the sorted joker list: ~200
+  // instructions that do not need them.
   uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
-  if (fresh && !prefetched) { const uint4* S4 = (const uint4*)(S + BG_SW_PK); q0 = S4[0]; q1 = S4[1]; }
+  if (fresh) { const uint4* S4 = (const uint4*)(S + BG_SW_PK); q0 = S4[0]; q1 = S4[1]; }
   double mult = bg_shop_cost_mult(e, w.jt);
   const uint64_t sj = bg_sorted_jokers(e);
   int owned145 = 0;
@@ -216,11 +206,6 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
   // The 24 top bytes are classified four at a time (SWAR): no LDS window of words, no 24 dependent LDS reads.  (Round 4: ~1 000 instructions and three
   // memory phases -- ~15 k cycles in nearly every play batch, since a batch of 20-30 plays nearly always holds a won blind.)
   if (fresh) {
-    if (prefetched) {
-      bg_dma_wait();
-      const bg_win_u32x4 a = bg_win_piece(w.lds, BG_WIN_SHOP_W, 0), b = bg_win_piece(w.lds, BG_WIN_SHOP_W, 1);
-      q0 = make_uint4(a.x, a.y, a.z, a.w); q1 = make_uint4(b.x, b.y, b.z, b.w);
-    }
     const BgPk6 pk{q0.x, q0.y, q0.z, q0.w, q1.x, q1.y};
     BG_PROBE(18);
     const uint32_t H = 0x80808080u;
@@ -259,7 +244,6 @@ __device__ __forceinline__ void bg_shop_inventory(const BgDev& d, int env, Env& 
     ca = (int)(bg_pk_byte(pk, i5 & 31) >> 2); cb = (int)(bg_pk_byte(pk, i6 & 31) >> 2);
     if (fast) e.s_idx += i6 + 1;
     w.s_start = e.s_idx; w.s_len = 0; w.g_len = 0; w.g_blk = -1;   // (as bg_sprefetch leaves the window: nothing of either stream is in it)
-    w.pre &= ~0xffu;
   }
   if (!fast) bg_sprefetch(d, env, e, w, BG_WIN); // shop.py:111-139: a rerolled stream (or the overflow block), or the one visit in thousands whose rejections outrun 24 words
   if (!fast) { // window too short for this lane's rejections (or no window): the plain loops
@@ -491,38 +475,6 @@ __device__ __forceinline__ void bg_boss_on_hand_drawn(const BgDev& d, int env, E
   }
 }
 
-// ---- LDS-DMA prefetches of a step's late global reads (bg_device.h RngWin; round 6) --------------------------------------------------------------
-// the NEXT shop slot's tail (packed top bytes of its first 24 words + seed): what a play that beats the blind will read ~30 k cycles from now
-__device__ __forceinline__ void bg_prefetch_shop(const BgDev& d, int env, const Env& e, RngWin& w) {
-  if (e.s_ready > 0) {
-    const int nxt = (e.s_cur + 1 == d.KS) ? 0 : e.s_cur + 1;
-    const uint32_t* p = bg_sblock(d, env, nxt) + BG_SW_PK;
-    bg_dma16(p, w.base_s + 4u * BG_WIN_SHOP_W);
-    bg_dma16(p + 4, w.base_s + 4u * (BG_WIN_SHOP_W + 4 * BG_BLOCK));
-    w.pre = (w.pre & ~0xffu) | (uint32_t)(nxt + 1);
-  }
-}
-// The FIRST Bloodstone's candidate words: pair (card c, joker slot jb) draws its random() 2 * (c * nj + jb) words ahead of the cursor (no 8 Ball owned:
-// nothing shifts them), and x2 is decided by the top bit of that ONE word (bg_joker_chain) -- one dword per played card, whether it turns out to be a
-// Heart or not (that is known behind the gather; the words share one or two lines), into word slot c of the lane's own window column.  Only when the
-// whole span lies inside the current block (one base address, a multiply-add per card: 7 plays in 8; the others read their words in the chain as before).
-// The caller has normalised the cursor (bg_gnorm).
-__device__ __forceinline__ void bg_prefetch_blood(const BgDev& d, int env, const Env& e, RngWin& w, int ncards, int jb) {
-  const int nj = e.njokers;
-  if (e.g_valid >= 1 && ncards >= 1 && e.g_idx + 2 * ((ncards - 1) * nj + jb) < BG_MT_N) {
-    const uint32_t* p0 = bg_gblock(d, env, e.g_cur) + e.g_idx + 2 * jb;
-#pragma unroll
-    for (int c = 0; c < 8; c++)
-      if (c < ncards) bg_dma4(p0 + 2 * c * nj, w.base_s + 4u * (uint32_t)(c * BG_BLOCK));
-    w.pre = (w.pre & ~0x7ff00u) | ((uint32_t)(jb + 1) << 8) | (((1u << ncards) - 1u) << 11);
-  }
-}
-__device__ __forceinline__ void bg_prefetch_tmpl(const BgDev& d, int env, RngWin& w) {
-  bg_dma16(&d.tmpl[env], w.base_s + 4u * BG_WIN_TMPL_W);
-  bg_dma16(&d.tmpl[(size_t)d.N + env], w.base_s + 4u * (BG_WIN_TMPL_W + 4 * BG_BLOCK));
-  w.pre |= BG_PRE_TMPL;
-}
-
 // unified_scoring.py:174-244: the joker chain of one scored hand -- individual phase (card-major, joker-minor), then the
 // main phase in joker order -- with the eager RNG draws of complete_joker_effects.py:42,161.  What it needs of
 // the hand is a few small histograms (ChainIn).  GENERAL = false is the step path (bg_step_play_hand: scoring cards == cards,
@@ -727,32 +679,22 @@ __device__ __forceinline__ void bg_joker_chain(const BgDev& d, int env, Env& e, 
       boff[c] = bg_chain_blood_off(c, code, st, n, nj, jb, m8, nb8, true, eights);
       if (c < n && nb8 && !st && rk == 8) eights++;
     }
+    // eight loads side by side (unconditional, from a harmless address where there is no word), looked at together: as eight `if (...) bg_gpeek()`
+    // every Heart was a branch region with its own wait -- up to five HBM round trips in a row inside a play batch
     uint32_t ra[8];
     uint32_t vm = 0;
     bool bad = false;
-    uint32_t need = 0;
+    // (requesting these eight words EARLY -- right behind the gather, so that their round trip runs beside the classification -- was measured in round 5:
+    //  -2 % at 20 steps, -1 % at 372, profiles/r05/play_path_ab.txt; fetched at the play's start by LDS-DMA, with no register held, in round 6: +-0,
+    //  profiles/r06/lds_dma_prefetch.txt)
 #pragma unroll
-    for (int c = 0; c < 8; c++) need |= (boff[c] >= 0 ? 1u : 0u) << c;
-    // Round 6: the words of the first Bloodstone were fetched into the window when the play began (bg_prefetch_blood: one dword per played card, by
-    // LDS-DMA) -- word slot c holds the word of pair (c, jb) whenever no 8 Ball shifts the pairs (the prefetch is only issued then) and the ring held it
-    if (BG_PRE_BLOOD(w) == jb + 1 && nb8 == 0 && (need & ~BG_PRE_BLOOD_OK(w)) == 0u) {
-      bg_dma_wait();
-#pragma unroll
-      for (int c = 0; c < 8; c++) ra[c] = w.lds[c * BG_BLOCK];
-      vm = need;
-      w.pre &= ~0x7ff00u;
-    } else {
-      // eight loads side by side (unconditional, from a harmless address where there is no word), looked at together: as eight `if (...) bg_gpeek()`
-      // every Heart was a branch region with its own wait -- up to five HBM round trips in a row inside a play batch
-#pragma unroll
-      for (int c = 0; c < 8; c++) {
-        const bool v = boff[c] >= 0;
-        bool okc;
-        const uint32_t* p = bg_gpeek_addr(d, env, e, v ? boff[c] : 0, okc);
-        ra[c] = *p;
-        bad = bad || (v && !okc);
-        vm |= (v && okc ? 1u : 0u) << c;
-      }
+    for (int c = 0; c < 8; c++) {
+      const bool v = boff[c] >= 0;
+      bool okc;
+      const uint32_t* p = bg_gpeek_addr(d, env, e, v ? boff[c] : 0, okc);
+      ra[c] = *p;
+      bad = bad || (v && !okc);
+      vm |= (v && okc ? 1u : 0u) << c;
     }
     if (bad) atomicOr(d.err, BG_DEVERR_GSTREAM);
 #pragma unroll
@@ -788,23 +730,19 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
 #pragma unroll
     for (int i = 0; i < 8; i++) npre += (i < e.nsel && bg_get8(e.sel, i) < e.nhand) ? 1 : 0;
     bool ball = false;
-    int blood = -1;   // the first slot holding a Bloodstone
 #pragma unroll
-    for (int j = 4; j >= 0; j--) { const int id = j < e.njokers ? bg_get8(e.jokers, j) : 0; ball = ball || id == 26; blood = id == 117 ? j : blood; }
+    for (int j = 0; j < 5; j++) ball = ball || (j < e.njokers && bg_get8(e.jokers, j) == 26);
     if (!ball) {
       bg_gnorm(d, e);
       pre.skip = 2 * npre * e.njokers;
       bg_gpeek12_raw(d, env, e, pre.skip, pre.mw, pre.avail);
       pre.ok = true;
-      // a Bloodstone's words, one per played card, on their way into the window beside the main phase's (they were a dependent ~2 us round trip of
-      // their own in the middle of the chain, for the whole batch: nearly every batch of 20-30 plays holds an owner with a Heart played)
-      if (blood >= 0 && w.lds) bg_prefetch_blood(d, env, e, w, npre, blood);
     }
   }
-  // A play that beats the blind generates a shop, whose fresh inventory reads the tail of the next pre-seeded shop slot (32 bytes of one line): fetched
-  // into the window NOW, by LDS-DMA -- nobody waits for it unless the play wins, and then it has long landed (it was six 16-byte loads of two lines behind
-  // _advance_round, ~6 k cycles of every play batch; rounds 3-5 could only TOUCH the lines from here: loads into registers cost more than they saved)
-  if (w.pre & BG_PRE_HAS_PIECES) bg_prefetch_shop(d, env, e, w);
+  // A play that beats the blind generates a shop, whose fresh inventory reads the tail of the next pre-seeded shop slot (32 bytes of one line): touch it
+  // now (a dword load nobody waits for) so that it comes from L2, not from HBM, if the play wins
+  uint32_t touch0 = 0;
+  if (e.s_ready > 0) touch0 = bg_sblock(d, env, (e.s_cur + 1 == d.KS) ? 0 : e.s_cur + 1)[BG_SW_PK];
   // card states (CardAdapter.to_scoring_format :287-325): BONUS +30, STONE +50 and no rank / suit, FOIL +50; the seals
   // and the GLASS / LUCKY rolls are settled after the scorer (:703-734)
   uint32_t stone = 0;                      // bit per play index
@@ -1040,6 +978,7 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   }
   BG_PROBE(12);
   o.reward = r;
+  asm volatile("" ::"v"(touch0)); // the touched word is dead: this only keeps the load alive
 }
 
 // DISCARD  balatro_env_2.py:962-1050
@@ -1367,7 +1306,6 @@ __device__ __forceinline__ void bg_use_consumable(const BgDev& d, int env, Env& 
           }
         }
         // compact the deck through this lane's RNG window (nothing is cached in it here), then HBM copy + kernel-local copy
-        bg_win_quiesce(w);   // (words 0..15: no prefetch may still be landing there)
         DK& mdk = const_cast<DK&>(dk);
         uint32_t cur = 0; int wpos = 0; uint64_t played = 0;
 #pragma unroll 1

@@ -264,9 +264,10 @@ def test_shop_stream_beyond_slot_vs_oracle():
 
 
 def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_index0=0, t0=0, cards=None, consumables=None, action_fn=None,
-                    env_indexes=None):
+                    env_indexes=None, caps=None):
     """SAME_STEP auto-reset rollout on the oracle; returns per-step obs/rewards/terminated and the stats dict.  `action_fn(oracle_env, i, t)`
-    replaces the counter-hash policy; `env_indexes[i]` = the GLOBAL index env i has in the job it is a slice of (default env_index0 + i)."""
+    replaces the counter-hash policy; `env_indexes[i]` = the GLOBAL index env i has in the job it is a slice of (default env_index0 + i);
+    `caps` = {step: per-env curriculum caps set BEFORE that step} (CurriculumBalatroEnv.current_max_ante, per env)."""
     orc = _oracle_envs(n, seeds, scorer, max_ante, jokers)
     if cards:
         for o, cs in zip(orc, cards):
@@ -280,6 +281,9 @@ def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_in
     stats = {"steps": 0, "episodes": 0, "plays": 0, "score_sum": 0, "reward_bits": 0}
     for t in range(T):
         row = []
+        if caps and t in caps:
+            for o, c in zip(orc, caps[t]):
+                o.set_max_ante(int(c))
         for i, o in enumerate(orc):
             a = action_fn(o, i, t) if action_fn else o.policy_action(policy, pseed, env_indexes[i] if env_indexes is not None else env_index0 + i, t0 + t)
             ob, r, term, _, info = o.step(a)
@@ -686,39 +690,47 @@ def test_configs1_all_4096_envs_vs_oracle():
     env.close()
 
 
-@pytest.mark.parametrize("config", ["configs2_jokers_antes_1_4", "configs3_share_consumables_all_jokers_antes_1_8"])
+@pytest.mark.parametrize("config", ["configs2_jokers_antes_1_4", "configs3_share_consumables_all_jokers_antes_1_8", "configs4_full_game_curriculum"])
 def test_full_size_slice_vs_oracle(config):
     """BASELINE.json's full size, compared with the ORACLE (not with itself): 65 536 envs on the benchmark's path -- 256 envs per workgroup,
     packed records 384 bytes apart, three launches of 20 fused steps (the driver's launch shape) -- and every record byte, reward bit
     pattern, action and terminated flag of 2 048 of them, spread over all 256 workgroups (eight per workgroup, a different lane and owner
     wave in each), against the oracle run on just those envs with their GLOBAL indexes.  configs[2]: 5 implemented jokers, Antes 1-4,
     blind by env index; configs[3]'s single-GPU share: 5 of all 150 joker ids, card states, two consumables per env and episode, Antes
-    1-8, uniform policy."""
+    1-8, uniform policy; configs[4]'s single-GPU share: the full game -- uniform policy over every valid action incl. the boss blind (47: 28 boss types,
+    boss_blinds.py:301-532) and shop buys / rerolls / sells (shop.py:160-205), 5 of all 150 joker ids, a PER-ENV curriculum cap (3..5) that rises by 3
+    between the first and the second launch."""
     import torch
     from balatro_gym_amd.vec_env import RowBuffers
     from oracle.gen_golden import IMPLEMENTED
     n, T, chunks = 65536, 20, 3
     cons3 = config.startswith("configs3")
+    full = config.startswith("configs4")
     seeds = [1000 + SEED_OFFSET + i for i in range(n)]
-    pool = list(range(1, 151)) if cons3 else IMPLEMENTED
+    pool = list(range(1, 151)) if (cons3 or full) else IMPLEMENTED
     jokers = [random.Random(i).sample(pool, 5) for i in range(n)]
     cons_ids = list(range(1, 23)) + list(range(30, 42)) + list(range(50, 68))
     cons = [[cons_ids[i % 52], cons_ids[(7 * i + 3) % 52]] for i in range(n)] if cons3 else None
     cards = [[(d, [0, 1, 4, 6, 8][(i + d) % 5], [0, 1, 3][d % 3], [0, 1, 2, 3, 4][(i // 3 + d) % 5]) for d in range(16)] if i % 3 == 0 else []
              for i in range(n)] if cons3 else None
-    policy, max_ante = (0, 8) if cons3 else (2, 4)
+    policy, max_ante = (0, 8) if cons3 else ((0, 3) if full else (2, 4))
+    caps = np.array([3 + (i % 3) for i in range(n)], np.int32)
     env = _vec(n, seeds, autoreset=True, scorer_jokers=True, max_ante=max_ante, card_states=cons3)
     if cons3:
         env.inject_cards(cards, apply_now=True)
     env.inject(jokers=jokers, apply_now=True)
     if cons3:
         env.inject_consumables(cons, apply_now=True)
+    if full:
+        env.set_max_ante(caps)
     pick = np.array([32 * j + (5 * j + j // 8) % 32 for j in range(2048)], dtype=np.int64)   # 8 per 256-env workgroup, lanes and waves vary
     assert len(set(pick.tolist())) == 2048 and pick.max() < n
     pick_t = torch.from_numpy(pick).to(env.device)
     rb = RowBuffers(n, env.device, steps=T, row_stride=384)
     got = []
     for c in range(chunks):
+        if full and c == 1:
+            env.set_max_ante(caps + 3)   # the curriculum: every env's cap rises between two launches
         env.rollout(T, policy=policy, policy_seed=21, env_index0=0, t0=c * T, obs_buffers=rb, zero_stats=(c == 0))
         got.append(rb.rows[:, pick_t, :].cpu().numpy().copy())   # [T, 2048, 384]
     env.check()
@@ -731,7 +743,9 @@ def test_full_size_slice_vs_oracle(config):
     sub.rows.copy_(torch.from_numpy(rows))
     wobs, wr, wt, wa, _ = _oracle_rollout(len(pick), [seeds[i] for i in pick], T * chunks, policy, 21, True, max_ante, [jokers[i] for i in pick],
                                           cards=[cards[i] for i in pick] if cons3 else None, consumables=[cons[i] for i in pick] if cons3 else None,
-                                          env_indexes=pick.tolist())
+                                          env_indexes=pick.tolist(), caps={0: caps[pick], T: caps[pick] + 3} if full else None)
+    if full:   # the workload is the one meant: boss blinds were played and shops were used (a buy / reroll leaves the shop phase with other money than it entered)
+        assert (sub.tensors["boss_blind_active"].numpy() != 0).any() and (wa == 47).any() and ((wa >= 20) & (wa <= 30)).any()
     assert np.array_equal(sub.action.numpy(), wa)
     assert np.array_equal(sub.terminated.numpy(), wt)
     assert np.array_equal(sub.reward.contiguous().numpy().view(np.uint64), wr.view(np.uint64))
