@@ -279,9 +279,7 @@ __shared__ unsigned long long bg_probe_lds[32];
 // and read the rest from HBM; the block-compacted rollout kernel keeps every deck of its workgroup in LDS
 // ([dword 0..15][lane of the workgroup], bank = lane) so that no card lookup of a step -- phase B's gather, the boss
 // checks, the observation's hand -- is an HBM round trip.
-#ifndef BG_RB
 #define BG_RB 128 // envs per workgroup of bg_rollout2_kernel: two workgroups per CU, whose phases overlap each other
-#endif
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
 struct Deck0 { uint64_t lo, hi; static constexpr bool kCards = false; };   // first 16 cards in registers, the rest read from HBM

@@ -30,10 +30,8 @@
 #define BG_ITEM_VALID 0x80000000u
 #define BG_SPIN_LIMIT (1u << 24)
 #define BG_DEVERR_SPIN 16u
-#ifndef BG_ENG_LNE
 #define BG_ENG_LNE 8     // log2 of the envs per workgroup.  Only 8 is supported: 7 (128 envs: twice the workgroups for a small job) passes the parity tests and
                          // gives +9 % at 4 096 envs, 6 gives +15 % but trips a bounded wait (profiles/r03_small_workgroups_ab.txt)
-#endif
 static_assert(BG_ENG_LNE == 8, "only 256 envs per workgroup are supported: items carry the env lane in 8 bits, copy-queue generations in 7, and the epilogue assumes NE = 256");
 #define BG_ENG_NE (1 << BG_ENG_LNE)   // envs per workgroup: 256 (an item holds the env's lane in 8 bits; rings have NE entries, an item's generation = position >> LNE)
 // Waves per workgroup.  SEVEN, not eight: a wave of this kernel needs 256 VGPRs, so eight fill the register file of all four SIMDs and
@@ -42,18 +40,10 @@ static_assert(BG_ENG_LNE == 8, "only 256 envs per workgroup are supported: items
 // workgroup leaves ~5 KB of LDS), the dispatcher places the refill's one-wave workgroups there (multi-wave workgroups do NOT fit:
 // tools/micro/corun.hip), and the refill runs beside the engine: +8.5 % env-steps/s measured on one box although the kernel itself
 // is slower with seven waves and a busy neighbour (3.86 -> 4.30 ms per 372-step launch; -DBG_ENG_NW=8 is the old shape).
-#ifndef BG_ENG_NW
 #define BG_ENG_NW 7
-#endif
-#ifndef BG_ENG_OCC
 #define BG_ENG_OCC 2     // waves per SIMD the register budget is set for (2 = 256 VGPRs; 3 = 168: measured, spills)
-#endif
-#ifndef BG_ENG_IMG_PIECES
 #define BG_ENG_IMG_PIECES 22 // 16-byte pieces from one env's LDS record image to the next (22 = dense; 23: fewer bank conflicts)
-#endif
-#ifndef BG_ENG_NSV
 #define BG_ENG_NSV 4    // of them, how many own an RNG window and may run service batches
-#endif
 #define BG_ENG_SMASK_DEFAULT (((1u << BG_ENG_NSV) - 1u) << (BG_ENG_NW - BG_ENG_NSV)) // which: the last NSV waves (BG_ENG_SMASK)
 
 struct EngineArgs {
@@ -112,12 +102,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   __shared__ uint4 s_c34[2][NE];              // hot chunks 3 and 4
   __shared__ uint32_t s_deck[16][NE];
   __shared__ unsigned long long s_mask[NE];
-#if BG_ENG_IMG_PIECES == 22
   __shared__ uint32_t s_t[NE], s_prod[NE];
-#else
-  __shared__ uint16_t s_t[NE];                // steps done in this launch (<= 372); 16 bits: the padded images leave the refill's deck waves their LDS
-  __shared__ uint32_t s_prod[NE];
-#endif
   __shared__ uint32_t s_q[3][NE];             // rings of items: env lane | generation of the ring position << 8 | action << 16 | VALID
   // queue control words, 32 bytes: [0..2] items ever queued per queue, [3] envs that have finished their T steps,
   // [4..6] items ever claimed per queue, [7] waves inside a batch -- a wave reads all eight with two 16-byte LDS loads
@@ -135,17 +120,9 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   __shared__ unsigned long long s_stats[6];   // the workgroup's share of bg_rollout_stats (bg_step.h bg_stats_wave / bg_stats_flush)
   __shared__ JTables jt;
   __builtin_amdgcn_s_setprio(3);
-#ifdef BG_TIMING4
-  const unsigned long long q_w0 = wall_clock64();   // 100 MHz, the same clock on every CU
-  const unsigned long long q_k0 = __builtin_readcyclecounter();
-#endif
   BG_PROBE_INIT();
   bg_tables_load(&jt, d.jtab);
-#ifdef BG_ENG_WAVE_PERM // development: which ROLE (wave index below) each physical wave takes, a hex digit per physical wave (0x6543210 = identity)
-  const int lane = threadIdx.x & 63, wave = (int)(((unsigned)BG_ENG_WAVE_PERM >> (4 * (threadIdx.x >> 6))) & 15u), tid = wave * 64 + lane;
-#else
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-#endif
   const int env0 = blockIdx.x * NE;
   const int n_live = d.N - env0 < NE ? d.N - env0 : NE;
   const bool can_serve = ((a.serve_mask >> wave) & 1u) != 0;
@@ -262,25 +239,15 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
           for (int u = 0; u < 4; u++)
 #pragma unroll
             for (int j = 0; j < 3; j++)
-#ifdef BG_ABL_NOSTORE   // development ablation: everything but the store itself (the value is kept alive)
-              { if (g0 + 8u * (uint32_t)u + rsel[j] < nb) asm volatile("" :: "v"(v[u][j]), "v"(ce[u][j].x)); }
-#else
               // NON-TEMPORAL stores: the records are a write-once stream nothing on the GPU reads back; written through the L2 as ordinary
               // stores they evicted the env state, the RNG rings and the shop streams every service step reads (+15 % with the `nt` bit)
               if (g0 + 8u * (uint32_t)u + rsel[j] < nb)
-#ifdef BG_COPIER_PLAIN
-                *(__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)ce[u][j].x * 384u + gl[j])) = v[u][j];
-#else
                 __builtin_nontemporal_store(v[u][j], (__attribute__((address_space(1))) bg_u32x4*)(a.obs.rows + ((size_t)ce[u][j].x * 384u + gl[j])));
-#endif
-#endif
         }
       } else {
       const uint32_t total = PR * nb;
       // the dense layout (or any other stride): KU pieces per lane and iteration, the record of a piece by a division
-#ifndef BG_COPIER_KU
 #define BG_COPIER_KU 12
-#endif
       constexpr int KU = BG_COPIER_KU;
       for (uint32_t q0 = (uint32_t)lane; q0 < total; q0 += (uint32_t)KU * BG_BLOCK) {
         uint2 ce[KU];
@@ -326,15 +293,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   int64_t ssum = 0;
   const uint32_t bmod3 = (uint32_t)(a.env_index0 % 3ull);
   uint32_t polls = 0;
-#ifdef BG_TIMING4
-  if (tid == 0 && d.dbg) { atomicAdd(&d.dbg[16], __builtin_readcyclecounter() - q_k0); atomicMax(&d.dbg[20], ~q_w0); }
-  unsigned long long q_batches[3] = {0, 0, 0}, q_items[3] = {0, 0, 0}, q_busy[3] = {0, 0, 0}, q_idle = 0, q_fail = 0, q_copy = 0, q_claim = 0, q_failt = 0, q_item = 0, q_cheap = 0, q_fin = 0, q_push = 0, q_small[2] = {0, 0}, q_smallt[2] = {0, 0};
-  const unsigned long long q_t0 = __builtin_readcyclecounter();
-#endif
   for (;;) {
-#ifdef BG_TIMING4
-    const unsigned long long q_l0 = __builtin_readcyclecounter();
-#endif
     // -- pick a queue: the eight control words with two 16-byte loads (one LDS round trip; each word is written atomically by its
     // owner, so a torn pair of words is no worse than two separate loads)
     // The HEADS are read first, the tails after them (a wave's LDS loads execute in order): a tail read BEFORE its head could be older
@@ -367,9 +326,6 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       if (__builtin_amdgcn_readfirstlane(ct.w) >= (uint32_t)n_live) break; // every env has done its T steps
       __builtin_amdgcn_s_sleep(8);
       if (++polls > BG_SPIN_LIMIT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
-#ifdef BG_TIMING4
-      q_idle += __builtin_readcyclecounter() - q_l0;
-#endif
       continue;
     }
     const uint32_t head = cls == BG_Q_RUN ? hr : (cls == BG_Q_PLAY ? hp : ho), navail = cls == BG_Q_RUN ? nr : (cls == BG_Q_PLAY ? np : no);
@@ -388,21 +344,12 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       if (lane == 0) got = atomicCAS(&s_head[cls], head, head + nb) == head ? 1u : 0u;
       if (lane == 0 && got) __hip_atomic_fetch_add(&s_busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       if (__builtin_amdgcn_readfirstlane(got) == 0u) {
-#ifdef BG_TIMING4
-        q_fail++; q_failt += __builtin_readcyclecounter() - q_l0;
-#endif
         continue;
       }
     }
     polls = 0;
-#ifndef BG_NO_SERVICE_PRIO
     // the service chains are the critical path of every env they hold: they issue ahead of the run batches on their SIMD
     if (cls == BG_Q_RUN) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
-#endif
-#ifdef BG_TIMING4
-    const unsigned long long q_b0 = __builtin_readcyclecounter();
-    q_claim += q_b0 - q_l0;
-#endif
     // A batch = the step the envs were queued for, then up to th_more further CHEAP steps of the same envs (a toggle is followed
     // by another toggle five times out of six): the env stays with the wave that has it instead of going through the run queue
     // -- and its wait for a free wave -- once per step.  A lane leaves the batch when its env has done its T steps or its next
@@ -417,10 +364,6 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       if ((item & (BG_ITEM_VALID | 0xff00u)) != want) atomicOr(d.err, BG_DEVERR_SPIN);
       else { active = true; l = (int)(item & 0xffu); env = env0 + l; t = s_t[l]; }
     }
-#ifdef BG_TIMING4
-    const unsigned long long q_i1 = __builtin_readcyclecounter();
-    if (cls == BG_Q_RUN) q_item += q_i1 - q_b0;
-#endif
     // one CHEAP step of this lane's env on its image: a card-select toggle, shop end, or an action the guards reject; anything
     // else is queued for a service batch and the lane gives the env up.  Returns true when a step was completed.
     auto cheap_step = [&](int& action, double& reward, StepOut& o) __attribute__((always_inline)) -> bool {
@@ -564,9 +507,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
         BG_PROBE(24);
         mask = bg_action_mask(d, env, e, sr);
         BG_PROBE(25);
-#ifndef BG_ABL_NOIMG   // (development ablation: a service step that leaves the image stale)
         bg_write_obs_impl<false, 3>(d, env, row, e, dk, a.obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u}, RowStage{(lds_u4*)&s_img[l][0], nullptr});
-#endif
         BG_PROBE(26);
         bg_pack(e, c);
 #pragma unroll
@@ -578,20 +519,10 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
         if (o.hand_type >= 0) { n_plays++; ssum += o.final_score; }
         fin = true;
         }
-#ifdef BG_TIMING4
-        const unsigned long long q_f0 = __builtin_readcyclecounter();
-        if (cls == BG_Q_RUN) q_cheap += q_f0 - q_i1;
-#endif
         if (fin) finish(cls == BG_Q_RUN, row, action, reward, terminated, o);
-#ifdef BG_TIMING4
-        if (cls == BG_Q_RUN) q_fin += __builtin_readcyclecounter() - q_f0;
-#endif
       }
       copy_out(fin, row);
     }
-#ifdef BG_TIMING4
-    const unsigned long long q_p0 = __builtin_readcyclecounter();
-#endif
     // ---------------- further cheap steps of the envs this wave still holds
     // (run batches only: a service wave hands its envs back at once -- service capacity is what the whole workgroup waits for)
     for (uint32_t sub = 0; cls == BG_Q_RUN && !a.copier && sub < a.th_more && __ballot(active) != 0ull; sub++) {
@@ -613,21 +544,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       bg_lds_st(&s_q[BG_Q_RUN][slot & (NE - 1)], (uint32_t)l | (((slot >> BG_ENG_LNE) & 0xffu) << 8) | BG_ITEM_VALID);
     }
     if (lane == 0) __hip_atomic_fetch_sub(&s_busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // after the pushes of this batch
-#ifdef BG_TIMING4
-    q_batches[cls]++; q_items[cls] += nb; q_busy[cls] += __builtin_readcyclecounter() - q_b0;
-    if (nb <= 4u && cls != BG_Q_RUN) { q_small[cls - 1]++; q_smallt[cls - 1] += __builtin_readcyclecounter() - q_b0; } // the batches of a launch's tail
-    if (cls == BG_Q_RUN) q_push += __builtin_readcyclecounter() - q_p0;
-#endif
   }
-#ifdef BG_TIMING4
-  if (lane == 0 && d.dbg) {
-    atomicAdd(&d.dbg[0], __builtin_readcyclecounter() - q_t0); atomicAdd(&d.dbg[1], 1ull);
-    for (int c = 0; c < 3; c++) { atomicAdd(&d.dbg[2 + 3 * c], q_batches[c]); atomicAdd(&d.dbg[3 + 3 * c], q_items[c]); atomicAdd(&d.dbg[4 + 3 * c], q_busy[c]); }
-    atomicAdd(&d.dbg[11], q_idle); atomicAdd(&d.dbg[12], q_fail); atomicAdd(&d.dbg[13], q_copy); atomicAdd(&d.dbg[14], q_claim); atomicAdd(&d.dbg[15], q_failt);
-    atomicAdd(&d.dbg[26], q_item); atomicAdd(&d.dbg[27], q_cheap); atomicAdd(&d.dbg[28], q_fin); atomicAdd(&d.dbg[29], q_push);
-    atomicAdd(&d.dbg[17], q_small[0]); atomicAdd(&d.dbg[18], q_smallt[0]); atomicAdd(&d.dbg[19], q_small[1]); atomicAdd(&d.dbg[30], q_smallt[1]);
-  }
-#endif
   // ---------------------------------------------------------------- epilogue: chunks 3 / 4 -> HBM, statistics
   BG_PROBE_FLUSH(d);
   __syncthreads();

@@ -19,34 +19,24 @@
 #define E3T(k) do { const unsigned long long n_ = __builtin_readcyclecounter(); e3t_[k] += n_ - e3t0_; e3t0_ = n_; } while (0)
 #define E3T_CNT(k, v) do { e3t_[k] += (v); } while (0)
 #define E3T_FLUSH(base) do { if (lane == 0 && d.dbg) for (int k_ = 0; k_ < 8; k_++) atomicAdd(&d.dbg[(base) + k_], e3t_[k_]); } while (0)
+constexpr bool kE3Timing = true, kE3Tl = true;
 #else
-#define E3T_DECL() do {} while (0)
+#define E3T_DECL() const unsigned long long e3t_[8] = {0,0,0,0,0,0,0,0}; (void)e3t_
 #define E3T(k) do {} while (0)
 #define E3T_CNT(k, v) do {} while (0)
 #define E3T_FLUSH(base) do {} while (0)
+constexpr bool kE3Timing = false;
+#ifdef BG_E3_TL   // development: only the workgroup timeline (tools/e3_timeline.py)
+constexpr bool kE3Tl = true;
+#else
+constexpr bool kE3Tl = false;
+#endif
 #endif
 
-// the record stores of the whole-line copy-out: non-temporal (development: -DBG_E3_STORE=1 sc1, 2 sc0 sc1, 3 plain, 4 sc1 nt)
-#ifndef BG_E3_STORE
+// the record stores of the whole-line copy-out: non-temporal (`sc1` / `sc0 sc1` / plain stores: -12 %, `sc1 nt`: the same; profiles/r04_engine3/record_stream_sensitivity.txt)
 #define BG_E3_REC_STORE(v, p) __builtin_nontemporal_store(v, p)
-#elif BG_E3_STORE == 1
-#define BG_E3_REC_STORE(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory")
-#elif BG_E3_STORE == 2
-#define BG_E3_REC_STORE(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory")
-#elif BG_E3_STORE == 3
-#define BG_E3_REC_STORE(v, p) (*(p) = (v))
-#else
-#define BG_E3_REC_STORE(v, p) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" ::"v"(p), "v"(v) : "memory")
-#endif
-#ifndef BG_E3_SPARSE
-#define BG_E3_SPARSE 8u   // records finished in an owner iteration up to which the copy-out takes its one-group path (0: never)
-#endif
-#ifndef BG_E3_SPARSE2
-#define BG_E3_SPARSE2 16u // ... its two-group path
-#endif
-#ifndef BG_E3_SPARSE3
-#define BG_E3_SPARSE3 0u  // ... and a three-group path (0: none; profiles/r05/sparse_copy_out.txt)
-#endif
+#define BG_E3_SPARSE 8u   // records finished in an owner iteration up to which the copy-out takes its one-group path
+#define BG_E3_SPARSE2 16u // ... its two-group path (a three-group tier: inside the noise, profiles/r05/sparse_copy_out.txt)
 template <int NOW, int KS, int NSV>
 struct E3Lds {
   static constexpr int NE = NOW * KS * BG_BLOCK;
@@ -72,16 +62,11 @@ struct E3Lds {
 };
 // A workgroup = NE = 64 * NOW * KS envs: NOW owner waves (each owns KS slices of 64 envs, lane = env of a slice) + NSV service waves.  256 envs per
 // workgroup fill the chip at 65 536 envs; a small job takes 64 or 128 per workgroup and spreads over four or two times as many CUs.
-#ifdef BG_E3_NUM_VGPR   // development: cap the kernel's registers below the 256 that two waves per SIMD leave each (what does a fourth service wave AND the refill beside it cost in spills?)
-#define BG_E3_VGPR_ATTR __attribute__((amdgpu_num_vgpr(BG_E3_NUM_VGPR)))
-#else
-#define BG_E3_VGPR_ATTR
-#endif
 template <bool HASH, bool CARDS, int NOW, int KS, int NSV>
 // (Round 5 measured reading the arguments THROUGH the kernarg segment pointer instead of as by-value parameters -- whose 16-register blocks the compiler
 //  spills to VGPR lanes and reloads whole, 12 % of the kernel's instructions being v_readlane / v_writelane / s_nop: SGPR spills 237 -> 61, 14 454 -> 13 114
 //  instructions, and 3.4 % SLOWER at both launch lengths: a scalar load per use waits longer than sixteen lane reads.  profiles/r05/play_path_ab.txt.)
-__global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_engine3_kernel(BgDev d, EngineArgs a) {
+__global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(BgDev d, EngineArgs a) {
   constexpr int NE = NOW * KS * BG_BLOCK, LNE = NE == 256 ? 8 : (NE == 128 ? 7 : 6);
   static_assert(NE == 64 || NE == 128 || NE == 256, "envs per workgroup (a request carries the env's lane in 8 bits)");
   // (static LDS: the compiler then pads the register allocation to the 256 VGPRs that two waves per SIMD leave each -- which this kernel needs
@@ -91,9 +76,7 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
   auto& s_ctl = L.s_ctl; auto& s_win = L.s_win; auto& s_list = L.s_list; auto& s_zero = L.s_zero; auto& s_owners_left = L.s_owners_left; auto& jt = L.jt;
   auto& s_nd = L.s_nd; auto& s_ndst = L.s_ndst;
   __builtin_amdgcn_s_setprio(2);
-#if defined(BG_E3_TIMING) || defined(BG_E3_TL)
-  const unsigned long long e3_k0 = wall_clock64();
-#endif
+  const unsigned long long e3_k0 = kE3Tl ? wall_clock64() : 0ull;
   BG_PROBE_INIT();
   bg_tables_load(&jt, d.jtab);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -138,20 +121,15 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
     }
   }
   __syncthreads();
-#ifdef BG_E3_TIMING
-  if (lane == 0) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); atomicOr(&s_ctl[2], ((hw >> 4) & 3u) << (2 * wave)); }   // (word 2: nobody's)
-#endif
-#if defined(BG_E3_TIMING) || defined(BG_E3_TL)
-  const unsigned long long e3_w0 = wall_clock64();
-  if (tid == 0 && d.dbg) atomicAdd(&d.dbg[28], e3_w0 - e3_k0);   // prologue (100 MHz ticks, summed over workgroups)
-  __syncthreads();
-#endif
+  if constexpr (kE3Timing) if (lane == 0) { uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); atomicOr(&s_ctl[2], ((hw >> 4) & 3u) << (2 * wave)); }   // (word 2: nobody's)
+  const unsigned long long e3_w0 = kE3Tl ? wall_clock64() : 0ull;
+  if constexpr (kE3Tl) {
+    if (tid == 0 && d.dbg) atomicAdd(&d.dbg[28], e3_w0 - e3_k0);   // prologue (100 MHz ticks, summed over workgroups)
+    __syncthreads();
+  }
   const uint32_t T = (uint32_t)a.T;
   if (wave < NOW) {
     // ============================================================== OWNER wave: lane = env of each of its KS slices, for the whole launch
-#ifdef BG_E3_OPRIO
-    __builtin_amdgcn_s_setprio(BG_E3_OPRIO);
-#endif
     const uint32_t bmod3 = (uint32_t)(a.env_index0 % 3ull);
     lds_cc* const imgb = (lds_cc*)&s_img[0][0];
     const bool whole = a.obs.row_stride == 384u;
@@ -307,27 +285,17 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
       }
       E3T(0);
       // ---- copy-out: lane <-> 16-byte piece, non-temporal (32 records per round of loads: the LDS round trips overlap)
-#ifdef BG_E3_NOCOPY   // development (sensitivity only, records are NOT written): what the launch would take with the copy-out for free
-      if (nb) { idle = 0; E3T(1); E3T_CNT(5, nb); } else
-#endif
       if (nb) {
         idle = 0;
         BG_WAVE_SYNC();
         typedef uint32_t bg_u32x2 __attribute__((ext_vector_type(2)));
         lds_cc* const lsb = (lds_cc*)&s_list[wave][0];
         // NU groups of eight records from list position G0: 3 NU list reads, 3 NU image reads (the LDS round trips of a group overlap), 3 NU stores.
-        // (BG_E3_NOSTORE / BG_E3_STORE_L2: development, sensitivity only.  Round 5: unconditional stores with the empty lanes aimed at a dump line -- no
-        //  exec-mask save and branch per store -- cost 7-8 % at both launch lengths: profiles/r05/play_path_ab.txt)
-#ifndef BG_E3_NOSTORE
+        // (Round 5: unconditional stores with the empty lanes aimed at a dump line -- no exec-mask save and branch per store -- cost 7-8 % at both launch
+        //  lengths: profiles/r05/play_path_ab.txt.  Round 4's sensitivity builds -- no copy-out / no stores / every record into 24 KB -- are in the history
+        //  at cdcab7a: profiles/r04_engine3/record_stream_sensitivity.txt)
 #define BG_E3_LIVE(idx) ((idx) < nb)
-#else
-#define BG_E3_LIVE(idx) ((idx) < nb && a.T == 0x7fffffff)
-#endif
-#ifdef BG_E3_STORE_L2   // every record into the first 64 rows -- the same instructions, no HBM write stream
-#define BG_E3_ROW(x) ((x) & 63u)
-#else
 #define BG_E3_ROW(x) (x)
-#endif
 #define BG_E3_COPY_GROUPS(NU, G0) do { \
           bg_u32x2 ce[NU][3]; \
           bg_u32x4 v[NU][3]; \
@@ -344,14 +312,8 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
           // A SPARSE iteration (a small job's 16 live envs per workgroup; the first and last iterations of a short launch): at most eight records = ONE
           // group -- three list reads, three image reads, three stores instead of twelve of each (nine of which had no lane to serve)
           BG_E3_COPY_GROUPS(1, 0u);
-#if BG_E3_SPARSE2
         } else if (whole && nbs <= BG_E3_SPARSE2) {
           BG_E3_COPY_GROUPS(2, 0u);
-#endif
-#if BG_E3_SPARSE3
-        } else if (whole && nbs <= BG_E3_SPARSE3) {
-          BG_E3_COPY_GROUPS(3, 0u);
-#endif
         } else if (whole) {
           for (uint32_t g0 = 0; g0 < nb; g0 += 32u) BG_E3_COPY_GROUPS(4, g0);
         } else {
@@ -409,10 +371,9 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
       }
     }
     E3T_FLUSH(0);
-#ifdef BG_E3_TIMING
     // (does the owner wave that shares its SIMD with the refill's waves instead of a service wave lag?)  by the number of engine waves on this wave's SIMD:
     // dbg[16 + 4 k ..] = sum of end times (100 MHz ticks since the workgroup started), iterations, waves, steps done
-    if (lane == 0 && d.dbg) {
+    if constexpr (kE3Timing) if (lane == 0 && d.dbg) {
       uint32_t hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       const uint32_t my = (hw >> 4) & 3u;
       int same = 0;
@@ -423,10 +384,7 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
       atomicAdd(&d.dbg[16 + 4 * (key - 1) + 1], e3t_[4]);
       atomicAdd(&d.dbg[16 + 4 * (key - 1) + 2], 1ull);
     }
-#endif
-#if defined(BG_E3_TIMING) || defined(BG_E3_TL)
-    if (lane == 0 && d.dbg) atomicAdd(&d.dbg[29], wall_clock64() - e3_k0);   // owner loop end, summed over owner waves
-#endif
+    if constexpr (kE3Tl) if (lane == 0 && d.dbg) atomicAdd(&d.dbg[29], wall_clock64() - e3_k0);   // owner loop end, summed over owner waves
 #pragma unroll
     for (int s = 0; s < KS; s++) { const int l = (wave * KS + s) * BG_BLOCK + lane; s_c34[0][l] = rc3[s]; s_c34[1][l] = rc4[s]; }   // (the epilogue stores them)
     if (lane == 0) __hip_atomic_fetch_sub(&s_owners_left, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -520,7 +478,10 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
           BG_PROBE(24);
           mask = bg_action_mask(d, env, e, sr);
           BG_PROBE(25);
-          bg_write_obs_impl<false, 3>(d, env, 0, e, dk, a.obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u}, RowStage{(lds_u4*)&s_img[l][0], nullptr});
+          // (the record goes to the env's IMAGE and nowhere else: an all-null ObsPtrs, as in the prologue.  Handed the launch's own -- whose `rows` the
+          //  compiler cannot know to be set -- the per-key writer's 31 pointers stayed live in scalar registers through the whole service step.)
+          const ObsPtrs none{};
+          bg_write_obs_impl<false, 3>(d, env, 0, e, dk, none, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u}, RowStage{(lds_u4*)&s_img[l][0], nullptr});
           BG_PROBE(26);
           bg_pack(e, c);
 #pragma unroll
@@ -536,9 +497,7 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
       E3T(1 + cls); E3T_CNT(4 + cls, 1); E3T_CNT(6 + cls, nb);
     }
     E3T_FLUSH(8);
-#if defined(BG_E3_TIMING) || defined(BG_E3_TL)
-    if (lane == 0 && d.dbg) atomicAdd(&d.dbg[30], wall_clock64() - e3_k0);   // service loop end, summed over service waves
-#endif
+    if constexpr (kE3Tl) if (lane == 0 && d.dbg) atomicAdd(&d.dbg[30], wall_clock64() - e3_k0);   // service loop end, summed over service waves
     if (a.stats) bg_stats_wave(L.s_stats, 0, n_eps, n_plays, ssum, 0, 0);
   }
   // ---------------------------------------------------------------- epilogue: chunks 3 / 4 -> HBM
@@ -549,7 +508,5 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) BG_E3_VGPR_ATTR void bg_
     d.hot[(size_t)4 * N + env0 + l] = s_c34[1][l];
   }
   if (a.stats) bg_stats_flush(a.stats, L.s_stats, tid);
-#if defined(BG_E3_TIMING) || defined(BG_E3_TL)
-  if (tid == 0 && d.dbg) atomicAdd(&d.dbg[31], wall_clock64() - e3_k0);   // workgroup end
-#endif
+  if constexpr (kE3Tl) if (tid == 0 && d.dbg) atomicAdd(&d.dbg[31], wall_clock64() - e3_k0);   // workgroup end
 }

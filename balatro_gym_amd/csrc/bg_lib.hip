@@ -239,16 +239,10 @@ __device__ void bg_mt_seed_slot(uint32_t* __restrict__ p, uint32_t key) { bg_mt_
 // take(y): consumes one untempered word, returns true while the lane wants another.  Returns the new cursor.  Every lane of
 // the wave must call this (lanes with active == false touch no memory); the loop runs until the last lane has had enough.
 __device__ __forceinline__ uint32_t bg_q156(uint32_t q) { return q >= 156u ? q - 156u : q; }
-#ifndef BG_LAZY_U
 #define BG_LAZY_U 4 // 16-byte groups per iteration of bg_lazy_stream
-#endif
-#ifndef BG_LAZY_U_SEEDRING
 #define BG_LAZY_U_SEEDRING 2 // the seed ring draws ~34 words per env and refill: shorter iterations, 70 registers -> three waves beside the engine
-#endif
 #define BG_WL_COUNTERS 32 // refill work-list counters: [0..3] list lengths, [4] the deck kernel's cursor, [8 + p] the cursor of its part p (p < 16)
-#ifndef BG_REFILL_WAVE_PRIO
 #define BG_REFILL_WAVE_PRIO 0 // s_setprio of the deck / seed-ring / block waves (the shop seeding stays at 0, the step engine runs at 3)
-#endif
 template <int U = BG_LAZY_U, class F>
 __device__ __forceinline__ uint32_t bg_lazy_stream(uint32_t* S, uint32_t c, bool active, F&& take) {
   uint4* S4 = (uint4*)S;

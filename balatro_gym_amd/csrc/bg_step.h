@@ -749,13 +749,8 @@ __device__ __forceinline__ void bg_step_play_hand(const BgDev& d, int env, Env& 
   uint64_t dhist = 0;                      // rank histogram of the DECK cards played (boss Plant, face synergy)
   uint64_t cst = 0;                        // enh | seal << 4 per play index, one byte each
   const DeckHead dh = bg_deck_head(d, env, dk); // deck[0..15]: the cards under the hand's indexes AND the classifier's positions
-#ifdef BG_GATHER_UNROLL
-#pragma unroll
-  for (int i = 0; i < 8; i++) if (i < e.nsel) {
-#else
 #pragma unroll 1
   for (int i = 0; i < e.nsel; i++) {
-#endif
     int pos = bg_get8(e.sel, i);
     if (pos < e.nhand) {
       int ci = bg_get8(e.hand, pos);
@@ -1409,9 +1404,6 @@ __device__ __forceinline__ void bg_env_dispatch(const BgDev& d, int env, Env& e,
     else bg_use_consumable(d, env, e, w, dk, action - 10, o); // 10..14
   } else if (e.phase == 1) bg_step_shop(d, env, e, w, sr, action, o);
   else if (e.phase == 2) bg_step_blind<DK::kCards>(d, env, e, w, sr, action, o);
-#ifdef BG_ABL_NOSHOP   // development ablation: what is the shop inventory worth (the shop rows stay stale)
-  w.need_inv = false;
-#endif
   if (w.need_inv) { BG_PROBE_BEGIN(); bg_shop_inventory(d, env, e, w, sr); w.need_inv = false; BG_PROBE(22); }
 }
 
@@ -1491,17 +1483,11 @@ __device__ __forceinline__ float bg_obs_prf(const Env& e) { // :1497 min(2, roun
 typedef uint32_t bg_u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) bg_u32x4 lds_u4;
 typedef __attribute__((address_space(3))) unsigned long long lds_u64;
-#ifndef BG_STAGE_NP
 #define BG_STAGE_NP 11 // 16-byte pieces of a record staged at a time: runs of 176 bytes per row and store instruction
-#endif
 struct RowStage { lds_u4* stage; lds_u64* addr; };
 // lanes of one wave exchanging data through LDS: the hardware queue is in order per wave, the compiler must not move
 // LDS accesses across the hand-over point
-#ifdef BG_WAVE_SYNC_FENCE
-#define BG_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
-#else
 #define BG_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
-#endif // reward / action / terminated ride in the record
 
 // Statistics of a launch (bg_rollout_stats).  A wave folds its lanes with shuffles and adds the result to six LDS words of its workgroup; behind the
 // workgroup's last barrier six lanes add those to the caller's struct.  One global atomic per wave and field -- 5 376 (engine 3) / 10 752 (bg_engine.h)
