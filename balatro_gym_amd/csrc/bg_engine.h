@@ -66,7 +66,9 @@ struct EngineArgs {
   uint32_t epw;                // bg_engine3.h, the 64-env workgroup shape only: envs per workgroup that are LIVE (8 .. 64; 0 = all 64) -- a small job spreads over more CUs
   // bg_engine3.h, sharded jobs (bg_set_gather_peers): the record of the launch's LAST step is also written into every rank's gather buffer
   // ([world][N][352] bytes, rank `grank`'s shard), by the owner waves' copy-out, while the launch runs.  gworld = 0: no gather.
-  uint8_t* gpeer[8];
+  // (gpeer: a DEVICE array of the `gworld` buffer pointers, read with scalar loads where a last-step record is written -- once per env and launch; as
+  //  eight by-value kernel arguments they were sixteen scalar registers live through the whole owner loop)
+  uint8_t* const* gpeer;
   uint32_t gworld, grank;
 };
 

@@ -347,8 +347,7 @@ __global__ __launch_bounds__((NOW + NSV) * BG_BLOCK, 2) void bg_engine3_kernel(B
               const uint32_t gl = ce.y & 0xffu;
               const bg_u32x4 v = s_img[gl][pc];
               const size_t off = ((size_t)a.grank * N + (size_t)(env0 + (int)gl)) * 352u + 16u * pc;
-#pragma unroll   // (constant indexes: a rank count known at run time only must not turn the kernel's arguments into a scratch array)
-              for (int g = 0; g < 8; g++) if ((uint32_t)g < a.gworld) __builtin_nontemporal_store(v, (__attribute__((address_space(1))) bg_u32x4*)(a.gpeer[g] + off));
+              for (uint32_t g = 0; g < a.gworld; g++) __builtin_nontemporal_store(v, (__attribute__((address_space(1))) bg_u32x4*)(a.gpeer[g] + off));   // (a.gpeer[g]: a scalar load)
             }
           }
         }

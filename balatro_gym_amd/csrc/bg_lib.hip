@@ -713,7 +713,7 @@ struct bg_handle {
   // thresholds (BG_E3_TH requests, or after BG_E3_WAIT ticks of 10 ns)
   int e3_cfg, e3_epw; uint32_t e3_th, e3_wait;
   // sharded jobs (bg_set_gather_peers): every rank's gather buffer as mapped into THIS process, the size of the job and this handle's rank
-  uint8_t* gpeer[8]; int gworld, grank;
+  uint8_t* gpeer[8]; uint8_t** d_gpeer; int gworld, grank;   // d_gpeer: the same eight pointers in device memory (what the kernel reads)
 };
 
 static std::string g_create_err;
@@ -908,6 +908,7 @@ int bg_create_ex(int n_envs, int device_id, uint32_t flags, int max_ante, int fu
     if (h->e3_cfg != 0 && h->e3_cfg != 113 && h->e3_cfg != 213 && h->e3_cfg != 413 && h->e3_cfg != 414) { delete h; g_create_err = "bg_create: BG_E3_CFG must be 113, 213, 413 or 414 (100 x owner waves + 10 x slices + service waves)"; return BG_E_ARG; }
     h->e3_th = (uint32_t)geti("BG_E3_TH", 0x7fffffff); h->e3_wait = (uint32_t)geti("BG_E3_WAIT", 0);
     for (int g = 0; g < 8; g++) h->gpeer[g] = nullptr;
+    h->d_gpeer = nullptr;
     h->gworld = 0; h->grank = 0;
     h->e3_epw = geti("BG_E3_EPW", 0);   // live envs per 64-env workgroup (0 = by env count)
     if (h->e3_epw != 0 && (h->e3_epw < 1 || h->e3_epw > 64)) { delete h; g_create_err = "bg_create: BG_E3_EPW must be in [1, 64]"; return BG_E_ARG; }
@@ -1022,7 +1023,7 @@ int bg_destroy(bg_handle* h) {
   for (auto* v : {&h->ev_rollout_t, &h->ev_refill_t, &h->ev_step_t}) for (hipEvent_t e : *v) (void)hipEventDestroy(e);
   hipFree(h->d_prod[0]); hipFree(h->d_prod[1]);
   hipFree(d.hot); hipFree(d.deck); hipFree(d.cold); hipFree(d.tmpl); hipFree(d.ndeck); hipFree(d.gblk); hipFree(d.sblk); hipFree(d.sovf);
-  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.wl_shop); hipFree(d.sseed); hipFree(d.smeta); hipFree(d.dbg); hipFree(h->d_jtab); hipFree(d.cstate); hipFree(d.ctmpl); hipFree(d.cardmt); hipFree(d.sealmt);
+  hipFree(d.deckmt); hipFree(d.shopgenmt); hipFree(d.err); hipFree(h->d_seeds); hipFree(h->d_mask); hipFree(d.wl_count); hipFree(d.wl); hipFree(d.wl_shop); hipFree(d.sseed); hipFree(d.smeta); hipFree(d.dbg); hipFree(h->d_jtab); hipFree(h->d_gpeer); hipFree(d.cstate); hipFree(d.ctmpl); hipFree(d.cardmt); hipFree(d.sealmt);
   }
   delete h;
   return 0;
@@ -1559,7 +1560,7 @@ static int bg_rollout_impl(bg_handle* h, int T, int policy, uint64_t policy_seed
       ea.obs = o; ea.obs_stride_steps = obs_stride_steps; ea.reward = rw; ea.term = tm; ea.actions_out = ac; ea.stats = stats_dev;
       ea.th_run = h->eng_run; ea.th_play = h->eng_play; ea.th_other = h->eng_other; ea.th_part = h->eng_part; ea.th_more = h->eng_more; ea.serve_mask = h->eng_smask; ea.autoreset = 1;
       if (h->gworld > 0 && rows_dev && h->engine == 3 && done + chunk == T) { // the call's LAST launch: its last step is every env's current record
-        for (int g = 0; g < h->gworld; g++) ea.gpeer[g] = h->gpeer[g];
+        ea.gpeer = h->d_gpeer;
         ea.gworld = (uint32_t)h->gworld; ea.grank = (uint32_t)h->grank;
       }
       bg_engine_launch(h, dv, ea, hash, false, st, ev_a, ev_b);
@@ -1619,7 +1620,10 @@ int bg_set_gather_peers(bg_handle* h, void* const* bufs, int world, int rank) {
       (void)hipGetLastError();
     }
   }
-  for (int g = 0; g < world; g++) h->gpeer[g] = (uint8_t*)bufs[g];
+  for (int g = 0; g < 8; g++) h->gpeer[g] = g < world ? (uint8_t*)bufs[g] : nullptr;
+  if (!h->d_gpeer) BG_HIP(hipMalloc((void**)&h->d_gpeer, sizeof(h->gpeer)));
+  BG_HIP(hipDeviceSynchronize());   // no launch of this handle may still be reading the old pointers
+  BG_HIP(hipMemcpy(h->d_gpeer, h->gpeer, sizeof(h->gpeer), hipMemcpyHostToDevice));
   h->gworld = world; h->grank = rank;
   return 0;
 }
