@@ -13,6 +13,7 @@ python bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver_shape.json" 
 # (under rocprofv3 the program itself follows `--`: no env / bash -c hop)
 rocprofv3 --kernel-trace --stats -d "$out/prof_driver" -o runc -- python3 bench.py --gpus 1 --steps 20 --warmup 5 > "$out/bench_driver_prof.json" 2> "$out/bench_driver_prof.err"
 python tools/rocpd_summary.py "$(find $out/prof_driver -name '*.db' | head -1)" "$out/driver_cmd_kernel_stats.txt" > /dev/null 2>&1
+python tools/driver_cmd_short.py "$(find $out/prof_driver -name '*.db' | head -1)" > "$out/driver_cmd_short_launches.txt" 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/prof_default" -o runc -- python3 bench.py --no-cpu-baseline --no-step-path > "$out/bench_default_prof.json" 2> "$out/bench_default_prof.err"
 python tools/rocpd_summary.py "$(find $out/prof_default -name '*.db' | head -1)" "$out/kernel_stats.txt" > /dev/null 2>&1
 rocprofv3 --kernel-trace --stats -d "$out/prof_t20" -o runc -- python3 bench.py --no-cpu-baseline --no-step-path --no-small-n --internal-warmup-launches 0 --chunk 20 --steps 2000 --warmup 400 --samples 0 > "$out/bench_t20_prof.json" 2> "$out/bench_t20_prof.err"
