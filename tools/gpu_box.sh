@@ -11,6 +11,7 @@
 #     timing:<lib>     tools/e3_timing.py with a -DBG_E3_TIMING library (cycles per batch / owner iteration), both shapes
 #     probes:<lib>     tools/probes4.py with a -DBG_TIMING library (cycle probes of the play path at full load)
 #     stress           tools/stress_parity.py in its five modes (every record byte against the oracle)
+#     campaign:<k>     k seed offsets x the stress modes (one launch / many short launches) + the GPU suite under BG_TEST_SEED_OFFSET
 #     sq               SQ counters of bg_engine3_kernel at both launch shapes (tools/sq_counters.sh passes)
 #     final            the round's artefacts: bench lines, rocprofv3 --kernel-trace --stats of the driver's command and the default one, PMC traffic
 set -u
@@ -66,6 +67,14 @@ for step in "$@"; do
     stress)
       (for mode in "" "wide 5 6" "wide 11 6" long consumables; do echo "== mode [$mode] STRIDE=384"; STRIDE=384 timeout 900 python tools/stress_parity.py $mode 2>&1 | grep -v amdgpu.ids; done) > "$out/stress_parity.txt" 2>&1
       grep -c "^ok" "$out/stress_parity.txt"; grep "STRESS OK\|FAIL\|Error" "$out/stress_parity.txt" | tr '\n' ' '; echo ;;
+    campaign:*)   # campaign:<k>: k seed offsets x (the five stress modes, once as ONE launch and once as short launches with the refill in pieces) + the GPU suite under BG_TEST_SEED_OFFSET
+      k="${step#campaign:}"
+      (for off in $(seq 1 "$k"); do for chunks in "" "20,13,30,7"; do for mode in "" "wide 5 6" long consumables; do
+          echo "== SEED_OFFSET=$((off * 100003)) CHUNKS=[$chunks] mode [$mode]"; SEED_OFFSET=$((off * 100003)) CHUNKS=$chunks STRIDE=384 timeout 900 python tools/stress_parity.py $mode 2>&1 | grep -v amdgpu.ids
+        done; done
+        echo "== BG_TEST_SEED_OFFSET=$((off * 7919)): the GPU suite"; BG_TEST_SEED_OFFSET=$((off * 7919)) timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
+      done) > "$out/stress_campaign.txt" 2>&1
+      grep -c "^ok" "$out/stress_campaign.txt"; grep -c "STRESS OK" "$out/stress_campaign.txt"; grep "passed\|failed\|Error\|FAIL" "$out/stress_campaign.txt" | tr '\n' ' '; echo ;;
     sq)
       tools/sq_counters.sh "$tag/sq372" 372 > /dev/null 2>&1; python tools/sq_summary.py "$tag/sq372" bg_engine3_kernel > "$out/sq_counters.txt" 2>&1
       tools/sq_counters.sh "$tag/sq20" 20 > /dev/null 2>&1; python tools/sq_summary.py "$tag/sq20" bg_engine3_kernel > "$out/sq_counters_T20.txt" 2>&1
