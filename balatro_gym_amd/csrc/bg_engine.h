@@ -91,6 +91,13 @@ __device__ __forceinline__ void bg_lds_st(uint16_t* p, uint32_t v) {
   __hip_atomic_store(p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 __device__ __forceinline__ void bg_vm_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+#ifdef BG_ENG_TL   // development: the timeline of a workgroup in 10 ns ticks, summed over workgroups into d.dbg (tools/eng_timeline.py)
+constexpr bool kEngTl = true;
+#else
+constexpr bool kEngTl = false;
+#endif
+// (sums in LDS, flushed by the workgroup's last instructions: 256 workgroups x a dozen global atomics on one line per event would be the timeline)
+#define BG_TL(k) do { if constexpr (kEngTl) __hip_atomic_fetch_add(&s_tl[k], wall_clock64() - tl_k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); } while (0)
 
 
 // INFO: the launch serves bg_step / bg_step_many (per-step info arrays); false for the rollouts
@@ -121,9 +128,11 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   __shared__ bg_u32x4 s_zero;                 // the two padding pieces of a 384-byte record are read from here
   __shared__ unsigned long long s_stats[6];   // the workgroup's share of bg_rollout_stats (bg_step.h bg_stats_wave / bg_stats_flush)
   __shared__ JTables jt;
+  __shared__ unsigned long long s_tl[kEngTl ? 32 : 1];
+  const unsigned long long tl_k0 = kEngTl ? wall_clock64() : 0ull;
+  if constexpr (kEngTl) { if (threadIdx.x < 32) s_tl[threadIdx.x] = 0ull; __syncthreads(); }
   __builtin_amdgcn_s_setprio(3);
   BG_PROBE_INIT();
-  bg_tables_load(&jt, d.jtab);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int env0 = blockIdx.x * NE;
   const int n_live = d.N - env0 < NE ? d.N - env0 : NE;
@@ -131,36 +140,96 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   const int serve_idx = __popc(a.serve_mask & ((1u << wave) - 1u)); // which RNG window
   using DeckT = DeckLdsS<NE, CARDS>;
   const size_t N = (size_t)d.N;
-  // ---------------------------------------------------------------- prologue: HBM -> LDS, images built, lane = env
-  if (tid < 3) { s_tail[tid] = tid == BG_Q_RUN ? (uint32_t)n_live : 0u; s_head[tid] = 0; }
+  // ---------------------------------------------------------------- prologue: HBM -> LDS, first actions classified, images built; thread = env
+  // Round 6 (tools/eng_timeline.py, profiles/r06/eng_timeline_*.txt): a ONE-step launch -- bg_step, bg_step_rows -- is all latency, and the prologue was
+  // four round trips in series: tables (global -> LDS, barrier), state, image builds (barrier), run queue -> first play batch at 11 us of a 30 us workgroup.
+  //  (a) every global load of the prologue is ISSUED before the first barrier: the joker tables (all threads) and, thread = env, the state, the deck, the
+  //      producer counter and the launch's first action -- one round trip; the queue words are zeroed in front of the same barrier;
+  //  (b) behind it the action mask -- and, when the caller supplies the actions (bg_step / bg_step_rows / bg_step_many), the env's FIRST action is
+  //      classified right here: one that needs a service batch (PLAY_HAND, DISCARD, blind select, shop buy / reroll / sell, a consumable, a terminal guard)
+  //      goes straight into its service queue WITHOUT a record image (the service step builds the env's image itself), in front of the second barrier --
+  //      so the waves that own no env thread find the launch's service batches complete when they enter their loops;
+  //  (c) behind the second barrier the envs whose first step is a cheap one build their image (a cheap step patches it) at LOW priority -- an image build
+  //      is ~900 back-to-back VALU instructions, and the service wave that shares its SIMD is the launch's critical path -- and join the run queue.
+  // (Classification only decides WHERE an action is settled: a service batch settles any action, so a cheap one sent there is still right.)
+  if (tid < 3) { s_tail[tid] = 0u; s_head[tid] = 0; }
   if (tid == 0) { s_done = 0; s_busy = 0; s_cqt = 0; s_zero = bg_u32x4{0u, 0u, 0u, 0u}; }
   if (tid < 6) s_stats[tid] = 0ull;
-  if (tid < NE) {
-    const int l = tid, env = env0 + l;
-    s_q[BG_Q_PLAY][l] = 0; s_q[BG_Q_OTHER][l] = 0; s_cq[l] = make_uint2(0u, 0u);
-    s_q[BG_Q_RUN][l] = l < n_live ? ((uint32_t)l | BG_ITEM_VALID) : 0u;
-    s_t[l] = 0;
-    if (l < n_live) {
-      uint4 c[BG_NHOT];
+  const bool mine = tid < NE && tid < n_live;
+  const int l0 = tid, envp = env0 + tid;
+  if (tid < NE) { s_q[BG_Q_RUN][l0] = 0; s_q[BG_Q_PLAY][l0] = 0; s_q[BG_Q_OTHER][l0] = 0; s_cq[l0] = make_uint2(0u, 0u); s_t[l0] = 0; }
+  constexpr int JW = (int)(sizeof(JTables) / 4), JPT = (JW + NW * BG_BLOCK - 1) / (NW * BG_BLOCK);
+  uint32_t jv[JPT];
 #pragma unroll
-      for (int k = 0; k < BG_NHOT; k++) c[k] = d.hot[(size_t)k * N + env];
-      s_c34[0][l] = c[3]; s_c34[1][l] = c[4];
-      DeckT dk; dk.col = (lds_u32*)&s_deck[0][l];
+  for (int k = 0; k < JPT; k++) { const int i = tid + k * NW * BG_BLOCK; jv[k] = i < JW ? d.jtab[i] : 0u; }
+  bool svc = false;   // this env's first step is a service queue's
+  {
+    uint4 c[BG_NHOT];
+    uint4 dw[BG_NDECK];
+    uint32_t prod = 0u;
+    int act0 = 0;
+    if (mine) {
 #pragma unroll
-      for (int k = 0; k < BG_NDECK; k++) bg_deck_set(dk, k, d.deck[(size_t)k * N + env]);
-      const uint32_t prod = d.prod_view ? d.prod_view[env] : 0u;
-      s_prod[l] = prod;
-      Env e;
-      bg_unpack(c, e);
-      bg_derive_ready(e, prod);
-      ShopRegs sr; sr.valid = false;
-      const uint64_t mask = bg_action_mask(d, env, e, sr);
-      s_mask[l] = mask;
-      const ObsPtrs none{};
-      bg_write_obs_impl<false, 3>(d, env, 0, e, dk, none, mask, sr, RowExtra{0.0, 0, 0u}, RowStage{(lds_u4*)&s_img[l][0], nullptr});
+      for (int k = 0; k < BG_NHOT; k++) c[k] = d.hot[(size_t)k * N + envp];
+#pragma unroll
+      for (int k = 0; k < BG_NDECK; k++) dw[k] = d.deck[(size_t)k * N + envp];
+      prod = d.prod_view ? d.prod_view[envp] : 0u;
+      if (a.actions_in) act0 = a.actions_in[envp];   // (step 0 of the launch)
+    }
+    __syncthreads();   // the queue words are zero and every slot of the three rings reads "not written" (0) before the first append
+    if (tid == 0) BG_TL(1);
+#pragma unroll
+    for (int k = 0; k < JPT; k++) { const int i = tid + k * NW * BG_BLOCK; if (i < JW) ((uint32_t*)&jt)[i] = jv[k]; }
+    if (mine) {
+      s_c34[0][l0] = c[3]; s_c34[1][l0] = c[4];
+      DeckT dk; dk.col = (lds_u32*)&s_deck[0][l0];
+#pragma unroll
+      for (int k = 0; k < BG_NDECK; k++) bg_deck_set(dk, k, dw[k]);
+      s_prod[l0] = prod;
+      Env pe;
+      ShopRegs psr; psr.valid = false;
+      bg_unpack(c, pe);
+      bg_derive_ready(pe, prod);
+      const uint64_t pmask = bg_action_mask(d, envp, pe, psr);
+      s_mask[l0] = pmask;
+      if (a.actions_in) {
+        const bool valid = act0 >= 0 && act0 < 60 && ((pmask >> (act0 & 63)) & 1ull);
+        const bool terminal = pe.ante > 100 || pe.chips_scored > 1000000000ll;
+        const bool cheap = !terminal && (!valid || (pe.phase == 0 && act0 >= 2 && act0 < 10) || (pe.phase == 1 && act0 == 31 && pe.hand_size <= pe.nhand));
+        svc = !cheap;
+        if (svc) {
+          const int q = (!terminal && pe.phase == 0 && act0 == 0) ? BG_Q_PLAY : BG_Q_OTHER;
+          const uint32_t slot = __hip_atomic_fetch_add(&s_tail[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (< NE: generation 0)
+          bg_lds_st(&s_q[q][slot & (NE - 1)], (uint32_t)l0 | (((slot >> BG_ENG_LNE) & 0xffu) << 8) | (((uint32_t)act0 & 0x7fffu) << 16) | BG_ITEM_VALID);
+        }
+      }
     }
   }
-  __syncthreads();
+  if (tid == 0) BG_TL(2);
+  __syncthreads();   // tables, chunks 3 / 4, decks, masks in LDS; the launch's first service batches are queued
+  if (tid == 0) BG_TL(3);
+  // (c): image first, queue word second (one lane's LDS operations execute in program order).  No barrier behind it: the other waves are already in their
+  // loops.  (The state is unpacked a second time, from lines this CU has just read: kept in registers across the barrier it was 30 spilled registers.)
+  {
+    if (mine && !svc) {
+      __builtin_amdgcn_s_setprio(1);
+      uint4 c[BG_NHOT];
+#pragma unroll
+      for (int k = 0; k < BG_NHOT; k++) if (k != 3 && k != 4) c[k] = d.hot[(size_t)k * N + envp];
+      c[3] = s_c34[0][l0]; c[4] = s_c34[1][l0];
+      Env pe;
+      ShopRegs psr; psr.valid = false;
+      bg_unpack(c, pe);
+      bg_derive_ready(pe, s_prod[l0]);
+      const uint64_t pmask = s_mask[l0];
+      DeckT dk; dk.col = (lds_u32*)&s_deck[0][l0];
+      const ObsPtrs none{};
+      bg_write_obs_impl<false, 3>(d, envp, 0, pe, dk, none, pmask, psr, RowExtra{0.0, 0, 0u}, RowStage{(lds_u4*)&s_img[l0][0], nullptr});
+      const uint32_t slot = __hip_atomic_fetch_add(&s_tail[BG_Q_RUN], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      bg_lds_st(&s_q[BG_Q_RUN][slot & (NE - 1)], (uint32_t)l0 | (((slot >> BG_ENG_LNE) & 0xffu) << 8) | BG_ITEM_VALID);
+    }
+  }
+  if (tid == 0) BG_TL(4);
   // A SHORT launch runs on fewer worker waves (bg_engine_waves): with all envs starting in step, fewer and fuller batches get the
   // stragglers -- the envs with many service steps, which decide when a 20-step launch ends -- through sooner (20 steps: 381 us on
   // seven waves, 330 on four; 200 steps: the other way round).  The surplus waves end here; the workgroup's later barriers count the
@@ -286,6 +355,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       head += nb;
       if (two && (head & 31u) == 0u) head += 32u * (a.copier - 1u);   // the next blocks are the other copiers'
     }
+    if (lane == 0 && wave == (int)a.n_waves) BG_TL(11);
     BG_PROBE_FLUSH(d);
     __syncthreads();   // (the workers' epilogue barrier)
     return;
@@ -295,6 +365,9 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   int64_t ssum = 0;
   const uint32_t bmod3 = (uint32_t)(a.env_index0 % 3ull);
   uint32_t polls = 0;
+  bool tl_first = kEngTl && wave == 4;   // (development: the first wave that owns no env thread -- when does it reach the loop, when does it get its first batch)
+  if (tl_first && lane == 0) BG_TL(24);
+  uint32_t tl_polls = 0; bool tl_seen = false;
   for (;;) {
     // -- pick a queue: the eight control words with two 16-byte loads (one LDS round trip; each word is written atomically by its
     // owner, so a torn pair of words is no worse than two separate loads)
@@ -324,9 +397,11 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       else if (nr) cls = BG_Q_RUN;
       else if (np >= need) cls = BG_Q_PLAY;
     }
+    if constexpr (kEngTl) if (tl_first && tl_polls == 0 && !tl_seen) { tl_seen = true; if (lane == 0) { BG_TL(30); s_tl[31] += np + 1000ull * nr + 1000000ull * no; } }
     if (cls < 0) {
       if (__builtin_amdgcn_readfirstlane(ct.w) >= (uint32_t)n_live) break; // every env has done its T steps
       __builtin_amdgcn_s_sleep(8);
+      tl_polls++;
       if (++polls > BG_SPIN_LIMIT) { if (lane == 0) atomicOr(d.err, BG_DEVERR_SPIN); break; }
       continue;
     }
@@ -350,6 +425,11 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       }
     }
     polls = 0;
+    const unsigned long long tl_b0 = kEngTl ? wall_clock64() : 0ull;
+    if constexpr (kEngTl) if (tl_first) {
+      if (lane == 0) { BG_TL(25); s_tl[26] += tl_polls; s_tl[27 + (cls == BG_Q_RUN ? 0 : (cls == BG_Q_PLAY ? 1 : 2))] += 1ull; }
+      tl_first = false;
+    }
     // the service chains are the critical path of every env they hold: they issue ahead of the run batches on their SIMD
     if (cls == BG_Q_RUN) __builtin_amdgcn_s_setprio(0); else __builtin_amdgcn_s_setprio(3);
     // A batch = the step the envs were queued for, then up to th_more further CHEAP steps of the same envs (a toggle is followed
@@ -546,10 +626,20 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
       bg_lds_st(&s_q[BG_Q_RUN][slot & (NE - 1)], (uint32_t)l | (((slot >> BG_ENG_LNE) & 0xffu) << 8) | BG_ITEM_VALID);
     }
     if (lane == 0) __hip_atomic_fetch_sub(&s_busy, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); // after the pushes of this batch
+    if constexpr (kEngTl) if (lane == 0) {
+      const int b = cls == BG_Q_RUN ? 5 : (cls == BG_Q_PLAY ? 16 : 20);   // start (since the workgroup's), count, duration, lanes
+      __hip_atomic_fetch_add(&s_tl[b], tl_b0 - tl_k0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&s_tl[b + 1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&s_tl[b + 2], wall_clock64() - tl_b0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      __hip_atomic_fetch_add(&s_tl[b + 3], (unsigned long long)nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
   }
   // ---------------------------------------------------------------- epilogue: chunks 3 / 4 -> HBM, statistics
+  if (lane == 0 && wave == 0) BG_TL(9);
+  if (lane == 0 && wave == (int)a.n_waves - 1) BG_TL(10);
   BG_PROBE_FLUSH(d);
   __syncthreads();
+  if (tid == 0) BG_TL(12);
   if (tid < n_live) {
     d.hot[(size_t)3 * N + env0 + tid] = s_c34[0][tid];
     d.hot[(size_t)4 * N + env0 + tid] = s_c34[1][tid];
@@ -558,5 +648,12 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     bg_stats_wave(s_stats, n_steps, n_eps, n_plays, ssum, rbits, ohash);
     __syncthreads();
     bg_stats_flush(a.stats, s_stats, tid);
+  }
+  if constexpr (kEngTl) if (d.dbg) {
+    if (tid == 0) { BG_TL(13); s_tl[0] = 1ull; }
+    __syncthreads();
+    if (tid < 32 && tid != 14 && tid != 15 && s_tl[tid]) atomicAdd(&d.dbg[tid], s_tl[tid]);
+    if (tid == 14) atomicMax(&d.dbg[14], ~tl_k0);
+    if (tid == 15) atomicMax(&d.dbg[15], wall_clock64());
   }
 }

@@ -1342,6 +1342,9 @@ static void bg_engine_launch(bg_handle* h, const BgDev& dv, const EngineArgs& a0
     return;
   }
   a.n_waves = (uint32_t)bg_engine_waves(h, (int)a.T);
+  // a ONE-step launch with the caller's actions (bg_step / bg_step_rows): the prologue has queued every service request of the launch before the first wave
+  // enters its loop -- nothing more will arrive, so a service-capable wave takes a service queue as it finds it instead of looking at the run queue first
+  if (a.T == 1 && a.actions_in) a.th_play = a.th_other = 1u;
   // packed records: one more wave, the COPIER (bg_engine.h), takes the record copy-out off the workers; with the seven-wave shape that
   // leaves room for the refill beside the launch it is one of the seven
   // ONE copier unless BG_ENG_COPIERS asks for more: a single copier drains the copy queue in order, so "one outstanding entry per env" bounds

@@ -327,6 +327,13 @@ class BalatroVecEnv:
         stride = 1 if (obs_buffers is not None and obs_buffers.steps > 1) else 0
         if stride and obs_buffers.steps < steps:
             raise ValueError("obs_buffers has fewer rows than steps")
+        if not stride and steps > 1:
+            # reward / terminated / actions share the observation's row stride (bg_rollout: row = env + t * N only when obs_stride_steps != 0):
+            # without per-step observation buffers every step writes ROW 0 of them.  A [steps, N] tensor here would come back with one filled row.
+            for name, tns in (("reward", reward), ("terminated", terminated), ("actions", actions)):
+                if tns is not None and tns.dim() > 1 and tns.shape[0] > 1:
+                    raise ValueError(f"{name} has {tns.shape[0]} rows but no per-step obs_buffers were given: every step would overwrite row 0 "
+                                     f"(pass ObsBuffers(n, device, steps={steps}), or a [N] tensor for the last step's values)")
         if zero_stats:
             self._stats.zero_()
         with torch.cuda.device(self.device):

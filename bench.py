@@ -530,9 +530,16 @@ def main():
         ks = 800   # more than two refill periods (372 steps): the look-ahead refill runs beside these launches too (in pieces), and is inside the figure
         twin = make_env()
         acts = torch.zeros((ks, n), dtype=torch.int32, device=dev)
-        twin.rollout(ks, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, env_index0=lo, actions=acts)
+        # (recorded in pieces WITH per-step observation buffers: without them every step of a rollout writes row 0 of its outputs -- until round 6 this
+        #  block replayed rows of zeros, i.e. 800 rejected PLAY_HANDs per env: figures of a step path that never ran a service step)
+        rec = 50
+        rec_ob = ObsBuffers(n, dev, steps=rec)
+        for c0 in range(0, ks, rec):
+            twin.rollout(rec, policy=POLICY_CYCLE3, policy_seed=POLICY_SEED, env_index0=lo, t0=c0, obs_buffers=rec_ob, actions=acts[c0:c0 + rec], zero_stats=c0 == 0)
         twin_stats = twin.stats()
         twin.close()
+        del rec_ob
+        replay_plays = int((acts == 0).sum().item())   # (PLAY_HAND is action 0: the policy only plays it when it is valid)
         res = {}
         for mode in ("bg_step", "bg_step_rows", "bg_step_many"):
             kw = {"obs_layout": "rows"} if mode == "bg_step_rows" else {}   # bg_step_rows: the observation as one packed 384-byte record per env
@@ -568,7 +575,7 @@ def main():
                          "roofline_frac": alg / (p["step_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if p["step_ms"] > 0 else None}
         out["step_path"] = {"what": f"{ks} steps of the same workload, actions from a device tensor [K, N]; bg_step / bg_step_many: observation as one array per key, "
                                     "bg_step_rows: as one packed 384-byte record per env (every key a strided view)",
-                            "twin_rollout_plays": twin_stats["plays"], **res}
+                            "twin_rollout_plays": twin_stats["plays"], "replayed_play_actions": replay_plays, **res}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

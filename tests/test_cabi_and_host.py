@@ -250,6 +250,18 @@ def test_operator_wrappers_validate_every_tensor():
     assert "n.to(device=hands.device, dtype=torch.int32)" in src and "flags.to(device=hands.device, dtype=torch.int32)" in src
 
 
+def test_rollout_refuses_per_step_outputs_without_per_step_buffers():
+    """bg_rollout writes reward / terminated / actions with the OBSERVATION's row stride: without per-step observation buffers every step lands in
+    row 0.  A [T, N] tensor there would come back with one filled row (bench.py's `step_path` replayed such rows of zeros until round 6): the wrapper refuses."""
+    import types
+    import torch
+    from balatro_gym_amd.vec_env import BalatroVecEnv
+    fake = types.SimpleNamespace(_obs=None)
+    for kw in ("reward", "terminated", "actions"):
+        with pytest.raises(ValueError, match="row 0"):
+            BalatroVecEnv.rollout(fake, 8, **{kw: torch.zeros((8, 4), dtype=torch.int32)})
+
+
 def test_build_signature_is_reproducible(tmp_path):
     """The identity of the device code (`bg_build_signature`, what profiles/*_hbm_traffic.json are keyed on) must survive a rebuild of
     unchanged sources: the library reports the sha256 prefix of sources + flags (12 digits) and compiler (4 digits) it was built from, and

@@ -311,6 +311,45 @@ def _oracle_rollout(n, seeds, T, policy, pseed, scorer, max_ante, jokers, env_in
     return {k: np.stack(v) for k, v in obs.items()}, rewards, terms, acts, stats
 
 
+@pytest.mark.parametrize("layout", ["keys", "rows"])
+def test_replayed_rollout_actions_reproduce_the_rollout(layout):
+    """What bench.py's `step_path` block does: the actions of a fused rollout, recorded per step, replayed through bg_step / bg_step_rows on a twin handle
+    -- every step's reward and termination flag and the final observation must be the rollout's (both sides are pinned to the oracle elsewhere; this pins
+    the RECORDING: it needs per-step buffers, the wrapper refuses a [T, N] tensor without them), and the replay must contain service steps."""
+    import torch
+    from balatro_gym_amd.vec_env import ObsBuffers
+    from oracle.gen_golden import IMPLEMENTED
+    n, T = 512, 120
+    seeds = [61_000 + SEED_OFFSET + i for i in range(n)]
+    jokers = [random.Random(300 + i).sample(IMPLEMENTED, 5) for i in range(n)]
+
+    def make(**kw):
+        e = _vec(n, seeds, scorer_jokers=True, autoreset=True, max_ante=4, **kw)
+        e.inject(jokers=jokers, apply_now=True)
+        return e
+    a = make()
+    ob = ObsBuffers(n, a.device, steps=T)
+    reward = torch.zeros((T, n), dtype=torch.float64, device=a.device)
+    term = torch.zeros((T, n), dtype=torch.uint8, device=a.device)
+    acts = torch.zeros((T, n), dtype=torch.int32, device=a.device)
+    with pytest.raises(ValueError, match="row 0"):
+        a.rollout(T, policy=2, policy_seed=99, actions=acts)
+    a.rollout(T, policy=2, policy_seed=99, obs_buffers=ob, reward=reward, terminated=term, actions=acts)
+    plays = a.stats()["plays"]
+    assert plays > n and int((acts == 0).sum().item()) >= plays          # PLAY_HAND (action 0) is in every row, not only in row 0
+    assert all(int((acts[t] != 0).sum().item()) > 0 for t in (1, T // 2, T - 1))
+    b = make(obs_layout=layout)
+    for t in range(T):
+        _, r, tm, _, _ = b.step(acts[t])
+        assert torch.equal(r.view(torch.int64), reward[t].view(torch.int64)), f"reward of step {t}"
+        assert torch.equal(tm.to(torch.uint8), term[t]), f"terminated of step {t}"
+    b.check()
+    got = _obs_np(b)
+    for k in OBS_KEYS:
+        assert np.array_equal(got[k], ob.tensors[k][T - 1].cpu().numpy()), k
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("policy,scorer", [(2, False), (0, False), (2, True)])
 def test_fused_rollout_vs_oracle(policy, scorer):
     """bg_rollout (policy on device, SAME_STEP auto-reset, every step's observation kept) against the oracle."""

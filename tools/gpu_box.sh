@@ -6,6 +6,7 @@
 #     tests            the whole GPU suite (-m gpu)
 #     test:<expr>      pytest -m gpu -k <expr>
 #     oldlib:<expr>    the same selection against build/variants/r05_shipped.so (a test that pins a fixed bug must FAIL there)
+#     steppath:<reps>:<lib>[,<lib>...]   bench.py's step_path block (bg_step / bg_step_rows / bg_step_many) of several libraries, interleaved
 #     ab:<reps>:<lib>[,<lib>...]   interleaved kernel-only bench (both launch shapes) of several libraries on this box; "tree" = the in-tree library
 #     abenv:<reps>:<VAR=a,b,..>    the same for values of one environment variable of the in-tree library
 #     timing:<lib>     tools/e3_timing.py with a -DBG_E3_TIMING library (cycles per batch / owner iteration), both shapes
@@ -51,6 +52,13 @@ for step in "$@"; do
         BALATRO_MI355X_LIB=$p timeout 300 python bench.py --no-cpu-baseline --no-step-path --no-small-n > "$out/default_${name}_$rep.json" 2>/dev/null
       done; done
       brief "$out"/T20_*.json "$out"/default_*.json | tee "$out/ab_summary.txt" ;;
+    steppath:*)   # steppath:<reps>:<lib>[,<lib>...]: the bg_step / bg_step_rows / bg_step_many figures of bench.py's `step_path` block, interleaved
+      IFS=: read -r _ reps libs <<< "$step"
+      (for rep in $(seq 1 "$reps"); do for lib in ${libs//,/ }; do p=$(libpath "$lib"); name=$(basename "$p" .so); [ "$lib" = tree ] && name=tree
+        BALATRO_MI355X_LIB=$p timeout 600 python bench.py --no-cpu-baseline --no-small-n --samples 0 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['step_path']
+print('$name rep $rep:', '  '.join('%s %.3f G (kernel %.2f us / step, wall %.2f)' % (k, s[k]['value']/1e9, s[k]['kernel_ms_per_step']*1e3, s[k]['ms_per_step']*1e3) for k in ('bg_step','bg_step_rows','bg_step_many')), ' headline %.3f G' % (d['value']/1e9))"
+      done; done) > "$out/step_path_ab.txt" 2>&1; cat "$out/step_path_ab.txt" ;;
     abenv:*)
       IFS=: read -r _ reps spec <<< "$step"; var=${spec%%=*}; vals=${spec#*=}
       for rep in $(seq 1 "$reps"); do for v in ${vals//,/ }; do
