@@ -575,7 +575,9 @@ def main():
                          "roofline_frac": alg / (p["step_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if p["step_ms"] > 0 else None}
         out["step_path"] = {"what": f"{ks} steps of the same workload, actions from a device tensor [K, N]; bg_step / bg_step_many: observation as one array per key, "
                                     "bg_step_rows: as one packed 384-byte record per env (every key a strided view)",
-                            "twin_rollout_plays": twin_stats["plays"], "replayed_play_actions": replay_plays, **res}
+                            "twin_rollout_plays": twin_stats["plays"], "replayed_play_actions": replay_plays,
+                            "note": "until round 6 this block replayed rows of ZERO actions (rejected PLAY_HANDs, no service step): its earlier figures (3.2 / 3.7 / 7.9 G) are not comparable",
+                            **res}
 
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:

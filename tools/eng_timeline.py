@@ -44,6 +44,17 @@ env.check()
 p = env.get_profile()
 L.bg_debug_counters(env._h, out)
 o = [float(v) for v in out]
+if os.environ.get("PROBES"):   # a -DBG_TIMING build: the BG_PROBE cycle sums of the service steps (first active lane of each batch), per workgroup and launch
+    names = {1: "boss checks + hand base (since classify)", 2: "chain: Bloodstone words", 3: "chain: main-phase words ready + skip", 5: "gather selected cards", 6: "classify",
+             7: "chain: individual", 8: "chain: peeks", 13: "chain: -", 14: "chain: main", 15: "hand base + joker chain (whole call)", 16: "final score + card-state effects",
+             17: "boss scoring ratio", 18: "shop: stream window (loads + twist)", 10: "progress, counters, boss bookkeeping", 11: "reward shaping",
+             12: "outcome (advance round / draw / boss)", 20: "play dispatch total", 21: "other dispatch total", 22: "shop inventory", 23: "service: state load + unpack",
+             24: "service: cap + reset", 25: "service: mask", 26: "service: image build", 27: "service: pack + state store"}
+    print(f"obs_layout {layout}: {K} one-step launches, kernel {p['step_ms'] / K * 1e3:.2f} us per launch; cycles per workgroup and launch (2.4 GHz: 2 400 = 1 us)")
+    for k in sorted(names):
+        print(f"  probe {k:2d} {names[k]:44s} {o[k] / (n / 256) / K:9.0f}")
+    env.close()
+    sys.exit(0)
 wgs = max(o[0], 1.0)
 us = lambda v, c=None: v / (c if c else wgs) / 100.0
 print(f"obs_layout {layout}: {K} one-step launches, kernel {p['step_ms'] / K * 1e3:.2f} us per launch (its own timestamps); {wgs / K:.0f} workgroups per launch")
