@@ -140,6 +140,11 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   const int serve_idx = __popc(a.serve_mask & ((1u << wave) - 1u)); // which RNG window
   using DeckT = DeckLdsS<NE, CARDS>;
   const size_t N = (size_t)d.N;
+  // One array per key, overwritten in place (bg_step; a rollout without per-step buffers): only the LAST observation of the launch is ever read, and every
+  // env's image holds it when the launch ends -- the arrays are written ONCE, behind the loop, thread = env (consecutive lanes = consecutive rows: whole
+  // lines per store), instead of 31 scattered partial stores per lane inside every batch (a one-step launch: its play batch 20.7 -> 17 us, its run batches
+  // 6.6 -> 2.8 us; the per-step values -- reward, terminated, action, info -- are still written by the step that produces them)
+  const bool keys_at_end = !a.obs.rows && a.obs_stride_steps == 0;
   // ---------------------------------------------------------------- prologue: HBM -> LDS, first actions classified, images built; thread = env
   // Round 6 (tools/eng_timeline.py, profiles/r06/eng_timeline_*.txt): a ONE-step launch -- bg_step, bg_step_rows -- is all latency, and the prologue was
   // four round trips in series: tables (global -> LDS, barrier), state, image builds (barrier), run queue -> first play batch at 11 us of a 30 us workgroup.
@@ -516,7 +521,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
     };
     // the outputs of a completed step other than the image, and the env's step counter
     auto finish = [&](bool cheap, size_t row, int action, double reward, bool terminated, const StepOut& o) __attribute__((always_inline)) {
-      if (cheap && !a.obs.rows) bg_emit_keys_from_image((const lds_u4*)&s_img[l][0], a.obs, row); // per-key arrays of a cheap step
+      if (!a.obs.rows && !keys_at_end) bg_emit_keys_from_image((const lds_u4*)&s_img[l][0], a.obs, row); // per-key arrays, every step kept ([T, N] buffers)
       if (a.reward) a.reward[row] = reward;
       if (a.term) a.term[row] = terminated ? 1 : 0;
       if (a.actions_out) a.actions_out[row] = action;
@@ -589,7 +594,10 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
         BG_PROBE(24);
         mask = bg_action_mask(d, env, e, sr);
         BG_PROBE(25);
-        bg_write_obs_impl<false, 3>(d, env, row, e, dk, a.obs, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u}, RowStage{(lds_u4*)&s_img[l][0], nullptr});
+        {
+          const ObsPtrs none{};   // (the image only -- per-key arrays are written from it, by finish() or behind the loop; bg_engine3.h's service step has the note on what passing a.obs costs in scalar registers)
+          bg_write_obs_impl<false, 3>(d, env, row, e, dk, none, mask, sr, RowExtra{o.reward, action, o.terminated ? 1u : 0u}, RowStage{(lds_u4*)&s_img[l][0], nullptr});
+        }
         BG_PROBE(26);
         bg_pack(e, c);
 #pragma unroll
@@ -643,6 +651,7 @@ __global__ __launch_bounds__(BG_ENG_NW * BG_BLOCK, BG_ENG_OCC) void bg_engine_ke
   if (tid < n_live) {
     d.hot[(size_t)3 * N + env0 + tid] = s_c34[0][tid];
     d.hot[(size_t)4 * N + env0 + tid] = s_c34[1][tid];
+    if (keys_at_end) bg_emit_keys_from_image((const lds_u4*)&s_img[tid][0], a.obs, (size_t)(env0 + tid));
   }
   if (a.stats) {   // (bg_step.h: one set of global atomics per workgroup, not per wave)
     bg_stats_wave(s_stats, n_steps, n_eps, n_plays, ssum, rbits, ohash);

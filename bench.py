@@ -541,7 +541,11 @@ def main():
         del rec_ob
         replay_plays = int((acts == 0).sum().item())   # (PLAY_HAND is action 0: the policy only plays it when it is valid)
         res = {}
-        for mode in ("bg_step", "bg_step_rows", "bg_step_many"):
+        kb = 100   # bg_step_many_kept: steps per call, every step's observation kept in [kb, N] buffers (2.3 GB)
+        kept_ob = ObsBuffers(n, dev, steps=kb)
+        kept_rw = torch.zeros((kb, n), dtype=torch.float64, device=dev)
+        kept_tm = torch.zeros((kb, n), dtype=torch.uint8, device=dev)
+        for mode in ("bg_step", "bg_step_rows", "bg_step_many", "bg_step_many_kept"):
             kw = {"obs_layout": "rows"} if mode == "bg_step_rows" else {}   # bg_step_rows: the observation as one packed 384-byte record per env
             e2 = make_env(**kw)
             e2.step(acts[0]); e2.reset(); torch.cuda.synchronize(dev)  # first-call costs out of the way
@@ -554,11 +558,14 @@ def main():
                 e2.set_profiling(profiled)
                 torch.cuda.synchronize(dev)
                 t0 = time.perf_counter()
-                if mode != "bg_step_many":
+                if mode == "bg_step_many":
+                    e2.step_many(acts)   # the observation arrays are overwritten in place: the caller sees the LAST step's (the library writes them once per launch)
+                elif mode == "bg_step_many_kept":
+                    for c0 in range(0, ks, kb):
+                        e2.step_many(acts[c0:c0 + kb], obs_buffers=kept_ob, reward=kept_rw, terminated=kept_tm)
+                else:
                     for k in range(ks):
                         e2.step(acts[k])
-                else:
-                    e2.step_many(acts)
                 torch.cuda.synchronize(dev)
                 if profiled:
                     p = e2.get_profile()
@@ -567,14 +574,18 @@ def main():
                 e2.check()
                 e2.close()
             a1 = OBS_BYTES + IO_BYTES + 2 * STATE_BYTES  # one launch per step: the state crosses HBM every step
-            a_k = OBS_BYTES + IO_BYTES + 2 * STATE_BYTES / ks
-            alg = (a_k if mode == "bg_step_many" else a1) * n * ks
+            a_k = OBS_BYTES + IO_BYTES + 2 * STATE_BYTES / ks                 # every step's observation kept
+            a_last = IO_BYTES + (OBS_BYTES + 2 * STATE_BYTES) / ks             # only the last step's observation leaves the chip
+            alg = {"bg_step_many": a_last, "bg_step_many_kept": a_k}.get(mode, a1) * n * ks
             res[mode] = {"value": n * ks / dt, "unit": "env-steps/s", "steps": ks, "ms_per_step": dt / ks * 1e3,
                          "kernel_ms_per_step": p["step_ms"] / ks, "launches": p["step_launches"],
                          "wall_over_kernel": (dt / ks * 1e3) / (p["step_ms"] / ks) if p["step_ms"] > 0 else None,
                          "roofline_frac": alg / (p["step_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBPS if p["step_ms"] > 0 else None}
-        out["step_path"] = {"what": f"{ks} steps of the same workload, actions from a device tensor [K, N]; bg_step / bg_step_many: observation as one array per key, "
-                                    "bg_step_rows: as one packed 384-byte record per env (every key a strided view)",
+        del kept_ob, kept_rw, kept_tm
+        out["step_path"] = {"what": f"{ks} steps of the same workload, actions from a device tensor [K, N]; bg_step / bg_step_many*: observation as one array per key, "
+                                    "bg_step_rows: as one packed 384-byte record per env (every key a strided view); bg_step_many: ONE call, the observation arrays "
+                                    f"overwritten in place (the last step's is what the caller sees); bg_step_many_kept: {kb} steps per call, every step's observation, reward and "
+                                    "termination flag kept in [K, N] buffers",
                             "twin_rollout_plays": twin_stats["plays"], "replayed_play_actions": replay_plays,
                             "note": "until round 6 this block replayed rows of ZERO actions (rejected PLAY_HANDs, no service step): its earlier figures (3.2 / 3.7 / 7.9 G) are not comparable",
                             **res}

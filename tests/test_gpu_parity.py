@@ -347,7 +347,22 @@ def test_replayed_rollout_actions_reproduce_the_rollout(layout):
     got = _obs_np(b)
     for k in OBS_KEYS:
         assert np.array_equal(got[k], ob.tensors[k][T - 1].cpu().numpy()), k
-    a.close(); b.close()
+    # ... and the launches that overwrite the observation arrays in place (the library writes them ONCE, behind the last step: bg_engine.h keys_at_end):
+    # all T steps as one bg_step_many call, and the same rollout again without per-step buffers -- the live observation is the last step's
+    c = make(obs_layout=layout)
+    _, r, tm, _, _ = c.step_many(acts)
+    assert torch.equal(r.view(torch.int64), reward[T - 1].view(torch.int64)) and torch.equal(tm.to(torch.uint8), term[T - 1])
+    c.check()
+    got = _obs_np(c)
+    for k in OBS_KEYS:
+        assert np.array_equal(got[k], ob.tensors[k][T - 1].cpu().numpy()), f"step_many, no buffers: {k}"
+    d2 = make(obs_layout=layout)
+    d2.rollout(T, policy=2, policy_seed=99)
+    d2.check()
+    got = _obs_np(d2)
+    for k in OBS_KEYS:
+        assert np.array_equal(got[k], ob.tensors[k][T - 1].cpu().numpy()), f"rollout, no buffers: {k}"
+    a.close(); b.close(); c.close(); d2.close()
 
 
 @pytest.mark.parametrize("policy,scorer", [(2, False), (0, False), (2, True)])

@@ -57,7 +57,7 @@ for step in "$@"; do
       (for rep in $(seq 1 "$reps"); do for lib in ${libs//,/ }; do p=$(libpath "$lib"); name=$(basename "$p" .so); [ "$lib" = tree ] && name=tree
         BALATRO_MI355X_LIB=$p timeout 600 python bench.py --no-cpu-baseline --no-small-n --samples 0 2>/dev/null | python -c "
 import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['step_path']
-print('$name rep $rep:', '  '.join('%s %.3f G (kernel %.2f us / step, wall %.2f)' % (k, s[k]['value']/1e9, s[k]['kernel_ms_per_step']*1e3, s[k]['ms_per_step']*1e3) for k in ('bg_step','bg_step_rows','bg_step_many')), ' headline %.3f G' % (d['value']/1e9))"
+print('$name rep $rep:', '  '.join('%s %.3f G (kernel %.2f us / step, wall %.2f)' % (k, s[k]['value']/1e9, s[k]['kernel_ms_per_step']*1e3, s[k]['ms_per_step']*1e3) for k in ('bg_step','bg_step_rows','bg_step_many','bg_step_many_kept') if k in s), ' headline %.3f G' % (d['value']/1e9))"
       done; done) > "$out/step_path_ab.txt" 2>&1; cat "$out/step_path_ab.txt" ;;
     abenv:*)
       IFS=: read -r _ reps spec <<< "$step"; var=${spec%%=*}; vals=${spec#*=}
@@ -77,7 +77,8 @@ print('$name rep $rep:', '  '.join('%s %.3f G (kernel %.2f us / step, wall %.2f)
       grep -c "^ok" "$out/stress_parity.txt"; grep "STRESS OK\|FAIL\|Error" "$out/stress_parity.txt" | tr '\n' ' '; echo ;;
     campaign:*)   # campaign:<k>: k seed offsets x (the five stress modes, once as ONE launch and once as short launches with the refill in pieces) + the GPU suite under BG_TEST_SEED_OFFSET
       k="${step#campaign:}"
-      (for off in $(seq 1 "$k"); do for chunks in "" "20,13,30,7"; do for mode in "" "wide 5 6" long consumables; do
+      (python -c "from balatro_gym_amd import build; print('library', build.library_signature(), 'sources', build.source_signature())"
+       for off in $(seq 1 "$k"); do for chunks in "" "20,13,30,7"; do for mode in "" "wide 5 6" long consumables; do
           echo "== SEED_OFFSET=$((off * 100003)) CHUNKS=[$chunks] mode [$mode]"; SEED_OFFSET=$((off * 100003)) CHUNKS=$chunks STRIDE=384 timeout 900 python tools/stress_parity.py $mode 2>&1 | grep -v amdgpu.ids
         done; done
         echo "== BG_TEST_SEED_OFFSET=$((off * 7919)): the GPU suite"; BG_TEST_SEED_OFFSET=$((off * 7919)) timeout 1500 python -m pytest tests -m gpu -q -x 2>&1 | tail -2
